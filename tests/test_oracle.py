@@ -1,0 +1,97 @@
+"""CPU: the oracle (oracle/*.py) against the committed golden fixtures, which were generated
+from the reference itself by oracle/validate_against_reference.py, plus the structural pins
+the reference's own tests hold (tests/test_state_dict_compat.py:33-55, test_unext2.py)."""
+
+import pytest
+import torch
+
+from oracle import loss_ref, transforms_ref, unext2_ref
+from tests.conftest import load_golden
+
+
+def test_state_dict_compat_atto():
+    m = unext2_ref.UNeXt2(backbone="convnextv2_atto")
+    sd = m.state_dict()
+    assert len(sd) == 213
+    assert {k.split(".")[0] for k in sd} == {"decoder", "encoder_stages", "head", "stem"}
+    for key in [
+        "stem.conv.weight",
+        "stem.conv.bias",
+        "encoder_stages.stages_1.blocks.1.mlp.fc2.bias",
+        "decoder.decoder_stages.0.conv.blocks.0.conv_dw.weight",
+        "decoder.decoder_stages.0.conv.blocks.0.mlp.fc1.bias",
+        "decoder.decoder_stages.2.conv.blocks.0.mlp.grn.bias",
+        "head.conv.1.weight",
+    ]:
+        assert key in sd
+
+
+def test_tiny_param_count_and_shapes():
+    m = unext2_ref.UNeXt2(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True)
+    n = sum(p.numel() for p in m.parameters())
+    assert abs(n - 32.04e6) < 0.05e6  # 32.04 M
+    assert len(m.state_dict()) == 273
+    x = torch.randn(1, 1, 5, 64, 64)
+    with torch.no_grad():
+        assert m(x).shape == (1, 2, 5, 64, 64)
+
+
+def test_bad_depth_raises():
+    with pytest.raises(ValueError, match="not divisible"):
+        unext2_ref.UNeXt2(in_stack_depth=7)
+
+
+@pytest.mark.parametrize("tag", ["atto_pool", "femto_z15", "tiny_pool"])
+def test_forward_golden(tag):
+    g = load_golden("unext2_forward.pt")[tag]
+    m = unext2_ref.randomize_(unext2_ref.UNeXt2(**g["kwargs"]), seed=g["seed"]).eval()
+    assert len(m.state_dict()) == g["n_keys"]
+    cs = sum(p.double().sum() for p in m.parameters()).item()
+    assert abs(cs - g["param_checksum"]) <= 1e-6 * max(1.0, abs(g["param_checksum"]))
+    x = torch.randn(g["x_shape"], generator=torch.Generator().manual_seed(g["x_seed"]))
+    with torch.no_grad():
+        y = m(x)
+    torch.testing.assert_close(y, g["y"], rtol=1e-5, atol=1e-6)
+
+
+def test_stem_golden():
+    g = load_golden("stem.pt")
+    s = unext2_ref.UNeXt2Stem(1, 96, (5, 4, 4), 5)
+    s.load_state_dict({"conv.weight": g["weight"], "conv.bias": g["bias"]})
+    with torch.no_grad():
+        torch.testing.assert_close(s(g["x"]), g["y"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["rand_192", "corr_192", "corr_256", "corr_176x208"])
+def test_loss_golden(tag):
+    c = load_golden("loss.pt")[tag]
+    gen = torch.Generator().manual_seed(c["seed"])
+    target = torch.rand(c["shape"], generator=gen)
+    pred = target + 0.1 * torch.randn(c["shape"], generator=gen) if c["corr"] else torch.rand(c["shape"], generator=gen)
+    pred.requires_grad_(True)
+    ms = loss_ref.ms_ssim_25d(pred, target, clamp=True)
+    torch.testing.assert_close(ms, c["ms_ssim"], rtol=1e-5, atol=1e-7)
+    loss = loss_ref.mixed_loss(pred, target, 0.5, 0.0, 0.5)
+    torch.testing.assert_close(loss, c["loss"], rtol=1e-5, atol=1e-7)
+    loss.backward()
+    sample = pred.grad.flatten()[:: max(1, pred.grad.numel() // 4096)]
+    torch.testing.assert_close(sample, c["grad_sample"], rtol=1e-4, atol=1e-9)
+    # L1-only branch is bit-exact vs F.l1_loss (reference test_mixed_loss.py:85-99)
+    assert torch.equal(loss_ref.mixed_loss(pred.detach(), target, 1.0, 0, 0), torch.nn.functional.l1_loss(pred.detach(), target))
+
+
+def test_mixed_loss_all_zero_raises():
+    with pytest.raises(ValueError):
+        loss_ref.mixed_loss(torch.zeros(1), torch.zeros(1), 0, 0, 0)
+
+
+def test_normalize_golden():
+    g = load_golden("normalize.pt")
+    assert torch.equal(transforms_ref.normalize_sampled(g["x"], g["mean"], g["std"]), g["y"])
+    out = transforms_ref.normalize_sampled(g["kat_in"], torch.tensor(60.0), torch.tensor(10.0))
+    torch.testing.assert_close(out, (g["kat_in"] - 60.0) / (10.0 + 1e-8))  # test_normalize.py:49-67
+    assert torch.equal(out, g["kat_out"])
+    assert torch.equal(transforms_ref.minmax_sampled(g["kat_in"], torch.tensor(55.0), torch.tensor(65.0)), g["mm_out"])
+    # clipping KAT (test_normalize.py:96-102)
+    x = torch.full((1, 1, 8, 64, 64), 200.0)
+    assert torch.allclose(transforms_ref.minmax_sampled(x, torch.tensor(5.0), torch.tensor(95.0)), torch.ones_like(x))
