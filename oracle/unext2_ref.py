@@ -82,14 +82,11 @@ class GlobalResponseNormMlp(nn.Module):
 
     def __init__(self, in_features: int, hidden_features: int, out_features: int, use_conv: bool):
         super().__init__()
-        if use_conv:
-            self.fc1 = nn.Conv2d(in_features, hidden_features, 1)
-            self.fc2 = nn.Conv2d(hidden_features, out_features, 1)
-        else:
-            self.fc1 = nn.Linear(in_features, hidden_features)
-            self.fc2 = nn.Linear(hidden_features, out_features)
+        # registration order as in timm: fc1, act, drop1, grn, fc2, drop2
+        self.fc1 = nn.Conv2d(in_features, hidden_features, 1) if use_conv else nn.Linear(in_features, hidden_features)
         self.act = nn.GELU()
         self.grn = GlobalResponseNorm(hidden_features, channels_last=not use_conv)
+        self.fc2 = nn.Conv2d(hidden_features, out_features, 1) if use_conv else nn.Linear(hidden_features, out_features)
 
     def forward(self, x: Tensor) -> Tensor:
         return self.fc2(self.grn(self.act(self.fc1(x))))

@@ -1,0 +1,28 @@
+// libvsx.so — error plumbing, version and debug knobs of the C-ABI (include/vsx.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "vsx_common.h"
+#include "../../include/vsx.h"
+
+static thread_local char g_err[512] = "";
+int g_vsx_tn_tr = 1;
+
+void vsx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int32_t vsx_version(void) { return 1; }
+extern "C" const char* vsx_last_error(void) { return g_err; }
+extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
+  if (name && !strcmp(name, "tn_tr")) { g_vsx_tn_tr = value; return 0; }
+  vsx_set_error("vsx_set_flag: unknown flag '%s'", name ? name : "(null)");
+  return 1;
+}
+extern "C" int32_t vsx_get_flag(const char* name) {
+  if (name && !strcmp(name, "tn_tr")) return g_vsx_tn_tr;
+  return -1;
+}

@@ -1,0 +1,614 @@
+// MFMA GEMMs for the pointwise / patch / 3x3 convolutions of UNeXt2.
+//
+//   gemm_nt : C[M,N]  = pro(A)[M,K] · B[N,K]^T      forward and data-gradient GEMMs
+//   gemm_tn : W[N,K] += X[M,N]^T · pro(A)[M,K]      weight-gradient GEMMs (contraction over pixels)
+//
+// gfx950 mapping: 256-thread workgroups = 4 wave64; 16x16 MFMA fragments
+// (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32 — same C layout, so one code path serves the
+// bf16 production mode and the exact-fp32 parity mode); operands staged global → VGPR → LDS in
+// 16-byte chunks (double-buffered LDS, one barrier per K step); LDS row strides chosen so the
+// ds_read_b128 fragment reads are bank-conflict free; accumulators go back through LDS so the
+// fused epilogues (bias, GELU + GRN sum-of-squares, residual, IN statistics …) run on row-contiguous
+// 16-byte vectors and HBM stores are fully coalesced.
+#include "vsx_common.h"
+#include "../../include/vsx.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+extern int g_vsx_tn_tr;
+
+// ------------------------------------------------------------------------------------------------
+// operand gather: returns the 16-byte chunk holding A(m, k .. k+VN-1) after the prologue
+// ------------------------------------------------------------------------------------------------
+struct RowCoord {
+  int b, y, x;
+  bool valid;
+};
+
+__device__ __forceinline__ RowCoord decode_row(const VsxGemm& p, int m) {
+  RowCoord r;
+  r.valid = m < p.M;
+  int mm = r.valid ? m : 0;
+  if (p.a_mode == VSX_A_ROWS && p.c_mode == VSX_A_ROWS) {
+    r.b = p.hw > 0 ? mm / p.hw : 0;
+    r.y = 0;
+    r.x = mm;  // plain row index
+  } else {
+    int hw = p.gh * p.gw;
+    r.b = mm / hw;
+    int rem = mm - r.b * hw;
+    r.y = rem / p.gw;
+    r.x = rem - r.y * p.gw;
+  }
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ typename VT<T>::vec load_a_chunk(const VsxGemm& p, const RowCoord& rc, int m, int k,
+                                                            int coff) {
+  constexpr int VN = VT<T>::N;
+  typedef typename VT<T>::vec vec;
+  if (!rc.valid || k >= p.K) return vzero<T>();
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* ptr;
+  if (p.a_mode == VSX_A_ROWS) {
+    ptr = A + (size_t)m * p.lda + coff + k;
+  } else {
+    int tap = k / p.cs;
+    int c = k - tap * p.cs;
+    size_t pix;
+    if (p.a_mode == VSX_A_PATCH2) {
+      int ky = tap >> 1, kx = tap & 1;
+      pix = ((size_t)rc.b * (2 * p.gh) + 2 * rc.y + ky) * (2 * p.gw) + 2 * rc.x + kx;
+    } else {
+      int ky = tap / 3, kx = tap - 3 * ky;
+      int yy = rc.y + ky - 1, xx = rc.x + kx - 1;
+      if (yy < 0 || yy >= p.gh || xx < 0 || xx >= p.gw) return vzero<T>();
+      pix = ((size_t)rc.b * p.gh + yy) * p.gw + xx;
+    }
+    ptr = A + pix * p.lda + coff + c;
+  }
+  vec v = ldvec<T>(ptr);
+  if (p.pro == VSX_PRO_GRN) {
+    float f[VN];
+    unpack<T>(v, f);
+    const float* s = p.grn_s + (size_t)rc.b * p.K + k;
+    const float* bt = p.grn_b + k;
+#pragma unroll
+    for (int j = 0; j < VN; ++j) f[j] = gelu_f(f[j]) * s[j] + bt[j];
+    v = pack<T>(f);
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA fragments
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct Frag;
+template <>
+struct Frag<bf16_t> {
+  typedef bf16x8 type;
+  static constexpr int MK = 32;
+};
+template <>
+struct Frag<float> {
+  typedef float type;
+  static constexpr int MK = 4;
+};
+
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(const float& a, const float& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// fragment of a [rows][k] (k contiguous) LDS tile, row stride RS bytes; kk = MFMA sub-step inside BK
+template <typename T>
+__device__ __forceinline__ typename Frag<T>::type lds_frag_rk(const char* tile, int row, int RS, int kk, int kq);
+template <>
+__device__ __forceinline__ bf16x8 lds_frag_rk<bf16_t>(const char* tile, int row, int RS, int kk, int kq) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * RS + kk * 64 + kq * 16);
+}
+template <>
+__device__ __forceinline__ float lds_frag_rk<float>(const char* tile, int row, int RS, int kk, int kq) {
+  return *reinterpret_cast<const float*>(tile + row * RS + (kk * 4 + kq) * 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM_, int WN_>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
+  constexpr int BK = 32;
+  constexpr int ES = sizeof(T);
+  constexpr int RS = BK * ES + (ES == 2 ? 32 : 16);
+  constexpr int CPR = BK * ES / 16;
+  constexpr int VN = VT<T>::N;
+  constexpr int FM = BM / WM_ / 16, FN = BN / WN_ / 16;
+  constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
+  constexpr int MAIN_BYTES = 2 * (BM + BN) * RS;
+  constexpr int CS_LD = BN + 4;
+  constexpr int EPI_BYTES = BM * CS_LD * 4 + 2 * BN * 4;
+  constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+  constexpr int MK = Frag<T>::MK;
+  typedef typename VT<T>::vec vec;
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN_, wn = wave % WN_;
+  const int p16 = lane & 15, kq = lane >> 4;
+  const int z = blockIdx.z;
+
+  // XCD-aware tile order: consecutive tile ids (sharing an A row-panel) stay on one XCD's L2
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+  const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int a_coff = p.a_coff[z];
+  const T* Bw = reinterpret_cast<const T*>(p.B) + p.b_off[z];
+
+  // per-thread staging descriptors
+  RowCoord arc[NA];
+  int arow[NA], ach[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    int cid = tid + i * 256;
+    arow[i] = cid / CPR;
+    ach[i] = cid % CPR;
+    arc[i] = decode_row(p, m0 + arow[i]);
+    if (cid >= BM * CPR) arc[i].valid = false;
+  }
+  vec areg[NA], breg[NB];
+
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int k = kt * BK + ach[i] * VN;
+      areg[i] = load_a_chunk<T>(p, arc[i], m0 + arow[i], k, a_coff);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int cid = tid + i * 256;
+      int row = cid / CPR, ch = cid % CPR;
+      int n = n0 + row, k = kt * BK + ch * VN;
+      if (cid < BN * CPR && n < p.N && k < p.K)
+        breg[i] = ldvec<T>(Bw + (size_t)n * p.ldb + k);
+      else
+        breg[i] = vzero<T>();
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    char* As = smem + buf * (BM + BN) * RS;
+    char* Bs = As + BM * RS;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      int cid = tid + i * 256;
+      if (cid < BM * CPR) *reinterpret_cast<vec*>(As + arow[i] * RS + ach[i] * 16) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int cid = tid + i * 256;
+      if (cid < BN * CPR) *reinterpret_cast<vec*>(Bs + (cid / CPR) * RS + (cid % CPR) * 16) = breg[i];
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const char* As = smem + (kt & 1) * (BM + BN) * RS;
+    const char* Bs = As + BM * RS;
+#pragma unroll
+    for (int kk = 0; kk < BK / MK; ++kk) {
+      frag_t af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = lds_frag_rk<T>(As, (wm * FM + i) * 16 + p16, RS, kk, kq);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[j] = lds_frag_rk<T>(Bs, (wn * FN + j) * 16 + p16, RS, kk, kq);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tiles((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators → LDS (fp32) → row-contiguous vectors
+  float* Cs = reinterpret_cast<float*>(smem);
+  float* red = Cs + BM * CS_LD;  // [2][BN]
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cs[((wm * FM + i) * 16 + kq * 4 + r) * CS_LD + (wn * FN + j) * 16 + p16] = acc[i][j][r];
+  if (tid < 2 * BN) red[tid] = 0.f;
+  __syncthreads();
+
+  constexpr int NCH = BN / VN;        // column chunks per row
+  constexpr int RSTEP = 256 / NCH;    // rows handled per pass
+  const int cc = tid % NCH, rr = tid / NCH;
+  const int n = n0 + cc * VN;
+  const bool ncol_ok = n < p.N;
+  const int epi = p.epi;
+  const bool reduce = (epi == VSX_EPI_BIAS_GELU_SQ || epi == VSX_EPI_DZ || epi == VSX_EPI_BIAS_STATS);
+  const int mlast = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
+  const int hwb = p.hw > 0 ? p.hw : p.M;
+  const int b_first = m0 / hwb;
+  const bool uniform = reduce && (b_first == mlast / hwb);
+  float r0[VN], r1[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) { r0[j] = 0.f; r1[j] = 0.f; }
+  float bias[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) bias[j] = 0.f;
+  if (ncol_ok && p.bias != nullptr && epi != VSX_EPI_NONE && epi != VSX_EPI_DZ) {
+#pragma unroll
+    for (int j = 0; j < VN; ++j) bias[j] = p.bias[n + j];
+  }
+  T* Cg = reinterpret_cast<T*>(p.C);
+  const int c_coff = p.c_coff[z];
+
+  if (ncol_ok) {
+    for (int row = rr; row < BM; row += RSTEP) {
+      const int m = m0 + row;
+      if (m >= p.M) break;
+      float v[VN];
+#pragma unroll
+      for (int j = 0; j < VN; j += 4) {
+        float4 t = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * VN + j);
+        v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+      }
+#pragma unroll
+      for (int j = 0; j < VN; ++j) v[j] += bias[j];
+      const int b = m / hwb;
+      if (epi == VSX_EPI_BIAS_RES) {
+        float rf[VN];
+        unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n), rf);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) v[j] += rf[j];
+      } else if (epi == VSX_EPI_BIAS_GELU_SQ) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          float g = gelu_f(round_to<T>(v[j]));
+          r0[j] += g * g;
+        }
+      } else if (epi == VSX_EPI_DZ) {
+        float hf[VN];
+        unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldx + n), hf);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          float dz = round_to<T>(v[j]);
+          r0[j] += dz * gelu_f(hf[j]);
+          r1[j] += dz;
+        }
+      } else if (epi == VSX_EPI_BIAS_STATS) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          float c = round_to<T>(v[j]);
+          r0[j] += c;
+          r1[j] += c * c;
+        }
+      }
+      // store
+      T* dst;
+      if (p.c_mode == VSX_A_PATCH2) {
+        int hw = p.gh * p.gw;
+        int bb = m / hw, rem = m - bb * hw;
+        int y = rem / p.gw, x = rem - y * p.gw;
+        int tap = n / p.c_cs, c = n - tap * p.c_cs;
+        size_t pix = ((size_t)bb * (2 * p.gh) + 2 * y + (tap >> 1)) * (2 * p.gw) + 2 * x + (tap & 1);
+        dst = Cg + pix * p.ldc + c_coff + c;
+      } else {
+        dst = Cg + (size_t)m * p.ldc + c_coff + n;
+      }
+      stvec<T>(dst, pack<T>(v));
+      if (reduce && !uniform) {
+        // tile spans several batch samples (tiny feature maps): direct atomics
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          atomicAdd(p.red0 + (size_t)b * p.N + n + j, r0[j]);
+          if (epi == VSX_EPI_BIAS_STATS) atomicAdd(p.red1 + (size_t)b * p.N + n + j, r1[j]);
+          if (epi == VSX_EPI_DZ) atomicAdd(p.red1 + n + j, r1[j]);
+          r0[j] = 0.f;
+          r1[j] = 0.f;
+        }
+      }
+    }
+  }
+  if (uniform) {
+    if (ncol_ok) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        atomicAdd(red + cc * VN + j, r0[j]);
+        if (epi != VSX_EPI_BIAS_GELU_SQ) atomicAdd(red + BN + cc * VN + j, r1[j]);
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      atomicAdd(p.red0 + (size_t)b_first * p.N + n0 + tid, red[tid]);
+      if (epi == VSX_EPI_BIAS_STATS) atomicAdd(p.red1 + (size_t)b_first * p.N + n0 + tid, red[BN + tid]);
+      if (epi == VSX_EPI_DZ) atomicAdd(p.red1 + n0 + tid, red[BN + tid]);
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM_, int WN_>
+static int launch_nt(const VsxGemm* p, hipStream_t s) {
+  int tiles = vsx_cdiv(p->M, BM) * vsx_cdiv(p->N, BN);
+  dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM_, WN_>), grid, dim3(256), 0, s, *p);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static int dispatch_nt(const VsxGemm* p, hipStream_t s) {
+  if (p->N > 64) return launch_nt<T, 128, 128, 2, 2>(p, s);
+  if (p->N > 32) return launch_nt<T, 128, 64, 2, 2>(p, s);
+  if (p->N > 16) return launch_nt<T, 128, 32, 4, 1>(p, s);
+  return launch_nt<T, 128, 16, 4, 1>(p, s);
+}
+
+static int check_common(const VsxGemm* p, int dtype, const char* who) {
+  int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(p != nullptr, "%s: null params", who);
+  VSX_CHECK(dtype == VSX_F32 || dtype == VSX_BF16, "%s: bad dtype %d", who, dtype);
+  VSX_CHECK(p->M > 0 && p->N > 0 && p->K > 0, "%s: empty GEMM %dx%dx%d", who, p->M, p->N, p->K);
+  VSX_CHECK(p->K % vn == 0 && p->N % vn == 0, "%s: N=%d and K=%d must be multiples of %d", who, p->N, p->K, vn);
+  VSX_CHECK(p->lda % vn == 0 && p->ldb % vn == 0, "%s: lda=%d ldb=%d must be multiples of %d", who, p->lda, p->ldb, vn);
+  VSX_CHECK(p->nz >= 0 && p->nz <= 8, "%s: nz=%d out of range", who, p->nz);
+  if (p->a_mode != VSX_A_ROWS) {
+    VSX_CHECK(p->gh > 0 && p->gw > 0 && p->cs > 0 && p->cs % vn == 0, "%s: bad gather grid %dx%d cs=%d", who, p->gh,
+              p->gw, p->cs);
+    VSX_CHECK(p->K % p->cs == 0, "%s: K=%d not a multiple of cs=%d", who, p->K, p->cs);
+    VSX_CHECK(p->M % (p->gh * p->gw) == 0, "%s: M=%d not a multiple of the %dx%d grid", who, p->M, p->gh, p->gw);
+  }
+  if (p->pro == VSX_PRO_GRN) VSX_CHECK(p->grn_s && p->grn_b && p->hw > 0, "%s: GRN prologue needs s, beta, hw", who);
+  for (int z = 0; z < (p->nz > 0 ? p->nz : 1); ++z)
+    VSX_CHECK(p->a_coff[z] % vn == 0 && p->b_off[z] % vn == 0 && p->c_coff[z] % vn == 0,
+              "%s: z offsets must be multiples of %d", who, vn);
+  return 0;
+}
+
+extern "C" int32_t vsx_gemm_nt(const VsxGemm* p, int32_t dtype, vsx_stream_t stream) {
+  if (int e = check_common(p, dtype, "vsx_gemm_nt")) return e;
+  int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(p->ldc % vn == 0, "vsx_gemm_nt: ldc=%d must be a multiple of %d", p->ldc, vn);
+  if (p->c_mode == VSX_A_PATCH2)
+    VSX_CHECK(p->c_cs > 0 && p->c_cs % vn == 0 && p->N % p->c_cs == 0 && p->gh > 0 && p->gw > 0,
+              "vsx_gemm_nt: bad patch scatter (c_cs=%d)", p->c_cs);
+  if (p->epi == VSX_EPI_BIAS_GELU_SQ || p->epi == VSX_EPI_DZ || p->epi == VSX_EPI_BIAS_STATS)
+    VSX_CHECK(p->red0 != nullptr && p->hw > 0, "vsx_gemm_nt: reduction epilogue needs red0 and hw");
+  if (p->epi == VSX_EPI_DZ) VSX_CHECK(p->aux && p->red1, "vsx_gemm_nt: EPI_DZ needs aux and red1");
+  if (p->epi == VSX_EPI_BIAS_STATS) VSX_CHECK(p->red1 != nullptr, "vsx_gemm_nt: EPI_BIAS_STATS needs red1");
+  if (p->epi == VSX_EPI_BIAS_RES) VSX_CHECK(p->res != nullptr, "vsx_gemm_nt: EPI_BIAS_RES needs res");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  return dtype == VSX_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn : W[n][k] += sum_m X[m][n] * Y[m][k]
+// LDS tiles keep the natural [m][n] / [m][k] layout; the MFMA operands need 8 consecutive
+// contraction (m) values per lane, which gfx950's ds_read_b64_tr_b16 delivers straight from a
+// row-major tile (TR = true).  TR = false is the scalar-read fallback, also used for fp32.
+// k-slot ↔ m mapping inside a 32-row step (bf16): slot (kq, j) ↔ m = kq*4 + j (j < 4), 16 + kq*4 + j - 4.
+// ------------------------------------------------------------------------------------------------
+template <bool TR>
+__device__ __forceinline__ bf16x8 lds_frag_mn_bf16(const char* tile, int LDB, int col0, int p16, int kq) {
+  // tile: [32][LD] bf16, LDB = row stride bytes; returns the fragment for column col0 + p16
+  if (TR) {
+    const int q = p16;
+    const char* a0 = tile + (kq * 4 + (q >> 2)) * LDB + (col0 + (q & 3) * 4) * 2;
+    const char* a1 = a0 + 16 * LDB;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a1));
+    union {
+      struct { s16x4 lo, hi; } s;
+      bf16x8 v;
+    } u;
+    u.s.lo = lo;
+    u.s.hi = hi;
+    return u.v;
+  } else {
+    union {
+      unsigned short h[8];
+      bf16x8 v;
+    } u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int mloc = j < 4 ? kq * 4 + j : 16 + kq * 4 + (j - 4);
+      u.h[j] = *reinterpret_cast<const unsigned short*>(tile + mloc * LDB + (col0 + p16) * 2);
+    }
+    return u.v;
+  }
+}
+
+template <typename T, bool TR>
+__device__ __forceinline__ typename Frag<T>::type lds_frag_mn(const char* tile, int LDB, int col0, int p16, int kq,
+                                                              int kk);
+template <>
+__device__ __forceinline__ bf16x8 lds_frag_mn<bf16_t, true>(const char* t, int LDB, int c0, int p16, int kq, int) {
+  return lds_frag_mn_bf16<true>(t, LDB, c0, p16, kq);
+}
+template <>
+__device__ __forceinline__ bf16x8 lds_frag_mn<bf16_t, false>(const char* t, int LDB, int c0, int p16, int kq, int) {
+  return lds_frag_mn_bf16<false>(t, LDB, c0, p16, kq);
+}
+template <>
+__device__ __forceinline__ float lds_frag_mn<float, false>(const char* t, int LDB, int c0, int p16, int kq, int kk) {
+  return *reinterpret_cast<const float*>(t + (kk * 4 + kq) * LDB + (c0 + p16) * 4);
+}
+template <>
+__device__ __forceinline__ float lds_frag_mn<float, true>(const char* t, int LDB, int c0, int p16, int kq, int kk) {
+  return *reinterpret_cast<const float*>(t + (kk * 4 + kq) * LDB + (c0 + p16) * 4);
+}
+
+template <typename T, int BT, bool TR>  // BT x BT output tile of W
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_per_block) {
+  constexpr int BMS = 32;                       // contraction rows per step
+  constexpr int ES = sizeof(T);
+  constexpr int VN = VT<T>::N;
+  constexpr int LD = BT + 16;                   // LDS row stride (elements)
+  constexpr int LDB = LD * ES;
+  constexpr int CPR = BT / VN;                  // chunks per tile row
+  constexpr int NCH = (BMS * CPR + 255) / 256;  // chunks per thread per operand
+  constexpr int TILE_BYTES = BMS * LDB;
+  constexpr int F = BT / 2 / 16;                // frags per wave per dim (2x2 waves)
+  constexpr int MK = Frag<T>::MK;
+  typedef typename VT<T>::vec vec;
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int p16 = lane & 15, kq = lane >> 4;
+  const int z = blockIdx.z;
+
+  const int tiles_k = (p.K + BT - 1) / BT;
+  const int tile_k = blockIdx.x % tiles_k, tile_n = blockIdx.x / tiles_k;
+  const int n0 = tile_n * BT, k0 = tile_k * BT;
+  const int mbeg = blockIdx.y * rows_per_block;
+  const int mend = (mbeg + rows_per_block < p.M) ? mbeg + rows_per_block : p.M;
+  if (mbeg >= mend) return;
+
+  const T* X = reinterpret_cast<const T*>(p.B);
+  const int x_coff = p.b_off[z];
+  const int a_coff = p.a_coff[z];
+
+  int crow[NCH], cch[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int cid = tid + i * 256;
+    crow[i] = cid / CPR;
+    cch[i] = cid % CPR;
+  }
+  vec xreg[NCH], yreg[NCH];
+  auto load_tiles = [&](int ms) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int cid = tid + i * 256;
+      int m = ms + crow[i];
+      bool ok = cid < BMS * CPR && m < mend;
+      int nn = n0 + cch[i] * VN;
+      xreg[i] = (ok && nn < p.N) ? ldvec<T>(X + (size_t)m * p.ldb + x_coff + nn) : vzero<T>();
+      int kk = k0 + cch[i] * VN;
+      if (ok && kk < p.K) {
+        RowCoord rc = decode_row(p, m);
+        yreg[i] = load_a_chunk<T>(p, rc, m, kk, a_coff);
+      } else {
+        yreg[i] = vzero<T>();
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    char* Xs = smem + buf * 2 * TILE_BYTES;
+    char* Ys = Xs + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int cid = tid + i * 256;
+      if (cid < BMS * CPR) {
+        *reinterpret_cast<vec*>(Xs + crow[i] * LDB + cch[i] * 16) = xreg[i];
+        *reinterpret_cast<vec*>(Ys + crow[i] * LDB + cch[i] * 16) = yreg[i];
+      }
+    }
+  };
+
+  f32x4 acc[F][F];
+#pragma unroll
+  for (int i = 0; i < F; ++i)
+#pragma unroll
+    for (int j = 0; j < F; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;  // bias-gradient partial for column n0 + tid (tile_k == 0 blocks only)
+  const bool do_colsum = p.colsum != nullptr && tile_k == 0 && tid < BT;
+
+  const int nsteps = (mend - mbeg + BMS - 1) / BMS;
+  load_tiles(mbeg);
+  store_tiles(0);
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) load_tiles(mbeg + (st + 1) * BMS);
+    const char* Xs = smem + (st & 1) * 2 * TILE_BYTES;
+    const char* Ys = Xs + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BMS / MK; ++kk) {
+      frag_t xf[F], yf[F];
+#pragma unroll
+      for (int i = 0; i < F; ++i) xf[i] = lds_frag_mn<T, TR>(Xs, LDB, (wn * F + i) * 16, p16, kq, kk);
+#pragma unroll
+      for (int j = 0; j < F; ++j) yf[j] = lds_frag_mn<T, TR>(Ys, LDB, (wk * F + j) * 16, p16, kq, kk);
+#pragma unroll
+      for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < F; ++j) acc[i][j] = mfma16(xf[i], yf[j], acc[i][j]);
+    }
+    if (do_colsum) {
+#pragma unroll 8
+      for (int r = 0; r < BMS; ++r) csum += to_f32<T>(*reinterpret_cast<const T*>(Xs + r * LDB + tid * ES));
+    }
+    if (st + 1 < nsteps) store_tiles((st + 1) & 1);
+    __syncthreads();
+  }
+
+  float* W = reinterpret_cast<float*>(p.C) + p.c_coff[z];
+#pragma unroll
+  for (int i = 0; i < F; ++i)
+#pragma unroll
+    for (int j = 0; j < F; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int n = n0 + (wn * F + i) * 16 + kq * 4 + r;
+        int k = k0 + (wk * F + j) * 16 + p16;
+        if (n < p.N && k < p.K) atomicAdd(W + (size_t)n * p.ldc + k, acc[i][j][r]);
+      }
+  if (do_colsum && n0 + tid < p.N) atomicAdd(p.colsum + n0 + tid, csum);
+}
+
+template <typename T, int BT, bool TR>
+static int launch_tn(const VsxGemm* p, hipStream_t s) {
+  int tiles = vsx_cdiv(p->N, BT) * vsx_cdiv(p->K, BT);
+  int nz = p->nz > 0 ? p->nz : 1;
+  // split the pixel (contraction) axis so that the launch has enough workgroups to fill 256 CUs
+  int want = vsx_cdiv(1024, tiles * nz);
+  int max_splits = vsx_cdiv(p->M, 256);
+  int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+  if (splits > 65535) splits = 65535;
+  int rpb = vsx_cdiv(vsx_cdiv(p->M, splits), 32) * 32;
+  splits = vsx_cdiv(p->M, rpb);
+  dim3 grid(tiles, splits, nz);
+  hipLaunchKernelGGL((gemm_tn_kernel<T, BT, TR>), grid, dim3(256), 0, s, *p, rpb);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t vsx_gemm_tn(const VsxGemm* p, int32_t dtype, vsx_stream_t stream) {
+  if (int e = check_common(p, dtype, "vsx_gemm_tn")) return e;
+  VSX_CHECK(p->epi == VSX_EPI_NONE && p->c_mode == VSX_A_ROWS, "vsx_gemm_tn: no epilogue / scatter modes");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  bool small = (long)p->N * p->K <= 128 * 128 || p->M <= 8192;
+  if (dtype == VSX_BF16) {
+    if (g_vsx_tn_tr) return small ? launch_tn<bf16_t, 64, true>(p, s) : launch_tn<bf16_t, 128, true>(p, s);
+    return small ? launch_tn<bf16_t, 64, false>(p, s) : launch_tn<bf16_t, 128, false>(p, s);
+  }
+  return small ? launch_tn<float, 64, false>(p, s) : launch_tn<float, 128, false>(p, s);
+}

@@ -1,0 +1,272 @@
+// PixelToVoxelHead tail: InstanceNorm3d + PReLU + 1x1x1 Conv3d + pixel
+// shuffle into the (B, C, Z, Y, X) output stack, forward and backward.  The 3x3x3 convolution
+// itself runs on the MFMA GEMM (gemm.hip, VSX_A_CONV3) whose epilogue accumulates the
+// per-(b, channel) sum / sum-of-squares this file turns into InstanceNorm statistics.
+//
+// Layout: U[b, y, x, z, o] (channels-last, o = Cmid contiguous); one thread per voxel (b, y, x, z),
+// lanes along x·z so both the 16-byte U reads and the 8-byte stores into the X-contiguous output
+// rows are coalesced.
+#include "vsx_common.h"
+#include "../../include/vsx.h"
+
+#define HEAD_MAX_CMID 64
+#define HEAD_MAX_CO4 16
+
+struct HeadDims {
+  int B, H2, W2, Z, Cmid, Cout;  // Cout = output channels (Cout*4 rows of the 1x1x1 conv)
+};
+
+template <typename T, int CMID>
+__device__ __forceinline__ void head_norm_act(const T* __restrict__ u, const float* __restrict__ mu,
+                                              const float* __restrict__ rs, float alpha, float* nh, float* a) {
+  constexpr int VN = VT<T>::N;
+#pragma unroll
+  for (int c = 0; c < CMID; c += VN) {
+    float v[VN];
+    unpack<T>(ldvec<T>(u + c), v);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      float n = (v[j] - mu[c + j]) * rs[c + j];
+      nh[c + j] = n;
+      a[c + j] = n > 0.f ? n : alpha * n;
+    }
+  }
+}
+
+// stats → mean / rstd in LDS for sample b
+__device__ __forceinline__ void head_load_stats(const float* __restrict__ ssum, const float* __restrict__ ssq, int b,
+                                                int Cmid, float count, float eps, float* mu, float* rs) {
+  for (int i = threadIdx.x; i < Cmid; i += blockDim.x) {
+    float m = ssum[b * Cmid + i] / count;
+    float var = ssq[b * Cmid + i] / count - m * m;
+    mu[i] = m;
+    rs[i] = rsqrtf(fmaxf(var, 0.f) + eps);
+  }
+}
+
+template <typename T, int CMID, int CO4>
+__global__ __launch_bounds__(256) void head_out_fwd_kernel(const T* __restrict__ U, const float* __restrict__ ssum,
+                                                           const float* __restrict__ ssq, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, const float* __restrict__ alpha_p,
+                                                           float* __restrict__ out, HeadDims d, float eps) {
+  __shared__ float mu[HEAD_MAX_CMID], rs[HEAD_MAX_CMID], w2s[HEAD_MAX_CO4 * HEAD_MAX_CMID], b2s[HEAD_MAX_CO4];
+  const int b = blockIdx.y;
+  constexpr int co4 = CO4;
+  head_load_stats(ssum, ssq, b, CMID, (float)d.Z * d.H2 * d.W2, eps, mu, rs);
+  for (int i = threadIdx.x; i < co4 * CMID; i += 256) w2s[i] = w2[i];
+  if (threadIdx.x < co4) b2s[threadIdx.x] = b2[threadIdx.x];
+  __syncthreads();
+  const float alpha = alpha_p[0];
+  const int nvox = d.H2 * d.W2 * d.Z;
+  const int vox = blockIdx.x * 256 + threadIdx.x;  // (y, x, z) with z fastest
+  if (vox >= nvox) return;
+  const int z = vox % d.Z;
+  const int px = vox / d.Z;
+  const int x = px % d.W2, y = px / d.W2;
+  float nh[CMID], a[CMID];
+  head_norm_act<T, CMID>(U + ((size_t)b * nvox + vox) * CMID, mu, rs, alpha, nh, a);
+  const int H = 2 * d.H2, W = 2 * d.W2;
+  _Pragma("unroll") for (int co = 0; co < CO4 / 4; ++co) {
+    float v[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float acc = b2s[co * 4 + s];
+      _Pragma("unroll") for (int c = 0; c < CMID; ++c) acc = fmaf(w2s[(co * 4 + s) * CMID + c], a[c], acc);
+      v[s] = acc;
+    }
+    float* o = out + ((((size_t)b * d.Cout + co) * d.Z + z) * H + 2 * y) * W + 2 * x;
+    *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+    *reinterpret_cast<float2*>(o + W) = make_float2(v[2], v[3]);
+  }
+}
+
+// backward pass 1: per voxel recompute n̂ / a, gather dv from dout, dA = W2^T dv, dn = dA * prelu'(n̂);
+// writes a (T) and dv (T) for the 1x1x1 weight-gradient GEMM; accumulates S1 = Σ dn, S2 = Σ dn·n̂ per
+// (b, channel) and the PReLU-slope gradient.
+template <typename T, int CMID, int CO4>
+__global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict__ U, const float* __restrict__ ssum,
+                                                            const float* __restrict__ ssq, const float* __restrict__ w2,
+                                                            const float* __restrict__ alpha_p,
+                                                            const float* __restrict__ dout, T* __restrict__ act,
+                                                            T* __restrict__ dvout, float* __restrict__ S1,
+                                                            float* __restrict__ S2, float* __restrict__ dalpha,
+                                                            HeadDims d, float eps, int vox_per_thread) {
+  constexpr int VN = VT<T>::N;
+  __shared__ float mu[HEAD_MAX_CMID], rs[HEAD_MAX_CMID], w2s[HEAD_MAX_CO4 * HEAD_MAX_CMID];
+  __shared__ float red[2 * HEAD_MAX_CMID + 1];
+  const int b = blockIdx.y;
+  constexpr int co4 = CO4;
+  head_load_stats(ssum, ssq, b, CMID, (float)d.Z * d.H2 * d.W2, eps, mu, rs);
+  for (int i = threadIdx.x; i < co4 * CMID; i += 256) w2s[i] = w2[i];
+  for (int i = threadIdx.x; i < 2 * CMID + 1; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const float alpha = alpha_p[0];
+  const int nvox = d.H2 * d.W2 * d.Z;
+  const int H = 2 * d.H2, W = 2 * d.W2;
+  float s1[CMID], s2[CMID];
+  _Pragma("unroll") for (int c = 0; c < CMID; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  float da = 0.f;
+  for (int it = 0; it < vox_per_thread; ++it) {
+    const int vox = (blockIdx.x * vox_per_thread + it) * 256 + threadIdx.x;
+    if (vox >= nvox) break;
+    const int z = vox % d.Z;
+    const int px = vox / d.Z;
+    const int x = px % d.W2, y = px / d.W2;
+    float nh[CMID], a[CMID];
+    const size_t row = (size_t)b * nvox + vox;
+    head_norm_act<T, CMID>(U + row * CMID, mu, rs, alpha, nh, a);
+    _Pragma("unroll") for (int c = 0; c < CMID; c += VN) stvec<T>(act + row * CMID + c, pack<T>(a + c));
+    float dv[CO4];
+    _Pragma("unroll") for (int co = 0; co < CO4 / 4; ++co) {
+      const float* o = dout + ((((size_t)b * d.Cout + co) * d.Z + z) * H + 2 * y) * W + 2 * x;
+      float2 t0 = *reinterpret_cast<const float2*>(o);
+      float2 t1 = *reinterpret_cast<const float2*>(o + W);
+      dv[co * 4 + 0] = round_to<T>(t0.x); dv[co * 4 + 1] = round_to<T>(t0.y);
+      dv[co * 4 + 2] = round_to<T>(t1.x); dv[co * 4 + 3] = round_to<T>(t1.y);
+    }
+    _Pragma("unroll") for (int k = 0; k < CO4; k += VN) stvec<T>(dvout + row * co4 + k, pack<T>(dv + k));
+    _Pragma("unroll") for (int c = 0; c < CMID; ++c) {
+      float dA = 0.f;
+      _Pragma("unroll") for (int k = 0; k < CO4; ++k) dA = fmaf(w2s[k * CMID + c], dv[k], dA);
+      float dn = nh[c] > 0.f ? dA : alpha * dA;
+      if (nh[c] <= 0.f) da += dA * nh[c];
+      s1[c] += dn;
+      s2[c] += dn * nh[c];
+    }
+  }
+  _Pragma("unroll") for (int c = 0; c < CMID; ++c) {
+    float t1 = wave_sum(s1[c]), t2 = wave_sum(s2[c]);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[c], t1); atomicAdd(&red[CMID + c], t2); }
+  }
+  da = wave_sum(da);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&red[2 * CMID], da);
+  __syncthreads();
+  for (int i = threadIdx.x; i < CMID; i += 256) {
+    atomicAdd(S1 + b * CMID + i, red[i]);
+    atomicAdd(S2 + b * CMID + i, red[CMID + i]);
+  }
+  if (threadIdx.x == 0) atomicAdd(dalpha, red[2 * CMID]);
+}
+
+// backward pass 2: dU = rstd * (dn - S1/cnt - n̂ * S2/cnt)
+template <typename T, int CMID, int CO4>
+__global__ __launch_bounds__(256) void head_out_bwd2_kernel(const T* __restrict__ U, const float* __restrict__ ssum,
+                                                            const float* __restrict__ ssq, const float* __restrict__ w2,
+                                                            const float* __restrict__ alpha_p,
+                                                            const T* __restrict__ dvin, const float* __restrict__ S1,
+                                                            const float* __restrict__ S2, T* __restrict__ dU,
+                                                            HeadDims d, float eps) {
+  constexpr int VN = VT<T>::N;
+  __shared__ float mu[HEAD_MAX_CMID], rs[HEAD_MAX_CMID], w2s[HEAD_MAX_CO4 * HEAD_MAX_CMID];
+  __shared__ float m1[HEAD_MAX_CMID], m2[HEAD_MAX_CMID];
+  const int b = blockIdx.y;
+  constexpr int co4 = CO4;
+  const float cnt = (float)d.Z * d.H2 * d.W2;
+  head_load_stats(ssum, ssq, b, CMID, cnt, eps, mu, rs);
+  for (int i = threadIdx.x; i < co4 * CMID; i += 256) w2s[i] = w2[i];
+  for (int i = threadIdx.x; i < CMID; i += 256) {
+    m1[i] = S1[b * CMID + i] / cnt;
+    m2[i] = S2[b * CMID + i] / cnt;
+  }
+  __syncthreads();
+  const float alpha = alpha_p[0];
+  const int nvox = d.H2 * d.W2 * d.Z;
+  const int vox = blockIdx.x * 256 + threadIdx.x;
+  if (vox >= nvox) return;
+  const size_t row = (size_t)b * nvox + vox;
+  float dv[CO4];
+  _Pragma("unroll") for (int k = 0; k < CO4; k += VN) unpack<T>(ldvec<T>(dvin + row * co4 + k), dv + k);
+  _Pragma("unroll") for (int c = 0; c < CMID; c += VN) {
+    float v[VN], o[VN];
+    unpack<T>(ldvec<T>(U + row * CMID + c), v);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      float n = (v[j] - mu[c + j]) * rs[c + j];
+      float dA = 0.f;
+      _Pragma("unroll") for (int k = 0; k < CO4; ++k) dA = fmaf(w2s[k * CMID + c + j], dv[k], dA);
+      float dn = n > 0.f ? dA : alpha * dA;
+      o[j] = rs[c + j] * (dn - m1[c + j] - n * m2[c + j]);
+    }
+    stvec<T>(dU + row * CMID + c, pack<T>(o));
+  }
+}
+
+#define HEAD_DISPATCH(KERNEL, TT, ...)                                                                         \
+  do {                                                                                                          \
+    if (Cmid == 16 && Cout == 1) hipLaunchKernelGGL((KERNEL<TT, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else if (Cmid == 32 && Cout == 2) hipLaunchKernelGGL((KERNEL<TT, 32, 8>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else if (Cmid == 48 && Cout == 3) hipLaunchKernelGGL((KERNEL<TT, 48, 12>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<TT, 64, 16>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);         \
+  } while (0)
+
+static int head_check(const char* who, HeadDims d, int dtype) {
+  int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(d.B > 0 && d.H2 > 0 && d.W2 > 0 && d.Z > 0, "%s: bad dims", who);
+  VSX_CHECK(d.Cmid > 0 && d.Cmid <= HEAD_MAX_CMID && d.Cmid % vn == 0, "%s: Cmid=%d must be <=%d and a multiple of %d", who,
+            d.Cmid, HEAD_MAX_CMID, vn);
+  VSX_CHECK(d.Cout > 0 && d.Cout * 4 <= HEAD_MAX_CO4 && (d.Cout * 4) % vn == 0,
+            "%s: out_channels*4=%d must be <=%d and a multiple of %d", who, d.Cout * 4, HEAD_MAX_CO4, vn);
+  VSX_CHECK(d.Cmid == 16 * d.Cout, "%s: only head_expansion_ratio=4 is built (Cmid=%d, out_channels=%d)", who, d.Cmid,
+            d.Cout);
+  return 0;
+}
+
+/* K13 (norm + act) + K14: MONAI Convolution ADN (InstanceNorm3d eps 1e-5 → PReLU), nn.Conv3d(mid, 4*out, 1),
+ * transpose + nn.PixelShuffle(2) + transpose (viscy_models/components/heads.py:617-625,638-641).
+ * U: [B, H2, W2, Z, Cmid] conv output; ssum/ssq: [B, Cmid] from the conv GEMM epilogue;
+ * out: (B, Cout, Z, 2*H2, 2*W2) fp32. */
+extern "C" int32_t vsx_head_out_fwd(const void* U, const float* ssum, const float* ssq, const float* w2, const float* b2,
+                                    const float* alpha, float* out, int32_t B, int32_t H2, int32_t W2, int32_t Z,
+                                    int32_t Cmid, int32_t Cout, float eps, int32_t dtype, vsx_stream_t stream) {
+  HeadDims d{B, H2, W2, Z, Cmid, Cout};
+  if (int e = head_check("vsx_head_out_fwd", d, dtype)) return e;
+  VSX_CHECK(U && ssum && ssq && w2 && b2 && alpha && out, "vsx_head_out_fwd: null pointer");
+  dim3 grid(vsx_cdiv((long)H2 * W2 * Z, 256), B);
+  if (dtype == VSX_BF16)
+    HEAD_DISPATCH(head_out_fwd_kernel, bf16_t, (const bf16_t*)U, ssum, ssq,
+                       w2, b2, alpha, out, d, eps);
+  else
+    HEAD_DISPATCH(head_out_fwd_kernel, float, (const float*)U, ssum, ssq,
+                       w2, b2, alpha, out, d, eps);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t vsx_head_out_bwd1(const void* U, const float* ssum, const float* ssq, const float* w2,
+                                     const float* alpha, const float* dout, void* act, void* dv, float* S1, float* S2,
+                                     float* dalpha, int32_t B, int32_t H2, int32_t W2, int32_t Z, int32_t Cmid,
+                                     int32_t Cout, float eps, int32_t dtype, vsx_stream_t stream) {
+  HeadDims d{B, H2, W2, Z, Cmid, Cout};
+  if (int e = head_check("vsx_head_out_bwd1", d, dtype)) return e;
+  VSX_CHECK(U && ssum && ssq && w2 && alpha && dout && act && dv && S1 && S2 && dalpha, "vsx_head_out_bwd1: null pointer");
+  long nvox = (long)H2 * W2 * Z;
+  int vpt = vsx_cdiv(nvox, 256L * 512);
+  if (vpt < 1) vpt = 1;
+  dim3 grid(vsx_cdiv(nvox, 256L * vpt), B);
+  if (dtype == VSX_BF16)
+    HEAD_DISPATCH(head_out_bwd1_kernel, bf16_t, (const bf16_t*)U, ssum, ssq,
+                       w2, alpha, dout, (bf16_t*)act, (bf16_t*)dv, S1, S2, dalpha, d, eps, vpt);
+  else
+    HEAD_DISPATCH(head_out_bwd1_kernel, float, (const float*)U, ssum, ssq,
+                       w2, alpha, dout, (float*)act, (float*)dv, S1, S2, dalpha, d, eps, vpt);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t vsx_head_out_bwd2(const void* U, const float* ssum, const float* ssq, const float* w2,
+                                     const float* alpha, const void* dv, const float* S1, const float* S2, void* dU,
+                                     int32_t B, int32_t H2, int32_t W2, int32_t Z, int32_t Cmid, int32_t Cout, float eps,
+                                     int32_t dtype, vsx_stream_t stream) {
+  HeadDims d{B, H2, W2, Z, Cmid, Cout};
+  if (int e = head_check("vsx_head_out_bwd2", d, dtype)) return e;
+  VSX_CHECK(U && ssum && ssq && w2 && alpha && dv && S1 && S2 && dU, "vsx_head_out_bwd2: null pointer");
+  dim3 grid(vsx_cdiv((long)H2 * W2 * Z, 256), B);
+  if (dtype == VSX_BF16)
+    HEAD_DISPATCH(head_out_bwd2_kernel, bf16_t, (const bf16_t*)U, ssum, ssq,
+                       w2, alpha, (const bf16_t*)dv, S1, S2, (bf16_t*)dU, d, eps);
+  else
+    HEAD_DISPATCH(head_out_bwd2_kernel, float, (const float*)U, ssum, ssq,
+                       w2, alpha, (const float*)dv, S1, S2, (float*)dU, d, eps);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,256 @@
+// Parameter-space kernels: fused AdamW over the flat parameter buffer, and the
+// per-step re-layout of fp32 master weights into GEMM operands (cast to the compute dtype, tap-major
+// K order, transposed copy for the data-gradient GEMM, LayerNorm affine folded into fc1) plus the
+// inverse mapping for gradients.  All are tiny HBM-bound passes over <=32 M parameters.
+#include "vsx_common.h"
+#include "../../include/vsx.h"
+
+// ------------------------------------------------------------------ AdamW (torch.optim.AdamW semantics)
+// hyper = {lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2, grad_scale}
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ hyper, long n) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5],
+              bc2 = hyper[6], gs = hyper[7];
+  const float step = lr / bc1, rbc2 = rsqrtf(bc2);
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 pv = *reinterpret_cast<float4*>(p + i);
+    float4 gv = *reinterpret_cast<const float4*>(g + i);
+    float4 mv = *reinterpret_cast<float4*>(m + i);
+    float4 vv = *reinterpret_cast<float4*>(v + i);
+    float* pp = &pv.x;
+    float* gp = &gv.x;
+    float* mp = &mv.x;
+    float* vp = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gr = gp[j] * gs;
+      float pj = pp[j] * (1.f - lr * wd);
+      mp[j] = b1 * mp[j] + (1.f - b1) * gr;
+      vp[j] = b2 * vp[j] + (1.f - b2) * gr * gr;
+      pp[j] = pj - step * mp[j] / (sqrtf(vp[j]) * rbc2 + eps);
+    }
+    *reinterpret_cast<float4*>(p + i) = pv;
+    *reinterpret_cast<float4*>(m + i) = mv;
+    *reinterpret_cast<float4*>(v + i) = vv;
+  }
+  // tail (n not a multiple of 4): handled by the first thread of the last stride window
+  if (i < n && i + 3 >= n) {
+    for (long k = i; k < n; ++k) {
+      float gr = g[k] * gs;
+      float pj = p[k] * (1.f - lr * wd);
+      float mk = b1 * m[k] + (1.f - b1) * gr;
+      float vk = b2 * v[k] + (1.f - b2) * gr * gr;
+      m[k] = mk;
+      v[k] = vk;
+      p[k] = pj - step * mk / (sqrtf(vk) * rbc2 + eps);
+    }
+  }
+}
+
+/* K26: torch.optim.AdamW step (viscy_utils/optimizers.py:50) on flat fp32 buffers; hyper is a
+ * device array of 8 floats so the launch is hipGraph-replayable while lr / step change. */
+extern "C" int32_t vsx_adamw(float* p, const float* g, float* m, float* v, const float* hyper, int64_t n,
+                             vsx_stream_t stream) {
+  VSX_CHECK(p && g && m && v && hyper && n > 0, "vsx_adamw: bad arguments");
+  int grid = vsx_cdiv(n, 256L * 4 * 4);
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, hyper, (long)n);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ weight preparation
+// tap order of the GEMM K axis: k = t_dst * Cs + c.  tapmode 0: t_dst = t_src; tapmode 1 (head
+// Conv3d [.., kz, ky, kx] → (ky, kx, kz)): t_src = (kz*3 + ky)*3 + kx, t_dst = (ky*3 + kx)*3 + kz.
+__device__ __forceinline__ int tap_dst(int t_src, int tapmode) {
+  if (tapmode == 0) return t_src;
+  int kx = t_src % 3, ky = (t_src / 3) % 3, kz = t_src / 9;
+  return (ky * 3 + kx) * 3 + kz;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_weight_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                          T* __restrict__ dstT, const float* __restrict__ gamma, int R,
+                                                          int Cs, int Tn, int tapmode) {
+  const long total = (long)R * Cs * Tn;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int t = (int)(gid % Tn);
+  const long rc = gid / Tn;
+  const int c = (int)(rc % Cs);
+  const int r = (int)(rc / Cs);
+  float v = src[gid];
+  if (gamma) v *= gamma[c];
+  const int K = Tn * Cs;
+  const int k = tap_dst(t, tapmode) * Cs + c;
+  const T o = from_f32<T>(v);
+  if (dst) dst[(size_t)r * K + k] = o;
+  if (dstT) dstT[(size_t)k * R + r] = o;
+}
+
+/* src: fp32 parameter viewed as [R, Cs, Tn] (out, in-channels, taps) → dst [R, Tn*Cs] and/or
+ * dstT [Tn*Cs, R] in `dtype`, optionally scaled per input channel by gamma[Cs] (LayerNorm fold). */
+extern "C" int32_t vsx_prep_weight(const float* src, void* dst, void* dstT, const float* gamma, int32_t R, int32_t Cs,
+                                   int32_t Tn, int32_t tapmode, int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(src && (dst || dstT) && R > 0 && Cs > 0 && Tn > 0, "vsx_prep_weight: bad arguments");
+  VSX_CHECK(tapmode == 0 || (tapmode == 1 && Tn == 27), "vsx_prep_weight: tapmode 1 needs 27 taps");
+  long total = (long)R * Cs * Tn;
+  dim3 grid(vsx_cdiv(total, 256));
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
+                       (bf16_t*)dstT, gamma, R, Cs, Tn, tapmode);
+  else
+    hipLaunchKernelGGL(prep_weight_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst,
+                       (float*)dstT, gamma, R, Cs, Tn, tapmode);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// gradient back-mapping: dparam[r][c][t] += g[r][tap_dst(t)*Cs + c] * (gamma ? gamma[c] : 1) + (u ? u[r]*beta[c] : 0);
+// dgamma[c] += Σ_{r,t} g[r][k] * W[r][c][t]
+// (u, beta): the folded bias b' = b + W·beta also depends on W  →  dW += u ⊗ beta with u = db'
+__global__ __launch_bounds__(256) void unprep_grad_kernel(const float* __restrict__ g, float* __restrict__ dparam,
+                                                          const float* __restrict__ gamma, const float* __restrict__ W,
+                                                          float* __restrict__ dgamma, const float* __restrict__ u,
+                                                          const float* __restrict__ beta, int R, int Cs, int Tn,
+                                                          int tapmode, int rows_per_block) {
+  // thread = one (c, t) column; loops a chunk of rows so dgamma needs one atomic per thread
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= Cs * Tn) return;
+  const int t = col % Tn, c = col / Tn;
+  const int K = Tn * Cs;
+  const int k = tap_dst(t, tapmode) * Cs + c;
+  const float gm = gamma ? gamma[c] : 1.f;
+  const float bt = u ? beta[c] : 0.f;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  float dg = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float gv = g[(size_t)r * K + k];
+    const size_t pi = ((size_t)r * Cs + c) * Tn + t;
+    dparam[pi] += gv * gm + (u ? u[r] * bt : 0.f);
+    if (dgamma) dg += gv * W[pi];
+  }
+  if (dgamma) atomicAdd(dgamma + c, dg);
+}
+
+extern "C" int32_t vsx_unprep_grad(const float* g, float* dparam, const float* gamma, const float* W, float* dgamma,
+                                   const float* u, const float* beta, int32_t R, int32_t Cs, int32_t Tn,
+                                   int32_t tapmode, vsx_stream_t stream) {
+  VSX_CHECK(g && dparam && R > 0 && Cs > 0 && Tn > 0, "vsx_unprep_grad: bad arguments");
+  VSX_CHECK((gamma == nullptr) == (dgamma == nullptr) && (gamma == nullptr || W != nullptr),
+            "vsx_unprep_grad: gamma / dgamma / W must come together");
+  VSX_CHECK((u == nullptr) == (beta == nullptr) && (u == nullptr || Tn == 1), "vsx_unprep_grad: u / beta need Tn == 1");
+  int rpb = vsx_cdiv(R, 64);
+  if (rpb < 8) rpb = 8;
+  dim3 grid(vsx_cdiv(Cs * Tn, 256), vsx_cdiv(R, rpb));
+  hipLaunchKernelGGL(unprep_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, dparam, gamma, W, dgamma, u, beta, R,
+                     Cs, Tn, tapmode, rpb);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[r] = (b ? b[r] : 0) + Σ_c W[r][c] * v[c]          (fold LN beta into the fc1 bias)
+__global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W, const float* __restrict__ v,
+                                                     const float* __restrict__ b, float* __restrict__ out, int R,
+                                                     int C) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float a = 0.f;
+  for (int c = threadIdx.x & 63; c < C; c += 64) a += W[(size_t)r * C + c] * v[c];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) out[r] = a + (b ? b[r] : 0.f);
+}
+// out[c] += Σ_r W[r][c] * u[r]                            (gradient of the folded LN beta)
+__global__ __launch_bounds__(256) void matvec_t_kernel(const float* __restrict__ W, const float* __restrict__ u,
+                                                       float* __restrict__ out, int R, int C, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  float a = 0.f;
+  for (int r = r0; r < r1; ++r) a += W[(size_t)r * C + c] * u[r];
+  atomicAdd(out + c, a);
+}
+
+extern "C" int32_t vsx_matvec(const float* W, const float* v, const float* b, float* out, int32_t R, int32_t C,
+                              vsx_stream_t stream) {
+  VSX_CHECK(W && v && out && R > 0 && C > 0, "vsx_matvec: bad arguments");
+  hipLaunchKernelGGL(matvec_kernel, dim3(vsx_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, W, v, b, out, R, C);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int32_t vsx_matvec_t_add(const float* W, const float* u, float* out, int32_t R, int32_t C,
+                                    vsx_stream_t stream) {
+  VSX_CHECK(W && u && out && R > 0 && C > 0, "vsx_matvec_t_add: bad arguments");
+  int rpb = vsx_cdiv(R, 32);
+  if (rpb < 16) rpb = 16;
+  dim3 grid(vsx_cdiv(C, 256), vsx_cdiv(R, rpb));
+  hipLaunchKernelGGL(matvec_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, u, out, R, C, rpb);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// dst[j][i] (+)= src[i][j]   (fp32; depthwise weights [C][49] <-> [49][C])
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int A,
+                                                            int Bn, int accumulate) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)A * Bn) return;
+  const int j = (int)(gid % Bn), i = (int)(gid / Bn);
+  const float v = src[gid];
+  float* d = dst + (size_t)j * A + i;
+  *d = accumulate ? *d + v : v;
+}
+extern "C" int32_t vsx_transpose_f32(const float* src, float* dst, int32_t A, int32_t Bn, int32_t accumulate,
+                                     vsx_stream_t stream) {
+  VSX_CHECK(src && dst && A > 0 && Bn > 0, "vsx_transpose_f32: bad arguments");
+  hipLaunchKernelGGL(transpose_f32_kernel, dim3(vsx_cdiv((long)A * Bn, 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     A, Bn, accumulate);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// head Conv3d data-gradient weights: dst[zp][c3][((ty*3+tx)*3 + j)*Cmid + o] =
+//   W[o][c3][kz][2-ty][2-tx]  with kz = zp - (zs + j), zs = clamp(zp-2, 0, Zout-3), zero when kz ∉ [0,2]
+template <typename T>
+__global__ __launch_bounds__(256) void prep_head_dgrad_kernel(const float* __restrict__ W, T* __restrict__ dst, int Cmid,
+                                                              int C3, int Zout) {
+  const int Zin = Zout + 2;
+  const int K = 27 * Cmid;
+  const long total = (long)Zin * C3 * K;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int k = (int)(gid % K);
+  const long r = gid / K;
+  const int c3 = (int)(r % C3);
+  const int zp = (int)(r / C3);
+  const int o = k % Cmid;
+  const int tj = k / Cmid;
+  const int j = tj % 3, tap = tj / 3;
+  const int ty = tap / 3, tx = tap % 3;
+  int zs = zp - 2;
+  if (zs < 0) zs = 0;
+  if (zs > Zout - 3) zs = Zout - 3;
+  const int kz = zp - (zs + j);
+  float v = 0.f;
+  if (kz >= 0 && kz <= 2) v = W[((((size_t)o * C3 + c3) * 3 + kz) * 3 + (2 - ty)) * 3 + (2 - tx)];
+  dst[gid] = from_f32<T>(v);
+}
+extern "C" int32_t vsx_prep_head_dgrad(const float* W, void* dst, int32_t Cmid, int32_t C3, int32_t Zout, int32_t dtype,
+                                       vsx_stream_t stream) {
+  VSX_CHECK(W && dst && Cmid > 0 && C3 > 0 && Zout >= 3, "vsx_prep_head_dgrad: bad arguments (Zout=%d must be >= 3)", Zout);
+  long total = (long)(Zout + 2) * C3 * 27 * Cmid;
+  dim3 grid(vsx_cdiv(total, 256));
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(prep_head_dgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, W, (bf16_t*)dst, Cmid, C3,
+                       Zout);
+  else
+    hipLaunchKernelGGL(prep_head_dgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, W, (float*)dst, Cmid, C3,
+                       Zout);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

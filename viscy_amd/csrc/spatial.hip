@@ -1,0 +1,293 @@
+// Pure data-movement kernels of the UNeXt2 path (SURVEY §2.1 K1 gather, K10, K12): stem patch
+// gather, pixel-shuffle + skip concat, head pixel-shuffle / pad-pool / depth re-layout.
+// All are HBM-bound permutations: one thread produces one 16-byte output vector, lanes run along
+// the contiguous output channel axis so stores are coalesced; the strided 2-byte gathers of a
+// pixel shuffle are absorbed by L1 (the 4 output pixels of a 2x2 quad share their input lines).
+#include "vsx_common.h"
+#include "../../include/vsx.h"
+
+// ------------------------------------------------------------------ stem im2col (K1)
+// P[(b, yo, xo), d*K + ((ci*kz + dz)*ky + dy)*kx + dx] = norm(x[b, ci, d*kz+dz, yo*ky+dy, xo*kx+dx])
+// norm(v) = sub ? (v - sub[b]) / (div[b] + 1e-8) : v      (NormalizeSampled fused into the load)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ P,
+                                                          const float* __restrict__ sub, const float* __restrict__ dv,
+                                                          int B, int Cin, int Z, int H, int W, int kz, int ky, int kx) {
+  constexpr int VN = VT<T>::N;
+  const int h = H / ky, w = W / kx, D = Z / kz;
+  const int K = Cin * kz * ky * kx;
+  const int KT = D * K;
+  const int nch = KT / VN;
+  const long total = (long)B * h * w * nch;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int ch = (int)(gid % nch);
+  long r = gid / nch;
+  const int xo = (int)(r % w);
+  r /= w;
+  const int yo = (int)(r % h);
+  const int b = (int)(r / h);
+  float s = 0.f, inv = 1.f;
+  if (sub) {
+    s = sub[b];
+    inv = 1.f / (dv[b] + 1e-8f);
+  }
+  float o[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) {
+    int col = ch * VN + j;
+    int d = col / K, k = col - d * K;
+    int dx = k % kx;
+    int t = k / kx;
+    int dy = t % ky;
+    t /= ky;
+    int dz = t % kz;
+    int ci = t / kz;
+    float v = x[((((size_t)b * Cin + ci) * Z + d * kz + dz) * H + yo * ky + dy) * W + xo * kx + dx];
+    o[j] = sub ? (v - s) * inv : v;
+  }
+  stvec<T>(P + ((size_t)(b * h + yo) * w + xo) * KT + ch * VN, pack<T>(o));
+}
+
+/* K1 gather half of UNeXt2Stem (viscy_models/components/stems.py:26-50): the Conv3d with
+ * kernel = stride = (kz,ky,kx) is a GEMM over non-overlapping patches; this writes the patch
+ * matrix, vsx_gemm_nt does the projection.  Optional per-sample (sub, div) fuses
+ * NormalizeSampled (viscy_transforms/_normalize.py:72-80) into the load. */
+extern "C" int32_t vsx_stem_im2col(const float* x, void* P, const float* sub, const float* div, int32_t B, int32_t Cin,
+                                   int32_t Z, int32_t H, int32_t W, int32_t kz, int32_t ky, int32_t kx, int32_t dtype,
+                                   vsx_stream_t stream) {
+  int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(x && P && B > 0 && Cin > 0, "vsx_stem_im2col: bad arguments");
+  VSX_CHECK(Z % kz == 0 && H % ky == 0 && W % kx == 0, "vsx_stem_im2col: (%d,%d,%d) not divisible by kernel (%d,%d,%d)",
+            Z, H, W, kz, ky, kx);
+  VSX_CHECK((Cin * kz * ky * kx) % vn == 0, "vsx_stem_im2col: patch size must be a multiple of %d", vn);
+  VSX_CHECK((sub == nullptr) == (div == nullptr), "vsx_stem_im2col: sub/div must both be set or both NULL");
+  long total = (long)B * (H / ky) * (W / kx) * ((Z / kz) * Cin * kz * ky * kx / vn);
+  dim3 grid(vsx_cdiv(total, 256));
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)P, sub, div, B,
+                       Cin, Z, H, W, kz, ky, kx);
+  else
+    hipLaunchKernelGGL(stem_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)P, sub, div, B,
+                       Cin, Z, H, W, kz, ky, kx);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ pixel shuffle x2 + concat (K10)
+// out[b, Y, X, j] = j < c ? low[b, Y/2, X/2, 4j + 2(Y&1) + (X&1)] : skip[b, Y, X, j - c]
+template <typename T>
+__global__ __launch_bounds__(256) void ps_cat_fwd_kernel(const T* __restrict__ low, const T* __restrict__ skip,
+                                                         T* __restrict__ out, int B, int h, int w, int c, int cs) {
+  constexpr int VN = VT<T>::N;
+  const int ct = c + cs;
+  const int nch = ct / VN;
+  const int H2 = 2 * h, W2 = 2 * w;
+  const long total = (long)B * H2 * W2 * nch;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int ch = (int)(gid % nch);
+  const long pix = gid / nch;
+  const int X = (int)(pix % W2);
+  const long r = pix / W2;
+  const int Y = (int)(r % H2);
+  const int b = (int)(r / H2);
+  const int j0 = ch * VN;
+  T* dst = out + (size_t)pix * ct + j0;
+  if (j0 >= c && ((j0 - c) % VN == 0) && (cs % VN == 0)) {
+    stvec<T>(dst, ldvec<T>(skip + (size_t)pix * cs + (j0 - c)));
+    return;
+  }
+  const T* lp = low + (((size_t)b * h + (Y >> 1)) * w + (X >> 1)) * (4 * c) + 2 * (Y & 1) + (X & 1);
+  typename VT<T>::vec tv;
+  T* tmp = reinterpret_cast<T*>(&tv);
+#pragma unroll
+  for (int j = 0; j < VN; ++j) {
+    int jj = j0 + j;
+    tmp[j] = jj < c ? lp[4 * jj] : skip[(size_t)pix * cs + (jj - c)];
+  }
+  stvec<T>(dst, tv);
+}
+
+// backward: one thread per dcat vector; low-part channels scatter to dlow (each element written once),
+// skip-part channels go to dskip.
+template <typename T>
+__global__ __launch_bounds__(256) void ps_cat_bwd_kernel(const T* __restrict__ dcat, T* __restrict__ dlow,
+                                                         T* __restrict__ dskip, int B, int h, int w, int c, int cs) {
+  constexpr int VN = VT<T>::N;
+  const int ct = c + cs;
+  const int nch = ct / VN;
+  const int H2 = 2 * h, W2 = 2 * w;
+  const long total = (long)B * H2 * W2 * nch;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int ch = (int)(gid % nch);
+  const long pix = gid / nch;
+  const int X = (int)(pix % W2);
+  const long r = pix / W2;
+  const int Y = (int)(r % H2);
+  const int b = (int)(r / H2);
+  const int j0 = ch * VN;
+  typename VT<T>::vec v = ldvec<T>(dcat + (size_t)pix * ct + j0);
+  if (j0 >= c && ((j0 - c) % VN == 0) && (cs % VN == 0)) {
+    stvec<T>(dskip + (size_t)pix * cs + (j0 - c), v);
+    return;
+  }
+  const T* tv = reinterpret_cast<const T*>(&v);
+  T* lp = dlow + (((size_t)b * h + (Y >> 1)) * w + (X >> 1)) * (4 * c) + 2 * (Y & 1) + (X & 1);
+#pragma unroll
+  for (int j = 0; j < VN; ++j) {
+    int jj = j0 + j;
+    if (jj < c)
+      lp[4 * jj] = tv[j];
+    else
+      dskip[(size_t)pix * cs + (jj - c)] = tv[j];
+  }
+}
+
+/* K10: MONAI UpSample(mode="pixelshuffle", pre_conv=None) + torch.cat([up, skip], 1)
+ * (viscy_models/components/blocks.py:138-146,170-171).  skip may be NULL (cs = 0). */
+extern "C" int32_t vsx_pixel_shuffle_cat_fwd(const void* low, const void* skip, void* out, int32_t B, int32_t h,
+                                             int32_t w, int32_t c, int32_t cs, int32_t dtype, vsx_stream_t stream) {
+  int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(low && out && B > 0 && h > 0 && w > 0 && c > 0 && cs >= 0, "vsx_pixel_shuffle_cat_fwd: bad arguments");
+  VSX_CHECK((cs == 0) == (skip == nullptr), "vsx_pixel_shuffle_cat_fwd: skip pointer / cs mismatch");
+  VSX_CHECK((c + cs) % vn == 0, "vsx_pixel_shuffle_cat_fwd: c+cs=%d must be a multiple of %d", c + cs, vn);
+  long total = (long)B * 4 * h * w * ((c + cs) / vn);
+  dim3 grid(vsx_cdiv(total, 256));
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(ps_cat_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)low,
+                       (const bf16_t*)skip, (bf16_t*)out, B, h, w, c, cs);
+  else
+    hipLaunchKernelGGL(ps_cat_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)low,
+                       (const float*)skip, (float*)out, B, h, w, c, cs);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int32_t vsx_pixel_shuffle_cat_bwd(const void* dcat, void* dlow, void* dskip, int32_t B, int32_t h, int32_t w,
+                                             int32_t c, int32_t cs, int32_t dtype, vsx_stream_t stream) {
+  int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(dcat && dlow && B > 0 && h > 0 && w > 0 && c > 0 && cs >= 0, "vsx_pixel_shuffle_cat_bwd: bad arguments");
+  VSX_CHECK((cs == 0) == (dskip == nullptr), "vsx_pixel_shuffle_cat_bwd: dskip pointer / cs mismatch");
+  VSX_CHECK((c + cs) % vn == 0, "vsx_pixel_shuffle_cat_bwd: c+cs=%d must be a multiple of %d", c + cs, vn);
+  long total = (long)B * 4 * h * w * ((c + cs) / vn);
+  dim3 grid(vsx_cdiv(total, 256));
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(ps_cat_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcat,
+                       (bf16_t*)dlow, (bf16_t*)dskip, B, h, w, c, cs);
+  else
+    hipLaunchKernelGGL(ps_cat_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dcat,
+                       (float*)dlow, (float*)dskip, B, h, w, c, cs);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ head pixel shuffle (+ pad-pool) (K12)
+// hin[b, Y, X, z*C3 + c3] = pool( v )(Y, X),  v(Y,X) = dec[b, Y/2, X/2, 4*(c3*D + z) + 2(Y&1) + (X&1)]
+// pool(v)(Y,X) = 0.25 * (v(Y,X) + v(Y-1,X) + v(Y,X-1) + v(Y-1,X-1)), zero outside  (ConstantPad2d((1,0,1,0)) + AvgPool2d(2,1))
+template <typename T>
+__global__ __launch_bounds__(256) void head_shuffle_fwd_kernel(const T* __restrict__ dec, T* __restrict__ hin, int B,
+                                                               int h, int w, int C3, int D, int pool) {
+  constexpr int VN = VT<T>::N;
+  const int Cm = C3 * D;
+  const int nch = Cm / VN;
+  const int H2 = 2 * h, W2 = 2 * w;
+  const long total = (long)B * H2 * W2 * nch;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int ch = (int)(gid % nch);
+  const long pix = gid / nch;
+  const int X = (int)(pix % W2);
+  const long r = pix / W2;
+  const int Y = (int)(r % H2);
+  const int b = (int)(r / H2);
+  float o[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) {
+    const int cp = ch * VN + j;
+    const int z = cp / C3, c3 = cp - z * C3;
+    const int src = 4 * (c3 * D + z);
+    float acc = 0.f;
+    const int ntap = pool ? 4 : 1;
+    for (int t = 0; t < ntap; ++t) {
+      const int yy = Y - (t >> 1), xx = X - (t & 1);
+      if (yy < 0 || xx < 0) continue;
+      acc += to_f32<T>(dec[(((size_t)b * h + (yy >> 1)) * w + (xx >> 1)) * (4 * Cm) + src + 2 * (yy & 1) + (xx & 1)]);
+    }
+    o[j] = pool ? 0.25f * acc : acc;
+  }
+  stvec<T>(hin + (size_t)pix * Cm + ch * VN, pack<T>(o));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_shuffle_bwd_kernel(const T* __restrict__ dhin, T* __restrict__ ddec, int B,
+                                                               int h, int w, int C3, int D, int pool) {
+  constexpr int VN = VT<T>::N;
+  const int Cm = C3 * D;
+  const int C4 = 4 * Cm;
+  const int nch = C4 / VN;
+  const int H2 = 2 * h, W2 = 2 * w;
+  const long total = (long)B * h * w * nch;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int ch = (int)(gid % nch);
+  const long pix = gid / nch;
+  const int x = (int)(pix % w);
+  const long r = pix / w;
+  const int y = (int)(r % h);
+  const int b = (int)(r / h);
+  float o[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) {
+    const int lc = ch * VN + j;
+    const int chn = lc >> 2, sub = lc & 3;
+    const int c3 = chn / D, z = chn - c3 * D;
+    const int cp = z * C3 + c3;
+    const int Y = 2 * y + (sub >> 1), X = 2 * x + (sub & 1);
+    float acc = 0.f;
+    const int ntap = pool ? 4 : 1;
+    for (int t = 0; t < ntap; ++t) {
+      const int yy = Y + (t >> 1), xx = X + (t & 1);
+      if (yy >= H2 || xx >= W2) continue;
+      acc += to_f32<T>(dhin[(((size_t)b * H2 + yy) * W2 + xx) * Cm + cp]);
+    }
+    o[j] = pool ? 0.25f * acc : acc;
+  }
+  stvec<T>(ddec + (size_t)pix * C4 + ch * VN, pack<T>(o));
+}
+
+/* K12: PixelToVoxelHead.upsample + reshape (viscy_models/components/heads.py:607-615,632-637).
+ * dec: [B, h, w, 4*C3*D] → hin: [B, 2h, 2w, D*C3] with the depth axis outermost inside a pixel
+ * (channel = z*C3 + c3), so the 3x3x3 head convolution reads contiguous channel slices per z. */
+extern "C" int32_t vsx_head_shuffle_fwd(const void* dec, void* hin, int32_t B, int32_t h, int32_t w, int32_t C3,
+                                        int32_t D, int32_t pool, int32_t dtype, vsx_stream_t stream) {
+  int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(dec && hin && B > 0 && h > 0 && w > 0 && C3 > 0 && D > 0, "vsx_head_shuffle_fwd: bad arguments");
+  VSX_CHECK((C3 * D) % vn == 0, "vsx_head_shuffle_fwd: C3*D=%d must be a multiple of %d", C3 * D, vn);
+  long total = (long)B * 4 * h * w * (C3 * D / vn);
+  dim3 grid(vsx_cdiv(total, 256));
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(head_shuffle_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dec,
+                       (bf16_t*)hin, B, h, w, C3, D, pool);
+  else
+    hipLaunchKernelGGL(head_shuffle_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dec,
+                       (float*)hin, B, h, w, C3, D, pool);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int32_t vsx_head_shuffle_bwd(const void* dhin, void* ddec, int32_t B, int32_t h, int32_t w, int32_t C3,
+                                        int32_t D, int32_t pool, int32_t dtype, vsx_stream_t stream) {
+  int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(dhin && ddec && B > 0 && h > 0 && w > 0 && C3 > 0 && D > 0, "vsx_head_shuffle_bwd: bad arguments");
+  VSX_CHECK((4 * C3 * D) % vn == 0, "vsx_head_shuffle_bwd: 4*C3*D must be a multiple of %d", vn);
+  long total = (long)B * h * w * (4 * C3 * D / vn);
+  dim3 grid(vsx_cdiv(total, 256));
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(head_shuffle_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dhin,
+                       (bf16_t*)ddec, B, h, w, C3, D, pool);
+  else
+    hipLaunchKernelGGL(head_shuffle_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dhin,
+                       (float*)ddec, B, h, w, C3, D, pool);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

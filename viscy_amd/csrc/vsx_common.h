@@ -1,0 +1,149 @@
+// viscy_amd — shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// wave = 64 lanes, 16-byte vector global/LDS accesses, fp32 accumulation everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+typedef __bf16 bf16_t;
+
+#define VSX_F32 0
+#define VSX_BF16 1
+
+// ------------------------------------------------------------------ error plumbing (host)
+void vsx_set_error(const char* fmt, ...);
+#define VSX_CHECK(cond, ...)            \
+  do {                                  \
+    if (!(cond)) {                      \
+      vsx_set_error(__VA_ARGS__);       \
+      return 1;                         \
+    }                                   \
+  } while (0)
+#define VSX_LAUNCH_CHECK()                                               \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      vsx_set_error("%s:%d launch: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return 2;                                                          \
+    }                                                                    \
+  } while (0)
+
+static inline int vsx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------ element traits
+template <typename T>
+struct VT;
+template <>
+struct VT<float> {
+  static constexpr int N = 4;  // elements per 16-byte vector
+  typedef float4 vec;
+};
+template <>
+struct VT<bf16_t> {
+  static constexpr int N = 8;
+  typedef uint4 vec;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) {
+  return bf16_bits_to_f32((uint32_t) * reinterpret_cast<const uint16_t*>(&v));
+}
+template <typename T>
+__device__ __forceinline__ T from_f32(float f);
+template <>
+__device__ __forceinline__ float from_f32<float>(float f) { return f; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) {
+  uint16_t b = (uint16_t)f32_to_bf16_bits(f);
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+// value after a round trip through storage type T (identity for fp32)
+template <typename T>
+__device__ __forceinline__ float round_to(float f);
+template <>
+__device__ __forceinline__ float round_to<float>(float f) { return f; }
+template <>
+__device__ __forceinline__ float round_to<bf16_t>(float f) { return round_bf16(f); }
+
+template <typename T>
+__device__ __forceinline__ void unpack(const typename VT<T>::vec& v, float* f);
+template <>
+__device__ __forceinline__ void unpack<float>(const float4& v, float* f) {
+  f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void unpack<bf16_t>(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ typename VT<T>::vec pack(const float* f);
+template <>
+__device__ __forceinline__ float4 pack<float>(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
+template <>
+__device__ __forceinline__ uint4 pack<bf16_t>(const float* f) {
+  uint4 v;
+  v.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
+  v.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
+  v.z = f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16);
+  v.w = f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ typename VT<T>::vec vzero();
+template <>
+__device__ __forceinline__ float4 vzero<float>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <>
+__device__ __forceinline__ uint4 vzero<bf16_t>() { return make_uint4(0u, 0u, 0u, 0u); }
+
+template <typename T>
+__device__ __forceinline__ typename VT<T>::vec ldvec(const T* p) {
+  return *reinterpret_cast<const typename VT<T>::vec*>(p);
+}
+template <typename T>
+__device__ __forceinline__ void stvec(T* p, const typename VT<T>::vec& v) {
+  *reinterpret_cast<typename VT<T>::vec*>(p) = v;
+}
+
+// ------------------------------------------------------------------ math
+// exact-erf GELU (nn.GELU default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ------------------------------------------------------------------ wave helpers (wave64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {  // sum over aligned groups of G lanes (G pow2 <= 64)
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

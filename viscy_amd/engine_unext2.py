@@ -1,0 +1,471 @@
+"""Kernel schedule of UNeXt2 forward / backward on MI355X (see viscy_amd/unext2.py).
+
+``Engine`` owns
+  * the flat fp32 master-parameter buffer (every nn.Parameter of the model is a view into it, in
+    *reverse forward order* so gradient buckets become ready front-to-back during backward) and
+    the matching flat gradient buffer;
+  * ``prepare()``: per-step re-layout of master weights into GEMM operands (compute dtype);
+  * ``forward()`` / ``backward()``: the explicit launch sequences.
+
+``ops`` is the kernel backend: ``viscy_amd.ops`` (HIP, the only backend the product ever uses).
+Tests may inject a reference implementation of the same call surface to validate the schedule
+itself on CPU (tests/ref_ops.py); nothing in the package does.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+
+class _BlockW:
+    """prepared operands + parameter handles of one ConvNeXt-V2 block"""
+
+    __slots__ = ("C", "p", "dw_w", "W1f", "W1fT", "b1f", "W2", "W2T")
+
+
+class _ProjW:
+    __slots__ = ("cin", "cout", "taps", "ln", "conv", "W", "WT")
+
+
+def _views(flat: Tensor, shapes):
+    out, off = [], 0
+    for shp in shapes:
+        n = 1
+        for s in shp:
+            n *= s
+        out.append(flat[off : off + n].view(shp))
+        off += n
+    return out
+
+
+class Engine:
+    def __init__(self, model, ops=None):
+        if ops is None:
+            from . import ops as hip_ops
+
+            ops = hip_ops
+        self.ops = ops
+        self.model = model
+        self.cfg = model.cfg
+        params = list(model.parameters())
+        self.device = params[0].device
+        # ---- flat parameter / gradient buffers, reverse forward order (head first, stem last)
+        order = self._param_order()
+        assert len(order) == len(params) and len({id(p) for p in order}) == len(order)
+        total = sum(p.numel() for p in order)
+        # keep every slice 16-byte aligned
+        offs, off = [], 0
+        for p in order:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad_of = {}
+        with torch.no_grad():
+            for p, o in zip(order, offs):
+                v = self.flat[o : o + p.numel()].view(p.shape)
+                v.copy_(p.detach().to(torch.float32))
+                p.data = v
+                self.grad_of[id(p)] = self.flat_grad[o : o + p.numel()].view(p.shape)
+        self.order, self.offsets, self.numel = order, offs, total
+        self.bucket_bounds = self._bucket_bounds()
+        self.on_bucket_ready = None  # callable(bucket_index) set by viscy_amd.parallel
+        self._prepared_for = None
+        self.W = None
+
+    # ------------------------------------------------------------------ parameter ordering
+    def _stage_params_rev(self, stage):
+        ps = []
+        for blk in reversed(list(stage.blocks)):
+            ps += [blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.mlp.grn.weight, blk.mlp.grn.bias, blk.mlp.fc1.weight,
+                   blk.mlp.fc1.bias, blk.norm.weight, blk.norm.bias, blk.conv_dw.weight, blk.conv_dw.bias]
+        if not isinstance(stage.downsample, torch.nn.Identity):
+            ps += [stage.downsample[1].weight, stage.downsample[1].bias, stage.downsample[0].weight,
+                   stage.downsample[0].bias]
+        return ps
+
+    def _param_order(self):
+        m = self.model
+        ps = [m.head.conv[1].weight, m.head.conv[1].bias, m.head.conv[0].adn.A.weight, m.head.conv[0].conv.weight,
+              m.head.conv[0].conv.bias]
+        self._bucket_marks = [0]
+        for st in reversed(list(m.decoder.decoder_stages)):
+            ps += self._stage_params_rev(st.conv)
+        self._bucket_marks.append(len(ps))  # bucket 0 = head + decoder
+        for i in (3, 2):
+            ps += self._stage_params_rev(getattr(m.encoder_stages, f"stages_{i}"))
+        self._bucket_marks.append(len(ps))  # bucket 1 = encoder stages 3, 2
+        for i in (1, 0):
+            ps += self._stage_params_rev(getattr(m.encoder_stages, f"stages_{i}"))
+        ps += [m.encoder_stages.stem_1.weight, m.encoder_stages.stem_1.bias, m.stem.conv.weight, m.stem.conv.bias]
+        self._bucket_marks.append(len(ps))  # bucket 2 = encoder stages 1, 0 + stem
+        return ps
+
+    def _bucket_bounds(self):
+        b = []
+        for i in range(len(self._bucket_marks) - 1):
+            lo = self.offsets[self._bucket_marks[i]]
+            hi_idx = self._bucket_marks[i + 1]
+            hi = self.offsets[hi_idx] if hi_idx < len(self.offsets) else self.flat.numel()
+            b.append((lo, hi))
+        return b
+
+    def g(self, p) -> Tensor:
+        return self.grad_of[id(p)]
+
+    def attach_grads(self) -> None:
+        for p in self.order:
+            p.grad = self.grad_of[id(p)]
+
+    # ------------------------------------------------------------------ weight preparation
+    def _prep_block(self, blk, dt, need_bwd):
+        o = self.ops
+        w = _BlockW()
+        C = blk.conv_dw.weight.shape[0]
+        w.C, w.p = C, blk
+        w.dw_w = torch.empty((49, C), dtype=torch.float32, device=self.device)
+        o.transpose_f32(blk.conv_dw.weight, w.dw_w, C, 49, False)
+        w.W1f, w.W1fT = o.prep_weight(blk.mlp.fc1.weight, 4 * C, C, 1, dt, want=True, want_t=need_bwd,
+                                      gamma=blk.norm.weight)
+        w.b1f = o.matvec(blk.mlp.fc1.weight, blk.norm.bias, blk.mlp.fc1.bias, 4 * C, C)
+        w.W2, w.W2T = o.prep_weight(blk.mlp.fc2.weight, C, 4 * C, 1, dt, want=True, want_t=need_bwd)
+        return w
+
+    def _prep_proj(self, ln, conv, dt, need_bwd):
+        o = self.ops
+        w = _ProjW()
+        cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+        taps = conv.weight.shape[2] * conv.weight.shape[3]
+        w.cin, w.cout, w.taps, w.ln, w.conv = cin, cout, taps, ln, conv
+        w.W, w.WT = o.prep_weight(conv.weight, cout, cin, taps, dt, want=True, want_t=need_bwd)
+        return w
+
+    def prepare(self, dt: torch.dtype, need_bwd: bool):
+        key = (dt, need_bwd)
+        m, cfg, o = self.model, self.cfg, self.ops
+        W = {"dt": dt}
+        # stem: [Cout3d, K] (block-diagonal expansion when the stem keeps D' > 1 depth slabs)
+        sw = m.stem.conv.weight
+        co3, K = sw.shape[0], sw[0].numel()
+        Dp = cfg["ratio"]
+        if Dp == 1:
+            W["stem_W"], _ = o.prep_weight(sw, co3, K, 1, dt)
+            W["stem_b"] = m.stem.conv.bias
+        else:  # rare configuration (Z = 15): tiny weight-space expansion done with tensor ops
+            we = torch.zeros((co3, Dp, Dp, K), dtype=torch.float32, device=self.device)
+            for d in range(Dp):
+                we[:, d, d, :] = sw.detach().reshape(co3, K)
+            W["stem_W"] = we.reshape(co3 * Dp, Dp * K).to(dt).contiguous()
+            W["stem_b"] = m.stem.conv.bias.detach().repeat_interleave(Dp).contiguous()
+        enc = []
+        for i in range(4):
+            st = getattr(m.encoder_stages, f"stages_{i}")
+            proj = None
+            if not isinstance(st.downsample, torch.nn.Identity):
+                proj = self._prep_proj(st.downsample[0], st.downsample[1], dt, need_bwd)
+            enc.append((proj, [self._prep_block(b, dt, need_bwd) for b in st.blocks]))
+        W["enc"] = enc
+        dec = []
+        for us in m.decoder.decoder_stages:
+            st = us.conv
+            proj = self._prep_proj(st.downsample[0], st.downsample[1], dt, need_bwd)
+            dec.append((proj, [self._prep_block(b, dt, need_bwd) for b in st.blocks]))
+        W["dec"] = dec
+        hc = m.head.conv[0].conv
+        cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
+        W["head_Wc"], _ = o.prep_weight(hc.weight, cmid, c3, 27, dt, tapmode=1)
+        if need_bwd:
+            W["head_Wd"] = o.prep_head_dgrad(hc.weight, cmid, c3, cfg["out_stack_depth"], dt)
+        self.W = W
+        self._prepared_for = key
+        return W
+
+    # ------------------------------------------------------------------ block forward / backward
+    def _block_fwd(self, x, w, B, H, Wd, dt, save):
+        o = self.ops
+        C, M = w.C, B * H * Wd
+        blk = w.p
+        y = o.dwconv7_fwd(x, w.dw_w, blk.conv_dw.bias, B, H, Wd, C)
+        xh, _, rstd = o.ln_fwd(y, None, None, M, C, 1e-6, need_mean=False)
+        del y
+        colsq = torch.zeros((B, 4 * C), dtype=torch.float32, device=x.device)
+        h = torch.empty((M, 4 * C), dtype=dt, device=x.device)
+        o.gemm("nt", xh, w.W1f, h, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=w.b1f, red0=colsq,
+               hw=H * Wd)
+        s = o.grn_scale(colsq, blk.mlp.grn.weight)
+        out = torch.empty((M, C), dtype=dt, device=x.device)
+        o.gemm("nt", h, w.W2, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
+               grn_b=blk.mlp.grn.bias, hw=H * Wd, epi=L.EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=x, ldr=C)
+        if save is not None:
+            save.append((x, xh, rstd, h, colsq, s))
+        return out
+
+    def _block_bwd(self, dout, w, saved, B, H, Wd, dt):
+        o, g = self.ops, self.g
+        C, M = w.C, B * H * Wd
+        blk = w.p
+        x, xh, rstd, h, colsq, s = saved
+        dev = dout.device
+        # fc2: weight gradient (Z recomputed in the operand prologue) + bias gradient
+        o.gemm("tn", h, dout, g(blk.mlp.fc2.weight), M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
+               grn_b=blk.mlp.grn.bias, hw=H * Wd, colsum=g(blk.mlp.fc2.bias))
+        # fc2 data gradient dZ, with Σ dZ·gelu(h) (GRN statistics path) and Σ dZ (GRN beta gradient)
+        P = torch.zeros((B, 4 * C), dtype=torch.float32, device=dev)
+        dz = torch.empty((M, 4 * C), dtype=dt, device=dev)
+        o.gemm("nt", dout, w.W2T, dz, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_DZ, aux=h, ldx=4 * C, red0=P,
+               red1=g(blk.mlp.grn.bias), hw=H * Wd)
+        t = o.grn_bwd_stats(colsq, P, blk.mlp.grn.weight, g(blk.mlp.grn.weight))
+        db1f = torch.zeros(4 * C, dtype=torch.float32, device=dev)
+        o.grn_gelu_bwd(dz, h, s, t, db1f, M, 4 * C, H * Wd)  # dz now holds dH
+        dxh = torch.empty((M, C), dtype=dt, device=dev)
+        o.gemm("nt", dz, w.W1fT, dxh, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt)
+        dW1f = torch.zeros((4 * C, C), dtype=torch.float32, device=dev)
+        o.gemm("tn", xh, dz, dW1f, M, 4 * C, C, C, 4 * C, C, dtype=dt)
+        del dz
+        # unfold the LayerNorm affine: dW1 = dW1f·diag(γ) + db1f ⊗ β, dγ = Σ_r dW1f ⊙ W1, dβ = W1ᵀ db1f, db1 = db1f
+        o.unprep_grad(dW1f, g(blk.mlp.fc1.weight), 4 * C, C, 1, gamma=blk.norm.weight, W=blk.mlp.fc1.weight,
+                      dgamma=g(blk.norm.weight), u=db1f, beta=blk.norm.bias)
+        o.matvec_t_add(blk.mlp.fc1.weight, db1f, g(blk.norm.bias), 4 * C, C)
+        g(blk.mlp.fc1.bias).add_(db1f)
+        dy = o.ln_bwd(dxh, xh, None, rstd, None, None, None, None, M, C)
+        del dxh
+        dx = o.dwconv7_bwd_data(dy, w.dw_w, dout, B, H, Wd, C)
+        ddw = torch.zeros((49, C), dtype=torch.float32, device=dev)
+        o.dwconv7_bwd_weight(dy, x, ddw, g(blk.conv_dw.bias), B, H, Wd, C)
+        o.transpose_f32(ddw, g(blk.conv_dw.weight), 49, C, True)
+        return dx
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: Tensor, dt: torch.dtype, need_bwd: bool):
+        o, cfg, m = self.ops, self.cfg, self.model
+        W = self.prepare(dt, need_bwd)
+        B, Cin, Z, H, Wd = x.shape
+        if Cin != cfg["in_channels"] or Z != cfg["in_stack_depth"]:
+            raise ValueError(f"expected input (B,{cfg['in_channels']},{cfg['in_stack_depth']},Y,X), got {tuple(x.shape)}")
+        if H % 32 or Wd % 32:
+            raise ValueError(f"Y and X must be divisible by 32 (got {H}x{Wd}); VSUNet pads to a multiple of 64")
+        kz, ky, kx = cfg["stem_kernel"]
+        h, w = H // ky, Wd // kx
+        dims = cfg["dims"]
+        C0 = dims[0]
+        sv = {"shape": (B, H, Wd), "dt": dt} if need_bwd else None
+        # ---- stem: patch gather + projection GEMM, then encoder stem_1 LayerNorm2d
+        P = o.stem_im2col(x.contiguous(), (kz, ky, kx), dt)
+        M0, K0 = B * h * w, P.shape[1]
+        f = torch.empty((M0, C0), dtype=dt, device=x.device)
+        o.gemm("nt", P, W["stem_W"], f, M0, C0, K0, K0, K0, C0, dtype=dt, epi=L.EPI_BIAS, bias=W["stem_b"])
+        ln1 = m.encoder_stages.stem_1
+        cur, mean, rstd = o.ln_fwd(f, ln1.weight, ln1.bias, M0, C0)
+        if need_bwd:
+            sv["stem"] = (P, f, mean, rstd)
+        else:
+            del P, f
+        # ---- encoder
+        feats, enc_sv = [], []
+        ch, cw, cc = h, w, C0
+        for i, (proj, blocks) in enumerate(W["enc"]):
+            st_sv = {"blocks": []}
+            if proj is not None:
+                M_in = B * ch * cw
+                xn, mean, rstd = o.ln_fwd(cur, proj.ln.weight, proj.ln.bias, M_in, cc)
+                ch, cw = ch // 2, cw // 2
+                nxt = torch.empty((B * ch * cw, proj.cout), dtype=dt, device=x.device)
+                o.gemm("nt", xn, proj.W, nxt, B * ch * cw, proj.cout, 4 * cc, cc, 4 * cc, proj.cout, dtype=dt,
+                       a_mode=L.A_PATCH2, gh=ch, gw=cw, cs=cc, epi=L.EPI_BIAS, bias=proj.conv.bias)
+                st_sv["proj"] = (cur, xn, mean, rstd)
+                cur, cc = nxt, proj.cout
+            for bw in blocks:
+                cur = self._block_fwd(cur, bw, B, ch, cw, dt, st_sv["blocks"] if need_bwd else None)
+            feats.append((cur, ch, cw, cc))
+            enc_sv.append(st_sv)
+        # ---- decoder
+        dec_sv = []
+        feat, fh, fw, fc = feats[3]
+        for k, (proj, blocks) in enumerate(W["dec"]):
+            skip, sh, sw_, sc = feats[2 - k]
+            assert sh == 2 * fh and sw_ == 2 * fw
+            c_up = fc // 4
+            cat = o.pixel_shuffle_cat_fwd(feat, skip, B, fh, fw, c_up, sc)
+            fh, fw = sh, sw_
+            Mk, ccat = B * fh * fw, c_up + sc
+            xn, mean, rstd = o.ln_fwd(cat, proj.ln.weight, proj.ln.bias, Mk, ccat)
+            cur = torch.empty((Mk, proj.cout), dtype=dt, device=x.device)
+            o.gemm("nt", xn, proj.W, cur, Mk, proj.cout, ccat, ccat, ccat, proj.cout, dtype=dt, epi=L.EPI_BIAS,
+                   bias=proj.conv.bias)
+            st_sv = {"proj": (cat, xn, mean, rstd, c_up, sc), "blocks": []}
+            for bw in blocks:
+                cur = self._block_fwd(cur, bw, B, fh, fw, dt, st_sv["blocks"] if need_bwd else None)
+            feat, fc = cur, proj.cout
+            dec_sv.append(st_sv)
+        # ---- head
+        Zo, D7 = cfg["out_stack_depth"], cfg["out_stack_depth"] + 2
+        hc = m.head.conv[0].conv
+        cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
+        cout = cfg["out_channels"]
+        hin = o.head_shuffle_fwd(feat, B, fh, fw, c3, D7, cfg["head_pool"])
+        H2, W2 = 2 * fh, 2 * fw
+        Mh = B * H2 * W2
+        U = torch.empty((Mh, Zo * cmid), dtype=dt, device=x.device)
+        stats = torch.zeros((2, B, cmid), dtype=torch.float32, device=x.device)
+        o.gemm_z("nt", hin, W["head_Wc"], U, Mh, cmid, 27 * c3, D7 * c3, 27 * c3, Zo * cmid, dtype=dt,
+                 a_mode=L.A_CONV3, gh=H2, gw=W2, cs=3 * c3, nz=Zo, a_coff=[z * c3 for z in range(Zo)],
+                 b_off=[0] * Zo, c_coff=[z * cmid for z in range(Zo)], epi=L.EPI_BIAS_STATS, bias=hc.bias,
+                 red0=stats[0], red1=stats[1], hw=H2 * W2)
+        w2 = m.head.conv[1].weight.view(4 * cout, cmid)
+        out = o.head_out_fwd(U, stats[0], stats[1], w2, m.head.conv[1].bias, m.head.conv[0].adn.A.weight, B, H2, W2, Zo,
+                             cmid, cout)
+        if need_bwd:
+            sv["enc"], sv["dec"] = enc_sv, dec_sv
+            sv["feat_dims"] = [(a, b_, c) for (_, a, b_, c) in feats]
+            sv["head"] = (hin, U, stats, fh, fw)
+        return out, sv
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, sv, dout: Tensor) -> None:
+        """Accumulates parameter gradients into the flat gradient buffer (no input gradient:
+        the image stack never requires grad on this path)."""
+        o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, self.W
+        dt = sv["dt"]
+        B, H, Wd = sv["shape"]
+        dev = dout.device
+        Zo, D7 = cfg["out_stack_depth"], cfg["out_stack_depth"] + 2
+        hc = m.head.conv[0].conv
+        cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
+        cout = cfg["out_channels"]
+        hin, U, stats, fh, fw = sv["head"]
+        H2, W2 = 2 * fh, 2 * fw
+        Mh = B * H2 * W2
+        alpha = m.head.conv[0].adn.A.weight
+        w2 = m.head.conv[1].weight.view(4 * cout, cmid)
+        # ---- head
+        S = torch.zeros((2, B, cmid), dtype=torch.float32, device=dev)
+        act, dv = o.head_out_bwd1(U, stats[0], stats[1], w2, alpha, dout.contiguous().float(), S[0], S[1], g(alpha), B, H2,
+                                  W2, Zo, cmid, cout)
+        M5 = Mh * Zo
+        o.gemm("tn", act, dv, g(m.head.conv[1].weight), M5, 4 * cout, cmid, cmid, 4 * cout, cmid, dtype=dt,
+               colsum=g(m.head.conv[1].bias))
+        del act
+        dU = o.head_out_bwd2(U, stats[0], stats[1], w2, alpha, dv, S[0], S[1], B, H2, W2, Zo, cmid, cout)
+        del dv
+        dWc = torch.zeros((cmid, 27 * c3), dtype=torch.float32, device=dev)
+        o.gemm_z("tn", hin, dU, dWc, Mh, cmid, 27 * c3, D7 * c3, Zo * cmid, 27 * c3, dtype=dt, a_mode=L.A_CONV3, gh=H2,
+                 gw=W2, cs=3 * c3, nz=Zo, a_coff=[z * c3 for z in range(Zo)], b_off=[z * cmid for z in range(Zo)],
+                 c_coff=[0] * Zo, colsum=g(hc.bias))
+        o.unprep_grad(dWc, g(hc.weight), cmid, c3, 27, tapmode=1)
+        dhin = torch.empty((Mh, D7 * c3), dtype=dt, device=dev)
+        zs = [min(max(zp - 2, 0), Zo - 3) for zp in range(D7)]
+        o.gemm_z("nt", dU, W["head_Wd"], dhin, Mh, c3, 27 * cmid, Zo * cmid, 27 * cmid, D7 * c3, dtype=dt,
+                 a_mode=L.A_CONV3, gh=H2, gw=W2, cs=3 * cmid, nz=D7, a_coff=[z * cmid for z in zs],
+                 b_off=[zp * c3 * 27 * cmid for zp in range(D7)], c_coff=[zp * c3 for zp in range(D7)])
+        del dU
+        d = o.head_shuffle_bwd(dhin, B, fh, fw, c3, D7, cfg["head_pool"])
+        del dhin
+        # ---- decoder (reverse)
+        dskips = {}
+        for k in (2, 1, 0):
+            proj, blocks = W["dec"][k]
+            st_sv = sv["dec"][k]
+            cat, xn, mean, rstd, c_up, sc = st_sv["proj"]
+            _, sh, sw_, _ = (None, *sv["feat_dims"][2 - k])
+            Mk, ccat = B * sh * sw_, c_up + sc
+            for bw, bsv in zip(reversed(blocks), reversed(st_sv["blocks"])):
+                d = self._block_bwd(d, bw, bsv, B, sh, sw_, dt)
+            o.gemm("tn", xn, d, g(proj.conv.weight), Mk, proj.cout, ccat, ccat, proj.cout, ccat, dtype=dt,
+                   colsum=g(proj.conv.bias))
+            dxn = torch.empty((Mk, ccat), dtype=dt, device=dev)
+            o.gemm("nt", d, proj.WT, dxn, Mk, ccat, proj.cout, proj.cout, proj.cout, ccat, dtype=dt)
+            dcat = o.ln_bwd(dxn, cat, mean, rstd, proj.ln.weight, None, g(proj.ln.weight), g(proj.ln.bias), Mk, ccat)
+            del dxn
+            d, dskips[2 - k] = o.pixel_shuffle_cat_bwd(dcat, B, sh // 2, sw_ // 2, c_up, sc)
+            del dcat
+        if self.on_bucket_ready:
+            self.on_bucket_ready(0)
+        # ---- encoder (reverse); d = gradient w.r.t. feats[3]
+        for i in (3, 2, 1, 0):
+            proj, blocks = W["enc"][i]
+            st_sv = sv["enc"][i]
+            ch, cw, cc = sv["feat_dims"][i]
+            for bw, bsv in zip(reversed(blocks), reversed(st_sv["blocks"])):
+                d = self._block_bwd(d, bw, bsv, B, ch, cw, dt)
+            if proj is not None:
+                prev, xn, mean, rstd = st_sv["proj"]
+                cin = proj.cin
+                Mo = B * ch * cw
+                dWg = torch.zeros((proj.cout, 4 * cin), dtype=torch.float32, device=dev)
+                o.gemm("tn", xn, d, dWg, Mo, proj.cout, 4 * cin, cin, proj.cout, 4 * cin, dtype=dt, a_mode=L.A_PATCH2,
+                       gh=ch, gw=cw, cs=cin, colsum=g(proj.conv.bias))
+                o.unprep_grad(dWg, g(proj.conv.weight), proj.cout, cin, 4)
+                dxn = torch.empty((B * 4 * ch * cw, cin), dtype=dt, device=dev)
+                o.gemm("nt", d, proj.WT, dxn, Mo, 4 * cin, proj.cout, proj.cout, proj.cout, cin, dtype=dt,
+                       c_mode=L.A_PATCH2, c_cs=cin, gh=ch, gw=cw)
+                d = o.ln_bwd(dxn, prev, mean, rstd, proj.ln.weight, dskips[i - 1], g(proj.ln.weight), g(proj.ln.bias),
+                             B * 4 * ch * cw, cin)
+                del dxn
+            if i == 2 and self.on_bucket_ready:
+                self.on_bucket_ready(1)
+        # ---- stem_1 LayerNorm + stem projection
+        P, f, mean, rstd = sv["stem"]
+        ln1 = m.encoder_stages.stem_1
+        M0, C0, K0 = f.shape[0], f.shape[1], P.shape[1]
+        df = o.ln_bwd(d, f, mean, rstd, ln1.weight, None, g(ln1.weight), g(ln1.bias), M0, C0)
+        Dp = cfg["ratio"]
+        if Dp == 1:
+            o.gemm("tn", P, df, g(m.stem.conv.weight), M0, C0, K0, K0, C0, K0, dtype=dt, colsum=g(m.stem.conv.bias))
+        else:
+            co3 = C0 // Dp
+            K = K0 // Dp
+            dWe = torch.zeros((C0, K0), dtype=torch.float32, device=dev)
+            dbe = torch.zeros(C0, dtype=torch.float32, device=dev)
+            o.gemm("tn", P, df, dWe, M0, C0, K0, K0, C0, K0, dtype=dt, colsum=dbe)
+            dWe = dWe.view(co3, Dp, Dp, K)
+            g(m.stem.conv.weight).add_(torch.stack([dWe[:, dd, dd] for dd in range(Dp)], 0).sum(0).view_as(m.stem.conv.weight))
+            g(m.stem.conv.bias).add_(dbe.view(co3, Dp).sum(1))
+        if self.on_bucket_ready:
+            self.on_bucket_ready(2)
+
+
+# ------------------------------------------------------------------------------------------------
+class _UNeXt2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, dt, need_bwd, *params):
+        eng = model.engine()
+        out, sv = eng.forward(x, dt, need_bwd)
+        ctx.model, ctx.sv = model, sv
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, sv = ctx.model, ctx.sv
+        if sv is None:
+            raise RuntimeError("viscy_amd.UNeXt2: backward called but the forward ran without gradient bookkeeping")
+        eng = model.engine()
+        ctx.sv = None
+        if model.grad_mode == "flat":
+            eng.backward(sv, dout)
+            return (None, None, None, None) + tuple(None for _ in eng.order)
+        # autograd mode: compute into a zeroed flat buffer and hand views back to autograd
+        saved = eng.flat_grad
+        eng.flat_grad = torch.zeros_like(saved)
+        old = eng.grad_of
+        eng.grad_of = {}
+        for p, off in zip(eng.order, eng.offsets):
+            eng.grad_of[id(p)] = eng.flat_grad[off : off + p.numel()].view(p.shape)
+        try:
+            eng.backward(sv, dout)
+            grads = tuple(eng.grad_of[id(p)] for p in eng.order)
+        finally:
+            eng.flat_grad, eng.grad_of = saved, old
+        return (None, None, None, None) + grads
+
+
+def unext2_apply(model, x: Tensor) -> Tensor:
+    eng = model.engine()
+    dt = model._resolve_dtype()
+    if model.grad_mode == "flat":
+        eng.attach_grads()
+    need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in eng.order)
+    with torch.autocast("cuda", enabled=False):
+        return _UNeXt2Fn.apply(x.float(), model, dt, need_bwd, *eng.order)

@@ -1,0 +1,251 @@
+"""Tensor-level wrappers over the libvsx C-ABI: PyTorch-ROCm tensors in, tensors out.
+
+PyTorch is used for device memory (caching allocator) and the current stream only; all
+arithmetic happens in the HIP kernels.  Every wrapper raises if a tensor is not on the GPU.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from ._lib import VsxGemm, check, dtype_code, lib, ptr, stream
+
+
+def _fill8(arr, vals: Sequence[int] | None):
+    if vals:
+        for i, v in enumerate(vals):
+            arr[i] = int(v)
+
+
+def gemm(
+    kind: str,
+    A: Tensor,
+    B: Tensor,
+    Cout: Tensor,
+    M: int,
+    N: int,
+    K: int,
+    lda: int,
+    ldb: int,
+    ldc: int,
+    *,
+    dtype: torch.dtype,
+    a_mode: int = L.A_ROWS,
+    gh: int = 0,
+    gw: int = 0,
+    cs: int = 0,
+    nz: int = 1,
+    a_coff: Sequence[int] | None = None,
+    b_off: Sequence[int] | None = None,
+    c_coff: Sequence[int] | None = None,
+    c_mode: int = L.A_ROWS,
+    c_cs: int = 0,
+    pro: int = L.PRO_NONE,
+    grn_s: Tensor | None = None,
+    grn_b: Tensor | None = None,
+    hw: int = 0,
+    epi: int = L.EPI_NONE,
+    bias: Tensor | None = None,
+    res: Tensor | None = None,
+    ldr: int = 0,
+    aux: Tensor | None = None,
+    ldx: int = 0,
+    red0: Tensor | None = None,
+    red1: Tensor | None = None,
+    colsum: Tensor | None = None,
+) -> None:
+    """kind='nt': C[M,N] = pro(A)[M,K]·B[N,K]^T (+epilogue);  kind='tn': C[N,K](fp32) += B[M,N]^T·pro(A)[M,K]."""
+    for t in (bias, grn_s, grn_b, red0, red1, colsum):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("bias / GRN / reduction buffers must be float32")
+    p = VsxGemm()
+    p.A, p.B, p.C = ptr(A), ptr(B), ptr(Cout)
+    p.M, p.N, p.K = M, N, K
+    p.lda, p.ldb, p.ldc = lda, ldb, ldc
+    p.a_mode, p.gh, p.gw, p.cs = a_mode, gh, gw, cs
+    p.nz = nz
+    _fill8(p.a_coff, a_coff)
+    _fill8(p.b_off, b_off)
+    _fill8(p.c_coff, c_coff)
+    p.c_mode, p.c_cs = c_mode, c_cs
+    p.pro = pro
+    p.grn_s, p.grn_b = ptr(grn_s), ptr(grn_b)
+    p.hw = hw
+    p.epi = epi
+    p.bias, p.res, p.ldr = ptr(bias), ptr(res), ldr
+    p.aux, p.ldx = ptr(aux), ldx
+    p.red0, p.red1, p.colsum = ptr(red0), ptr(red1), ptr(colsum)
+    fn = lib().vsx_gemm_nt if kind == "nt" else lib().vsx_gemm_tn
+    check(fn(C.byref(p), dtype_code(dtype), stream()), f"gemm_{kind}")
+
+
+def gemm_z(kind: str, *args, nz: int, a_coff, b_off, c_coff, **kw) -> None:
+    """z-batched GEMM with more than 8 slabs: issue in groups of <= 8."""
+    for s in range(0, nz, 8):
+        e = min(nz, s + 8)
+        gemm(kind, *args, nz=e - s, a_coff=a_coff[s:e], b_off=b_off[s:e], c_coff=c_coff[s:e], **kw)
+
+
+def ln_fwd(x: Tensor, gamma: Tensor | None, beta: Tensor | None, rows: int, Cc: int, eps: float = 1e-6,
+           need_mean: bool = True):
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if need_mean else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().vsx_ln_fwd(ptr(x), ptr(y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), rows, Cc, eps,
+                           dtype_code(x.dtype), stream()), "ln_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd(dy: Tensor, x: Tensor, mean: Tensor | None, rstd: Tensor, gamma: Tensor | None, add: Tensor | None,
+           dgamma: Tensor | None, dbeta: Tensor | None, rows: int, Cc: int) -> Tensor:
+    dx = torch.empty_like(dy)
+    check(lib().vsx_ln_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(add), ptr(dx), ptr(dgamma),
+                           ptr(dbeta), rows, Cc, dtype_code(dy.dtype), stream()), "ln_bwd")
+    return dx
+
+
+def grn_scale(colsq: Tensor, gamma: Tensor, eps: float = 1e-6) -> Tensor:
+    s = torch.empty_like(colsq)
+    check(lib().vsx_grn_scale(ptr(colsq), ptr(gamma), ptr(s), colsq.shape[0], colsq.shape[1], eps, stream()), "grn_scale")
+    return s
+
+
+def grn_bwd_stats(colsq: Tensor, P: Tensor, gamma: Tensor, dgamma: Tensor, eps: float = 1e-6) -> Tensor:
+    t = torch.empty_like(colsq)
+    check(lib().vsx_grn_bwd_stats(ptr(colsq), ptr(P), ptr(gamma), ptr(t), ptr(dgamma), colsq.shape[0], colsq.shape[1],
+                                  eps, stream()), "grn_bwd_stats")
+    return t
+
+
+def grn_gelu_bwd(dz: Tensor, h: Tensor, s: Tensor, t: Tensor, colsum: Tensor, M: int, N: int, hw: int) -> None:
+    check(lib().vsx_grn_gelu_bwd(ptr(dz), ptr(h), ptr(s), ptr(t), ptr(colsum), M, N, hw, dtype_code(dz.dtype), stream()),
+          "grn_gelu_bwd")
+
+
+def dwconv7_fwd(x: Tensor, w: Tensor, bias: Tensor | None, B: int, H: int, W: int, Cc: int) -> Tensor:
+    y = torch.empty_like(x)
+    check(lib().vsx_dwconv7_fwd(ptr(x), ptr(w), ptr(bias), None, ptr(y), B, H, W, Cc, dtype_code(x.dtype), stream()),
+          "dwconv7_fwd")
+    return y
+
+
+def dwconv7_bwd_data(dy: Tensor, w: Tensor, add: Tensor | None, B: int, H: int, W: int, Cc: int) -> Tensor:
+    dx = torch.empty_like(dy)
+    check(lib().vsx_dwconv7_bwd_data(ptr(dy), ptr(w), ptr(add), ptr(dx), B, H, W, Cc, dtype_code(dy.dtype), stream()),
+          "dwconv7_bwd_data")
+    return dx
+
+
+def dwconv7_bwd_weight(dy: Tensor, x: Tensor, dw: Tensor, db: Tensor | None, B: int, H: int, W: int, Cc: int) -> None:
+    check(lib().vsx_dwconv7_bwd_weight(ptr(dy), ptr(x), ptr(dw), ptr(db), B, H, W, Cc, dtype_code(dy.dtype), stream()),
+          "dwconv7_bwd_weight")
+
+
+def stem_im2col(x: Tensor, kernel: tuple[int, int, int], dtype: torch.dtype, sub: Tensor | None = None,
+                div: Tensor | None = None) -> Tensor:
+    if x.dtype != torch.float32:
+        raise TypeError("input stacks are float32")
+    B, Cin, Z, H, W = x.shape
+    kz, ky, kx = kernel
+    P = torch.empty((B * (H // ky) * (W // kx), (Z // kz) * Cin * kz * ky * kx), dtype=dtype, device=x.device)
+    check(lib().vsx_stem_im2col(ptr(x), ptr(P), ptr(sub), ptr(div), B, Cin, Z, H, W, kz, ky, kx, dtype_code(dtype),
+                                stream()), "stem_im2col")
+    return P
+
+
+def pixel_shuffle_cat_fwd(low: Tensor, skip: Tensor | None, B: int, h: int, w: int, c: int, cs: int) -> Tensor:
+    out = torch.empty((B * 4 * h * w, c + cs), dtype=low.dtype, device=low.device)
+    check(lib().vsx_pixel_shuffle_cat_fwd(ptr(low), ptr(skip), ptr(out), B, h, w, c, cs, dtype_code(low.dtype), stream()),
+          "pixel_shuffle_cat_fwd")
+    return out
+
+
+def pixel_shuffle_cat_bwd(dcat: Tensor, B: int, h: int, w: int, c: int, cs: int):
+    dlow = torch.empty((B * h * w, 4 * c), dtype=dcat.dtype, device=dcat.device)
+    dskip = torch.empty((B * 4 * h * w, cs), dtype=dcat.dtype, device=dcat.device) if cs else None
+    check(lib().vsx_pixel_shuffle_cat_bwd(ptr(dcat), ptr(dlow), ptr(dskip), B, h, w, c, cs, dtype_code(dcat.dtype),
+                                          stream()), "pixel_shuffle_cat_bwd")
+    return dlow, dskip
+
+
+def head_shuffle_fwd(dec: Tensor, B: int, h: int, w: int, C3: int, D: int, pool: bool) -> Tensor:
+    hin = torch.empty((B * 4 * h * w, C3 * D), dtype=dec.dtype, device=dec.device)
+    check(lib().vsx_head_shuffle_fwd(ptr(dec), ptr(hin), B, h, w, C3, D, int(pool), dtype_code(dec.dtype), stream()),
+          "head_shuffle_fwd")
+    return hin
+
+
+def head_shuffle_bwd(dhin: Tensor, B: int, h: int, w: int, C3: int, D: int, pool: bool) -> Tensor:
+    ddec = torch.empty((B * h * w, 4 * C3 * D), dtype=dhin.dtype, device=dhin.device)
+    check(lib().vsx_head_shuffle_bwd(ptr(dhin), ptr(ddec), B, h, w, C3, D, int(pool), dtype_code(dhin.dtype), stream()),
+          "head_shuffle_bwd")
+    return ddec
+
+
+def head_out_fwd(U, ssum, ssq, w2, b2, alpha, B, H2, W2, Z, Cmid, Cout, eps=1e-5) -> Tensor:
+    out = torch.empty((B, Cout, Z, 2 * H2, 2 * W2), dtype=torch.float32, device=U.device)
+    check(lib().vsx_head_out_fwd(ptr(U), ptr(ssum), ptr(ssq), ptr(w2), ptr(b2), ptr(alpha), ptr(out), B, H2, W2, Z, Cmid,
+                                 Cout, eps, dtype_code(U.dtype), stream()), "head_out_fwd")
+    return out
+
+
+def head_out_bwd1(U, ssum, ssq, w2, alpha, dout, S1, S2, dalpha, B, H2, W2, Z, Cmid, Cout, eps=1e-5):
+    M5 = B * H2 * W2 * Z
+    act = torch.empty((M5, Cmid), dtype=U.dtype, device=U.device)
+    dv = torch.empty((M5, 4 * Cout), dtype=U.dtype, device=U.device)
+    check(lib().vsx_head_out_bwd1(ptr(U), ptr(ssum), ptr(ssq), ptr(w2), ptr(alpha), ptr(dout), ptr(act), ptr(dv), ptr(S1),
+                                  ptr(S2), ptr(dalpha), B, H2, W2, Z, Cmid, Cout, eps, dtype_code(U.dtype), stream()),
+          "head_out_bwd1")
+    return act, dv
+
+
+def head_out_bwd2(U, ssum, ssq, w2, alpha, dv, S1, S2, B, H2, W2, Z, Cmid, Cout, eps=1e-5) -> Tensor:
+    dU = torch.empty_like(U)
+    check(lib().vsx_head_out_bwd2(ptr(U), ptr(ssum), ptr(ssq), ptr(w2), ptr(alpha), ptr(dv), ptr(S1), ptr(S2), ptr(dU), B,
+                                  H2, W2, Z, Cmid, Cout, eps, dtype_code(U.dtype), stream()), "head_out_bwd2")
+    return dU
+
+
+def prep_weight(src: Tensor, R: int, Cs: int, Tn: int, dtype: torch.dtype, *, want: bool = True, want_t: bool = False,
+                gamma: Tensor | None = None, tapmode: int = 0):
+    K = Cs * Tn
+    dst = torch.empty((R, K), dtype=dtype, device=src.device) if want else None
+    dstT = torch.empty((K, R), dtype=dtype, device=src.device) if want_t else None
+    check(lib().vsx_prep_weight(ptr(src), ptr(dst), ptr(dstT), ptr(gamma), R, Cs, Tn, tapmode, dtype_code(dtype), stream()),
+          "prep_weight")
+    return dst, dstT
+
+
+def unprep_grad(g: Tensor, dparam: Tensor, R: int, Cs: int, Tn: int, *, gamma=None, W=None, dgamma=None, u=None,
+                beta=None, tapmode=0):
+    check(lib().vsx_unprep_grad(ptr(g), ptr(dparam), ptr(gamma), ptr(W), ptr(dgamma), ptr(u), ptr(beta), R, Cs, Tn,
+                                tapmode, stream()), "unprep_grad")
+
+
+def matvec(W: Tensor, v: Tensor, b: Tensor | None, R: int, Cc: int) -> Tensor:
+    out = torch.empty(R, dtype=torch.float32, device=W.device)
+    check(lib().vsx_matvec(ptr(W), ptr(v), ptr(b), ptr(out), R, Cc, stream()), "matvec")
+    return out
+
+
+def matvec_t_add(W: Tensor, u: Tensor, out: Tensor, R: int, Cc: int) -> None:
+    check(lib().vsx_matvec_t_add(ptr(W), ptr(u), ptr(out), R, Cc, stream()), "matvec_t_add")
+
+
+def transpose_f32(src: Tensor, dst: Tensor, A: int, Bn: int, accumulate: bool) -> None:
+    check(lib().vsx_transpose_f32(ptr(src), ptr(dst), A, Bn, int(accumulate), stream()), "transpose_f32")
+
+
+def prep_head_dgrad(W: Tensor, Cmid: int, C3: int, Zout: int, dtype: torch.dtype) -> Tensor:
+    dst = torch.empty(((Zout + 2) * C3, 27 * Cmid), dtype=dtype, device=W.device)
+    check(lib().vsx_prep_head_dgrad(ptr(W), ptr(dst), Cmid, C3, Zout, dtype_code(dtype), stream()), "prep_head_dgrad")
+    return dst
+
+
+def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor) -> None:
+    check(lib().vsx_adamw(ptr(p), ptr(g), ptr(m), ptr(v), ptr(hyper), p.numel(), stream()), "adamw")
