@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""bench.py — training throughput of the UNeXt2 virtual-staining hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): UNeXt2 2.5D (convnextv2_tiny, Z=5, 256x256, 1→2 ch, head_pool,
+2 decoder blocks/stage) bf16 training on synthetic patches; one "step" = forward + MixedLoss(0.5, 0, 0.5)
++ backward + AdamW on one batch, all in hand-written HIP kernels.  Inputs are resident in HBM before
+the timed region.  N > 1: one process per GPU (torch.distributed.run), batch sharded (weak scaling),
+RCCL all-reduce of the flat gradient buffer overlapped with backward.
+
+Prints ONE JSON line (rank 0) with the contract fields + "roofline" (dominant kernel class, timed
+live with HIP events on the launch stream inside the timed region) + "cpu_baseline" (the oracle —
+pure-torch fp32 restatement of the reference — timed on the host cores over a bounded sample).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_GFLOP_PER_PATCH = 22.56  # SURVEY §8d / BASELINE.md §2 (256x256, Z=5, tiny)
+ALGO_MB_PER_PATCH = 226.5    # fwd+bwd two-pass-GRN floor, bf16 activations
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def make_batch(B, H, W, device, seed=42):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, 1, 5, H, W), generator=g)
+    smooth = torch.nn.functional.avg_pool3d(x, (1, 5, 5), stride=1, padding=(0, 2, 2))
+    tgt = 0.5 * smooth.repeat(1, 2, 1, 1, 1) + 0.1 * torch.randn((B, 2, 5, H, W), generator=g)
+    return x.to(device), tgt.contiguous().to(device)
+
+
+def nonzero_grn_(model, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".grn." in n:
+                p.copy_((torch.randn(p.shape, generator=g) * 0.1).to(p.device))
+
+
+# ------------------------------------------------------------------ per-op event timing
+class OpTimer:
+    """Wraps viscy_amd.ops launch wrappers with torch.cuda events (recorded on the current stream,
+    which is the stream every kernel is launched on)."""
+
+    GEMM_EPI = {0: "none", 1: "bias", 2: "bias_gelu_sq", 3: "bias_res", 4: "dz", 5: "bias_stats"}
+
+    def __init__(self, ops, only: str | None = None):
+        self.ops, self.only = ops, only
+        self.records = {}  # name -> list of (start, end, flops, bytes)
+        self._orig = {}
+
+    @staticmethod
+    def _bytes(args, out):
+        n = 0
+        seen = set()
+        stack = list(args) + (list(out) if isinstance(out, (tuple, list)) else [out])
+        for t in stack:
+            if torch.is_tensor(t) and t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                n += t.numel() * t.element_size()
+        return n
+
+    def _wrap(self, name, fn):
+        def wrapped(*a, **k):
+            cls, flops, nbytes = name, 0.0, None
+            if name == "gemm":
+                kind, M, N, K = a[0], a[4], a[5], a[6]
+                nz = k.get("nz", 1)
+                es = 2 if k.get("dtype") == torch.bfloat16 else 4
+                cls = f"gemm_{kind}"
+                flops = 2.0 * M * N * K * nz
+                nbytes = (M * K + M * N) * es * nz + N * K * (es if kind == "nt" else 4)
+            if self.only is not None and cls != self.only:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            if nbytes is None:
+                nbytes = self._bytes(list(a) + list(k.values()), out)
+            self.records.setdefault(cls, []).append((e0, e1, flops, nbytes))
+            return out
+
+        return wrapped
+
+    def __enter__(self):
+        for name in dir(self.ops):
+            fn = getattr(self.ops, name)
+            if callable(fn) and not name.startswith("_") and getattr(fn, "__module__", "") == self.ops.__name__ and name not in ("gemm_z",):
+                self._orig[name] = fn
+                setattr(self.ops, name, self._wrap(name, fn))
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self._orig.items():
+            setattr(self.ops, name, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for cls, recs in self.records.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
+            out[cls] = {"launches": len(recs), "ms": ms, "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs)}
+        return out
+
+
+def cpu_baseline(budget_s: float = 20.0):
+    """One training step of the oracle (reference restatement) on the host cores, bounded sample."""
+    from oracle import loss_ref, unext2_ref
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    kw = dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True)
+    model = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=0)
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4)
+    B = 2
+    x, tgt = make_batch(B, 256, 256, "cpu")
+    times = []
+    t_start = time.perf_counter()
+    for i in range(6):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = loss_ref.mixed_loss(model(x), tgt, 0.5, 0.0, 0.5)
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        if i >= 1:
+            times.append(dt)
+        if time.perf_counter() - t_start > budget_s and len(times) >= 2:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} timed training steps (fwd+MixedLoss+bwd+AdamW) of the fp32 oracle at B={B}, Z=5, 256x256, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("VSX_BENCH_BATCH", 32)), help="patches per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-ops", action="store_true", help="print the per-op-class event-timing table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from viscy_amd import ops
+    from viscy_amd.losses import MixedLoss
+    from viscy_amd.optim import FlatAdamW
+    from viscy_amd.parallel import FlatDataParallel
+    from viscy_amd.unext2 import UNeXt2
+
+    torch.manual_seed(42)
+    model = UNeXt2(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True,
+                   head_expansion_ratio=4, decoder_conv_blocks=2).to(dev)
+    nonzero_grn_(model)
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.grad_mode = "flat"
+    eng = model.engine()
+    total_steps = args.steps + args.warmup
+    opt = FlatAdamW(eng, lr=2e-4, schedule="WarmupCosine", warmup_steps=3, t_total=max(total_steps, 4), warmup_multiplier=1e-3)
+    ddp = FlatDataParallel(eng, opt)
+    crit = MixedLoss(0.5, 0.0, 0.5)
+    B = args.batch
+    x, tgt = make_batch(B, args.size, args.size, dev, seed=42 + rank)
+
+    def step():
+        opt.zero_grad()
+        loss = crit(model(x), tgt)
+        loss.backward()
+        ddp.finish()
+        opt.step()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup (the last warmup step is instrumented per op class to find the dominant kernel)
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    with OpTimer(ops) as tm:
+        l0 = step()
+    table = tm.summary()
+    dominant = max(table, key=lambda c: table[c]["ms"]) if table else None
+    if args.profile_ops and rank == 0:
+        tot = sum(v["ms"] for v in table.values())
+        for c, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+            print(f"[ops] {c:28s} {v['launches']:5d} launches {v['ms']:9.3f} ms {100 * v['ms'] / tot:5.1f}%  "
+                  f"{v['bytes'] / max(v['ms'], 1e-9) / 1e6:9.1f} GB/s {v['flops'] / max(v['ms'], 1e-9) / 1e9:9.1f} TFLOP/s", file=sys.stderr)
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    barrier()
+    t0 = time.perf_counter()
+    with OpTimer(ops, only=dominant) as tm:
+        for _ in range(args.steps):
+            loss = step()
+        barrier()
+        t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tt.item()
+    dom = tm.summary().get(dominant) if dominant else None
+
+    if rank == 0:
+        patches = world * B * args.steps
+        value = patches / elapsed
+        scale = (args.size / 256.0) ** 2
+        roof = None
+        if dom:
+            ms = dom["ms"] / dom["launches"]
+            tf = dom["flops"] / dom["launches"] / (ms * 1e-3) / 1e12
+            gbs = dom["bytes"] / dom["launches"] / (ms * 1e-3) / 1e9
+            if dominant.startswith("gemm") and tf / MFMA_BF16_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS:
+                roof = {"kernel": dominant, "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "avg_launch_ms": round(ms, 5), "launches": dom["launches"],
+                        "hbm_side_GBs": round(gbs, 1)}
+            else:
+                roof = {"kernel": dominant, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 5),
+                        "launches": dom["launches"]}
+        res = {
+            "metric": "training patches/sec (Z=5, 256x256, 1->2ch UNeXt2)",
+            "value": round(value, 2),
+            "unit": "patches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"UNeXt2 2.5D convnextv2_tiny Z=5 {args.size}x{args.size} 1->2ch, fwd+MixedLoss(0.5,0,0.5)+bwd+AdamW",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "whole_path": {
+                "hbm_frac_of_algorithmic_floor": round(value * ALGO_MB_PER_PATCH * scale * 1e6 / (world * HBM_PEAK_GBS * 1e9), 4),
+                "mfma_frac": round(value * 3 * FWD_GFLOP_PER_PATCH * scale * 1e9 / (world * MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
+                "final_loss": round(float(loss.item()), 5), "first_loss": round(float(l0.item()), 5),
+            },
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

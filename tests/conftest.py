@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() or os.environ.get("VSX_TEST_SELF"):
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:

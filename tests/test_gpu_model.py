@@ -1,0 +1,201 @@
+"""GPU: the full HIP path (UNeXt2 forward/backward, MixedLoss, AdamW) against the oracle
+(oracle/*.py, pinned to the reference) and the committed golden fixtures.
+
+Bar (BASELINE.json north_star): <= 1e-3 relative error in fp32 vs the reference CPU path;
+bf16 production mode is checked with the tolerance the reference accepts for its own GPU
+inference reproducibility test (atol 0.02 / rtol 1e-2, test_inference_reproducibility.py:70-73)."""
+
+import pytest
+import torch
+
+from oracle import loss_ref, unext2_ref
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def _pair(kw, seed=7):
+    from viscy_amd.unext2 import UNeXt2
+
+    ref = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=seed).eval()
+    mine = UNeXt2(**kw)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    return ref, mine.cuda()
+
+
+@pytest.mark.parametrize("tag", ["atto_pool", "femto_z15", "tiny_pool"])
+def test_forward_matches_reference_golden_fp32(tag):
+    """fixtures were produced by the REFERENCE's own unext2.py/blocks.py/heads.py (oracle/validate_against_reference.py G8)"""
+    g = load_golden("unext2_forward.pt")[tag]
+    _, mine = _pair(g["kwargs"], seed=g["seed"])
+    mine.compute_dtype = torch.float32
+    x = torch.randn(g["x_shape"], generator=torch.Generator().manual_seed(g["x_seed"]))
+    with torch.no_grad():
+        y = mine(x.cuda())
+    assert y.shape == g["y"].shape and y.dtype == torch.float32
+    assert relerr(y, g["y"]) <= 1e-3
+
+
+CASES = [
+    ("atto_pool", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_atto", head_pool=True), (2, 64, 96)),
+    ("femto_z15", dict(in_channels=2, out_channels=2, in_stack_depth=15, out_stack_depth=5, backbone="convnextv2_femto"), (1, 64, 64)),
+    ("tiny_pool", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True), (2, 128, 128)),
+]
+
+
+@pytest.mark.parametrize("tag,kw,bhw", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("mode", ["autograd", "flat"])
+def test_forward_backward_vs_oracle_fp32(tag, kw, bhw, mode):
+    torch.manual_seed(0)
+    ref, mine = _pair(kw)
+    mine.compute_dtype = torch.float32
+    mine.grad_mode = mode
+    B, H, W = bhw
+    x = torch.randn(B, kw["in_channels"], kw["in_stack_depth"], H, W)
+    y = ref(x)
+    dout = torch.randn_like(y)
+    y.backward(dout)
+    if mode == "flat":
+        mine.engine().flat_grad.zero_()
+    out = mine(x.cuda())
+    assert relerr(out, y) <= 1e-3
+    out.backward(dout.cuda())
+    worst = 0.0
+    for (name, pr), pm in zip(ref.named_parameters(), mine.parameters()):
+        assert pm.grad is not None, name
+        if name == "head.conv.0.conv.bias":  # exactly-zero gradient (bias in front of InstanceNorm)
+            assert pm.grad.abs().max().item() < 1e-3
+            continue
+        e = relerr(pm.grad, pr.grad)
+        worst = max(worst, e)
+        assert e <= 2e-3, (name, e)
+    print(tag, mode, "worst relative gradient error", worst)
+
+
+def test_forward_backward_bf16_tracks_fp32():
+    kw = CASES[2][1]
+    ref, mine = _pair(kw)
+    x = torch.randn(2, 1, 5, 128, 128, generator=torch.Generator().manual_seed(1))
+    y = ref(x)
+    dout = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    y.backward(dout)
+    mine.compute_dtype = torch.bfloat16
+    out = mine(x.cuda())
+    assert out.dtype == torch.float32
+    torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-2, atol=0.02 * y.detach().abs().max().item())
+    out.backward(dout.cuda())
+    # cosine similarity of the full gradient vector (bf16 activations, fp32 accumulation)
+    gm = torch.cat([p.grad.flatten().cpu() for p in mine.parameters()])
+    gr = torch.cat([p.grad.flatten() for p in ref.parameters()])
+    cos = torch.nn.functional.cosine_similarity(gm, gr, dim=0).item()
+    assert cos > 0.995, cos
+    # autocast contract: bf16 is selected by torch.autocast like Lightning's bf16-mixed
+    mine.compute_dtype = None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert mine._resolve_dtype() == torch.bfloat16
+    assert mine._resolve_dtype() == torch.float32
+
+
+def test_input_validation_and_state_dict_roundtrip():
+    from viscy_amd.unext2 import UNeXt2
+
+    m = UNeXt2(in_channels=1, out_channels=2, backbone="convnextv2_atto").cuda()
+    with pytest.raises(ValueError, match="divisible by 32"):
+        m(torch.zeros(1, 1, 5, 48, 64, device="cuda"))
+    with pytest.raises(ValueError, match="expected input"):
+        m(torch.zeros(1, 2, 5, 64, 64, device="cuda"))
+    x = torch.randn(1, 1, 5, 64, 64, device="cuda")
+    with torch.no_grad():
+        y0 = m(x)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m2 = UNeXt2(in_channels=1, out_channels=2, backbone="convnextv2_atto").cuda()
+    m2.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        assert torch.equal(m2(x), y0)
+    assert y0.shape == (1, 2, 5, 64, 64)
+
+
+# ------------------------------------------------------------------ loss
+@pytest.mark.parametrize("tag", ["rand_192", "corr_192", "corr_256", "corr_176x208"])
+def test_mixed_loss_vs_reference_golden(tag):
+    """golden values/gradients come from the reference's own ms_ssim_25d / MixedLoss (G2)."""
+    from viscy_amd.losses import MixedLoss
+
+    c = load_golden("loss.pt")[tag]
+    gen = torch.Generator().manual_seed(c["seed"])
+    target = torch.rand(c["shape"], generator=gen)
+    pred = target + 0.1 * torch.randn(c["shape"], generator=gen) if c["corr"] else torch.rand(c["shape"], generator=gen)
+    p = pred.cuda().requires_grad_(True)
+    loss = MixedLoss(0.5, 0.0, 0.5)(p, target.cuda())
+    assert abs(loss.item() - c["loss"].item()) <= 1e-3 * abs(c["loss"].item()), (loss.item(), c["loss"].item())
+    loss.backward()
+    g = p.grad.cpu()
+    sample = g.flatten()[:: max(1, g.numel() // 4096)]
+    scale = c["grad_absmax"].item()
+    # bf16 rounding inside the SSIM window means makes individual pixels flip by one bf16 ulp between
+    # implementations; compare the gradient field in aggregate and per-sample loosely
+    assert (sample - c["grad_sample"]).abs().mean().item() <= 2e-2 * c["grad_sample"].abs().mean().item()
+    assert abs(g.double().sum().item() - c["grad_sum"].item()) <= 2e-2 * max(abs(c["grad_sum"].item()), scale)
+    # full-tensor comparison against the oracle run here (same seeds)
+    pr = pred.clone().requires_grad_(True)
+    lr = loss_ref.mixed_loss(pr, target, 0.5, 0.0, 0.5)
+    lr.backward()
+    cos = torch.nn.functional.cosine_similarity(g.flatten(), pr.grad.flatten(), dim=0).item()
+    assert cos > 0.999, cos
+
+
+def test_mixed_loss_branches_and_errors():
+    from viscy_amd.losses import MixedLoss
+
+    gen = torch.Generator().manual_seed(3)
+    t = torch.rand((2, 2, 5, 64, 64), generator=gen)
+    p = torch.rand((2, 2, 5, 64, 64), generator=gen)
+    # L1-only / L2-only branches need no 176-pixel minimum; bit-level agreement is not expected (sum order)
+    for a1, a2 in [(1.0, 0.0), (0.0, 1.0), (0.3, 0.7)]:
+        pc = p.cuda().requires_grad_(True)
+        l = MixedLoss(a1, a2, 0.0)(pc, t.cuda())
+        pr = p.clone().requires_grad_(True)
+        lr = loss_ref.mixed_loss(pr, t, a1, a2, 0.0)
+        assert abs(l.item() - lr.item()) <= 1e-5 * abs(lr.item())
+        (l * 2.0).backward()
+        (lr * 2.0).backward()
+        assert relerr(pc.grad, pr.grad) <= 1e-4
+    with pytest.raises(ValueError):
+        MixedLoss(0, 0, 0)
+    with pytest.raises(ValueError, match="176"):
+        MixedLoss()(p.cuda(), t.cuda())
+    with pytest.raises(RuntimeError, match="no CPU"):
+        MixedLoss()(p, t)
+
+
+# ------------------------------------------------------------------ one training step, end to end
+def test_training_steps_reduce_loss_and_match_torch_adamw():
+    from viscy_amd.losses import MixedLoss
+    from viscy_amd.optim import FlatAdamW
+    from viscy_amd.unext2 import UNeXt2
+
+    torch.manual_seed(0)
+    kw = dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_atto", head_pool=True)
+    m = UNeXt2(**kw).cuda()
+    m.compute_dtype = torch.bfloat16
+    m.grad_mode = "flat"
+    eng = m.engine()
+    opt = FlatAdamW(eng, lr=2e-3)
+    crit = MixedLoss(0.5, 0.0, 0.5)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 1, 5, 192, 192), generator=g).cuda()
+    tgt = (torch.nn.functional.avg_pool3d(x, (1, 5, 5), 1, (0, 2, 2)).repeat(1, 2, 1, 1, 1) * 0.5).contiguous()
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        loss = crit(m(x), tgt)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < losses[0], losses

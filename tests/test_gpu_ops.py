@@ -1,0 +1,455 @@
+"""GPU: every HIP op (through the C-ABI, viscy_amd.ops) against its plain-PyTorch statement
+(tests/ref_ops.py) on identical seeded inputs, in fp32 (parity mode) and bf16 (production mode).
+
+fp32 tolerance: 1e-3 relative to the tensor's max magnitude (the north-star bar);
+bf16 tolerance: 2e-2 (storage rounding of operands/outputs is shared by both sides, the residual
+is accumulation order).
+"""
+
+import os
+
+import pytest
+import torch
+
+from tests import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+SELF_CHECK = bool(os.environ.get("VSX_TEST_SELF"))  # harness self-check on CPU: reference vs reference
+DEV = "cpu" if SELF_CHECK else "cuda"
+
+
+def _hip():
+    if SELF_CHECK:
+        return R
+    from viscy_amd import ops
+
+    return ops
+
+
+def tol(dt):
+    return 1e-3 if dt == torch.float32 else 2e-2
+
+
+def close(a, b, dt, what="", scale=None):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    s = scale if scale is not None else b.abs().max().clamp_min(1e-6).item()
+    err = (a - b).abs().max().item() / s
+    assert err <= tol(dt), f"{what}: max err {err:.3e} (scale {s:.3e}) > {tol(dt)}"
+    return err
+
+
+def rnd(*shape, dt=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dt)
+
+
+def cuda(*ts):
+    return [t.to(DEV) if t is not None else None for t in ts]
+
+
+# ------------------------------------------------------------------ ABI / library
+def test_library_loads_and_reports_errors():
+    if SELF_CHECK:
+        pytest.skip("self-check")
+    from viscy_amd import _lib
+
+    l = _lib.lib()
+    assert l.vsx_version() >= 1
+    with pytest.raises(RuntimeError, match="bad arguments|null"):
+        _lib.check(l.vsx_adamw(None, None, None, None, None, 0, None), "adamw")
+
+
+# ------------------------------------------------------------------ GEMM nt
+GEMM_CASES = [
+    # M, N, K, hw
+    (256, 128, 96, 256),
+    (200, 96, 80, 100),     # ragged M, tile spans 2 samples
+    (8, 384, 40, 4),        # tiny feature map: many samples per tile
+    (640, 224, 144, 320),
+    (384, 32, 216, 384),
+    (130, 8, 64, 130),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K,hw", GEMM_CASES)
+@pytest.mark.parametrize("epi", [R.EPI_NONE, R.EPI_BIAS, R.EPI_BIAS_GELU_SQ, R.EPI_BIAS_RES, R.EPI_DZ, R.EPI_BIAS_STATS])
+def test_gemm_nt_rows(dt, M, N, K, hw, epi):
+    H = _hip()
+    nb = (M + hw - 1) // hw
+    A = rnd(M, K, dt=dt, seed=1)
+    Bw = rnd(N, K, dt=dt, seed=2, scale=K**-0.5)
+    bias = rnd(N, seed=3)
+    res = rnd(M, N, dt=dt, seed=4)
+    aux = rnd(M, N, dt=dt, seed=5)
+    kw = dict(dtype=dt, hw=hw, epi=epi)
+    if epi in (R.EPI_BIAS, R.EPI_BIAS_GELU_SQ, R.EPI_BIAS_RES, R.EPI_BIAS_STATS):
+        kw["bias"] = bias
+    if epi == R.EPI_BIAS_RES:
+        kw.update(res=res, ldr=N)
+    if epi == R.EPI_DZ:
+        kw.update(aux=aux, ldx=N)
+
+    def run(ops, dev):
+        k2 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+        C = torch.zeros(M, N, dtype=dt, device=dev)
+        r0 = torch.zeros(nb, N, device=dev)
+        r1 = torch.zeros(nb, N, device=dev) if epi == R.EPI_BIAS_STATS else torch.zeros(N, device=dev)
+        if epi in (R.EPI_BIAS_GELU_SQ, R.EPI_DZ, R.EPI_BIAS_STATS):
+            k2.update(red0=r0, red1=r1)
+        ops.gemm("nt", A.to(dev), Bw.to(dev), C, M, N, K, K, K, N, **k2)
+        return C, r0, r1
+
+    Cr, r0r, r1r = run(R, "cpu")
+    Cg, r0g, r1g = run(H, DEV)
+    close(Cg, Cr, dt, "C")
+    if epi in (R.EPI_BIAS_GELU_SQ, R.EPI_DZ, R.EPI_BIAS_STATS):
+        close(r0g, r0r, dt, "red0")
+    if epi in (R.EPI_DZ, R.EPI_BIAS_STATS):
+        close(r1g, r1r, dt, "red1")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_gemm_nt_grn_prologue(dt):
+    H = _hip()
+    M, N, K, hw = 192, 40, 160, 64
+    A, Bw = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, seed=2, scale=K**-0.5)
+    s, beta = 1 + 0.3 * rnd(3, K, seed=3), 0.1 * rnd(K, seed=4)
+    res, bias = rnd(M, N, dt=dt, seed=5), rnd(N, seed=6)
+
+    def run(ops, dev):
+        C = torch.zeros(M, N, dtype=dt, device=dev)
+        ops.gemm("nt", A.to(dev), Bw.to(dev), C, M, N, K, K, K, N, dtype=dt, pro=R.PRO_GRN, grn_s=s.to(dev),
+                 grn_b=beta.to(dev), hw=hw, epi=R.EPI_BIAS_RES, bias=bias.to(dev), res=res.to(dev), ldr=N)
+        return C
+
+    close(run(H, DEV), run(R, "cpu"), dt, "grn-prologue gemm")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_gemm_nt_patch2_gather_and_scatter(dt):
+    H = _hip()
+    B, gh, gw, cin, cout = 2, 6, 5, 16, 24
+    M = B * gh * gw
+    src = rnd(B * 4 * gh * gw, cin, dt=dt, seed=1)
+    Wd = rnd(cout, 4 * cin, dt=dt, seed=2, scale=0.2)
+    bias = rnd(cout, seed=3)
+    d = rnd(M, cout, dt=dt, seed=4)
+    WT = Wd.t().contiguous()
+
+    def run(ops, dev):
+        C = torch.zeros(M, cout, dtype=dt, device=dev)
+        ops.gemm("nt", src.to(dev), Wd.to(dev), C, M, cout, 4 * cin, cin, 4 * cin, cout, dtype=dt, a_mode=R.A_PATCH2,
+                 gh=gh, gw=gw, cs=cin, epi=R.EPI_BIAS, bias=bias.to(dev))
+        dx = torch.zeros(B * 4 * gh * gw, cin, dtype=dt, device=dev)
+        ops.gemm("nt", d.to(dev), WT.to(dev), dx, M, 4 * cin, cout, cout, cout, cin, dtype=dt, c_mode=R.A_PATCH2,
+                 c_cs=cin, gh=gh, gw=gw)
+        return C, dx
+
+    (Cg, dxg), (Cr, dxr) = run(H, DEV), run(R, "cpu")
+    close(Cg, Cr, dt, "patch2 gather")
+    close(dxg, dxr, dt, "patch2 scatter")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_gemm_conv3_z_batched(dt):
+    """the head 3x3x3 convolution as 5 z-batched implicit GEMMs + its data / weight gradients"""
+    H = _hip()
+    B, gh, gw, c3, cmid, Zo = 2, 9, 7, 8, 32, 5
+    D7 = Zo + 2
+    Mh = B * gh * gw
+    hin = rnd(Mh, D7 * c3, dt=dt, seed=1)
+    Wc = rnd(cmid, c3, 3, 3, 3, seed=2, scale=0.1)
+    bias = rnd(cmid, seed=3)
+    dU = rnd(Mh, Zo * cmid, dt=dt, seed=4)
+    zs = [min(max(zp - 2, 0), Zo - 3) for zp in range(D7)]
+
+    def run(ops, dev):
+        Wg, _ = ops.prep_weight(Wc.to(dev), cmid, c3, 27, dt, tapmode=1)
+        Wdg = ops.prep_head_dgrad(Wc.to(dev), cmid, c3, Zo, dt)
+        U = torch.zeros(Mh, Zo * cmid, dtype=dt, device=dev)
+        st = torch.zeros(2, B, cmid, device=dev)
+        ops.gemm_z("nt", hin.to(dev), Wg, U, Mh, cmid, 27 * c3, D7 * c3, 27 * c3, Zo * cmid, dtype=dt, a_mode=R.A_CONV3,
+                   gh=gh, gw=gw, cs=3 * c3, nz=Zo, a_coff=[z * c3 for z in range(Zo)], b_off=[0] * Zo,
+                   c_coff=[z * cmid for z in range(Zo)], epi=R.EPI_BIAS_STATS, bias=bias.to(dev), red0=st[0], red1=st[1],
+                   hw=gh * gw)
+        dWc = torch.zeros(cmid, 27 * c3, device=dev)
+        db = torch.zeros(cmid, device=dev)
+        ops.gemm_z("tn", hin.to(dev), dU.to(dev), dWc, Mh, cmid, 27 * c3, D7 * c3, Zo * cmid, 27 * c3, dtype=dt,
+                   a_mode=R.A_CONV3, gh=gh, gw=gw, cs=3 * c3, nz=Zo, a_coff=[z * c3 for z in range(Zo)],
+                   b_off=[z * cmid for z in range(Zo)], c_coff=[0] * Zo, colsum=db)
+        dWp = torch.zeros(cmid, c3, 3, 3, 3, device=dev)
+        ops.unprep_grad(dWc, dWp, cmid, c3, 27, tapmode=1)
+        dhin = torch.zeros(Mh, D7 * c3, dtype=dt, device=dev)
+        ops.gemm_z("nt", dU.to(dev), Wdg, dhin, Mh, c3, 27 * cmid, Zo * cmid, 27 * cmid, D7 * c3, dtype=dt,
+                   a_mode=R.A_CONV3, gh=gh, gw=gw, cs=3 * cmid, nz=D7, a_coff=[z * cmid for z in zs],
+                   b_off=[zp * c3 * 27 * cmid for zp in range(D7)], c_coff=[zp * c3 for zp in range(D7)])
+        return U, st, dWp, db, dhin
+
+    g, r = run(H, DEV), run(R, "cpu")
+    for name, a, b in zip(["U", "stats", "dW", "db", "dhin"], g, r):
+        close(a, b, dt, name)
+    # independent check of the whole construction against F.conv3d autograd (fp32 only)
+    if dt == torch.float32:
+        x5 = hin.view(B, gh, gw, D7, c3).permute(0, 4, 3, 1, 2).clone().requires_grad_(True)  # B, c3, D7, H, W
+        w = Wc.clone().requires_grad_(True)
+        bb = bias.clone().requires_grad_(True)
+        y = torch.nn.functional.conv3d(x5, w, bb, padding=(0, 1, 1))  # B, cmid, Zo, H, W
+        Uref = y.permute(0, 3, 4, 2, 1).reshape(Mh, Zo * cmid)
+        close(g[0], Uref, dt, "U vs conv3d")
+        y.backward(dU.view(B, gh, gw, Zo, cmid).permute(0, 4, 3, 1, 2))
+        close(g[2], w.grad, dt, "dW vs conv3d")
+        close(g[4], x5.grad.permute(0, 3, 4, 2, 1).reshape(Mh, D7 * c3), dt, "dhin vs conv3d")
+
+
+# ------------------------------------------------------------------ GEMM tn
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("tr", [1, 0], ids=["tr_read", "scalar_read"])
+@pytest.mark.parametrize("M,N,K", [(512, 160, 40), (1000, 96, 384), (70, 8, 32), (9000, 384, 96), (4100, 768, 3072)])
+def test_gemm_tn(dt, tr, M, N, K):
+    from viscy_amd import _lib
+
+    H = _hip()
+    if SELF_CHECK and M * N * K > 1e9:
+        pytest.skip("self-check")
+    if K * N > 1_000_000 and dt == torch.float32 and tr == 0:
+        pytest.skip("covered by the tr_read id")
+    X, Y = rnd(M, N, dt=dt, seed=1), rnd(M, K, dt=dt, seed=2)
+    if not SELF_CHECK:
+        _lib.lib().vsx_set_flag(b"tn_tr", tr)
+    try:
+        def run(ops, dev):
+            Wt = torch.zeros(N, K, device=dev)
+            cs = torch.zeros(N, device=dev)
+            ops.gemm("tn", Y.to(dev), X.to(dev), Wt, M, N, K, K, N, K, dtype=dt, colsum=cs)
+            return Wt, cs
+
+        (Wg, cg), (Wr, cr) = run(H, DEV), run(R, "cpu")
+    finally:
+        if not SELF_CHECK:
+            _lib.lib().vsx_set_flag(b"tn_tr", 1)
+    close(Wg, Wr, dt, "W")
+    close(cg, cr, dt, "colsum")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_gemm_tn_grn_and_patch2(dt):
+    H = _hip()
+    M, N, K, hw = 300, 40, 160, 100
+    X, Hh = rnd(M, N, dt=dt, seed=1), rnd(M, K, dt=dt, seed=2)
+    s, beta = 1 + 0.3 * rnd(3, K, seed=3), 0.1 * rnd(K, seed=4)
+    B, gh, gw, cin, cout = 2, 6, 5, 16, 24
+    Mp = B * gh * gw
+    src, d = rnd(B * 4 * gh * gw, cin, dt=dt, seed=5), rnd(Mp, cout, dt=dt, seed=6)
+
+    def run(ops, dev):
+        W1 = torch.zeros(N, K, device=dev)
+        ops.gemm("tn", Hh.to(dev), X.to(dev), W1, M, N, K, K, N, K, dtype=dt, pro=R.PRO_GRN, grn_s=s.to(dev),
+                 grn_b=beta.to(dev), hw=hw)
+        W2 = torch.zeros(cout, 4 * cin, device=dev)
+        cs = torch.zeros(cout, device=dev)
+        ops.gemm("tn", src.to(dev), d.to(dev), W2, Mp, cout, 4 * cin, cin, cout, 4 * cin, dtype=dt, a_mode=R.A_PATCH2,
+                 gh=gh, gw=gw, cs=cin, colsum=cs)
+        return W1, W2, cs
+
+    for name, a, b in zip(["grn wgrad", "patch2 wgrad", "colsum"], run(H, DEV), run(R, "cpu")):
+        close(a, b, dt, name)
+
+
+# ------------------------------------------------------------------ LayerNorm / GRN
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("rows,C", [(300, 96), (64, 768), (17, 40), (100, 144), (33, 1024), (50, 224)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_layernorm_fwd_bwd(dt, rows, C, affine):
+    H = _hip()
+    x = rnd(rows, C, dt=dt, seed=1, scale=2.0) + 0.5
+    dy = rnd(rows, C, dt=dt, seed=2)
+    add = rnd(rows, C, dt=dt, seed=3)
+    gamma = (1 + 0.2 * rnd(C, seed=4)) if affine else None
+    beta = 0.1 * rnd(C, seed=5) if affine else None
+
+    def run(ops, dev):
+        mv = lambda t: t.to(dev) if t is not None else None  # noqa: E731
+        y, mean, rstd = ops.ln_fwd(mv(x), mv(gamma), mv(beta), rows, C)
+        dg = torch.zeros(C, device=dev) if affine else None
+        db = torch.zeros(C, device=dev) if affine else None
+        if affine:
+            dx = ops.ln_bwd(mv(dy), mv(x), mean, rstd, mv(gamma), mv(add), dg, db, rows, C)
+        else:  # block LN: backward from the saved normalised activations
+            dx = ops.ln_bwd(mv(dy), y, None, rstd, None, None, None, None, rows, C)
+        return y, mean, rstd, dx, dg, db
+
+    g, r = run(H, DEV), run(R, "cpu")
+    for name, a, b in zip(["y", "mean", "rstd", "dx", "dgamma", "dbeta"], g, r):
+        if a is not None:
+            close(a, b, dt, name)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_grn_stats_and_gelu_bwd(dt):
+    H = _hip()
+    B, N, hw = 3, 160, 50
+    M = B * hw
+    colsq = rnd(B, N, seed=1).abs() * 40 + 1
+    colsq[1, 5] = 0.0  # zero-norm channel: gradient must be 0, not NaN
+    P = rnd(B, N, seed=2)
+    gamma = 0.3 * rnd(N, seed=3)
+    dz, h = rnd(M, N, dt=dt, seed=4), rnd(M, N, dt=dt, seed=5, scale=1.5)
+
+    def run(ops, dev):
+        s = ops.grn_scale(colsq.to(dev), gamma.to(dev))
+        dg = torch.zeros(N, device=dev)
+        t = ops.grn_bwd_stats(colsq.to(dev), P.to(dev), gamma.to(dev), dg)
+        d = dz.clone().to(dev)
+        cs = torch.zeros(N, device=dev)
+        ops.grn_gelu_bwd(d, h.to(dev), s, t, cs, M, N, hw)
+        return s, t, dg, d, cs
+
+    for name, a, b in zip(["s", "t", "dgamma", "dh", "colsum"], run(H, DEV), run(R, "cpu")):
+        assert torch.isfinite(a).all(), name
+        close(a, b, dt, name)
+
+
+# ------------------------------------------------------------------ depthwise conv
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("B,Hh,Ww,C", [(2, 16, 16, 96), (1, 8, 12, 40), (2, 4, 4, 192), (1, 2, 2, 768), (1, 33, 19, 24)])
+def test_dwconv7(dt, B, Hh, Ww, C):
+    H = _hip()
+    M = B * Hh * Ww
+    x, dy, add = rnd(M, C, dt=dt, seed=1), rnd(M, C, dt=dt, seed=2), rnd(M, C, dt=dt, seed=3)
+    w, bias = rnd(49, C, seed=4, scale=0.2), rnd(C, seed=5)
+
+    def run(ops, dev):
+        y = ops.dwconv7_fwd(x.to(dev), w.to(dev), bias.to(dev), B, Hh, Ww, C)
+        dx = ops.dwconv7_bwd_data(dy.to(dev), w.to(dev), add.to(dev), B, Hh, Ww, C)
+        dw, db = torch.zeros(49, C, device=dev), torch.zeros(C, device=dev)
+        ops.dwconv7_bwd_weight(dy.to(dev), x.to(dev), dw, db, B, Hh, Ww, C)
+        return y, dx, dw, db
+
+    for name, a, b in zip(["y", "dx", "dw", "db"], run(H, DEV), run(R, "cpu")):
+        close(a, b, dt, name)
+
+
+# ------------------------------------------------------------------ data movement
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_stem_im2col_and_normalize_fusion(dt):
+    H = _hip()
+    for (B, Cin, Z, Hh, Ww) in [(2, 1, 5, 32, 64), (1, 2, 15, 32, 32)]:
+        x = rnd(B, Cin, Z, Hh, Ww, seed=1) * 10 + 3
+        sub, div = torch.tensor([1.0, 2.0][:B]), torch.tensor([3.0, 0.5][:B])
+        close(H.stem_im2col(x.to(DEV), (5, 4, 4), dt), R.stem_im2col(x, (5, 4, 4), dt), dt, "im2col")
+        close(H.stem_im2col(x.to(DEV), (5, 4, 4), dt, sub.to(DEV), div.to(DEV)), R.stem_im2col(x, (5, 4, 4), dt, sub, div), dt,
+              "im2col+normalize")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("c,cs", [(48, 96), (20, 40), (96, 0)])
+def test_pixel_shuffle_cat(dt, c, cs):
+    H = _hip()
+    B, h, w = 2, 5, 3
+    low = rnd(B * h * w, 4 * c, dt=dt, seed=1)
+    skip = rnd(B * 4 * h * w, cs, dt=dt, seed=2) if cs else None
+    dcat = rnd(B * 4 * h * w, c + cs, dt=dt, seed=3)
+    cat_g = H.pixel_shuffle_cat_fwd(low.to(DEV), skip.to(DEV) if cs else None, B, h, w, c, cs)
+    assert torch.equal(cat_g.cpu(), R.pixel_shuffle_cat_fwd(low, skip, B, h, w, c, cs))
+    dl_g, ds_g = H.pixel_shuffle_cat_bwd(dcat.to(DEV), B, h, w, c, cs)
+    dl_r, ds_r = R.pixel_shuffle_cat_bwd(dcat, B, h, w, c, cs)
+    assert torch.equal(dl_g.cpu(), dl_r)
+    if cs:
+        assert torch.equal(ds_g.cpu(), ds_r)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("pool", [True, False])
+def test_head_shuffle(dt, pool):
+    H = _hip()
+    B, h, w, C3, D = 2, 4, 6, 8, 7
+    dec = rnd(B * h * w, 4 * C3 * D, dt=dt, seed=1)
+    dh = rnd(B * 4 * h * w, C3 * D, dt=dt, seed=2)
+    close(H.head_shuffle_fwd(dec.to(DEV), B, h, w, C3, D, pool), R.head_shuffle_fwd(dec, B, h, w, C3, D, pool), dt, "fwd")
+    close(H.head_shuffle_bwd(dh.to(DEV), B, h, w, C3, D, pool), R.head_shuffle_bwd(dh, B, h, w, C3, D, pool), dt, "bwd")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_head_tail_fwd_bwd(dt):
+    H = _hip()
+    B, H2, W2, Z, Cmid, Cout = 2, 6, 10, 5, 32, 2
+    Mh = B * H2 * W2
+    U = rnd(Mh, Z * Cmid, dt=dt, seed=1, scale=2.0) + 0.3
+    w2, b2, alpha = rnd(4 * Cout, Cmid, seed=2, scale=0.2), rnd(4 * Cout, seed=3), torch.tensor([0.25])
+    dout = rnd(B, Cout, Z, 2 * H2, 2 * W2, seed=4)
+    u3 = U.float().view(B, H2 * W2 * Z, Cmid)
+    ssum, ssq = u3.sum(1), (u3 * u3).sum(1)
+
+    def run(ops, dev):
+        mv = lambda t: t.to(dev)  # noqa: E731
+        out = ops.head_out_fwd(mv(U), mv(ssum), mv(ssq), mv(w2), mv(b2), mv(alpha), B, H2, W2, Z, Cmid, Cout)
+        S = torch.zeros(2, B, Cmid, device=dev)
+        dal = torch.zeros(1, device=dev)
+        act, dv = ops.head_out_bwd1(mv(U), mv(ssum), mv(ssq), mv(w2), mv(alpha), mv(dout), S[0], S[1], dal, B, H2, W2, Z,
+                                    Cmid, Cout)
+        dU = ops.head_out_bwd2(mv(U), mv(ssum), mv(ssq), mv(w2), mv(alpha), dv, S[0], S[1], B, H2, W2, Z, Cmid, Cout)
+        return out, act, dv, S, dal, dU
+
+    g, r = run(H, DEV), run(R, "cpu")
+    for name, a, b in zip(["out", "act", "dv", "S", "dalpha", "dU"], g, r):
+        close(a, b, dt, name)
+    if dt == torch.float32:  # independent: autograd through InstanceNorm3d + PReLU + 1x1x1 conv + pixel shuffle
+        Ur = U.clone().requires_grad_(True)
+        al = alpha.clone().requires_grad_(True)
+        out_ref, _ = R._head_full(Ur, w2, b2, al, B, H2, W2, Z, Cmid, Cout, 1e-5)
+        close(g[0], out_ref, dt, "out vs autograd")
+        out_ref.backward(dout)
+        close(g[5], Ur.grad, dt, "dU vs autograd")
+        close(g[4], al.grad, dt, "dalpha vs autograd")
+
+
+# ------------------------------------------------------------------ parameter space
+def test_prep_unprep_adamw():
+    H = _hip()
+    dt = torch.bfloat16
+    W = rnd(24, 16, 2, 2, seed=1)
+    gamma = 1 + 0.1 * rnd(16, seed=2)
+    for ops, dev in ((H, DEV), (R, "cpu")):
+        pass
+    dg, dgT = H.prep_weight(W.to(DEV), 24, 16, 4, dt, want=True, want_t=True, gamma=gamma.to(DEV))
+    rg, rgT = R.prep_weight(W, 24, 16, 4, dt, want=True, want_t=True, gamma=gamma)
+    assert torch.equal(dg.cpu(), rg) and torch.equal(dgT.cpu(), rgT)
+    g = rnd(24, 64, seed=3)
+    u, beta = rnd(40, seed=4), rnd(16, seed=5)
+    W1 = rnd(40, 16, seed=6)
+    g1 = rnd(40, 16, seed=7)
+    outs = []
+    for ops, dev in ((H, DEV), (R, "cpu")):
+        dp = torch.zeros(24, 16, 2, 2, device=dev)
+        ops.unprep_grad(g.to(dev), dp, 24, 16, 4)
+        dp1, dgam = torch.zeros(40, 16, device=dev), torch.zeros(16, device=dev)
+        ops.unprep_grad(g1.to(dev), dp1, 40, 16, 1, gamma=gamma.to(dev), W=W1.to(dev), dgamma=dgam, u=u.to(dev),
+                        beta=beta.to(dev))
+        mv = ops.matvec(W1.to(dev), beta.to(dev), u.to(dev), 40, 16)
+        acc = torch.zeros(16, device=dev)
+        ops.matvec_t_add(W1.to(dev), u.to(dev), acc, 40, 16)
+        tr = torch.zeros(49, 24, device=dev)
+        ops.transpose_f32(rnd(24, 49, seed=8).to(dev), tr, 24, 49, False)
+        outs.append((dp, dp1, dgam, mv, acc, tr))
+    for name, a, b in zip(["unprep", "unprep-fold", "dgamma", "matvec", "matvec_t", "transpose"], *outs):
+        close(a, b, torch.float32, name)
+    # AdamW: 3 steps vs torch.optim.AdamW
+    n = 1003
+    p0, grads = rnd(n, seed=10), [rnd(n, seed=11 + i) for i in range(3)]
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-2)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for i, gr in enumerate(grads):
+        pt.grad = gr.clone()
+        opt.step()
+        t = i + 1
+        hyper = torch.tensor([1e-2, 0.9, 0.999, 1e-8, 0.01, 1 - 0.9**t, 1 - 0.999**t, 1.0]).to(DEV)
+        H.adamw(p, gr.to(DEV), m, v, hyper)
+    close(p, pt.detach(), torch.float32, "adamw")

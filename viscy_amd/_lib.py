@@ -66,8 +66,8 @@ _SIGS = {
     "vsx_head_out_bwd2": (_I32, [_P] * 9 + [_I32] * 6 + [_F32, _I32, _P]),
     "vsx_loss_pool": (_I32, [_P] * 7 + [_I32] * 3 + [_P]),
     "vsx_ssim_scale_fwd": (_I32, [_P] * 5 + [_I32] * 5 + [_P]),
-    "vsx_ssim_scale_bwd": (_I32, [_P] * 7 + [_I32] * 5 + [_F32, _F32, _I32, _P]),
-    "vsx_loss_finalize": (_I32, [_P] * 5 + [_F32, _I32, _I32, _F32, _F32, _F32, _F32, _P, _P, _P, _P]),
+    "vsx_ssim_scale_bwd": (_I32, [_P] * 7 + [_I32] * 5 + [_F32, _F32, _P, _I32, _P]),
+    "vsx_loss_finalize": (_I32, [_P] * 5 + [_F32, _I32, _I32, _F32, _F32, _F32, _P, _P, _P, _P, _P]),
     "vsx_adamw": (_I32, [_P, _P, _P, _P, _P, _I64, _P]),
     "vsx_prep_weight": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_unprep_grad": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),

@@ -199,14 +199,16 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
 //            + 0.25 * dPnext(z, y/2, x/2)  + l1c * sign(p - t) + l2c * 2 (p - t)
 __global__ __launch_bounds__(256) void ssim_bwd_in_kernel(const float* __restrict__ P, const float* __restrict__ T,
                                                           const float* __restrict__ dmu, const float* __restrict__ dPn,
-                                                          float* __restrict__ dP, int D, int H, int W, float l1c,
-                                                          float l2c, int has_ssim) {
+                                                          float* __restrict__ dP, int D, int H, int W, float l1c_,
+                                                          float l2c_, const float* __restrict__ gout_p, int has_ssim) {
   __shared__ float S[3][SI][SLD];
   __shared__ float R[3][SI][ST];
   const int bc = blockIdx.z;
   const int iy0 = blockIdx.y * ST, ix0 = blockIdx.x * ST;
   const int Ho = H - 10, Wo = W - 10;
   const float kb = round_bf16(1.0f / (float)(D * 121));
+  const float gsc = gout_p ? gout_p[0] : 1.f;
+  const float l1c = l1c_ * gsc, l2c = l2c_ * gsc;
   if (has_ssim) {
     const size_t plane = (size_t)Ho * Wo;
     const size_t nbc = (size_t)gridDim.z;
@@ -270,10 +272,11 @@ __global__ __launch_bounds__(256) void ssim_bwd_in_kernel(const float* __restric
 __global__ void loss_finalize_kernel(const float* __restrict__ sum_ssim, const float* __restrict__ sum_cs,
                                      const float* __restrict__ l1sum, const float* __restrict__ l2sum,
                                      const float* __restrict__ npix, float nelem, int B, int nscale, float a1, float a2,
-                                     float a3, float gout, float* __restrict__ loss, float* __restrict__ coef,
-                                     float* __restrict__ ms_out) {
+                                     float a3, const float* __restrict__ gout_p, float* __restrict__ loss,
+                                     float* __restrict__ coef, float* __restrict__ ms_out) {
   const float betas[5] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float gout = gout_p ? gout_p[0] : 1.f;
   float ms_mean = 0.f;
   if (a3 != 0.f) {
     for (int b = 0; b < B; ++b) {
@@ -335,7 +338,8 @@ extern "C" int32_t vsx_ssim_scale_fwd(const float* P, const float* T, const floa
  * dP: [B, C, D, H, W] gradient w.r.t. this scale's preds (written, not accumulated). */
 extern "C" int32_t vsx_ssim_scale_bwd(const float* P, const float* T, const float* tmax, const float* coef, float* dmu,
                                       const float* dPnext, float* dP, int32_t B, int32_t C, int32_t D, int32_t H,
-                                      int32_t W, float l1c, float l2c, int32_t has_ssim, vsx_stream_t stream) {
+                                      int32_t W, float l1c, float l2c, const float* gout, int32_t has_ssim,
+                                      vsx_stream_t stream) {
   VSX_CHECK(P && T && dP, "vsx_ssim_scale_bwd: null pointer");
   if (has_ssim) {
     VSX_CHECK(tmax && coef && dmu && H >= 11 && W >= 11, "vsx_ssim_scale_bwd: SSIM term needs tmax/coef/dmu and a >=11 plane");
@@ -346,7 +350,7 @@ extern "C" int32_t vsx_ssim_scale_bwd(const float* P, const float* T, const floa
   }
   dim3 g2(vsx_cdiv(W, ST), vsx_cdiv(H, ST), B * C);
   hipLaunchKernelGGL(ssim_bwd_in_kernel, g2, dim3(256), 0, (hipStream_t)stream, P, T, dmu, dPnext, dP, D, H, W, l1c, l2c,
-                     has_ssim);
+                     gout, has_ssim);
   VSX_LAUNCH_CHECK();
   return 0;
 }
@@ -355,7 +359,7 @@ extern "C" int32_t vsx_ssim_scale_bwd(const float* P, const float* T, const floa
  * sums: [nscale][B]; npix: [nscale] (= C*(H_s-10)*(W_s-10)); coef out: [nscale][B][2]. */
 extern "C" int32_t vsx_loss_finalize(const float* sum_ssim, const float* sum_cs, const float* l1sum, const float* l2sum,
                                      const float* npix, float nelem, int32_t B, int32_t nscale, float a1, float a2,
-                                     float a3, float gout, float* loss, float* coef, float* ms_out,
+                                     float a3, const float* gout, float* loss, float* coef, float* ms_out,
                                      vsx_stream_t stream) {
   VSX_CHECK(loss && B > 0 && nscale >= 1 && nscale <= 5, "vsx_loss_finalize: bad arguments");
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sum_ssim, sum_cs, l1sum, l2sum,

@@ -1,0 +1,115 @@
+"""MixedLoss on MI355X — drop-in for ``viscy_utils.losses.MixedLoss``
+(/root/reference/packages/viscy-utils/src/viscy_utils/losses/mixed_loss.py:13-69) with the
+MS-SSIM-2.5D of ``viscy_utils.evaluation.metrics.ms_ssim_25d`` (metrics.py:308-349, clamp=True).
+
+Same constructor (l1_alpha, l2_alpha, ms_dssim_alpha), same ``forward(preds, target) -> scalar``;
+the whole loss (L1 / L2 sums, 5-scale separable box-filter SSIM, pooling, data-range max) and its
+gradient run in the HIP kernels of viscy_amd/csrc/loss.hip.  No CPU / eager fallback.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+from ._lib import check, lib, ptr, stream
+
+BETAS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+class _MixedLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds: Tensor, target: Tensor, a1: float, a2: float, a3: float):
+        if preds.shape != target.shape or preds.ndim != 5:
+            raise ValueError(f"preds/target must be (B, C, D, H, W) of equal shape, got {preds.shape} / {target.shape}")
+        P0 = preds.detach().float().contiguous()
+        T0 = target.detach().float().contiguous()
+        B, C, D, H, W = P0.shape
+        dev = P0.device
+        ns = len(BETAS) if a3 else 0
+        if a3 and (H // 16 < 11 or W // 16 < 11):
+            raise ValueError(f"MS-SSIM with 5 scales needs Y, X >= 176 (got {H}x{W}): the 11x11 window must fit at 1/16 scale")
+        l = lib()
+        s = stream()
+        scal = torch.zeros(2 + 5 + 10 * B, dtype=torch.float32, device=dev)
+        l1sum, l2sum = scal[0:1], scal[1:2]
+        tmax = scal[2:7]
+        tmax.fill_(float("-inf"))
+        sum_ssim = scal[7 : 7 + 5 * B]
+        sum_cs = scal[7 + 5 * B : 7 + 10 * B]
+        Ps, Ts, dims = [P0], [T0], [(H, W)]
+        planes = B * C * D
+        nlev = max(ns, 1)
+        for sc in range(nlev):
+            h, w = dims[sc]
+            last = sc == nlev - 1
+            Po = To = None
+            if not last:
+                Po = torch.empty((B, C, D, h // 2, w // 2), dtype=torch.float32, device=dev)
+                To = torch.empty_like(Po)
+            check(l.vsx_loss_pool(ptr(Ps[sc]), ptr(Ts[sc]), ptr(Po), ptr(To), ptr(tmax[sc : sc + 1]),
+                                  ptr(l1sum) if sc == 0 else None, ptr(l2sum) if sc == 0 else None, planes, h, w, s),
+                  "loss_pool")
+            if not last:
+                Ps.append(Po)
+                Ts.append(To)
+                dims.append((h // 2, w // 2))
+        npix = torch.tensor([C * (h - 10) * (w - 10) for (h, w) in dims] + [1.0] * (5 - len(dims)), dtype=torch.float32)
+        npix_d = npix.to(dev, non_blocking=True)
+        for sc in range(ns):
+            h, w = dims[sc]
+            check(l.vsx_ssim_scale_fwd(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc : sc + 1]), ptr(sum_ssim[sc * B : (sc + 1) * B]),
+                                       ptr(sum_cs[sc * B : (sc + 1) * B]), B, C, D, h, w, s), "ssim_scale_fwd")
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        coef = torch.empty(max(ns, 1) * B * 2, dtype=torch.float32, device=dev)
+        nelem = float(P0.numel())
+        check(l.vsx_loss_finalize(ptr(sum_ssim), ptr(sum_cs), ptr(l1sum), ptr(l2sum), ptr(npix_d), nelem, B, max(ns, 1),
+                                  a1, a2, a3, None, ptr(out[0:1]), ptr(coef), ptr(out[1:2]), s), "loss_finalize")
+        ctx.saved = (Ps, Ts, dims, tmax, scal, npix_d, (B, C, D), (a1, a2, a3), ns, nelem, preds.dtype)
+        ctx.ms_ssim = out[1]
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        Ps, Ts, dims, tmax, scal, npix_d, (B, C, D), (a1, a2, a3), ns, nelem, in_dtype = ctx.saved
+        dev = Ps[0].device
+        l, s = lib(), stream()
+        go = gout.detach().float().reshape(1).contiguous()  # stays on the device: no host sync
+        sum_ssim = scal[7 : 7 + 5 * B]
+        sum_cs = scal[7 + 5 * B : 7 + 10 * B]
+        coef = torch.empty(max(ns, 1) * B * 2, dtype=torch.float32, device=dev)
+        tmp = torch.empty(2, dtype=torch.float32, device=dev)
+        check(l.vsx_loss_finalize(ptr(sum_ssim), ptr(sum_cs), ptr(scal[0:1]), ptr(scal[1:2]), ptr(npix_d), nelem, B,
+                                  max(ns, 1), a1, a2, a3, ptr(go), ptr(tmp[0:1]), ptr(coef), ptr(tmp[1:2]), s), "loss_finalize")
+        h0, w0 = dims[0]
+        dmu = torch.empty(3 * B * C * max(h0 - 10, 1) * max(w0 - 10, 1), dtype=torch.float32, device=dev) if ns else None
+        dnext = None
+        for sc in range(max(ns, 1) - 1, -1, -1):
+            h, w = dims[sc]
+            dP = torch.empty((B, C, D, h, w), dtype=torch.float32, device=dev)
+            l1c = a1 / nelem if sc == 0 else 0.0
+            l2c = a2 / nelem if sc == 0 else 0.0
+            check(l.vsx_ssim_scale_bwd(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc : sc + 1]) if ns else None,
+                                       ptr(coef[sc * B * 2 : (sc + 1) * B * 2]) if ns else None, ptr(dmu), ptr(dnext),
+                                       ptr(dP), B, C, D, h, w, l1c, l2c, ptr(go), 1 if ns else 0, s), "ssim_scale_bwd")
+            dnext = dP
+        return dnext.to(in_dtype), None, None, None, None
+
+
+class MixedLoss(nn.Module):
+    """Mixed reconstruction loss (Zhao et al.), see module docstring."""
+
+    def __init__(self, l1_alpha: float = 0.5, l2_alpha: float = 0.0, ms_dssim_alpha: float = 0.5):
+        super().__init__()
+        if not any([l1_alpha, l2_alpha, ms_dssim_alpha]):
+            raise ValueError("Loss term weights cannot be all zero!")
+        self.l1_alpha = l1_alpha
+        self.l2_alpha = l2_alpha
+        self.ms_dssim_alpha = ms_dssim_alpha
+
+    def forward(self, preds: Tensor, target: Tensor) -> Tensor:
+        if not preds.is_cuda:
+            raise RuntimeError("viscy_amd.MixedLoss runs on MI355X HIP kernels only (no CPU / eager fallback)")
+        L.lib()
+        return _MixedLossFn.apply(preds, target, float(self.l1_alpha), float(self.l2_alpha), float(self.ms_dssim_alpha))

@@ -1,0 +1,71 @@
+"""AdamW + warm-up cosine schedule on the flat parameter buffer of a viscy_amd model.
+
+Mirrors ``viscy_utils.optimizers.configure_adamw_scheduler``
+(/root/reference/packages/viscy-utils/src/viscy_utils/optimizers.py:10-62): torch AdamW defaults
+(betas (0.9, 0.999), eps 1e-8, weight_decay 0.01) over *all* parameters, and MONAI
+``WarmupCosineSchedule(warmup_steps, t_total, warmup_multiplier)`` stepped per batch
+(λ(step) = m + (1-m)·step/max(1,warmup) during warm-up, then max(0, ½(1+cos(π·progress)))).
+The update itself is ONE fused HIP launch over the flat fp32 buffers (csrc/optim.hip).
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops as hip_ops
+
+
+def warmup_cosine_lambda(step: int, warmup_steps: int, t_total: int, warmup_multiplier: float = 0.0,
+                         cycles: float = 0.5) -> float:
+    if step < warmup_steps:
+        f = float(step) / float(max(1.0, warmup_steps))
+        return warmup_multiplier + (1 - warmup_multiplier) * f
+    progress = float(step - warmup_steps) / float(max(1, t_total - warmup_steps))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(cycles) * 2.0 * progress)))
+
+
+class FlatAdamW:
+    """AdamW over ``engine.flat`` / ``engine.flat_grad`` (see viscy_amd.engine_unext2.Engine)."""
+
+    def __init__(self, engine, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
+                 schedule: str = "Constant", warmup_steps: int = 0, t_total: int = 0, warmup_multiplier: float = 0.0,
+                 ops=None):
+        self.engine = engine
+        self.ops = ops or hip_ops
+        self.base_lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.schedule, self.warmup_steps, self.t_total, self.warmup_multiplier = schedule, warmup_steps, t_total, warmup_multiplier
+        dev = engine.flat.device
+        self.m = torch.zeros_like(engine.flat)
+        self.v = torch.zeros_like(engine.flat)
+        self.t = 0
+        self.grad_scale = 1.0
+        self._hyper_host = torch.zeros(8, dtype=torch.float32, pin_memory=dev.type == "cuda")
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+
+    def current_lr(self) -> float:
+        if self.schedule == "WarmupCosine":
+            return self.base_lr * warmup_cosine_lambda(self.t, self.warmup_steps, self.t_total, self.warmup_multiplier)
+        return self.base_lr
+
+    def zero_grad(self) -> None:
+        self.engine.flat_grad.zero_()
+
+    def step(self) -> None:
+        lr = self.current_lr()
+        self.t += 1
+        b1, b2 = self.betas
+        h = self._hyper_host
+        h[0], h[1], h[2], h[3], h[4] = lr, b1, b2, self.eps, self.wd
+        h[5], h[6], h[7] = 1 - b1**self.t, 1 - b2**self.t, self.grad_scale
+        self.hyper.copy_(h, non_blocking=True)
+        self.ops.adamw(self.engine.flat, self.engine.flat_grad, self.m, self.v, self.hyper)
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "t": self.t}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.t = int(sd["t"])
