@@ -55,8 +55,8 @@ class OpTimer:
 
     GEMM_EPI = {0: "none", 1: "bias", 2: "bias_gelu_sq", 3: "bias_res", 4: "dz", 5: "bias_stats"}
 
-    def __init__(self, ops, only: str | None = None):
-        self.ops, self.only = ops, only
+    def __init__(self, ops, only: str | None = None, by_shape: bool = False):
+        self.ops, self.only, self.by_shape = ops, only, by_shape
         self.records = {}  # name -> list of (start, end, flops, bytes)
         self._orig = {}
 
@@ -78,7 +78,7 @@ class OpTimer:
                 kind, M, N, K = a[0], a[4], a[5], a[6]
                 nz = k.get("nz", 1)
                 es = 2 if k.get("dtype") == torch.bfloat16 else 4
-                cls = f"gemm_{kind}"
+                cls = f"gemm_{kind}" if not self.by_shape else f"gemm_{kind} M{M} N{N} K{K} z{nz} e{k.get('epi', 0)} p{k.get('pro', 0)} a{k.get('a_mode', 0)}"
                 flops = 2.0 * M * N * K * nz
                 nbytes = (M * K + M * N) * es * nz + N * K * (es if kind == "nt" else 4)
             if self.only is not None and cls != self.only:
@@ -115,8 +115,8 @@ class OpTimer:
         return out
 
 
-def cpu_baseline(budget_s: float = 20.0):
-    """One training step of the oracle (reference restatement) on the host cores, bounded sample."""
+def _cpu_baseline_child():
+    """Runs in a child process; prints one JSON line per completed measurement (the parent keeps the last)."""
     from oracle import loss_ref, unext2_ref
 
     torch.set_num_threads(os.cpu_count() or 1)
@@ -126,7 +126,6 @@ def cpu_baseline(budget_s: float = 20.0):
     B = 2
     x, tgt = make_batch(B, 256, 256, "cpu")
     times = []
-    t_start = time.perf_counter()
     for i in range(6):
         t0 = time.perf_counter()
         opt.zero_grad()
@@ -134,17 +133,36 @@ def cpu_baseline(budget_s: float = 20.0):
         loss.backward()
         opt.step()
         dt = time.perf_counter() - t0
-        if i >= 1:
+        if i >= 1 or dt > 8.0:  # first iteration is warm-up unless the host is so slow that one step is all we get
             times.append(dt)
-        if time.perf_counter() - t_start > budget_s and len(times) >= 2:
-            break
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": round(B / med, 3), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} timed training steps (fwd+MixedLoss+bwd+AdamW) of the fp32 oracle at B={B}, Z=5, 256x256, median"}
+            ts = sorted(times)
+            med = ts[len(ts) // 2]
+            print(json.dumps({"value": round(B / med, 3), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+                              "sample": f"{len(times)} timed training step(s) (fwd+MixedLoss+bwd+AdamW) of the fp32 oracle "
+                                        f"(pure-torch restatement of the reference) at B={B}, Z=5, 256x256, median"}), flush=True)
+
+
+def cpu_baseline(budget_s: float = 45.0):
+    """The oracle timed on the host cores over a bounded sample (child process, hard time limit)."""
+    import subprocess
+
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"], capture_output=True, text=True,
+                           timeout=budget_s)
+        out = p.stdout
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if not lines:
+        return {"value": None, "unit": "patches/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"no oracle training step finished within {budget_s:.0f} s on this host"}
+    return json.loads(lines[-1])
 
 
 def main():
+    if "--cpu-baseline-child" in sys.argv:
+        _cpu_baseline_child()
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -153,6 +171,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured step")
     ap.add_argument("--profile-ops", action="store_true", help="print the per-op-class event-timing table to stderr")
     args = ap.parse_args()
 
@@ -189,13 +208,13 @@ def main():
     B = args.batch
     x, tgt = make_batch(B, args.size, args.size, dev, seed=42 + rank)
 
+    from viscy_amd.step import TrainStep
+
+    eager = TrainStep(model, crit, opt, ddp, use_graph=False)
+    graphed = TrainStep(model, crit, opt, ddp, use_graph=not args.no_graph)
+
     def step():
-        opt.zero_grad()
-        loss = crit(model(x), tgt)
-        loss.backward()
-        ddp.finish()
-        opt.step()
-        return loss
+        return graphed(x, tgt)
 
     def barrier():
         torch.cuda.synchronize()
@@ -204,11 +223,18 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warmup (the last warmup step is instrumented per op class to find the dominant kernel)
-    for _ in range(max(args.warmup - 1, 0)):
-        step()
-    with OpTimer(ops) as tm:
-        l0 = step()
+    if args.profile_ops:
+        with OpTimer(ops, by_shape=True) as tm:
+            eager(x, tgt)
+        if rank == 0:
+            for c, v in sorted(tm.summary().items(), key=lambda kv: -kv[1]["ms"])[:40]:
+                print(f"[shape] {c:58s} {v['launches']:3d}x {v['ms'] / v['launches'] * 1e3:9.1f} us  "
+                      f"{v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s {v['flops'] / max(v['ms'], 1e-9) / 1e9:8.1f} TFLOP/s", file=sys.stderr)
+    with OpTimer(ops) as tm:  # one eager, instrumented step: per-op-class times → dominant kernel class
+        l0 = eager(x, tgt)
     table = tm.summary()
+    for _ in range(max(args.warmup, 1)):
+        step()
     dominant = max(table, key=lambda c: table[c]["ms"]) if table else None
     if args.profile_ops and rank == 0:
         tot = sum(v["ms"] for v in table.values())
@@ -219,12 +245,16 @@ def main():
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
     barrier()
     t0 = time.perf_counter()
-    with OpTimer(ops, only=dominant) as tm:
-        for _ in range(args.steps):
-            loss = step()
-        barrier()
-        t1 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    t1 = time.perf_counter()
     elapsed = t1 - t0
+    # dominant kernel class: average launch duration measured live with HIP events on the launch stream, over
+    # eager replays of the same step right behind the timed region (events cannot be recorded inside a graph replay)
+    with OpTimer(ops, only=dominant) as tm:
+        for _ in range(3):
+            eager(x, tgt)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)

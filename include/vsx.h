@@ -55,7 +55,7 @@ int32_t vsx_get_flag(const char* name);
 #define VSX_EPI_BIAS 1         /* c = acc + bias[n] */
 #define VSX_EPI_BIAS_GELU_SQ 2 /* c = h = acc + bias; red0[b, n] += gelu(h)^2            (fc1 + GRN pass A) */
 #define VSX_EPI_BIAS_RES 3     /* c = acc + bias[n] + res[m, n]   (bias may be NULL)      (fc2 + residual)   */
-#define VSX_EPI_DZ 4           /* c = dz = acc; red0[b, n] += dz * gelu(aux[m, n]); red1[n] += dz  (fc2 dgrad) */
+#define VSX_EPI_DZ 4           /* c = dz = acc; red0[b, n] += dz * gelu(aux[m, n]); red1[b, n] += dz  (fc2 dgrad) */
 #define VSX_EPI_BIAS_STATS 5   /* c = acc + bias; red0[b, n] += c; red1[b, n] += c^2      (head conv + IN)   */
 
 typedef struct VsxGemm {

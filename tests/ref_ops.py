@@ -73,7 +73,7 @@ def gemm(kind, A, B, Cout, M, N, K, lda, ldb, ldc, *, dtype, a_mode=A_ROWS, gh=0
         elif epi == EPI_DZ:
             h = aux.reshape(-1, ldx).float()[:M, :N]
             red0.index_add_(0, bidx, out * _gelu(h))
-            red1 += out.sum(0)
+            red1.index_add_(0, bidx, out)
         elif epi == EPI_BIAS_STATS:
             red0.index_add_(0, bidx, out)
             red1.index_add_(0, bidx, out * out)
@@ -121,7 +121,9 @@ def grn_scale(colsq, gamma, eps=1e-6):
 
 
 @torch.enable_grad()
-def grn_bwd_stats(colsq, P, gamma, dgamma, eps=1e-6):
+def grn_bwd_stats(colsq, P, gamma, dgamma, eps=1e-6, Sb=None, dbeta=None):
+    if Sb is not None:
+        dbeta += Sb.sum(0)
     # autograd through n = g / (mean g + eps) with upstream dn = gamma * P
     gq = colsq.sqrt().clone().requires_grad_(True)
     n = gq / (gq.mean(1, keepdim=True) + eps)

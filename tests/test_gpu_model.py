@@ -65,16 +65,17 @@ def test_forward_backward_vs_oracle_fp32(tag, kw, bhw, mode):
     out = mine(x.cuda())
     assert relerr(out, y) <= 1e-3
     out.backward(dout.cuda())
-    worst = 0.0
+    worst, worst_name = 0.0, ""
     for (name, pr), pm in zip(ref.named_parameters(), mine.parameters()):
         assert pm.grad is not None, name
         if name == "head.conv.0.conv.bias":  # exactly-zero gradient (bias in front of InstanceNorm)
             assert pm.grad.abs().max().item() < 1e-3
             continue
         e = relerr(pm.grad, pr.grad)
-        worst = max(worst, e)
+        if e > worst:
+            worst, worst_name = e, name
         assert e <= 2e-3, (name, e)
-    print(tag, mode, "worst relative gradient error", worst)
+    print(tag, mode, "worst relative gradient error", worst, worst_name)
 
 
 def test_forward_backward_bf16_tracks_fp32():
@@ -116,7 +117,8 @@ def test_input_validation_and_state_dict_roundtrip():
     m2 = UNeXt2(in_channels=1, out_channels=2, backbone="convnextv2_atto").cuda()
     m2.load_state_dict(sd, strict=True)
     with torch.no_grad():
-        assert torch.equal(m2(x), y0)
+        # reductions use fp32 atomics (order varies run to run) → agreement to round-off, not bitwise
+        torch.testing.assert_close(m2(x), y0, rtol=1e-4, atol=1e-5)
     assert y0.shape == (1, 2, 5, 64, 64)
 
 
@@ -180,7 +182,7 @@ def test_training_steps_reduce_loss_and_match_torch_adamw():
     from viscy_amd.unext2 import UNeXt2
 
     torch.manual_seed(0)
-    kw = dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_atto", head_pool=True)
+    kw = dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_femto", head_pool=True)
     m = UNeXt2(**kw).cuda()
     m.compute_dtype = torch.bfloat16
     m.grad_mode = "flat"

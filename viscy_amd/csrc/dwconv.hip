@@ -74,26 +74,32 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, c
 }
 
 // weight gradient: dw[ky*7+kx][c] += sum_{b,y,x} dy[b,y,x,c] * x[b,y+ky-3,x+kx-3,c];  db[c] += sum dy
-// thread = (channel vector, chunk of (b,y) rows) for the block's ky (blockIdx.y); loops x with 7 x VN
-// register accumulators.  A block is [256/NCVB row-chunk slots][NCVB channel vectors]; slots are
-// reduced through LDS atomics so that each block issues one global atomic per (tap, channel).
-template <typename T>
+// thread = (channel vector, x-segment of SEG pixels, row slot) for the block's ky (blockIdx.y): per (b,y)
+// row it loads SEG dy vectors and the SEG+6 input vectors of row y+ky-3 once and feeds 7 taps from
+// registers (sliding window), looping over the rows dealt to its slot.  Block partials are combined
+// in LDS and written to one workspace row per block; a second tiny kernel (reduce_rows) folds the
+// workspace into dw / db — no same-address atomic storms (they serialise at ~0.2 us each).
+template <typename T, int SEG>
 __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                            float* __restrict__ dw, float* __restrict__ db, int B,
-                                                            int H, int W, int C, int rows_per_chunk, int ncvb,
-                                                            int ncvblocks) {
+                                                            float* __restrict__ ws, int B, int H, int W, int C, int ncvb,
+                                                            int nseg, int nrowslots) {
   constexpr int VN = VT<T>::N;
-  __shared__ float red[8 * VN * 64];  // [(7 taps + bias)][VN][ncvb <= 64]
+  extern __shared__ float red[];  // [8][VN][ncvb*nseg_b] → reduced to [8][VN][ncvb]
   const int ncv = C / VN;
   const int nrows = B * H;
   const int ky = blockIdx.y;
-  const int cvl = threadIdx.x % ncvb, slot = threadIdx.x / ncvb, nslot = 256 / ncvb;
-  const int cvblock = blockIdx.x % ncvblocks, chunkblock = blockIdx.x / ncvblocks;
+  // thread → (cvl, seg, rslot): cvl fastest (coalescing along channels)
+  const int lanes_per_row = ncvb * nseg;          // threads covering one image row (all x-segments)
+  const int cvl = threadIdx.x % ncvb;
+  const int seg = (threadIdx.x / ncvb) % nseg;
+  const int rs_in_block = threadIdx.x / lanes_per_row;
+  const int rs_per_block = 256 / lanes_per_row;
+  const int ncvblocks = (ncv + ncvb - 1) / ncvb;
+  const int cvblock = blockIdx.x % ncvblocks, rblock = blockIdx.x / ncvblocks;
   const int cv = cvblock * ncvb + cvl;
-  const int chunk = chunkblock * nslot + slot;
-  for (int i = threadIdx.x; i < 8 * VN * ncvb; i += 256) red[i] = 0.f;
-  __syncthreads();
+  const int rslot = rblock * rs_per_block + rs_in_block;
   const int c0 = cv * VN;
+  const int x0 = seg * SEG;
   float acc[7][VN], bsum[VN];
 #pragma unroll
   for (int k = 0; k < 7; ++k)
@@ -101,37 +107,55 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
     for (int j = 0; j < VN; ++j) acc[k][j] = 0.f;
 #pragma unroll
   for (int j = 0; j < VN; ++j) bsum[j] = 0.f;
-  const int rbeg = chunk * rows_per_chunk;
-  const int rend = rbeg + rows_per_chunk < nrows ? rbeg + rows_per_chunk : nrows;
-  if (cv < ncv) {
-    for (int rr = rbeg; rr < rend; ++rr) {
+  const bool active = cv < ncv && rs_in_block < rs_per_block && rslot < nrowslots && x0 < W;
+  if (active) {
+    for (int rr = rslot; rr < nrows; rr += nrowslots) {
       const int b = rr / H, y = rr - b * H;
       const int yy = y + ky - 3;
       const bool row_ok = yy >= 0 && yy < H;
       if (!row_ok && ky != 3) continue;
       const T* dyr = dy + ((size_t)rr * W) * C + c0;
       const T* xr = x + (((size_t)b * H + (row_ok ? yy : 0)) * W) * C + c0;
-      for (int xx = 0; xx < W; ++xx) {
-        float d[VN];
-        unpack<T>(ldvec<T>(dyr + (size_t)xx * C), d);
-        if (ky == 3) {
+      float d[SEG][VN];
 #pragma unroll
-          for (int j = 0; j < VN; ++j) bsum[j] += d[j];
+      for (int i = 0; i < SEG; ++i) {
+        if (x0 + i < W) {
+          unpack<T>(ldvec<T>(dyr + (size_t)(x0 + i) * C), d[i]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < VN; ++j) d[i][j] = 0.f;
         }
-        if (row_ok) {
+      }
+      if (ky == 3) {
+#pragma unroll
+        for (int i = 0; i < SEG; ++i)
+#pragma unroll
+          for (int j = 0; j < VN; ++j) bsum[j] += d[i][j];
+      }
+      if (row_ok) {
+#pragma unroll
+        for (int i = 0; i < SEG + 6; ++i) {
+          const int xs = x0 + i - 3;
+          if (xs < 0 || xs >= W) continue;
+          float v[VN];
+          unpack<T>(ldvec<T>(xr + (size_t)xs * C), v);
 #pragma unroll
           for (int kx = 0; kx < 7; ++kx) {
-            const int xs = xx + kx - 3;
-            if (xs >= 0 && xs < W) {
-              float v[VN];
-              unpack<T>(ldvec<T>(xr + (size_t)xs * C), v);
+            const int o = i - kx;  // output pixel (within the segment) this input feeds through tap kx
+            if (o >= 0 && o < SEG) {
 #pragma unroll
-              for (int j = 0; j < VN; ++j) acc[kx][j] = fmaf(d[j], v[j], acc[kx][j]);
+              for (int j = 0; j < VN; ++j) acc[kx][j] = fmaf(d[o][j], v[j], acc[kx][j]);
             }
           }
         }
       }
     }
+  }
+  // block reduction over (seg, rslot) → [8][VN][ncvb]
+  const int nred = 8 * VN * ncvb;
+  for (int i = threadIdx.x; i < nred; i += 256) red[i] = 0.f;
+  __syncthreads();
+  if (active) {
 #pragma unroll
     for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
@@ -142,15 +166,42 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 8 * VN * ncvb; i += 256) {
+  // workspace row layout: [50][C] (taps 0..48, then bias at row 49); this block owns rows ky*7..ky*7+6 (+49 if ky==3)
+  float* wrow = ws + (size_t)rblock * 50 * C;
+  for (int i = threadIdx.x; i < nred; i += 256) {
     const int l = i % ncvb, kj = i / ncvb;
     const int j = kj % VN, kx = kj / VN;
     const int c = (cvblock * ncvb + l) * VN + j;
     if (c >= C) continue;
     if (kx < 7)
-      atomicAdd(dw + (size_t)(ky * 7 + kx) * C + c, red[i]);
-    else if (ky == 3 && db)
-      atomicAdd(db + c, red[i]);
+      wrow[(size_t)(ky * 7 + kx) * C + c] = red[i];
+    else if (ky == 3)
+      wrow[(size_t)49 * C + c] = red[i];
+  }
+}
+
+// out[n] += sum_r ws[r][n]   (same structure as norm.hip's reduce_rows; kept local to this TU)
+__global__ __launch_bounds__(256) void dw_reduce_rows_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                             float* __restrict__ db, int R, int C) {
+  __shared__ float red[4][64];
+  const int N = 50 * C;
+  const int nl = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + nl;
+  const int r0 = blockIdx.y * 64;
+  const int r1 = r0 + 64 < R ? r0 + 64 : R;
+  float a = 0.f;
+  if (n < N) {
+#pragma unroll 4
+    for (int r = r0 + slot; r < r1; r += 4) a += ws[(size_t)r * N + n];
+  }
+  red[slot][nl] = a;
+  __syncthreads();
+  if (slot == 0 && n < N) {
+    const float v = red[0][nl] + red[1][nl] + red[2][nl] + red[3][nl];
+    if (n < 49 * C)
+      atomicAdd(dw + n, v);
+    else if (db)
+      atomicAdd(db + (n - 49 * C), v);
   }
 }
 
@@ -188,29 +239,44 @@ extern "C" int32_t vsx_dwconv7_bwd_data(const void* dy, const float* w, const vo
   return dtype == VSX_BF16 ? dw_launch<bf16_t>(dy, w, nullptr, add, dx, B, H, W, C, true, (hipStream_t)stream)
                            : dw_launch<float>(dy, w, nullptr, add, dx, B, H, W, C, true, (hipStream_t)stream);
 }
-/* weight gradient, accumulated (atomicAdd) into dw[49][C] and db[C] (fp32) */
-extern "C" int32_t vsx_dwconv7_bwd_weight(const void* dy, const void* x, float* dw, float* db, int32_t B, int32_t H,
-                                          int32_t W, int32_t C, int32_t dtype, vsx_stream_t stream) {
+/* weight gradient, accumulated into dw[49][C] and db[C] (fp32).  ws: caller-provided fp32 workspace of
+ * ws_rows * 50 * C floats (one row of partials per block, folded by a second kernel). */
+extern "C" int32_t vsx_dwconv7_bwd_weight(const void* dy, const void* x, float* dw, float* db, float* ws, int32_t ws_rows,
+                                          int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                          vsx_stream_t stream) {
   int vn = dtype == VSX_BF16 ? 8 : 4;
-  VSX_CHECK(dy && x && dw && B > 0 && H > 0 && W > 0 && C > 0 && C % vn == 0, "vsx_dwconv7_bwd_weight: bad arguments");
+  VSX_CHECK(dy && x && dw && ws && ws_rows > 0 && B > 0 && H > 0 && W > 0 && C > 0 && C % vn == 0,
+            "vsx_dwconv7_bwd_weight: bad arguments");
+  constexpr int SEG = 8;
   int ncv = C / vn;
   int nrows = B * H;
+  int nseg = vsx_cdiv(W, SEG);
   int ncvb = 1;
-  while (ncvb < ncv && ncvb < 64) ncvb <<= 1;
+  while (ncvb < ncv && ncvb * nseg < 256 && ncvb < 64) ncvb <<= 1;   // channel-vector lanes per row segment
+  while (ncvb * nseg > 256 && ncvb > 1) ncvb >>= 1;
+  VSX_CHECK(ncvb * nseg <= 256, "vsx_dwconv7_bwd_weight: image width %d too large for one block row", W);
   int ncvblocks = vsx_cdiv(ncv, ncvb);
-  int nslot = 256 / ncvb;
-  // aim for ~2048 blocks (x 7 ky); each chunk is a set of whole (b, y) rows
-  int want_chunks = vsx_cdiv(2048, 7 * ncvblocks) * nslot;
-  if (want_chunks > nrows) want_chunks = nrows;
-  int rpc = vsx_cdiv(nrows, want_chunks);
-  int nchunk = vsx_cdiv(nrows, rpc);
-  dim3 grid(ncvblocks * vsx_cdiv(nchunk, nslot), 7);
+  int rs_per_block = 256 / (ncvb * nseg);
+  // row slots: enough threads to fill the chip (~256k threads over the 7 ky planes), >= 2 rows per slot
+  long want_threads = 262144 / 7;
+  int rblocks = vsx_cdiv(want_threads, 256L * ncvblocks);
+  if (rblocks > vsx_cdiv(nrows, 2 * rs_per_block)) rblocks = vsx_cdiv(nrows, 2 * rs_per_block);
+  if (rblocks > ws_rows) rblocks = ws_rows;
+  if (rblocks < 1) rblocks = 1;
+  int nrowslots = rblocks * rs_per_block;
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(ws, 0, (size_t)rblocks * 50 * C * sizeof(float), st);
+  dim3 grid(ncvblocks * rblocks, 7);
+  size_t sh = (size_t)8 * vn * ncvb * sizeof(float);
   if (dtype == VSX_BF16)
-    hipLaunchKernelGGL(dwconv7_wgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                       (const bf16_t*)x, dw, db, B, H, W, C, rpc, ncvb, ncvblocks);
+    hipLaunchKernelGGL((dwconv7_wgrad_kernel<bf16_t, SEG>), grid, dim3(256), sh, st, (const bf16_t*)dy, (const bf16_t*)x, ws,
+                       B, H, W, C, ncvb, nseg, nrowslots);
   else
-    hipLaunchKernelGGL(dwconv7_wgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy,
-                       (const float*)x, dw, db, B, H, W, C, rpc, ncvb, ncvblocks);
+    hipLaunchKernelGGL((dwconv7_wgrad_kernel<float, SEG>), grid, dim3(256), sh, st, (const float*)dy, (const float*)x, ws, B,
+                       H, W, C, ncvb, nseg, nrowslots);
+  VSX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dw_reduce_rows_kernel, dim3(vsx_cdiv(50 * C, 64), vsx_cdiv(rblocks, 64)), dim3(256), 0, st, ws, dw, db,
+                     rblocks, C);
   VSX_LAUNCH_CHECK();
   return 0;
 }

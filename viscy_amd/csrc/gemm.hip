@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
   constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
   constexpr int MAIN_BYTES = 2 * (BM + BN) * RS;
   constexpr int CS_LD = BN + 4;
-  constexpr int EPI_BYTES = BM * CS_LD * 4 + 2 * BN * 4;
+  constexpr int MAXBT = 8;  // batch samples one tile may span on the LDS reduction path
+  constexpr int EPI_BYTES = BM * CS_LD * 4 + 2 * MAXBT * BN * 4;
   constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   constexpr int MK = Frag<T>::MK;
   typedef typename VT<T>::vec vec;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
 
   // ---- epilogue: accumulators → LDS (fp32) → row-contiguous vectors
   float* Cs = reinterpret_cast<float*>(smem);
-  float* red = Cs + BM * CS_LD;  // [2][BN]
+  float* red = Cs + BM * CS_LD;  // [2][MAXBT][BN]
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         Cs[((wm * FM + i) * 16 + kq * 4 + r) * CS_LD + (wn * FN + j) * 16 + p16] = acc[i][j][r];
-  if (tid < 2 * BN) red[tid] = 0.f;
+  for (int i = tid; i < 2 * MAXBT * BN; i += 256) red[i] = 0.f;
   __syncthreads();
 
   constexpr int NCH = BN / VN;        // column chunks per row
@@ -254,7 +255,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
   const int mlast = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
   const int hwb = p.hw > 0 ? p.hw : p.M;
   const int b_first = m0 / hwb;
-  const bool uniform = reduce && (b_first == mlast / hwb);
+  const int nbt = mlast / hwb - b_first + 1;       // samples covered by this tile
+  const bool uniform = reduce && nbt <= MAXBT;     // LDS reduction path (else: direct global atomics)
+  int bcur = -1;
   float r0[VN], r1[VN];
 #pragma unroll
   for (int j = 0; j < VN; ++j) { r0[j] = 0.f; r1[j] = 0.f; }
@@ -323,31 +326,43 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
       }
       stvec<T>(dst, pack<T>(v));
       if (reduce && !uniform) {
-        // tile spans several batch samples (tiny feature maps): direct atomics
+        // tile spans more than MAXBT batch samples (very small feature maps): direct atomics
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
           atomicAdd(p.red0 + (size_t)b * p.N + n + j, r0[j]);
           if (epi == VSX_EPI_BIAS_STATS) atomicAdd(p.red1 + (size_t)b * p.N + n + j, r1[j]);
-          if (epi == VSX_EPI_DZ) atomicAdd(p.red1 + n + j, r1[j]);
+          if (epi == VSX_EPI_DZ) atomicAdd(p.red1 + (size_t)b * p.N + n + j, r1[j]);
           r0[j] = 0.f;
           r1[j] = 0.f;
+        }
+      } else if (reduce) {
+        // rows of one sample are contiguous: keep accumulating in registers while the sample is
+        // unchanged, flush to the sample's LDS slot when the next row belongs to another sample
+        const int rnext = row + RSTEP;
+        const bool flush = rnext >= BM || m0 + rnext >= p.M || (m0 + rnext) / hwb != b;
+        if (flush) {
+          float* rs = red + (size_t)(b - b_first) * BN + cc * VN;
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            atomicAdd(rs + j, r0[j]);
+            if (epi != VSX_EPI_BIAS_GELU_SQ) atomicAdd(rs + MAXBT * BN + j, r1[j]);
+            r0[j] = 0.f;
+            r1[j] = 0.f;
+          }
         }
       }
     }
   }
+  (void)bcur;
   if (uniform) {
-    if (ncol_ok) {
-#pragma unroll
-      for (int j = 0; j < VN; ++j) {
-        atomicAdd(red + cc * VN + j, r0[j]);
-        if (epi != VSX_EPI_BIAS_GELU_SQ) atomicAdd(red + BN + cc * VN + j, r1[j]);
-      }
-    }
     __syncthreads();
-    if (tid < BN && n0 + tid < p.N) {
-      atomicAdd(p.red0 + (size_t)b_first * p.N + n0 + tid, red[tid]);
-      if (epi == VSX_EPI_BIAS_STATS) atomicAdd(p.red1 + (size_t)b_first * p.N + n0 + tid, red[BN + tid]);
-      if (epi == VSX_EPI_DZ) atomicAdd(p.red1 + n0 + tid, red[BN + tid]);
+    for (int i = tid; i < nbt * BN; i += 256) {
+      const int bs = i / BN, c = i - bs * BN;
+      if (n0 + c < p.N) {
+        atomicAdd(p.red0 + (size_t)(b_first + bs) * p.N + n0 + c, red[i]);
+        if (epi == VSX_EPI_BIAS_STATS || epi == VSX_EPI_DZ)
+          atomicAdd(p.red1 + (size_t)(b_first + bs) * p.N + n0 + c, red[MAXBT * BN + i]);
+      }
     }
   }
 }
@@ -488,9 +503,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
   const int tiles_k = (p.K + BT - 1) / BT;
   const int tile_k = blockIdx.x % tiles_k, tile_n = blockIdx.x / tiles_k;
   const int n0 = tile_n * BT, k0 = tile_k * BT;
-  const int mbeg = blockIdx.y * rows_per_block;
-  const int mend = (mbeg + rows_per_block < p.M) ? mbeg + rows_per_block : p.M;
-  if (mbeg >= mend) return;
+  // the 32-row contraction steps are dealt round-robin to the gridDim.y splits: at any instant the
+  // splits stream one contiguous window of X / Y (blocked ranges would camp on a few HBM channels)
+  (void)rows_per_block;
+  const int mend = p.M;
+  const int total_steps = (p.M + BMS - 1) / BMS;
+  const int nsplit = gridDim.y;
+  if ((int)blockIdx.y >= total_steps) return;
 
   const T* X = reinterpret_cast<const T*>(p.B);
   const int x_coff = p.b_off[z];
@@ -542,12 +561,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
   float csum = 0.f;  // bias-gradient partial for column n0 + tid (tile_k == 0 blocks only)
   const bool do_colsum = p.colsum != nullptr && tile_k == 0 && tid < BT;
 
-  const int nsteps = (mend - mbeg + BMS - 1) / BMS;
-  load_tiles(mbeg);
+  const int nsteps = (total_steps - (int)blockIdx.y + nsplit - 1) / nsplit;
+  load_tiles((int)blockIdx.y * BMS);
   store_tiles(0);
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) load_tiles(mbeg + (st + 1) * BMS);
+    if (st + 1 < nsteps) load_tiles(((st + 1) * nsplit + (int)blockIdx.y) * BMS);
     const char* Xs = smem + (st & 1) * 2 * TILE_BYTES;
     const char* Ys = Xs + TILE_BYTES;
 #pragma unroll
@@ -588,13 +607,17 @@ template <typename T, int BT, bool TR>
 static int launch_tn(const VsxGemm* p, hipStream_t s) {
   int tiles = vsx_cdiv(p->N, BT) * vsx_cdiv(p->K, BT);
   int nz = p->nz > 0 ? p->nz : 1;
-  // split the pixel (contraction) axis so that the launch has enough workgroups to fill 256 CUs
-  int want = vsx_cdiv(1024, tiles * nz);
+  // split the pixel (contraction) axis so that the launch fills 256 CUs, but keep the number of
+  // same-address atomics (= splits) small: they serialise at ~0.2 us each
+  int want = vsx_cdiv(768, tiles * nz);
   int max_splits = vsx_cdiv(p->M, 256);
   int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
-  if (splits > 65535) splits = 65535;
-  int rpb = vsx_cdiv(vsx_cdiv(p->M, splits), 32) * 32;
-  splits = vsx_cdiv(p->M, rpb);
+  // few tiles (skinny weight matrices, e.g. the head's 8x32): the atomics spread over few addresses anyway,
+  // parallelism matters more
+  int cap = tiles * nz <= 4 ? 384 : (tiles * nz <= 16 ? 96 : 48);
+  if (splits > cap) splits = cap;
+  int rpb = 0;
+  if (splits > vsx_cdiv(p->M, 32)) splits = vsx_cdiv(p->M, 32);
   dim3 grid(tiles, splits, nz);
   hipLaunchKernelGGL((gemm_tn_kernel<T, BT, TR>), grid, dim3(256), 0, s, *p, rpb);
   VSX_LAUNCH_CHECK();
@@ -605,7 +628,8 @@ extern "C" int32_t vsx_gemm_tn(const VsxGemm* p, int32_t dtype, vsx_stream_t str
   if (int e = check_common(p, dtype, "vsx_gemm_tn")) return e;
   VSX_CHECK(p->epi == VSX_EPI_NONE && p->c_mode == VSX_A_ROWS, "vsx_gemm_tn: no epilogue / scatter modes");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  bool small = (long)p->N * p->K <= 128 * 128 || p->M <= 8192;
+  // 64x64 tiles unless the 128x128 grid alone already yields >= 24 tiles
+  bool small = (long)vsx_cdiv(p->N, 128) * vsx_cdiv(p->K, 128) < 24;
   if (dtype == VSX_BF16) {
     if (g_vsx_tn_tr) return small ? launch_tn<bf16_t, 64, true>(p, s) : launch_tn<bf16_t, 128, true>(p, s);
     return small ? launch_tn<bf16_t, 64, false>(p, s) : launch_tn<bf16_t, 128, false>(p, s);

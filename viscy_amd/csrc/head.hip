@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
   _Pragma("unroll") for (int c = 0; c < CMID; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
   float da = 0.f;
   for (int it = 0; it < vox_per_thread; ++it) {
-    const int vox = (blockIdx.x * vox_per_thread + it) * 256 + threadIdx.x;
+    const int vox = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
     if (vox >= nvox) break;
     const int z = vox % d.Z;
     const int px = vox / d.Z;

@@ -41,9 +41,8 @@ __global__ __launch_bounds__(256) void loss_pool_kernel(const float* __restrict_
   const int Ho = H / 2, Wo = W / 2;
   const int Hc = (H + 1) / 2, Wc = (W + 1) / 2;
   const long total = (long)planes * Hc * Wc;
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   float mx = -INFINITY, a1 = 0.f, a2 = 0.f;
-  if (gid < total) {
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
     const int xq = (int)(gid % Wc);
     const long r = gid / Wc;
     const int yq = (int)(r % Hc);
@@ -314,7 +313,9 @@ extern "C" int32_t vsx_loss_pool(const float* P, const float* T, float* Po, floa
   VSX_CHECK(P && T && tmax && planes > 0 && H > 0 && W > 0, "vsx_loss_pool: bad arguments");
   VSX_CHECK((Po == nullptr) == (To == nullptr) && (l1sum == nullptr) == (l2sum == nullptr), "vsx_loss_pool: pointer pairs");
   long total = (long)planes * ((H + 1) / 2) * ((W + 1) / 2);
-  hipLaunchKernelGGL(loss_pool_kernel, dim3(vsx_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, P, T, Po, To, tmax,
+  int nblk = vsx_cdiv(total, 256);
+  if (nblk > 2048) nblk = 2048;  // grid-stride: bounds the same-address atomics (max / L1 / L2 sums) to 2048 per launch
+  hipLaunchKernelGGL(loss_pool_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, P, T, Po, To, tmax,
                      l1sum, l2sum, planes, H, W);
   VSX_LAUNCH_CHECK();
   return 0;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   }
   for (int it = 0; it < iters; ++it) {
-    const int row = (blockIdx.x * iters + it) * RPI + rslot;
+    const int row = (it * gridDim.x + blockIdx.x) * RPI + rslot;  // interleaved: the grid sweeps a contiguous window
     if (row >= rows) break;
     const float mu = mean ? mean[row] : 0.f;
     const float rs = rstd[row];
@@ -170,7 +170,7 @@ static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float*
     hipLaunchKernelGGL((ln_fwd_kernel<T, G, CPL>), dim3(vsx_cdiv(rows, RPI)), dim3(256), 0, s, (const T*)a0, (T*)out,
                        mean, rstd, gamma, beta, rows, C, eps);
   } else {
-    int iters = vsx_cdiv(rows, RPI * 2048);
+    int iters = vsx_cdiv(rows, RPI * 512);  // <= 512 blocks → <= 512 same-address atomics on dgamma / dbeta
     if (iters < 1) iters = 1;
     int grid = vsx_cdiv(rows, RPI * iters);
     size_t sh = dgamma ? 2 * (size_t)C * sizeof(float) : 0;
@@ -248,8 +248,10 @@ __global__ __launch_bounds__(256) void grn_scale_kernel(const float* __restrict_
 
 // backward of the statistics path: P[b,n] = sum_hw dz * g_act ;  t[b,n] multiplies g_act in dG = dz*s + g_act*t
 __global__ __launch_bounds__(256) void grn_bwd_stats_kernel(const float* __restrict__ colsq, const float* __restrict__ P,
+                                                            const float* __restrict__ Sb,
                                                             const float* __restrict__ gamma, float* __restrict__ t,
-                                                            float* __restrict__ dgamma, int N, float eps) {
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int N, float eps) {
   __shared__ float part[2][4];
   const int b = blockIdx.x;
   float a0 = 0.f, a1 = 0.f;
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(256) void grn_bwd_stats_kernel(const float* __restr
     float dgv = dn * inv - sdg * inv * inv / (float)N;
     t[(size_t)b * N + n] = g > 0.f ? dgv / g : 0.f;
     atomicAdd(dgamma + n, pn * g * inv);
+    if (Sb) atomicAdd(dbeta + n, Sb[(size_t)b * N + n]);  // GRN beta gradient = Σ_b Σ_hw dz (nb atomics per address)
   }
 }
 
@@ -283,76 +286,136 @@ extern "C" int32_t vsx_grn_scale(const float* colsq, const float* gamma, float* 
   VSX_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int32_t vsx_grn_bwd_stats(const float* colsq, const float* P, const float* gamma, float* t, float* dgamma,
-                                     int32_t nb, int32_t N, float eps, vsx_stream_t stream) {
+extern "C" int32_t vsx_grn_bwd_stats(const float* colsq, const float* P, const float* Sb, const float* gamma, float* t,
+                                     float* dgamma, float* dbeta, int32_t nb, int32_t N, float eps,
+                                     vsx_stream_t stream) {
   VSX_CHECK(colsq && P && gamma && t && dgamma && nb > 0 && N > 0, "vsx_grn_bwd_stats: bad arguments");
-  hipLaunchKernelGGL(grn_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, colsq, P, gamma, t, dgamma, N,
-                     eps);
+  VSX_CHECK((Sb == nullptr) == (dbeta == nullptr), "vsx_grn_bwd_stats: Sb and dbeta come together");
+  hipLaunchKernelGGL(grn_bwd_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, colsq, P, Sb, gamma, t, dgamma,
+                     dbeta, N, eps);
   VSX_LAUNCH_CHECK();
   return 0;
 }
 
 // ------------------------------------------------------------------ GRN + GELU backward (pass 2)
-// dh = (dz * s[b,n] + gelu(h) * t[b,n]) * gelu'(h), written over dz; colsum[n] += dh
+// dh = (dz * s[b,n] + gelu(h) * t[b,n]) * gelu'(h), written over dz; colsum[n] += Σ_m dh
+// Block = [256/tpr row slots][tpr column chunks]; every thread streams its column chunk down the
+// rows it is dealt (16-byte loads, lanes along the contiguous channel axis, two rows in flight).
+// Same-address global atomics serialise at ~0.2 us each on this chip, so the column sums go
+// block → LDS → one workspace row per block → a second tiny kernel, never thousands of atomics
+// onto one address.
 template <typename T>
 __global__ __launch_bounds__(256) void grn_gelu_bwd_kernel(T* __restrict__ dz, const T* __restrict__ h,
                                                            const float* __restrict__ s, const float* __restrict__ t,
-                                                           float* __restrict__ colsum, int M, int N, int hw,
-                                                           int rows_per_block, int tpr) {
+                                                           float* __restrict__ ws, int M, int N, int hw, int tpr) {
   constexpr int VN = VT<T>::N;
-  // tpr threads (a power of two <= 256) span the column chunks of a row; 256/tpr row slots per block
-  const int cc = blockIdx.x * tpr + threadIdx.x % tpr;
+  __shared__ float red[256 * VN];
+  const int cl = threadIdx.x % tpr;
+  const int cc = blockIdx.x * tpr + cl;
   const int slot = threadIdx.x / tpr, nslot = 256 / tpr;
-  if (cc * VN >= N) return;
+  const bool active = cc * VN < N;
   const int n = cc * VN;
-  const int r0 = blockIdx.y * rows_per_block + slot;
-  const int rend = blockIdx.y * rows_per_block + rows_per_block;
-  const int r1 = rend < M ? rend : M;
   float cs[VN];
 #pragma unroll
   for (int j = 0; j < VN; ++j) cs[j] = 0.f;
-  int bcur = -1;
-  float sv[VN], tv[VN];
-  for (int m = r0; m < r1; m += nslot) {
-    const int b = m / hw;
-    if (b != bcur) {
-      bcur = b;
+  if (active) {
+    int bcur = -1;
+    float sv[VN], tv[VN];
+    const int mstep = gridDim.y * nslot;
+    for (int m0 = blockIdx.y * nslot + slot; m0 < M; m0 += 2 * mstep) {
+      const int m1 = m0 + mstep;
+      const bool has1 = m1 < M;
+      typename VT<T>::vec d0 = ldvec<T>(dz + (size_t)m0 * N + n), h0 = ldvec<T>(h + (size_t)m0 * N + n);
+      typename VT<T>::vec d1 = vzero<T>(), h1 = vzero<T>();
+      if (has1) {
+        d1 = ldvec<T>(dz + (size_t)m1 * N + n);
+        h1 = ldvec<T>(h + (size_t)m1 * N + n);
+      }
 #pragma unroll
-      for (int j = 0; j < VN; ++j) { sv[j] = s[(size_t)b * N + n + j]; tv[j] = t[(size_t)b * N + n + j]; }
-    }
-    float dv[VN], hv[VN], o[VN];
-    unpack<T>(ldvec<T>(dz + (size_t)m * N + n), dv);
-    unpack<T>(ldvec<T>(h + (size_t)m * N + n), hv);
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !has1) break;
+        const int m = u ? m1 : m0;
+        const int b = m / hw;
+        if (b != bcur) {
+          bcur = b;
 #pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      float dgv = dv[j] * sv[j] + gelu_f(hv[j]) * tv[j];
-      o[j] = round_to<T>(dgv * gelu_grad_f(hv[j]));
-      cs[j] += o[j];
+          for (int j = 0; j < VN; ++j) { sv[j] = s[(size_t)b * N + n + j]; tv[j] = t[(size_t)b * N + n + j]; }
+        }
+        float dv[VN], hv[VN], o[VN];
+        unpack<T>(u ? d1 : d0, dv);
+        unpack<T>(u ? h1 : h0, hv);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          float gv, dgv;
+          gelu_both(hv[j], gv, dgv);
+          o[j] = round_to<T>((dv[j] * sv[j] + gv * tv[j]) * dgv);
+          cs[j] += o[j];
+        }
+        stvec<T>(dz + (size_t)m * N + n, pack<T>(o));
+      }
     }
-    stvec<T>(dz + (size_t)m * N + n, pack<T>(o));
   }
 #pragma unroll
-  for (int j = 0; j < VN; ++j) atomicAdd(colsum + n + j, cs[j]);
+  for (int j = 0; j < VN; ++j) red[(slot * tpr + cl) * VN + j] = cs[j];
+  __syncthreads();
+  if (slot == 0 && active) {
+    float o[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      float a = 0.f;
+      for (int q = 0; q < nslot; ++q) a += red[(q * tpr + cl) * VN + j];
+      o[j] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < VN; ++j) ws[(size_t)blockIdx.y * N + n + j] = o[j];
+  }
 }
 
-extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, const float* t, float* colsum, int32_t M,
-                                    int32_t N, int32_t hw, int32_t dtype, vsx_stream_t stream) {
+// out[n] += Σ_r ws[r][n].  Block = 64 columns x 4 row slots over a 64-row slab (blockIdx.y); slots are
+// combined in LDS, slabs with <= R/64 atomics per address.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ ws, float* __restrict__ out, int R,
+                                                          int N) {
+  __shared__ float red[4][64];
+  const int nl = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + nl;
+  const int r0 = blockIdx.y * 64;
+  const int r1 = r0 + 64 < R ? r0 + 64 : R;
+  float a = 0.f;
+  if (n < N) {
+#pragma unroll 4
+    for (int r = r0 + slot; r < r1; r += 4) a += ws[(size_t)r * N + n];
+  }
+  red[slot][nl] = a;
+  __syncthreads();
+  if (slot == 0 && n < N) atomicAdd(out + n, red[0][nl] + red[1][nl] + red[2][nl] + red[3][nl]);
+}
+
+extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, const float* t, float* colsum, float* ws,
+                                    int32_t ws_rows, int32_t M, int32_t N, int32_t hw, int32_t dtype,
+                                    vsx_stream_t stream) {
   int vn = dtype == VSX_BF16 ? 8 : 4;
-  VSX_CHECK(dz && h && s && t && colsum && M > 0 && N > 0 && hw > 0 && N % vn == 0, "vsx_grn_gelu_bwd: bad arguments");
+  VSX_CHECK(dz && h && s && t && colsum && ws && ws_rows > 0 && M > 0 && N > 0 && hw > 0 && N % vn == 0,
+            "vsx_grn_gelu_bwd: bad arguments");
   int ncc = N / vn;
   int tpr = 1;
   while (tpr < ncc && tpr < 256) tpr <<= 1;
   int gx = vsx_cdiv(ncc, tpr);
-  int rpb = vsx_cdiv(M, vsx_cdiv(4096, gx));
-  int min_rows = 16 * (256 / tpr);
-  if (rpb < min_rows) rpb = min_rows;
-  dim3 grid(gx, vsx_cdiv(M, rpb));
+  int nslot = 256 / tpr;
+  int ngroups = vsx_cdiv(M, nslot);
+  int gy = vsx_cdiv(2048, gx);
+  if (gy > vsx_cdiv(ngroups, 4)) gy = vsx_cdiv(ngroups, 4);  // >= 4 rows per thread
+  if (gy > ws_rows) gy = ws_rows;
+  if (gy < 1) gy = 1;
+  dim3 grid(gx, gy);
+  hipStream_t st = (hipStream_t)stream;
   if (dtype == VSX_BF16)
-    hipLaunchKernelGGL(grn_gelu_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)dz,
-                       (const bf16_t*)h, s, t, colsum, M, N, hw, rpb, tpr);
+    hipLaunchKernelGGL(grn_gelu_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)dz, (const bf16_t*)h, s, t, ws, M, N,
+                       hw, tpr);
   else
-    hipLaunchKernelGGL(grn_gelu_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (float*)dz, (const float*)h,
-                       s, t, colsum, M, N, hw, rpb, tpr);
+    hipLaunchKernelGGL(grn_gelu_bwd_kernel<float>, grid, dim3(256), 0, st, (float*)dz, (const float*)h, s, t, ws, M, N, hw,
+                       tpr);
+  VSX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv(N, 64), vsx_cdiv(gy, 64)), dim3(256), 0, st, ws, colsum, gy, N);
   VSX_LAUNCH_CHECK();
   return 0;
 }

@@ -122,12 +122,38 @@ __device__ __forceinline__ void stvec(T* p, const typename VT<T>::vec& v) {
 }
 
 // ------------------------------------------------------------------ math
-// exact-erf GELU (nn.GELU default) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (nn.GELU default) and its derivative.  erf via Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, below fp32 round-off of the surrounding arithmetic): one v_rcp, one v_exp
+// and a 5-term Horner chain instead of the ~50-instruction branchy libm erff; exp(-x^2/2) is shared
+// between the erf tail and the Gaussian pdf of the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float e = __expf(-z * z);  // = exp(-x^2 / 2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));  // v_rcp_f32 (1 ulp), no IEEE division sequence
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erf_abs = 1.0f - p * t * e;
+  const float erf_v = copysignf(erf_abs, x);
+  cdf = 0.5f * (1.0f + erf_v);
+  pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
   return cdf + x * pdf;
+}
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  g = x * cdf;
+  dg = cdf + x * pdf;
 }
 
 // ------------------------------------------------------------------ wave helpers (wave64)

@@ -213,11 +213,11 @@ class Engine:
         o.gemm("tn", h, dout, g(blk.mlp.fc2.weight), M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
                grn_b=blk.mlp.grn.bias, hw=H * Wd, colsum=g(blk.mlp.fc2.bias))
         # fc2 data gradient dZ, with Σ dZ·gelu(h) (GRN statistics path) and Σ dZ (GRN beta gradient)
-        P = torch.zeros((B, 4 * C), dtype=torch.float32, device=dev)
+        PS = torch.zeros((2, B, 4 * C), dtype=torch.float32, device=dev)
         dz = torch.empty((M, 4 * C), dtype=dt, device=dev)
-        o.gemm("nt", dout, w.W2T, dz, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_DZ, aux=h, ldx=4 * C, red0=P,
-               red1=g(blk.mlp.grn.bias), hw=H * Wd)
-        t = o.grn_bwd_stats(colsq, P, blk.mlp.grn.weight, g(blk.mlp.grn.weight))
+        o.gemm("nt", dout, w.W2T, dz, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_DZ, aux=h, ldx=4 * C, red0=PS[0],
+               red1=PS[1], hw=H * Wd)
+        t = o.grn_bwd_stats(colsq, PS[0], blk.mlp.grn.weight, g(blk.mlp.grn.weight), Sb=PS[1], dbeta=g(blk.mlp.grn.bias))
         db1f = torch.zeros(4 * C, dtype=torch.float32, device=dev)
         o.grn_gelu_bwd(dz, h, s, t, db1f, M, 4 * C, H * Wd)  # dz now holds dH
         dxh = torch.empty((M, C), dtype=dt, device=dev)

@@ -18,6 +18,19 @@ from ._lib import check, lib, ptr, stream
 BETAS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
 
 
+_NPIX: dict = {}
+
+
+def _npix_cached(dims, C, dev):
+    """per-scale pixel counts of the SSIM maps, kept on the device (no H2D copy inside a captured step)"""
+    key = (dims, C, str(dev))
+    t = _NPIX.get(key)
+    if t is None:
+        t = torch.tensor([float(C * (h - 10) * (w - 10)) for (h, w) in dims] + [1.0] * (5 - len(dims)), dtype=torch.float32).to(dev)
+        _NPIX[key] = t
+    return t
+
+
 class _MixedLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, preds: Tensor, target: Tensor, a1: float, a2: float, a3: float):
@@ -55,8 +68,7 @@ class _MixedLossFn(torch.autograd.Function):
                 Ps.append(Po)
                 Ts.append(To)
                 dims.append((h // 2, w // 2))
-        npix = torch.tensor([C * (h - 10) * (w - 10) for (h, w) in dims] + [1.0] * (5 - len(dims)), dtype=torch.float32)
-        npix_d = npix.to(dev, non_blocking=True)
+        npix_d = _npix_cached(tuple(dims), C, dev)
         for sc in range(ns):
             h, w = dims[sc]
             check(l.vsx_ssim_scale_fwd(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc : sc + 1]), ptr(sum_ssim[sc * B : (sc + 1) * B]),

@@ -16,6 +16,18 @@ from . import _lib as L
 from ._lib import VsxGemm, check, dtype_code, lib, ptr, stream
 
 
+_WS: dict = {}
+
+
+def _workspace(dev, numel: int) -> Tensor:
+    """fp32 scratch the two-stage reductions write their per-block partials into (caller-owned, reused)."""
+    w = _WS.get(dev)
+    if w is None or w.numel() < numel:
+        w = torch.empty(numel, dtype=torch.float32, device=dev)
+        _WS[dev] = w
+    return w
+
+
 def _fill8(arr, vals: Sequence[int] | None):
     if vals:
         for i, v in enumerate(vals):
@@ -115,16 +127,20 @@ def grn_scale(colsq: Tensor, gamma: Tensor, eps: float = 1e-6) -> Tensor:
     return s
 
 
-def grn_bwd_stats(colsq: Tensor, P: Tensor, gamma: Tensor, dgamma: Tensor, eps: float = 1e-6) -> Tensor:
+def grn_bwd_stats(colsq: Tensor, P: Tensor, gamma: Tensor, dgamma: Tensor, eps: float = 1e-6, Sb: Tensor | None = None,
+                  dbeta: Tensor | None = None) -> Tensor:
+    """Sb [nb, N] = per-sample Σ_hw dz (EPI_DZ red1); dbeta[N] += Σ_b Sb."""
     t = torch.empty_like(colsq)
-    check(lib().vsx_grn_bwd_stats(ptr(colsq), ptr(P), ptr(gamma), ptr(t), ptr(dgamma), colsq.shape[0], colsq.shape[1],
-                                  eps, stream()), "grn_bwd_stats")
+    check(lib().vsx_grn_bwd_stats(ptr(colsq), ptr(P), ptr(Sb), ptr(gamma), ptr(t), ptr(dgamma), ptr(dbeta), colsq.shape[0],
+                                  colsq.shape[1], eps, stream()), "grn_bwd_stats")
     return t
 
 
 def grn_gelu_bwd(dz: Tensor, h: Tensor, s: Tensor, t: Tensor, colsum: Tensor, M: int, N: int, hw: int) -> None:
-    check(lib().vsx_grn_gelu_bwd(ptr(dz), ptr(h), ptr(s), ptr(t), ptr(colsum), M, N, hw, dtype_code(dz.dtype), stream()),
-          "grn_gelu_bwd")
+    rows = 1024
+    ws = _workspace(dz.device, rows * N)
+    check(lib().vsx_grn_gelu_bwd(ptr(dz), ptr(h), ptr(s), ptr(t), ptr(colsum), ptr(ws), rows, M, N, hw,
+                                 dtype_code(dz.dtype), stream()), "grn_gelu_bwd")
 
 
 def dwconv7_fwd(x: Tensor, w: Tensor, bias: Tensor | None, B: int, H: int, W: int, Cc: int) -> Tensor:
@@ -142,8 +158,10 @@ def dwconv7_bwd_data(dy: Tensor, w: Tensor, add: Tensor | None, B: int, H: int, 
 
 
 def dwconv7_bwd_weight(dy: Tensor, x: Tensor, dw: Tensor, db: Tensor | None, B: int, H: int, W: int, Cc: int) -> None:
-    check(lib().vsx_dwconv7_bwd_weight(ptr(dy), ptr(x), ptr(dw), ptr(db), B, H, W, Cc, dtype_code(dy.dtype), stream()),
-          "dwconv7_bwd_weight")
+    rows = 256
+    ws = _workspace(dy.device, rows * 50 * Cc)
+    check(lib().vsx_dwconv7_bwd_weight(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), rows, B, H, W, Cc, dtype_code(dy.dtype),
+                                       stream()), "dwconv7_bwd_weight")
 
 
 def stem_im2col(x: Tensor, kernel: tuple[int, int, int], dtype: torch.dtype, sub: Tensor | None = None,

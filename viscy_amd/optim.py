@@ -52,15 +52,23 @@ class FlatAdamW:
     def zero_grad(self) -> None:
         self.engine.flat_grad.zero_()
 
-    def step(self) -> None:
+    def host_prepare(self) -> None:
+        """host half of a step: advance the schedule and refresh the pinned hyper-parameter block"""
         lr = self.current_lr()
         self.t += 1
         b1, b2 = self.betas
         h = self._hyper_host
         h[0], h[1], h[2], h[3], h[4] = lr, b1, b2, self.eps, self.wd
         h[5], h[6], h[7] = 1 - b1**self.t, 1 - b2**self.t, self.grad_scale
-        self.hyper.copy_(h, non_blocking=True)
+
+    def device_step(self) -> None:
+        """device half (hipGraph-capturable): pinned → device copy of the 8 scalars + ONE fused AdamW launch"""
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
         self.ops.adamw(self.engine.flat, self.engine.flat_grad, self.m, self.v, self.hyper)
+
+    def step(self) -> None:
+        self.host_prepare()
+        self.device_step()
 
     def state_dict(self):
         return {"m": self.m, "v": self.v, "t": self.t}

@@ -1,0 +1,81 @@
+"""One training step of the hot path as a replayable HIP graph.
+
+Eager PyTorch issues ~700 kernel launches per UNeXt2 step through Python + ctypes; at the metric's
+small patch size (256x256) the launch gaps are a double-digit share of the step.  Every kernel of
+the path is launched on the caller's stream with caller-owned buffers (include/vsx.h), so the whole
+step — zero-grad, forward, MixedLoss, backward, AdamW — can be captured once into a hipGraph
+(``torch.cuda.CUDAGraph`` is the capture/replay plumbing) and replayed with ONE launch per step.
+Shapes must stay fixed between replays (the data loader's batch is copied into the static input
+buffers); hyper-parameters that change per step (lr schedule, Adam bias corrections) live in a
+pinned host buffer that is refreshed before every replay.
+
+With world_size > 1 the graph holds forward + backward; the RCCL all-reduce of the flat gradient
+buffer and the fused AdamW launch run eagerly behind it (collectives stay outside the capture).
+"""
+
+from __future__ import annotations
+
+import torch
+
+
+class TrainStep:
+    def __init__(self, model, criterion, optimizer, ddp=None, use_graph: bool = True):
+        self.model, self.crit, self.opt, self.ddp = model, criterion, optimizer, ddp
+        self.use_graph = use_graph
+        self.graph = None
+        self.x = self.t = self.loss = None
+        self.world = ddp.world if ddp is not None else 1
+
+    # ---- the captured body
+    def _fwd_bwd(self):
+        self.opt.zero_grad()
+        loss = self.crit(self.model(self.x), self.t)
+        loss.backward()
+        return loss.detach()
+
+    def _capture(self):
+        eng = self.model.engine()
+        hook = eng.on_bucket_ready
+        eng.on_bucket_ready = None  # collectives are issued outside the capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):  # warm-up on a side stream (allocator / workspace sizing)
+            for _ in range(2):
+                self.opt.host_prepare()
+                self._fwd_bwd()
+                if self.world == 1:
+                    self.opt.device_step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        self.opt.host_prepare()
+        with torch.cuda.graph(g):
+            self.loss = self._fwd_bwd()
+            if self.world == 1:
+                self.opt.device_step()
+        self.opt.t -= 1  # the capture pass records but does not execute: it is not an optimisation step
+        self.graph = g
+        eng.on_bucket_ready = hook
+
+    def __call__(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        if not self.use_graph:
+            self.x, self.t = x, t
+            loss = self._fwd_bwd()
+            if self.ddp is not None:
+                self.ddp.finish()
+            self.opt.step()
+            return loss
+        if self.graph is None:
+            self.x, self.t = x.clone(), t.clone()
+            self._capture()
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+            self.t.copy_(t, non_blocking=True)
+        self.opt.host_prepare()
+        self.graph.replay()
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(self.model.engine().flat_grad, op=dist.ReduceOp.SUM, group=self.ddp.pg)
+            self.opt.device_step()
+        return self.loss
