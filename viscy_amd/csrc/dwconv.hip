@@ -1,105 +1,145 @@
 // Depthwise 7x7 convolution, channels-last — forward, data gradient, weight gradient.
 // VALU stencil (no MFMA: there is no channel contraction).  Lanes run along the contiguous channel
-// axis (16-byte vectors), each thread owns a strip of TW output pixels along X and slides the
-// 7-tap window over a register-held input row, so every loaded vector feeds up to 7 FMAs per
-// channel; the 7x halo re-reads along Y are served by L1/L2.
+// axis (16-byte vectors); halo tiles are staged through LDS.
 #include "vsx_common.h"
 #include "../../include/vsx.h"
 
-template <typename T, int TW, bool FLIP>
+// ---------------------------------------------------------------------------------------------------
+// forward / data-gradient: LDS-tiled stencil.  A block owns TH x TW output pixels x (NCV*VN) channels:
+// the (TH+6) x (TW+6) input halo tile and the 49 x CB weights are staged in LDS with independent 16-byte
+// loads (all in flight at once — a register-only version serialised its dependent global loads),
+// then every thread slides a 7-tap window along a strip of K outputs reading 16-byte vectors from LDS
+// (pixel pitch padded by 16 B so the ds_read_b128 of a wave are bank-conflict free).
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int NCV, int TH, int TW, int K, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, const T* __restrict__ add,
                                                       T* __restrict__ y, int B, int H, int W, int C) {
   constexpr int VN = VT<T>::N;
-  const int ncv = C / VN;
-  const int nstrip = (W + TW - 1) / TW;
-  const long total = (long)B * H * nstrip * ncv;
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const int cv = (int)(gid % ncv);
-  long r = gid / ncv;
-  const int xs = (int)(r % nstrip);
-  r /= nstrip;
-  const int yy0 = (int)(r % H);
-  const int b = (int)(r / H);
-  const int x0 = xs * TW, c0 = cv * VN;
+  constexpr int CB = NCV * VN;
+  constexpr int PITCH = CB * (int)sizeof(T) + 16;        // bytes per staged pixel
+  constexpr int IH = TH + 6, IW = TW + 6;
+  constexpr int SPR = TW / K;                             // strips per tile row
+  static_assert(NCV * TH * SPR == 256, "thread mapping");
+  typedef typename VT<T>::vec vec;
+  __shared__ __attribute__((aligned(16))) char tile[IH * IW * PITCH];
+  __shared__ __attribute__((aligned(16))) float wl[49 * CB];
 
-  float acc[TW][VN];
-#pragma unroll
-  for (int o = 0; o < TW; ++o)
-#pragma unroll
-    for (int j = 0; j < VN; ++j) acc[o][j] = bias ? bias[c0 + j] : 0.f;
+  const int ncb = (C + CB - 1) / CB;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int cb = bid % ncb; bid /= ncb;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int c_base = cb * CB;
+  const int y0 = ty * TH, x0 = tx * TW;
 
+  // stage weights (tap-major [49][C] fp32) and the input halo tile
+  for (int i = threadIdx.x; i < 49 * CB; i += 256) {
+    const int t = i / CB, c = i - t * CB;
+    const int tap = FLIP ? 48 - t : t;
+    wl[i] = (c_base + c < C) ? w[(size_t)tap * C + c_base + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < IH * IW * NCV; i += 256) {
+    const int cv = i % NCV;
+    const int p = i / NCV;
+    const int ix = p % IW, iy = p / IW;
+    const int gy = y0 + iy - 3, gx = x0 + ix - 3;
+    vec v = vzero<T>();
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cv * VN < C)
+      v = ldvec<T>(x + (((size_t)b * H + gy) * W + gx) * C + c_base + cv * VN);
+    *reinterpret_cast<vec*>(tile + p * PITCH + cv * 16) = v;
+  }
+  __syncthreads();
+
+  const int cv = threadIdx.x % NCV;
+  const int pt = threadIdx.x / NCV;
+  const int sx = pt % SPR, sy = pt / SPR;   // strip (sx) of row sy
+  const int c0 = c_base + cv * VN;
+  float acc[K][VN];
+#pragma unroll
+  for (int o = 0; o < K; ++o)
+#pragma unroll
+    for (int j = 0; j < VN; ++j) acc[o][j] = (bias && c0 + j < C) ? bias[c0 + j] : 0.f;
+
+#pragma unroll 1
   for (int ky = 0; ky < 7; ++ky) {
-    const int yy = yy0 + ky - 3;
-    if (yy < 0 || yy >= H) continue;
     float wk[7][VN];
 #pragma unroll
-    for (int kx = 0; kx < 7; ++kx) {
-      const int tap = FLIP ? (6 - ky) * 7 + (6 - kx) : ky * 7 + kx;
+    for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
-      for (int j = 0; j < VN; ++j) wk[kx][j] = w[(size_t)tap * C + c0 + j];
-    }
-    const T* row = x + (((size_t)b * H + yy) * W) * C + c0;
+      for (int j = 0; j < VN; j += 4) {
+        float4 t = *reinterpret_cast<const float4*>(wl + (ky * 7 + kx) * CB + cv * VN + j);
+        wk[kx][j] = t.x; wk[kx][j + 1] = t.y; wk[kx][j + 2] = t.z; wk[kx][j + 3] = t.w;
+      }
+    const char* rowp = tile + ((sy + ky) * IW + sx * K) * PITCH + cv * 16;
 #pragma unroll
-    for (int i = 0; i < TW + 6; ++i) {
-      const int xx = x0 + i - 3;
-      if (xx < 0 || xx >= W) continue;
+    for (int i = 0; i < K + 6; ++i) {
       float v[VN];
-      unpack<T>(ldvec<T>(row + (size_t)xx * C), v);
+      unpack<T>(*reinterpret_cast<const vec*>(rowp + i * PITCH), v);
 #pragma unroll
       for (int kx = 0; kx < 7; ++kx) {
         const int o = i - kx;
-        if (o >= 0 && o < TW) {
+        if (o >= 0 && o < K) {
 #pragma unroll
           for (int j = 0; j < VN; ++j) acc[o][j] = fmaf(v[j], wk[kx][j], acc[o][j]);
         }
       }
     }
   }
+  const int gy = y0 + sy;
+  if (gy < H && c0 < C) {
 #pragma unroll
-  for (int o = 0; o < TW; ++o) {
-    const int xx = x0 + o;
-    if (xx < W) {
-      const size_t off = (((size_t)b * H + yy0) * W + xx) * C + c0;
-      if (add) {
-        float a[VN];
-        unpack<T>(ldvec<T>(add + off), a);
+    for (int o = 0; o < K; ++o) {
+      const int gx = x0 + sx * K + o;
+      if (gx < W) {
+        const size_t off = (((size_t)b * H + gy) * W + gx) * C + c0;
+        if (add) {
+          float a[VN];
+          unpack<T>(ldvec<T>(add + off), a);
 #pragma unroll
-        for (int j = 0; j < VN; ++j) acc[o][j] += a[j];
+          for (int j = 0; j < VN; ++j) acc[o][j] += a[j];
+        }
+        stvec<T>(y + off, pack<T>(acc[o]));
       }
-      stvec<T>(y + off, pack<T>(acc[o]));
     }
   }
 }
 
 // weight gradient: dw[ky*7+kx][c] += sum_{b,y,x} dy[b,y,x,c] * x[b,y+ky-3,x+kx-3,c];  db[c] += sum dy
-// thread = (channel vector, x-segment of SEG pixels, row slot) for the block's ky (blockIdx.y): per (b,y)
-// row it loads SEG dy vectors and the SEG+6 input vectors of row y+ky-3 once and feeds 7 taps from
-// registers (sliding window), looping over the rows dealt to its slot.  Block partials are combined
-// in LDS and written to one workspace row per block; a second tiny kernel (reduce_rows) folds the
-// workspace into dw / db — no same-address atomic storms (they serialise at ~0.2 us each).
-template <typename T, int SEG>
+// LDS-tiled like the forward: a block stages the (TH+6)x(TW+6) input halo tile and the TH x TW dy tile of
+// NCV*VN channels, thread = (channel vector, ky, tile row) walks its dy row once with a 7-vector sliding
+// window of the input row y+ky-3 held in registers (7 taps x VN accumulators).  A block loops over the
+// tiles dealt to it, then combines its threads in LDS and writes ONE workspace row of partials; a second
+// tiny kernel folds the workspace into dw / db (same-address global atomics serialise at ~0.2 us each).
+template <typename T, int NCV, int TH, int TW>
 __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                            float* __restrict__ ws, int B, int H, int W, int C, int ncvb,
-                                                            int nseg, int nrowslots) {
+                                                            float* __restrict__ ws, int B, int H, int W, int C,
+                                                            int ngroups) {
   constexpr int VN = VT<T>::N;
-  extern __shared__ float red[];  // [8][VN][ncvb*nseg_b] → reduced to [8][VN][ncvb]
-  const int ncv = C / VN;
-  const int nrows = B * H;
-  const int ky = blockIdx.y;
-  // thread → (cvl, seg, rslot): cvl fastest (coalescing along channels)
-  const int lanes_per_row = ncvb * nseg;          // threads covering one image row (all x-segments)
-  const int cvl = threadIdx.x % ncvb;
-  const int seg = (threadIdx.x / ncvb) % nseg;
-  const int rs_in_block = threadIdx.x / lanes_per_row;
-  const int rs_per_block = 256 / lanes_per_row;
-  const int ncvblocks = (ncv + ncvb - 1) / ncvb;
-  const int cvblock = blockIdx.x % ncvblocks, rblock = blockIdx.x / ncvblocks;
-  const int cv = cvblock * ncvb + cvl;
-  const int rslot = rblock * rs_per_block + rs_in_block;
-  const int c0 = cv * VN;
-  const int x0 = seg * SEG;
+  constexpr int CB = NCV * VN;
+  constexpr int PITCH = CB * (int)sizeof(T) + 16;
+  constexpr int IH = TH + 6, IW = TW + 6;
+  constexpr int XT_BYTES = IH * IW * PITCH, DT_BYTES = TH * TW * PITCH;
+  static_assert(NCV * 7 * TH <= 256, "thread mapping");
+  typedef typename VT<T>::vec vec;
+  constexpr int PART_BYTES = TH * 50 * CB * 4;
+  constexpr int SMEM_BYTES = XT_BYTES + DT_BYTES > PART_BYTES ? XT_BYTES + DT_BYTES : PART_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+  char* xt = smem;
+  char* dt = smem + XT_BYTES;
+
+  const int ncb = (C + CB - 1) / CB;
+  const int cb = blockIdx.x % ncb, group = blockIdx.x / ncb;
+  const int c_base = cb * CB;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int ntiles = B * tiles_y * tiles_x;
+
+  const int cv = threadIdx.x % NCV;
+  const int ky = (threadIdx.x / NCV) % 7;
+  const int row = threadIdx.x / (NCV * 7);
+  const bool worker = row < TH;
   float acc[7][VN], bsum[VN];
 #pragma unroll
   for (int k = 0; k < 7; ++k)
@@ -107,76 +147,89 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
     for (int j = 0; j < VN; ++j) acc[k][j] = 0.f;
 #pragma unroll
   for (int j = 0; j < VN; ++j) bsum[j] = 0.f;
-  const bool active = cv < ncv && rs_in_block < rs_per_block && rslot < nrowslots && x0 < W;
-  if (active) {
-    for (int rr = rslot; rr < nrows; rr += nrowslots) {
-      const int b = rr / H, y = rr - b * H;
-      const int yy = y + ky - 3;
-      const bool row_ok = yy >= 0 && yy < H;
-      if (!row_ok && ky != 3) continue;
-      const T* dyr = dy + ((size_t)rr * W) * C + c0;
-      const T* xr = x + (((size_t)b * H + (row_ok ? yy : 0)) * W) * C + c0;
-      float d[SEG][VN];
+
+  for (int tile = group; tile < ntiles; tile += ngroups) {
+    int t = tile;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    __syncthreads();  // previous tile fully consumed
+    for (int i = threadIdx.x; i < IH * IW * NCV; i += 256) {
+      const int c = i % NCV, p = i / NCV;
+      const int ix = p % IW, iy = p / IW;
+      const int gy = y0 + iy - 3, gx = x0 + ix - 3;
+      vec v = vzero<T>();
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + c * VN < C)
+        v = ldvec<T>(x + (((size_t)b * H + gy) * W + gx) * C + c_base + c * VN);
+      *reinterpret_cast<vec*>(xt + p * PITCH + c * 16) = v;
+    }
+    for (int i = threadIdx.x; i < TH * TW * NCV; i += 256) {
+      const int c = i % NCV, p = i / NCV;
+      const int ix = p % TW, iy = p / TW;
+      const int gy = y0 + iy, gx = x0 + ix;
+      vec v = vzero<T>();
+      if (gy < H && gx < W && c_base + c * VN < C)
+        v = ldvec<T>(dy + (((size_t)b * H + gy) * W + gx) * C + c_base + c * VN);
+      *reinterpret_cast<vec*>(dt + p * PITCH + c * 16) = v;
+    }
+    __syncthreads();
+    if (worker) {
+      const char* xr = xt + ((row + ky) * IW) * PITCH + cv * 16;
+      const char* dr = dt + (row * TW) * PITCH + cv * 16;
+      float win[7][VN];
 #pragma unroll
-      for (int i = 0; i < SEG; ++i) {
-        if (x0 + i < W) {
-          unpack<T>(ldvec<T>(dyr + (size_t)(x0 + i) * C), d[i]);
-        } else {
+      for (int i = 0; i < 6; ++i) unpack<T>(*reinterpret_cast<const vec*>(xr + i * PITCH), win[i]);
+      // the window index (o + kx) % 7 is static inside a 7-step body; the outer loop stays rolled so the
+      // compiler cannot hoist every LDS read of the row into registers
+#pragma unroll 1
+      for (int ob = 0; ob < TW; ob += 7) {
 #pragma unroll
-          for (int j = 0; j < VN; ++j) d[i][j] = 0.f;
-        }
-      }
-      if (ky == 3) {
+        for (int u = 0; u < 7; ++u) {
+          const int o = ob + u;
+          if (o < TW) {
+            unpack<T>(*reinterpret_cast<const vec*>(xr + (o + 6) * PITCH), win[(u + 6) % 7]);
+            float d[VN];
+            unpack<T>(*reinterpret_cast<const vec*>(dr + o * PITCH), d);
+            if (ky == 3) {
 #pragma unroll
-        for (int i = 0; i < SEG; ++i)
-#pragma unroll
-          for (int j = 0; j < VN; ++j) bsum[j] += d[i][j];
-      }
-      if (row_ok) {
-#pragma unroll
-        for (int i = 0; i < SEG + 6; ++i) {
-          const int xs = x0 + i - 3;
-          if (xs < 0 || xs >= W) continue;
-          float v[VN];
-          unpack<T>(ldvec<T>(xr + (size_t)xs * C), v);
-#pragma unroll
-          for (int kx = 0; kx < 7; ++kx) {
-            const int o = i - kx;  // output pixel (within the segment) this input feeds through tap kx
-            if (o >= 0 && o < SEG) {
-#pragma unroll
-              for (int j = 0; j < VN; ++j) acc[kx][j] = fmaf(d[o][j], v[j], acc[kx][j]);
+              for (int j = 0; j < VN; ++j) bsum[j] += d[j];
             }
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+              for (int j = 0; j < VN; ++j) acc[kx][j] = fmaf(d[j], win[(u + kx) % 7][j], acc[kx][j]);
           }
         }
       }
     }
   }
-  // block reduction over (seg, rslot) → [8][VN][ncvb]
-  const int nred = 8 * VN * ncvb;
-  for (int i = threadIdx.x; i < nred; i += 256) red[i] = 0.f;
+  // block reduction over the TH row-threads without atomics: every worker parks its 7 (+1) x VN partials
+  // in LDS as part[row][50][CB] (aliases the tiles), then 50*CB threads-strided sums over the rows
   __syncthreads();
-  if (active) {
+  float* part = reinterpret_cast<float*>(smem);
+  if (worker) {
+    float* pr = part + (size_t)row * 50 * CB;
 #pragma unroll
     for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
-      for (int j = 0; j < VN; ++j) atomicAdd(&red[(kx * VN + j) * ncvb + cvl], acc[kx][j]);
+      for (int j = 0; j < VN; j += 4)
+        *reinterpret_cast<float4*>(pr + (ky * 7 + kx) * CB + cv * VN + j) =
+            make_float4(acc[kx][j], acc[kx][j + 1], acc[kx][j + 2], acc[kx][j + 3]);
     if (ky == 3) {
 #pragma unroll
-      for (int j = 0; j < VN; ++j) atomicAdd(&red[(7 * VN + j) * ncvb + cvl], bsum[j]);
+      for (int j = 0; j < VN; j += 4)
+        *reinterpret_cast<float4*>(pr + 49 * CB + cv * VN + j) = make_float4(bsum[j], bsum[j + 1], bsum[j + 2], bsum[j + 3]);
     }
   }
   __syncthreads();
-  // workspace row layout: [50][C] (taps 0..48, then bias at row 49); this block owns rows ky*7..ky*7+6 (+49 if ky==3)
-  float* wrow = ws + (size_t)rblock * 50 * C;
-  for (int i = threadIdx.x; i < nred; i += 256) {
-    const int l = i % ncvb, kj = i / ncvb;
-    const int j = kj % VN, kx = kj / VN;
-    const int c = (cvblock * ncvb + l) * VN + j;
-    if (c >= C) continue;
-    if (kx < 7)
-      wrow[(size_t)(ky * 7 + kx) * C + c] = red[i];
-    else if (ky == 3)
-      wrow[(size_t)49 * C + c] = red[i];
+  float* wrow = ws + (size_t)group * 50 * C;
+  for (int i = threadIdx.x; i < 50 * CB; i += 256) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < TH; ++r) a += part[(size_t)r * 50 * CB + i];
+    const int t = i / CB, c = c_base + (i - t * CB);
+    if (c < C) wrow[(size_t)t * C + c] = a;
   }
 }
 
@@ -205,21 +258,36 @@ __global__ __launch_bounds__(256) void dw_reduce_rows_kernel(const float* __rest
   }
 }
 
-template <typename T>
-static int dw_launch(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W,
-                     int C, bool flip, hipStream_t s) {
-  constexpr int VN = VT<T>::N;
-  constexpr int TW = 8;
-  long total = (long)B * H * vsx_cdiv(W, TW) * (C / VN);
-  dim3 grid(vsx_cdiv(total, 256));
+template <typename T, int NCV, int TH, int TW, int K>
+static int dw_launch_cfg(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W,
+                         int C, bool flip, hipStream_t s) {
+  constexpr int CB = NCV * VT<T>::N;
+  long blocks = (long)B * vsx_cdiv(H, TH) * vsx_cdiv(W, TW) * vsx_cdiv(C, CB);
+  dim3 grid((unsigned)blocks);
   if (flip)
-    hipLaunchKernelGGL((dwconv7_kernel<T, TW, true>), grid, dim3(256), 0, s, (const T*)x, w, bias, (const T*)add, (T*)y,
-                       B, H, W, C);
+    hipLaunchKernelGGL((dwconv7_kernel<T, NCV, TH, TW, K, true>), grid, dim3(256), 0, s, (const T*)x, w, bias,
+                       (const T*)add, (T*)y, B, H, W, C);
   else
-    hipLaunchKernelGGL((dwconv7_kernel<T, TW, false>), grid, dim3(256), 0, s, (const T*)x, w, bias, (const T*)add,
-                       (T*)y, B, H, W, C);
+    hipLaunchKernelGGL((dwconv7_kernel<T, NCV, TH, TW, K, false>), grid, dim3(256), 0, s, (const T*)x, w, bias,
+                       (const T*)add, (T*)y, B, H, W, C);
   VSX_LAUNCH_CHECK();
   return 0;
+}
+
+template <typename T>
+static int dw_launch(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W,
+                     int C, bool flip, hipStream_t s);
+template <>
+int dw_launch<bf16_t>(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W,
+                      int C, bool flip, hipStream_t s) {
+  if (W >= 24) return dw_launch_cfg<bf16_t, 4, 8, 32, 4>(x, w, bias, add, y, B, H, W, C, flip, s);   // 32 ch x 8x32 px
+  return dw_launch_cfg<bf16_t, 8, 8, 8, 2>(x, w, bias, add, y, B, H, W, C, flip, s);                 // 64 ch x 8x8 px
+}
+template <>
+int dw_launch<float>(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W,
+                     int C, bool flip, hipStream_t s) {
+  if (W >= 24) return dw_launch_cfg<float, 8, 4, 32, 4>(x, w, bias, add, y, B, H, W, C, flip, s);    // 32 ch x 4x32 px
+  return dw_launch_cfg<float, 8, 8, 8, 2>(x, w, bias, add, y, B, H, W, C, flip, s);                  // 32 ch x 8x8 px
 }
 
 /* K3: timm ConvNeXtBlock.conv_dw (nn.Conv2d(C, C, 7, padding=3, groups=C)).  w is the prepared
@@ -239,44 +307,37 @@ extern "C" int32_t vsx_dwconv7_bwd_data(const void* dy, const float* w, const vo
   return dtype == VSX_BF16 ? dw_launch<bf16_t>(dy, w, nullptr, add, dx, B, H, W, C, true, (hipStream_t)stream)
                            : dw_launch<float>(dy, w, nullptr, add, dx, B, H, W, C, true, (hipStream_t)stream);
 }
+template <typename T, int NCV, int TH, int TW>
+static int dw_wgrad_cfg(const void* dy, const void* x, float* dw, float* db, float* ws, int ws_rows, int B, int H, int W,
+                        int C, hipStream_t st) {
+  constexpr int CB = NCV * VT<T>::N;
+  const int ncb = vsx_cdiv(C, CB);
+  const int ntiles = B * vsx_cdiv(H, TH) * vsx_cdiv(W, TW);
+  int ngroups = ntiles < ws_rows ? ntiles : ws_rows;
+  // keep >= ~1024 blocks in flight when there are enough tiles, but no more workspace rows than needed
+  if ((long)ngroups * ncb > 4096) ngroups = (int)(4096 / ncb) > 0 ? (int)(4096 / ncb) : 1;
+  hipLaunchKernelGGL((dwconv7_wgrad_kernel<T, NCV, TH, TW>), dim3(ngroups * ncb), dim3(256), 0, st, (const T*)dy,
+                     (const T*)x, ws, B, H, W, C, ngroups);
+  VSX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(dw_reduce_rows_kernel, dim3(vsx_cdiv(50 * C, 64), vsx_cdiv(ngroups, 64)), dim3(256), 0, st, ws, dw, db,
+                     ngroups, C);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
 /* weight gradient, accumulated into dw[49][C] and db[C] (fp32).  ws: caller-provided fp32 workspace of
- * ws_rows * 50 * C floats (one row of partials per block, folded by a second kernel). */
+ * ws_rows * 50 * C floats (one row of partials per tile group, folded by a second kernel). */
 extern "C" int32_t vsx_dwconv7_bwd_weight(const void* dy, const void* x, float* dw, float* db, float* ws, int32_t ws_rows,
                                           int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
                                           vsx_stream_t stream) {
   int vn = dtype == VSX_BF16 ? 8 : 4;
   VSX_CHECK(dy && x && dw && ws && ws_rows > 0 && B > 0 && H > 0 && W > 0 && C > 0 && C % vn == 0,
             "vsx_dwconv7_bwd_weight: bad arguments");
-  constexpr int SEG = 8;
-  int ncv = C / vn;
-  int nrows = B * H;
-  int nseg = vsx_cdiv(W, SEG);
-  int ncvb = 1;
-  while (ncvb < ncv && ncvb * nseg < 256 && ncvb < 64) ncvb <<= 1;   // channel-vector lanes per row segment
-  while (ncvb * nseg > 256 && ncvb > 1) ncvb >>= 1;
-  VSX_CHECK(ncvb * nseg <= 256, "vsx_dwconv7_bwd_weight: image width %d too large for one block row", W);
-  int ncvblocks = vsx_cdiv(ncv, ncvb);
-  int rs_per_block = 256 / (ncvb * nseg);
-  // row slots: enough threads to fill the chip (~256k threads over the 7 ky planes), >= 2 rows per slot
-  long want_threads = 262144 / 7;
-  int rblocks = vsx_cdiv(want_threads, 256L * ncvblocks);
-  if (rblocks > vsx_cdiv(nrows, 2 * rs_per_block)) rblocks = vsx_cdiv(nrows, 2 * rs_per_block);
-  if (rblocks > ws_rows) rblocks = ws_rows;
-  if (rblocks < 1) rblocks = 1;
-  int nrowslots = rblocks * rs_per_block;
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(ws, 0, (size_t)rblocks * 50 * C * sizeof(float), st);
-  dim3 grid(ncvblocks * rblocks, 7);
-  size_t sh = (size_t)8 * vn * ncvb * sizeof(float);
-  if (dtype == VSX_BF16)
-    hipLaunchKernelGGL((dwconv7_wgrad_kernel<bf16_t, SEG>), grid, dim3(256), sh, st, (const bf16_t*)dy, (const bf16_t*)x, ws,
-                       B, H, W, C, ncvb, nseg, nrowslots);
-  else
-    hipLaunchKernelGGL((dwconv7_wgrad_kernel<float, SEG>), grid, dim3(256), sh, st, (const float*)dy, (const float*)x, ws, B,
-                       H, W, C, ncvb, nseg, nrowslots);
-  VSX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(dw_reduce_rows_kernel, dim3(vsx_cdiv(50 * C, 64), vsx_cdiv(rblocks, 64)), dim3(256), 0, st, ws, dw, db,
-                     rblocks, C);
-  VSX_LAUNCH_CHECK();
-  return 0;
+  if (dtype == VSX_BF16) {
+    if (W >= 24) return dw_wgrad_cfg<bf16_t, 4, 8, 32>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
+    return dw_wgrad_cfg<bf16_t, 4, 8, 8>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
+  }
+  if (W >= 24) return dw_wgrad_cfg<float, 4, 8, 32>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
+  return dw_wgrad_cfg<float, 4, 8, 8>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
 }
