@@ -49,13 +49,13 @@ int32_t vsx_get_flag(const char* name);
 #define VSX_A_CONV3 2
 
 #define VSX_PRO_NONE 0
-#define VSX_PRO_GRN 1 /* a = gelu(h) * s[b, k] + beta[k]   (GRN applied on the fly) */
+#define VSX_PRO_GRN 1 /* a = g * s[b, k] + beta[k]   (GRN applied on the fly to the stored activation g = gelu(h)) */
 
 #define VSX_EPI_NONE 0
 #define VSX_EPI_BIAS 1         /* c = acc + bias[n] */
-#define VSX_EPI_BIAS_GELU_SQ 2 /* c = h = acc + bias; red0[b, n] += gelu(h)^2            (fc1 + GRN pass A) */
+#define VSX_EPI_BIAS_GELU_SQ 2 /* c = h = acc + bias; c2 = g = gelu(h); red0[b, n] += g^2     (fc1 + GRN pass A) */
 #define VSX_EPI_BIAS_RES 3     /* c = acc + bias[n] + res[m, n]   (bias may be NULL)      (fc2 + residual)   */
-#define VSX_EPI_DZ 4           /* c = dz = acc; red0[b, n] += dz * gelu(aux[m, n]); red1[b, n] += dz  (fc2 dgrad) */
+#define VSX_EPI_DZ 4           /* c = dz = acc; red0[b, n] += dz * aux[m, n] (aux = g); red1[b, n] += dz  (fc2 dgrad) */
 #define VSX_EPI_BIAS_STATS 5   /* c = acc + bias; red0[b, n] += c; red1[b, n] += c^2      (head conv + IN)   */
 
 typedef struct VsxGemm {
@@ -80,11 +80,12 @@ typedef struct VsxGemm {
   const float* bias;    /* [N] */
   const void* res;      /* [M, ldr] dtype */
   int32_t ldr;
-  const void* aux;      /* [M, ldx] dtype (EPI_DZ: pre-activation h) */
+  const void* aux;      /* [M, ldx] dtype (EPI_DZ: stored activation g) */
   int32_t ldx;
   float* red0;
   float* red1;
   float* colsum;        /* TN only: [N] += sum_m X[m, n] (bias gradient), may be NULL */
+  void* C2;             /* NT, EPI_BIAS_GELU_SQ: second output g = gelu(h), same layout as C */
 } VsxGemm;
 
 /* K5/K8/K9/K11/K13 (pointwise / patch / 3x3 convolutions as MFMA GEMMs) — replaces

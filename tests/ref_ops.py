@@ -39,13 +39,13 @@ def _gather(A: Tensor, M, K, lda, a_mode, gh, gw, cs, coff, pro, grn_s, grn_b, h
         a = torch.stack(taps, dim=3).reshape(M, 9 * cs)
     if pro == PRO_GRN:
         b = torch.arange(M, device=A.device) // hw
-        a = _gelu(a) * grn_s[b] + grn_b[None, :]
+        a = a * grn_s[b] + grn_b[None, :]
     return a
 
 
 def gemm(kind, A, B, Cout, M, N, K, lda, ldb, ldc, *, dtype, a_mode=A_ROWS, gh=0, gw=0, cs=0, nz=1, a_coff=None,
          b_off=None, c_coff=None, c_mode=A_ROWS, c_cs=0, pro=PRO_NONE, grn_s=None, grn_b=None, hw=0, epi=EPI_NONE,
-         bias=None, res=None, ldr=0, aux=None, ldx=0, red0=None, red1=None, colsum=None):
+         bias=None, res=None, ldr=0, aux=None, ldx=0, red0=None, red1=None, colsum=None, C2=None):
     a_coff = list(a_coff) if a_coff else [0] * nz
     b_off = list(b_off) if b_off else [0] * nz
     c_coff = list(c_coff) if c_coff else [0] * nz
@@ -69,10 +69,12 @@ def gemm(kind, A, B, Cout, M, N, K, lda, ldb, ldc, *, dtype, a_mode=A_ROWS, gh=0
             acc = acc + res.reshape(-1, ldr).float()[:M, :N]
         out = rd(acc)
         if epi == EPI_BIAS_GELU_SQ:
-            red0.index_add_(0, bidx, _gelu(out) ** 2)
+            gq = rd(_gelu(out))
+            red0.index_add_(0, bidx, gq**2)
+            C2.reshape(-1, ldc)[:M, c_coff[z] : c_coff[z] + N] = gq.to(C2.dtype)
         elif epi == EPI_DZ:
-            h = aux.reshape(-1, ldx).float()[:M, :N]
-            red0.index_add_(0, bidx, out * _gelu(h))
+            gact = aux.reshape(-1, ldx).float()[:M, :N]
+            red0.index_add_(0, bidx, out * gact)
             red1.index_add_(0, bidx, out)
         elif epi == EPI_BIAS_STATS:
             red0.index_add_(0, bidx, out)

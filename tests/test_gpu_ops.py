@@ -102,12 +102,16 @@ def test_gemm_nt_rows(dt, M, N, K, hw, epi):
         r1 = torch.zeros(nb, N, device=dev)
         if epi in (R.EPI_BIAS_GELU_SQ, R.EPI_DZ, R.EPI_BIAS_STATS):
             k2.update(red0=r0, red1=r1)
+        C2 = torch.zeros(M, N, dtype=dt, device=dev)
+        if epi == R.EPI_BIAS_GELU_SQ:
+            k2.update(C2=C2)
         ops.gemm("nt", A.to(dev), Bw.to(dev), C, M, N, K, K, K, N, **k2)
-        return C, r0, r1
+        return C, r0, r1, C2
 
-    Cr, r0r, r1r = run(R, "cpu")
-    Cg, r0g, r1g = run(H, DEV)
+    Cr, r0r, r1r, C2r = run(R, "cpu")
+    Cg, r0g, r1g, C2g = run(H, DEV)
     close(Cg, Cr, dt, "C")
+    close(C2g, C2r, dt, "C2", scale=1.0)
     if epi in (R.EPI_BIAS_GELU_SQ, R.EPI_DZ, R.EPI_BIAS_STATS):
         close(r0g, r0r, dt, "red0")
     if epi in (R.EPI_DZ, R.EPI_BIAS_STATS):

@@ -37,7 +37,7 @@ class VsxGemm(C.Structure):
         ("epi", _I32),
         ("bias", _P), ("res", _P), ("ldr", _I32),
         ("aux", _P), ("ldx", _I32),
-        ("red0", _P), ("red1", _P), ("colsum", _P),
+        ("red0", _P), ("red1", _P), ("colsum", _P), ("C2", _P),
     ]
 
 

@@ -70,17 +70,28 @@ __device__ __forceinline__ typename VT<T>::vec load_a_chunk(const VsxGemm& p, co
     }
     ptr = A + pix * p.lda + coff + c;
   }
-  vec v = ldvec<T>(ptr);
-  if (p.pro == VSX_PRO_GRN) {
-    float f[VN];
-    unpack<T>(v, f);
-    const float* s = p.grn_s + (size_t)rc.b * p.K + k;
-    const float* bt = p.grn_b + k;
+  return ldvec<T>(ptr);
+}
+
+// GRN applied on the fly to an already-activated operand: a = g * s[b, k] + beta[k].  Runs when the staged
+// registers are written to LDS (AFTER the MFMA work of the current tile), so the global loads of the raw
+// chunk stay in flight across the compute phase.
+template <typename T>
+__device__ __forceinline__ typename VT<T>::vec apply_prologue(const VsxGemm& p, typename VT<T>::vec v, int b, int k) {
+  constexpr int VN = VT<T>::N;
+  if (p.pro != VSX_PRO_GRN || k >= p.K) return v;
+  float f[VN];
+  unpack<T>(v, f);
+  const float* s = p.grn_s + (size_t)b * p.K + k;
+  const float* bt = p.grn_b + k;
 #pragma unroll
-    for (int j = 0; j < VN; ++j) f[j] = gelu_f(f[j]) * s[j] + bt[j];
-    v = pack<T>(f);
+  for (int j = 0; j < VN; j += 4) {
+    const float4 sv = *reinterpret_cast<const float4*>(s + j);
+    const float4 bv = *reinterpret_cast<const float4*>(bt + j);
+    f[j] = fmaf(f[j], sv.x, bv.x); f[j + 1] = fmaf(f[j + 1], sv.y, bv.y);
+    f[j + 2] = fmaf(f[j + 2], sv.z, bv.z); f[j + 3] = fmaf(f[j + 3], sv.w, bv.w);
   }
-  return v;
+  return pack<T>(f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
   constexpr int MAIN_BYTES = 2 * (BM + BN) * RS;
   constexpr int CS_LD = BN + 4;
   constexpr int MAXBT = 8;  // batch samples one tile may span on the LDS reduction path
-  constexpr int EPI_BYTES = BM * CS_LD * 4 + 2 * MAXBT * BN * 4;
+  constexpr int EPI_BYTES = (BM / 2) * CS_LD * 4 + 2 * MAXBT * BN * 4;
   constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   constexpr int MK = Frag<T>::MK;
   typedef typename VT<T>::vec vec;
@@ -168,13 +179,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
     arc[i] = decode_row(p, m0 + arow[i]);
     if (cid >= BM * CPR) arc[i].valid = false;
   }
-  vec areg[NA], breg[NB];
+  vec areg[1][NA], breg[1][NB];
 
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](int kt, vec* ar, vec* br) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int k = kt * BK + ach[i] * VN;
-      areg[i] = load_a_chunk<T>(p, arc[i], m0 + arow[i], k, a_coff);
+      ar[i] = load_a_chunk<T>(p, arc[i], m0 + arow[i], k, a_coff);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -182,23 +193,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
       int row = cid / CPR, ch = cid % CPR;
       int n = n0 + row, k = kt * BK + ch * VN;
       if (cid < BN * CPR && n < p.N && k < p.K)
-        breg[i] = ldvec<T>(Bw + (size_t)n * p.ldb + k);
+        br[i] = ldvec<T>(Bw + (size_t)n * p.ldb + k);
       else
-        breg[i] = vzero<T>();
+        br[i] = vzero<T>();
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int kt, int buf, const vec* ar, const vec* br) {
     char* As = smem + buf * (BM + BN) * RS;
     char* Bs = As + BM * RS;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int cid = tid + i * 256;
-      if (cid < BM * CPR) *reinterpret_cast<vec*>(As + arow[i] * RS + ach[i] * 16) = areg[i];
+      if (cid < BM * CPR) {
+        vec v = ar[i];
+        if (p.pro != VSX_PRO_NONE && arc[i].valid) v = apply_prologue<T>(p, v, arc[i].b, kt * BK + ach[i] * VN);
+        *reinterpret_cast<vec*>(As + arow[i] * RS + ach[i] * 16) = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int cid = tid + i * 256;
-      if (cid < BN * CPR) *reinterpret_cast<vec*>(Bs + (cid / CPR) * RS + (cid % CPR) * 16) = breg[i];
+      if (cid < BN * CPR) *reinterpret_cast<vec*>(Bs + (cid / CPR) * RS + (cid % CPR) * 16) = br[i];
     }
   };
 
@@ -208,13 +223,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tiles(kt + 1);
-    const char* As = smem + (kt & 1) * (BM + BN) * RS;
+  auto compute = [&](int buf) {
+    const char* As = smem + buf * (BM + BN) * RS;
     const char* Bs = As + BM * RS;
 #pragma unroll
     for (int kk = 0; kk < BK / MK; ++kk) {
@@ -228,25 +238,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tiles((kt + 1) & 1);
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tiles(0, areg[0], breg[0]);
+  store_tiles(0, 0, areg[0], breg[0]);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tiles(kt + 1, areg[0], breg[0]);   // in flight across the MFMA phase
+    compute(kt & 1);
+    if (kt + 1 < nk) store_tiles(kt + 1, (kt + 1) & 1, areg[0], breg[0]);  // prologue math happens here
     __syncthreads();
   }
 
-  // ---- epilogue: accumulators → LDS (fp32) → row-contiguous vectors
+  // ---- epilogue: accumulators → LDS (fp32) → row-contiguous vectors, in two passes of BM/2 rows so that the
+  // staging buffer (not the K-loop buffers) never decides how many workgroups fit on a CU
+  constexpr int HR = BM / 2;  // rows per pass
   float* Cs = reinterpret_cast<float*>(smem);
-  float* red = Cs + BM * CS_LD;  // [2][MAXBT][BN]
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Cs[((wm * FM + i) * 16 + kq * 4 + r) * CS_LD + (wn * FN + j) * 16 + p16] = acc[i][j][r];
-  for (int i = tid; i < 2 * MAXBT * BN; i += 256) red[i] = 0.f;
-  __syncthreads();
-
+  float* red = Cs + HR * CS_LD;  // [2][MAXBT][BN]
   constexpr int NCH = BN / VN;        // column chunks per row
-  constexpr int RSTEP = 256 / NCH;    // rows handled per pass
+  constexpr int RSTEP = 256 / NCH;    // rows handled per sweep
+  constexpr bool PARK = 2 * RSTEP <= HR;  // partial-sum parking needs two Cs rows per thread
   const int cc = tid % NCH, rr = tid / NCH;
   const int n = n0 + cc * VN;
   const bool ncol_ok = n < p.N;
@@ -257,7 +269,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
   const int b_first = m0 / hwb;
   const int nbt = mlast / hwb - b_first + 1;       // samples covered by this tile
   const bool uniform = reduce && nbt <= MAXBT;     // LDS reduction path (else: direct global atomics)
-  int bcur = -1;
+  const bool park = uniform && nbt == 1 && PARK;
   float r0[VN], r1[VN];
 #pragma unroll
   for (int j = 0; j < VN; ++j) { r0[j] = 0.f; r1[j] = 0.f; }
@@ -270,91 +282,131 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
   }
   T* Cg = reinterpret_cast<T*>(p.C);
   const int c_coff = p.c_coff[z];
+  if (reduce) {
+    for (int i = tid; i < 2 * MAXBT * BN; i += 256) red[i] = 0.f;
+  }
 
-  if (ncol_ok) {
-    for (int row = rr; row < BM; row += RSTEP) {
-      const int m = m0 + row;
-      if (m >= p.M) break;
-      float v[VN];
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();  // K-loop buffers / previous pass no longer read
+    if ((wm * FM * 16) / HR == half) {
 #pragma unroll
-      for (int j = 0; j < VN; j += 4) {
-        float4 t = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * VN + j);
-        v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
-      }
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < VN; ++j) v[j] += bias[j];
-      const int b = m / hwb;
-      if (epi == VSX_EPI_BIAS_RES) {
-        float rf[VN];
-        unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n), rf);
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
-        for (int j = 0; j < VN; ++j) v[j] += rf[j];
-      } else if (epi == VSX_EPI_BIAS_GELU_SQ) {
+          for (int r = 0; r < 4; ++r)
+            Cs[((wm * FM + i) * 16 - half * HR + kq * 4 + r) * CS_LD + (wn * FN + j) * 16 + p16] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (ncol_ok) {
+      for (int row = rr; row < HR; row += RSTEP) {
+        const int m = m0 + half * HR + row;
+        if (m >= p.M) break;
+        float v[VN];
 #pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          float g = gelu_f(round_to<T>(v[j]));
-          r0[j] += g * g;
+        for (int j = 0; j < VN; j += 4) {
+          float4 t = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * VN + j);
+          v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
         }
-      } else if (epi == VSX_EPI_DZ) {
-        float hf[VN];
-        unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldx + n), hf);
 #pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          float dz = round_to<T>(v[j]);
-          r0[j] += dz * gelu_f(hf[j]);
-          r1[j] += dz;
-        }
-      } else if (epi == VSX_EPI_BIAS_STATS) {
+        for (int j = 0; j < VN; ++j) v[j] += bias[j];
+        const int b = m / hwb;
+        if (epi == VSX_EPI_BIAS_RES) {
+          float rf[VN];
+          unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n), rf);
 #pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          float c = round_to<T>(v[j]);
-          r0[j] += c;
-          r1[j] += c * c;
-        }
-      }
-      // store
-      T* dst;
-      if (p.c_mode == VSX_A_PATCH2) {
-        int hw = p.gh * p.gw;
-        int bb = m / hw, rem = m - bb * hw;
-        int y = rem / p.gw, x = rem - y * p.gw;
-        int tap = n / p.c_cs, c = n - tap * p.c_cs;
-        size_t pix = ((size_t)bb * (2 * p.gh) + 2 * y + (tap >> 1)) * (2 * p.gw) + 2 * x + (tap & 1);
-        dst = Cg + pix * p.ldc + c_coff + c;
-      } else {
-        dst = Cg + (size_t)m * p.ldc + c_coff + n;
-      }
-      stvec<T>(dst, pack<T>(v));
-      if (reduce && !uniform) {
-        // tile spans more than MAXBT batch samples (very small feature maps): direct atomics
-#pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          atomicAdd(p.red0 + (size_t)b * p.N + n + j, r0[j]);
-          if (epi == VSX_EPI_BIAS_STATS) atomicAdd(p.red1 + (size_t)b * p.N + n + j, r1[j]);
-          if (epi == VSX_EPI_DZ) atomicAdd(p.red1 + (size_t)b * p.N + n + j, r1[j]);
-          r0[j] = 0.f;
-          r1[j] = 0.f;
-        }
-      } else if (reduce) {
-        // rows of one sample are contiguous: keep accumulating in registers while the sample is
-        // unchanged, flush to the sample's LDS slot when the next row belongs to another sample
-        const int rnext = row + RSTEP;
-        const bool flush = rnext >= BM || m0 + rnext >= p.M || (m0 + rnext) / hwb != b;
-        if (flush) {
-          float* rs = red + (size_t)(b - b_first) * BN + cc * VN;
+          for (int j = 0; j < VN; ++j) v[j] += rf[j];
+        } else if (epi == VSX_EPI_BIAS_GELU_SQ) {
+          // second output: the activation g = gelu(h) (storage-rounded); the GRN statistics use the stored value
+          float gv[VN];
 #pragma unroll
           for (int j = 0; j < VN; ++j) {
-            atomicAdd(rs + j, r0[j]);
-            if (epi != VSX_EPI_BIAS_GELU_SQ) atomicAdd(rs + MAXBT * BN + j, r1[j]);
+            gv[j] = round_to<T>(gelu_f(round_to<T>(v[j])));
+            r0[j] += gv[j] * gv[j];
+          }
+          stvec<T>(reinterpret_cast<T*>(p.C2) + (size_t)m * p.ldc + c_coff + n, pack<T>(gv));
+        } else if (epi == VSX_EPI_DZ) {
+          float gf[VN];  // aux = stored activation g
+          unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldx + n), gf);
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            float dz = round_to<T>(v[j]);
+            r0[j] += dz * gf[j];
+            r1[j] += dz;
+          }
+        } else if (epi == VSX_EPI_BIAS_STATS) {
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            float c = round_to<T>(v[j]);
+            r0[j] += c;
+            r1[j] += c * c;
+          }
+        }
+        T* dst;
+        if (p.c_mode == VSX_A_PATCH2) {
+          int hw = p.gh * p.gw;
+          int bb = m / hw, rem = m - bb * hw;
+          int y = rem / p.gw, x = rem - y * p.gw;
+          int tap = n / p.c_cs, c = n - tap * p.c_cs;
+          size_t pix = ((size_t)bb * (2 * p.gh) + 2 * y + (tap >> 1)) * (2 * p.gw) + 2 * x + (tap & 1);
+          dst = Cg + pix * p.ldc + c_coff + c;
+        } else {
+          dst = Cg + (size_t)m * p.ldc + c_coff + n;
+        }
+        stvec<T>(dst, pack<T>(v));
+        if (reduce && !uniform) {
+          // tile spans more than MAXBT batch samples (very small feature maps): direct atomics
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            atomicAdd(p.red0 + (size_t)b * p.N + n + j, r0[j]);
+            if (epi == VSX_EPI_BIAS_STATS || epi == VSX_EPI_DZ) atomicAdd(p.red1 + (size_t)b * p.N + n + j, r1[j]);
             r0[j] = 0.f;
             r1[j] = 0.f;
+          }
+        } else if (reduce && !park) {
+          // rows of one sample are contiguous: keep accumulating in registers while the sample is
+          // unchanged, flush to the sample's LDS slot when the next row belongs to another sample
+          const int rnext = row + RSTEP;
+          const bool flush = rnext >= HR || m0 + half * HR + rnext >= p.M || (m0 + half * HR + rnext) / hwb != b;
+          if (flush) {
+            float* rs = red + (size_t)(b - b_first) * BN + cc * VN;
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+              atomicAdd(rs + j, r0[j]);
+              if (epi != VSX_EPI_BIAS_GELU_SQ) atomicAdd(rs + MAXBT * BN + j, r1[j]);
+              r0[j] = 0.f;
+              r1[j] = 0.f;
+            }
           }
         }
       }
     }
   }
-  (void)bcur;
-  if (uniform) {
+  if (park) {
+    // single-sample tile (the common case): no atomics in LDS.  A thread's Cs rows are dead once it has
+    // read them, so it parks its partial column sums (both passes) in its own first two rows; then BN
+    // threads add the RSTEP partial rows of each column.
+    __syncthreads();
+    if (ncol_ok) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        Cs[rr * CS_LD + cc * VN + j] = r0[j];
+        Cs[(rr + RSTEP) * CS_LD + cc * VN + j] = r1[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+      for (int r = 0; r < RSTEP; ++r) {
+        a0 += Cs[r * CS_LD + tid];
+        a1 += Cs[(r + RSTEP) * CS_LD + tid];
+      }
+      atomicAdd(p.red0 + (size_t)b_first * p.N + n0 + tid, a0);
+      if (epi == VSX_EPI_BIAS_STATS || epi == VSX_EPI_DZ) atomicAdd(p.red1 + (size_t)b_first * p.N + n0 + tid, a1);
+    }
+  } else if (uniform) {
     __syncthreads();
     for (int i = tid; i < nbt * BN; i += 256) {
       const int bs = i / BN, c = i - bs * BN;
@@ -415,6 +467,7 @@ extern "C" int32_t vsx_gemm_nt(const VsxGemm* p, int32_t dtype, vsx_stream_t str
   if (p->epi == VSX_EPI_BIAS_GELU_SQ || p->epi == VSX_EPI_DZ || p->epi == VSX_EPI_BIAS_STATS)
     VSX_CHECK(p->red0 != nullptr && p->hw > 0, "vsx_gemm_nt: reduction epilogue needs red0 and hw");
   if (p->epi == VSX_EPI_DZ) VSX_CHECK(p->aux && p->red1, "vsx_gemm_nt: EPI_DZ needs aux and red1");
+  if (p->epi == VSX_EPI_BIAS_GELU_SQ) VSX_CHECK(p->C2 != nullptr, "vsx_gemm_nt: EPI_BIAS_GELU_SQ needs the second output C2");
   if (p->epi == VSX_EPI_BIAS_STATS) VSX_CHECK(p->red1 != nullptr, "vsx_gemm_nt: EPI_BIAS_STATS needs red1");
   if (p->epi == VSX_EPI_BIAS_RES) VSX_CHECK(p->res != nullptr, "vsx_gemm_nt: EPI_BIAS_RES needs res");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -523,6 +576,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
     cch[i] = cid % CPR;
   }
   vec xreg[NCH], yreg[NCH];
+  int yb[NCH];
   auto load_tiles = [&](int ms) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -535,8 +589,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
       if (ok && kk < p.K) {
         RowCoord rc = decode_row(p, m);
         yreg[i] = load_a_chunk<T>(p, rc, m, kk, a_coff);
+        yb[i] = rc.b;
       } else {
         yreg[i] = vzero<T>();
+        yb[i] = -1;
       }
     }
   };
@@ -548,7 +604,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
       int cid = tid + i * 256;
       if (cid < BMS * CPR) {
         *reinterpret_cast<vec*>(Xs + crow[i] * LDB + cch[i] * 16) = xreg[i];
-        *reinterpret_cast<vec*>(Ys + crow[i] * LDB + cch[i] * 16) = yreg[i];
+        vec yv = yreg[i];
+        if (p.pro != VSX_PRO_NONE && yb[i] >= 0) yv = apply_prologue<T>(p, yv, yb[i], k0 + cch[i] * VN);
+        *reinterpret_cast<vec*>(Ys + crow[i] * LDB + cch[i] * 16) = yv;
       }
     }
   };

@@ -192,30 +192,33 @@ class Engine:
         xh, _, rstd = o.ln_fwd(y, None, None, M, C, 1e-6, need_mean=False)
         del y
         colsq = torch.zeros((B, 4 * C), dtype=torch.float32, device=x.device)
+        # fc1 writes the pre-activation h (needed for gelu' in backward) AND the activation g = gelu(h):
+        # fc2, the fc2 weight gradient and the GRN statistics path all consume g, so GELU is evaluated once
         h = torch.empty((M, 4 * C), dtype=dt, device=x.device)
+        gact = torch.empty((M, 4 * C), dtype=dt, device=x.device)
         o.gemm("nt", xh, w.W1f, h, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=w.b1f, red0=colsq,
-               hw=H * Wd)
+               hw=H * Wd, C2=gact)
         s = o.grn_scale(colsq, blk.mlp.grn.weight)
         out = torch.empty((M, C), dtype=dt, device=x.device)
-        o.gemm("nt", h, w.W2, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
+        o.gemm("nt", gact, w.W2, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
                grn_b=blk.mlp.grn.bias, hw=H * Wd, epi=L.EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=x, ldr=C)
         if save is not None:
-            save.append((x, xh, rstd, h, colsq, s))
+            save.append((x, xh, rstd, h, gact, colsq, s))
         return out
 
     def _block_bwd(self, dout, w, saved, B, H, Wd, dt):
         o, g = self.ops, self.g
         C, M = w.C, B * H * Wd
         blk = w.p
-        x, xh, rstd, h, colsq, s = saved
+        x, xh, rstd, h, gact, colsq, s = saved
         dev = dout.device
         # fc2: weight gradient (Z recomputed in the operand prologue) + bias gradient
-        o.gemm("tn", h, dout, g(blk.mlp.fc2.weight), M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
+        o.gemm("tn", gact, dout, g(blk.mlp.fc2.weight), M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
                grn_b=blk.mlp.grn.bias, hw=H * Wd, colsum=g(blk.mlp.fc2.bias))
         # fc2 data gradient dZ, with Σ dZ·gelu(h) (GRN statistics path) and Σ dZ (GRN beta gradient)
         PS = torch.zeros((2, B, 4 * C), dtype=torch.float32, device=dev)
         dz = torch.empty((M, 4 * C), dtype=dt, device=dev)
-        o.gemm("nt", dout, w.W2T, dz, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_DZ, aux=h, ldx=4 * C, red0=PS[0],
+        o.gemm("nt", dout, w.W2T, dz, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_DZ, aux=gact, ldx=4 * C, red0=PS[0],
                red1=PS[1], hw=H * Wd)
         t = o.grn_bwd_stats(colsq, PS[0], blk.mlp.grn.weight, g(blk.mlp.grn.weight), Sb=PS[1], dbeta=g(blk.mlp.grn.bias))
         db1f = torch.zeros(4 * C, dtype=torch.float32, device=dev)

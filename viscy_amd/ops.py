@@ -70,6 +70,7 @@ def gemm(
     red0: Tensor | None = None,
     red1: Tensor | None = None,
     colsum: Tensor | None = None,
+    C2: Tensor | None = None,
 ) -> None:
     """kind='nt': C[M,N] = pro(A)[M,K]·B[N,K]^T (+epilogue);  kind='tn': C[N,K](fp32) += B[M,N]^T·pro(A)[M,K]."""
     for t in (bias, grn_s, grn_b, red0, red1, colsum):
@@ -92,6 +93,7 @@ def gemm(
     p.bias, p.res, p.ldr = ptr(bias), ptr(res), ldr
     p.aux, p.ldx = ptr(aux), ldx
     p.red0, p.red1, p.colsum = ptr(red0), ptr(red1), ptr(colsum)
+    p.C2 = ptr(C2)
     fn = lib().vsx_gemm_nt if kind == "nt" else lib().vsx_gemm_tn
     check(fn(C.byref(p), dtype_code(dtype), stream()), f"gemm_{kind}")
 
