@@ -96,6 +96,161 @@ int32_t vsx_gemm_nt(const VsxGemm* p, int32_t dtype, vsx_stream_t stream);
 /* weight-gradient GEMM (contraction over pixels) for the same layers */
 int32_t vsx_gemm_tn(const VsxGemm* p, int32_t dtype, vsx_stream_t stream);
 
+
+/* =============================================================================================
+ * Remaining entry points (one per fused kernel of the path).  `ws` arguments are caller-owned fp32
+ * scratch for two-stage reductions (per-block partials + a fold kernel): same-address global atomics
+ * serialise at ~0.2 us each on MI355X, so no kernel issues more than a few dozen per address.
+ * ============================================================================================= */
+
+/* K3 depthwise 7x7 conv — timm ConvNeXtBlock.conv_dw = nn.Conv2d(C, C, 7, padding=3, groups=C) (block math restated in-repo at
+ * viscy_models/unet/fcmae.py:174-221).  x,y: [B,H,W,C] channels-last; w: tap-major fp32 [49][C]; y = conv(x) + bias [+ add]. */
+int32_t vsx_dwconv7_fwd(const void* x, const float* w, const float* bias, const void* add, void* y,
+    int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, vsx_stream_t stream);
+
+/* data gradient of K3: dx = conv(dy, flipped w) [+ add]; add = gradient arriving through the residual branch. */
+int32_t vsx_dwconv7_bwd_data(const void* dy, const float* w, const void* add, void* dx, int32_t B, int32_t H,
+    int32_t W, int32_t C, int32_t dtype, vsx_stream_t stream);
+
+/* weight/bias gradient of K3 accumulated into dw[49][C], db[C] (fp32).  ws: caller-owned workspace of ws_rows*50*C floats. */
+int32_t vsx_dwconv7_bwd_weight(const void* dy, const void* x, float* dw, float* db, float* ws,
+    int32_t ws_rows, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, vsx_stream_t stream);
+
+/* K13 (norm+act) + K14: MONAI Convolution ADN (InstanceNorm3d eps 1e-5 → PReLU) → nn.Conv3d(mid, 4*out, 1) → transpose /
+ * nn.PixelShuffle(2) / transpose (viscy_models/components/heads.py:617-625,638-641).  U: [B,H2,W2,Z,Cmid] conv output;
+ * ssum/ssq: [B,Cmid] from the conv GEMM epilogue (VSX_EPI_BIAS_STATS); out: (B, Cout, Z, 2*H2, 2*W2) fp32. */
+int32_t vsx_head_out_fwd(const void* U, const float* ssum, const float* ssq, const float* w2,
+    const float* b2, const float* alpha, float* out, int32_t B, int32_t H2, int32_t W2, int32_t Z, int32_t Cmid,
+    int32_t Cout, float eps, int32_t dtype, vsx_stream_t stream);
+
+/* backward pass 1 of the head tail: writes act = PReLU(IN(U)) and dv (gathered output gradient) for the 1x1x1 weight-gradient GEMM;
+ * accumulates S1 = Σ dn, S2 = Σ dn·n̂ per (b, channel) and the PReLU slope gradient. */
+int32_t vsx_head_out_bwd1(const void* U, const float* ssum, const float* ssq, const float* w2,
+    const float* alpha, const float* dout, void* act, void* dv, float* S1, float* S2, float* dalpha, int32_t B,
+    int32_t H2, int32_t W2, int32_t Z, int32_t Cmid, int32_t Cout, float eps, int32_t dtype,
+    vsx_stream_t stream);
+
+/* backward pass 2: dU = rstd * (dn - S1/cnt - n̂ * S2/cnt)  (InstanceNorm3d backward). */
+int32_t vsx_head_out_bwd2(const void* U, const float* ssum, const float* ssq, const float* w2,
+    const float* alpha, const void* dv, const float* S1, const float* S2, void* dU, int32_t B, int32_t H2,
+    int32_t W2, int32_t Z, int32_t Cmid, int32_t Cout, float eps, int32_t dtype, vsx_stream_t stream);
+
+/* avg_pool3d(·,(1,2,2)) of preds/target (viscy_utils/evaluation/metrics.py:340-341), target.max() of the INPUT planes (metrics.py:298) and the
+ * L1 / L2 sums of MixedLoss (viscy_utils/losses/mixed_loss.py:58-63) in one pass.  tmax must be pre-set to -inf. */
+int32_t vsx_loss_pool(const float* P, const float* T, float* Po, float* To, float* tmax, float* l1sum,
+    float* l2sum, int32_t planes, int32_t H, int32_t W, vsx_stream_t stream);
+
+/* one scale of ssim_25d (metrics.py:174-305): per-sample sums of the SSIM and contrast-sensitivity maps, bf16 rounding points as in
+ * _compute_ssim_and_cs_bf16 (metrics.py:243-255). */
+int32_t vsx_ssim_scale_fwd(const float* P, const float* T, const float* tmax, float* sum_ssim, float* sum_cs,
+    int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, vsx_stream_t stream);
+
+/* backward of one scale (+ pooled-gradient chain from the next scale, + L1/L2 gradient at scale 0); gout: device scalar (upstream gradient) or NULL = 1. */
+int32_t vsx_ssim_scale_bwd(const float* P, const float* T, const float* tmax, const float* coef, float* dmu,
+    const float* dPnext, float* dP, int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, float l1c, float l2c,
+    const float* gout, int32_t has_ssim, vsx_stream_t stream);
+
+/* ms_ssim_25d combination with clamp(min=1e-4) (metrics.py:326-349) + MixedLoss weights (mixed_loss.py:56-69); writes loss, MS-SSIM and the per-(scale, sample) map-pixel gradients. */
+int32_t vsx_loss_finalize(const float* sum_ssim, const float* sum_cs, const float* l1sum, const float* l2sum,
+    const float* npix, float nelem, int32_t B, int32_t nscale, float a1, float a2, float a3, const float* gout,
+    float* loss, float* coef, float* ms_out, vsx_stream_t stream);
+
+/* K2/K4: timm LayerNorm2d / nn.LayerNorm over channels, eps 1e-6 (reached via timm ConvNeXtStage / ConvNeXtBlock at viscy_models/unet/unext2.py:79,
+ * viscy_models/components/blocks.py:60-69).  gamma == NULL → no affine (the block LN's affine is folded into fc1). */
+int32_t vsx_ln_fwd(const void* x, void* y, float* mean, float* rstd, const float* gamma, const float* beta,
+    int32_t rows, int32_t C, float eps, int32_t dtype, vsx_stream_t stream);
+
+/* LayerNorm backward: x̂ = mean ? (x-mean)*rstd : x; dx = rstd*(g - mean(g) - x̂*mean(g*x̂)) [+ add], g = dy*gamma; dgamma/dbeta accumulated. */
+int32_t vsx_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+    const void* add, void* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, int32_t dtype,
+    vsx_stream_t stream);
+
+/* K7: timm GlobalResponseNorm statistics: s[b,n] = 1 + gamma[n]*g/(mean_n g + eps), g = sqrt(colsq[b,n]); colsq comes from the fc1 GEMM epilogue. */
+int32_t vsx_grn_scale(const float* colsq, const float* gamma, float* s, int32_t nb, int32_t N, float eps,
+    vsx_stream_t stream);
+
+/* backward of the GRN statistics path: P[b,n] = Σ_hw dz*g, Sb[b,n] = Σ_hw dz → t[b,n] (factor of g in dG), dgamma, dbeta. */
+int32_t vsx_grn_bwd_stats(const float* colsq, const float* P, const float* Sb, const float* gamma, float* t,
+    float* dgamma, float* dbeta, int32_t nb, int32_t N, float eps, vsx_stream_t stream);
+
+/* K6/K7 backward, elementwise pass: dh = (dz*s + gelu(h)*t) * gelu'(h) written over dz; colsum[n] += Σ_m dh.  ws: ws_rows*N floats. */
+int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, const float* t, float* colsum, float* ws,
+    int32_t ws_rows, int32_t M, int32_t N, int32_t hw, int32_t dtype, vsx_stream_t stream);
+
+/* K26: torch.optim.AdamW step (viscy_utils/optimizers.py:50) on flat fp32 buffers; hyper = device array
+ * {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, grad_scale} so the launch is hipGraph-replayable. */
+int32_t vsx_adamw(float* p, const float* g, float* m, float* v, const float* hyper, int64_t n,
+    vsx_stream_t stream);
+
+/* fp32 parameter viewed as [R, Cs, Tn] (out, in, taps) → GEMM operand dst [R, Tn*Cs] and/or dstT [Tn*Cs, R] in `dtype`, optionally scaled per
+ * input channel by gamma (LayerNorm fold).  tapmode 1 = head Conv3d tap order (kz,ky,kx) → (ky,kx,kz). */
+int32_t vsx_prep_weight(const float* src, void* dst, void* dstT, const float* gamma, int32_t R, int32_t Cs,
+    int32_t Tn, int32_t tapmode, int32_t dtype, vsx_stream_t stream);
+
+/* inverse of vsx_prep_weight for gradients: dparam[r][c][t] += g[r][k]*gamma[c] + u[r]*beta[c]; dgamma[c] += Σ g*W. */
+int32_t vsx_unprep_grad(const float* g, float* dparam, const float* gamma, const float* W, float* dgamma,
+    const float* u, const float* beta, int32_t R, int32_t Cs, int32_t Tn, int32_t tapmode, vsx_stream_t stream);
+
+/* out[r] = (b ? b[r] : 0) + Σ_c W[r][c]*v[c]   (fold LayerNorm beta into the fc1 bias). */
+int32_t vsx_matvec(const float* W, const float* v, const float* b, float* out, int32_t R, int32_t C,
+    vsx_stream_t stream);
+
+/* out[c] += Σ_r W[r][c]*u[r]   (gradient of the folded LayerNorm beta). */
+int32_t vsx_matvec_t_add(const float* W, const float* u, float* out, int32_t R, int32_t C,
+    vsx_stream_t stream);
+
+/* dst[j][i] (+)= src[i][j]  (depthwise weights [C][49] <-> [49][C]). */
+int32_t vsx_transpose_f32(const float* src, float* dst, int32_t A, int32_t Bn, int32_t accumulate,
+    vsx_stream_t stream);
+
+/* head Conv3d data-gradient weights: [Zout+2][C3][27*Cmid], zero where the depth tap falls outside [0,2]. */
+int32_t vsx_prep_head_dgrad(const float* W, void* dst, int32_t Cmid, int32_t C3, int32_t Zout, int32_t dtype,
+    vsx_stream_t stream);
+
+/* K1 gather half of UNeXt2Stem (viscy_models/components/stems.py:26-50): the Conv3d with kernel = stride = (kz,ky,kx) is a GEMM over
+ * non-overlapping patches; writes the patch matrix [B*h*w, D'*K].  Optional per-sample (sub, div) fuses NormalizeSampled
+ * (viscy_transforms/_normalize.py:72-80): (x - sub)/(div + 1e-8). */
+int32_t vsx_stem_im2col(const float* x, void* P, const float* sub, const float* div, int32_t B, int32_t Cin,
+    int32_t Z, int32_t H, int32_t W, int32_t kz, int32_t ky, int32_t kx, int32_t dtype, vsx_stream_t stream);
+
+/* K10: MONAI UpSample(mode="pixelshuffle", pre_conv=None) + torch.cat([up, skip], 1) (viscy_models/components/blocks.py:138-146,170-171). */
+int32_t vsx_pixel_shuffle_cat_fwd(const void* low, const void* skip, void* out, int32_t B, int32_t h,
+    int32_t w, int32_t c, int32_t cs, int32_t dtype, vsx_stream_t stream);
+
+/* backward of K10: scatter dcat into dlow (inverse shuffle) and dskip. */
+int32_t vsx_pixel_shuffle_cat_bwd(const void* dcat, void* dlow, void* dskip, int32_t B, int32_t h, int32_t w,
+    int32_t c, int32_t cs, int32_t dtype, vsx_stream_t stream);
+
+/* K12: PixelToVoxelHead.upsample (pixel shuffle x2 + optional ConstantPad2d((1,0,1,0)) + AvgPool2d(2,1)) + reshape (heads.py:607-615,632-637);
+ * output channel = z*C3 + c3 so the 3x3x3 conv reads contiguous channel slices per depth. */
+int32_t vsx_head_shuffle_fwd(const void* dec, void* hin, int32_t B, int32_t h, int32_t w, int32_t C3,
+    int32_t D, int32_t pool, int32_t dtype, vsx_stream_t stream);
+
+/* backward of K12. */
+int32_t vsx_head_shuffle_bwd(const void* dhin, void* ddec, int32_t B, int32_t h, int32_t w, int32_t C3,
+    int32_t D, int32_t pool, int32_t dtype, vsx_stream_t stream);
+
+/* K17 NormalizeSampled.__call__ (viscy_transforms/_normalize.py:72-80) on a (B, ...) fp32 batch with (B,) statistics. */
+int32_t vsx_normalize(const float* x, float* y, const float* sub, const float* div, int32_t B, int64_t per_sample,
+    vsx_stream_t stream);
+
+/* MinMaxSampled.__call__ (viscy_transforms/_normalize.py:124-134). */
+int32_t vsx_minmax_norm(const float* x, float* y, const float* lo, const float* hi, int32_t B, int64_t per_sample,
+    vsx_stream_t stream);
+
+/* per-sample min / max needed by MONAI AdjustContrast (K19); mn / mx must be pre-set to +inf / -inf. */
+int32_t vsx_sample_minmax(const float* x, float* mn, float* mx, int32_t B, int64_t per_sample, vsx_stream_t stream);
+
+/* K19-K21 fused: BatchedRandAdjustContrast (_adjust_contrast.py:54-86) -> BatchedRandScaleIntensity
+ * (_scale_intensity.py:59-77) -> BatchedRandGaussianNoise (_noise.py:158-204) with injected per-sample parameters. */
+int32_t vsx_intensity_aug(const float* x, float* y, const float* mn, const float* mx, const float* gamma,
+    const float* factor, const float* noise, const float* nstd, float nmean, int32_t B, int64_t per_sample,
+    vsx_stream_t stream);
+
+/* K25 _blend_in (viscy_utils/callbacks/prediction_writer.py:74-111): Z-feathered running average, fz[Z] = factors. */
+int32_t vsx_blend_in(const float* oldp, const float* newp, float* out, const float* fz, int32_t Z, int64_t plane,
+    int64_t total, vsx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

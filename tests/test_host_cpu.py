@@ -1,0 +1,160 @@
+"""CPU: host-side logic around the hot path — OME-Zarr HCS I/O, HCSDataModule batch contract, DP sharding
+(world_size-2 gloo), LR schedule, CPU-worker normalisation against the reference-generated golden."""
+
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.conftest import load_golden
+from viscy_amd.data import HCSDataModule, SlidingWindowDataset, open_ome_zarr, write_hcs_plate
+from viscy_amd.optim import warmup_cosine_lambda
+from viscy_amd.parallel import FlatDataParallel, shard_indices
+from viscy_amd.transforms import MinMaxSampled, NormalizeSampled
+
+
+@pytest.fixture(scope="module")
+def tiny_hcs_zarr():
+    """4 FOVs (1,2,5,128,128) float32 rng(42) with norm meta mean .5 / std .29 — the reference's integration fixture
+    (applications/cytoland/tests/conftest.py:243-268)."""
+    d = tempfile.mkdtemp()
+    rng = np.random.default_rng(42)
+    pos = {f"A/{c}/{f}": rng.random((1, 2, 5, 128, 128), dtype=np.float32) for c in (1, 2) for f in (0, 1)}
+    meta = {ch: {"fov_statistics": {"mean": 0.5, "std": 0.29}, "dataset_statistics": {"mean": 0.5, "std": 0.29}}
+            for ch in ("Phase3D", "Nuclei")}
+    path = os.path.join(d, "tiny.zarr")
+    write_hcs_plate(path, pos, ["Phase3D", "Nuclei"], norm_meta=meta)
+    return path, pos
+
+
+@pytest.mark.parametrize("compress,chunks", [(False, None), (True, (1, 1, 1, 64, 128)), (False, (1, 1, 2, 50, 70))])
+def test_zarr_roundtrip(compress, chunks):
+    d = tempfile.mkdtemp()
+    rng = np.random.default_rng(0)
+    arr = rng.random((2, 3, 7, 90, 130), dtype=np.float32)
+    write_hcs_plate(os.path.join(d, "p.zarr"), {"B/3/0": arr}, ["a", "b", "c"], chunks=chunks, compress=compress)
+    plate = open_ome_zarr(os.path.join(d, "p.zarr"))
+    (name, pos), = list(plate.positions())
+    assert name == "B/3/0" and pos.channel_names == ["a", "b", "c"] and pos.get_channel_index("c") == 2
+    img = pos["0"]
+    assert img.shape == arr.shape and (img.frames, img.channels, img.slices, img.height, img.width) == arr.shape
+    np.testing.assert_array_equal(img.oindex[slice(1, 2), [2, 0], slice(2, 6)], arr[1:2][:, [2, 0], 2:6])
+    with pytest.raises(FileNotFoundError):
+        open_ome_zarr(os.path.join(d, "missing.zarr"))
+
+
+def test_datamodule_fit_contract(tiny_hcs_zarr):
+    path, pos = tiny_hcs_zarr
+    dm = HCSDataModule(path, "Phase3D", "Nuclei", z_window_size=5, batch_size=2, num_workers=0, yx_patch_size=(128, 128),
+                       normalizations=[NormalizeSampled(["Phase3D", "Nuclei"], "fov_statistics")], split_ratio=0.5)
+    dm.setup("fit")
+    assert len(dm.train_dataset) == 2 and len(dm.val_dataset) == 2
+    b = next(iter(dm.train_dataloader()))
+    assert b["source"].shape == (2, 1, 5, 128, 128) and b["target"].shape == (2, 1, 5, 128, 128)
+    assert b["source"].dtype == torch.float32
+    names, t, z = b["index"]
+    assert all(n.startswith("/A/") and n.endswith("/0") for n in names) and t.tolist() == [0, 0] and z.tolist() == [0, 0]
+    assert b["norm_meta"]["Phase3D"]["fov_statistics"]["mean"].shape == (2,)
+    raw = pos[names[0][1:-2]][0, 0]
+    torch.testing.assert_close(b["source"][0, 0], (torch.from_numpy(raw) - 0.5) / (0.29 + 1e-8))
+    assert dm.on_after_batch_transfer(b, 0) is b
+    # same seed → same split; wrong patch size → the reference's error
+    dm2 = HCSDataModule(path, "Phase3D", "Nuclei", z_window_size=5, batch_size=2, num_workers=0, yx_patch_size=(64, 64), split_ratio=0.5)
+    dm2.setup("fit")
+    assert [p.name for p in dm2.train_dataset.positions] == [p.name for p in dm.train_dataset.positions]
+    with pytest.raises(ValueError, match="does not match expected"):
+        dm2.on_after_batch_transfer(next(iter(dm2.train_dataloader())), 0)
+    with pytest.raises(ValueError, match="No positions left"):
+        HCSDataModule(path, "Phase3D", "Nuclei", 5, include_fov_names=["Z/9/9"]).setup("fit")
+
+
+def test_sliding_windows_and_predict(tiny_hcs_zarr):
+    path, pos = tiny_hcs_zarr
+    dm = HCSDataModule(path, "Phase3D", "Nuclei", z_window_size=3, batch_size=4, num_workers=0)
+    dm.setup("predict")
+    ds = dm.predict_dataset
+    assert len(ds) == 4 * (5 - 3 + 1) and "target" not in ds[0]
+    s = ds[4]  # second FOV, z = 1
+    assert s["index"][2] == 1 and s["source"].shape == (1, 3, 128, 128)
+    with pytest.raises(ValueError, match="exceeds"):
+        SlidingWindowDataset(ds.positions, {"source": ["Phase3D"]}, z_window_size=9)
+
+
+def test_normalize_cpu_worker_path_matches_reference_golden():
+    g = load_golden("normalize.pt")  # produced by the reference's NormalizeSampled / MinMaxSampled
+    meta = {"ch": {"fov_statistics": {"mean": g["mean"], "std": g["std"]}}}
+    out = NormalizeSampled(["ch"], "fov_statistics")({"ch": g["x"].clone(), "norm_meta": meta})
+    assert torch.equal(out["ch"], g["y"]) and "norm_meta" in out
+    kat = {"ch": {"fov_statistics": {"mean": torch.tensor(60.0), "std": torch.tensor(10.0), "p1": torch.tensor(55.0), "p99": torch.tensor(65.0)}}}
+    assert torch.equal(NormalizeSampled("ch", "fov_statistics", remove_meta=True)({"ch": g["kat_in"].clone(), "norm_meta": kat})["ch"], g["kat_out"])
+    assert torch.equal(MinMaxSampled("ch", "fov_statistics")({"ch": g["kat_in"].clone(), "norm_meta": kat})["ch"], g["mm_out"])
+    with pytest.raises(ValueError, match="Invalid data_range"):
+        MinMaxSampled("ch", "fov_statistics", data_range="nope")
+
+
+def test_warmup_cosine_schedule():
+    # MONAI WarmupCosineSchedule(warmup_steps=3, t_total=10, warmup_multiplier=1e-3)
+    lam = [warmup_cosine_lambda(s, 3, 10, 1e-3) for s in range(11)]
+    assert lam[0] == pytest.approx(1e-3) and lam[3] == pytest.approx(1.0) and lam[10] == pytest.approx(0.0, abs=1e-12)
+    assert all(a < b for a, b in zip(lam[:3], lam[1:4])) and all(a > b for a, b in zip(lam[3:10], lam[4:11]))
+    assert lam[1] == pytest.approx(1e-3 + (1 - 1e-3) / 3)
+
+
+def test_shard_indices_equal_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+
+    ds = list(range(103))
+    for world in (1, 2, 4, 8):
+        seen = []
+        for r in range(world):
+            ref = DistributedSampler(ds, num_replicas=world, rank=r, shuffle=True, seed=42, drop_last=True)
+            ref.set_epoch(3)
+            mine = shard_indices(len(ds), r, world, seed=42, epoch=3, shuffle=True, drop_last=True)
+            assert mine == list(ref)
+            seen += mine
+        assert len(set(seen)) == len(seen) == 103 // world * world  # disjoint shards
+
+
+class _FakeEngine:
+    def __init__(self, n, rank):
+        g = torch.Generator().manual_seed(100 + rank)
+        self.flat = torch.randn(n, generator=g)
+        self.flat_grad = torch.zeros(n)
+        self.bucket_bounds = [(0, n // 3), (n // 3, 2 * n // 3), (2 * n // 3, n)]
+        self.on_bucket_ready = None
+
+
+class _FakeOpt:
+    grad_scale = 1.0
+
+
+def _ddp_worker(rank, world, init_file, out):
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    eng, opt = _FakeEngine(1000, rank), _FakeOpt()
+    ddp = FlatDataParallel(eng, opt)
+    params_after_broadcast = eng.flat.clone()
+    eng.flat_grad.copy_(torch.arange(1000, dtype=torch.float32) * (rank + 1))
+    for i in range(3):  # what Engine.backward does as buckets complete
+        eng.on_bucket_ready(i)
+    ddp.finish()
+    loss = ddp.all_reduce_mean(torch.tensor(float(rank + 1)))
+    out[rank] = (params_after_broadcast, eng.flat_grad.clone(), opt.grad_scale, float(loss))
+    dist.destroy_process_group()
+
+
+def test_flat_data_parallel_gloo_world2():
+    world = 2
+    init_file = tempfile.mktemp()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(world, init_file, out), nprocs=world, join=True)
+    (p0, g0, s0, l0), (p1, g1, s1, l1) = out[0], out[1]
+    assert torch.equal(p0, p1)                       # rank 0's parameters were broadcast
+    expect = torch.arange(1000, dtype=torch.float32) * 3.0
+    assert torch.equal(g0, expect) and torch.equal(g1, expect)   # SUM all-reduce of every bucket
+    assert s0 == s1 == 0.5                           # averaging folded into the optimizer's grad_scale
+    assert l0 == l1 == 1.5                           # sync_dist mean of a logged scalar

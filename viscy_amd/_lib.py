@@ -75,6 +75,11 @@ _SIGS = {
     "vsx_matvec_t_add": (_I32, [_P, _P, _P, _I32, _I32, _P]),
     "vsx_transpose_f32": (_I32, [_P, _P, _I32, _I32, _I32, _P]),
     "vsx_prep_head_dgrad": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "vsx_normalize": (_I32, [_P, _P, _P, _P, _I32, _I64, _P]),
+    "vsx_minmax_norm": (_I32, [_P, _P, _P, _P, _I32, _I64, _P]),
+    "vsx_sample_minmax": (_I32, [_P, _P, _P, _I32, _I64, _P]),
+    "vsx_intensity_aug": (_I32, [_P] * 8 + [_F32, _I32, _I64, _P]),
+    "vsx_blend_in": (_I32, [_P, _P, _P, _P, _I32, _I64, _I64, _P]),
 }
 
 _lib = None

@@ -132,9 +132,8 @@ __device__ __forceinline__ float lds_frag_rk<float>(const char* tile, int row, i
 // ------------------------------------------------------------------------------------------------
 // gemm_nt
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM_, int WN_>
+template <typename T, int BM, int BN, int WM_, int WN_, int BK>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
-  constexpr int BK = 32;
   constexpr int ES = sizeof(T);
   constexpr int RS = BK * ES + (ES == 2 ? 32 : 16);
   constexpr int CPR = BK * ES / 16;
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
   constexpr int MAIN_BYTES = 2 * (BM + BN) * RS;
   constexpr int CS_LD = BN + 4;
   constexpr int MAXBT = 8;  // batch samples one tile may span on the LDS reduction path
-  constexpr int EPI_BYTES = (BM / 2) * CS_LD * 4 + 2 * MAXBT * BN * 4;
+  constexpr int EPI_BYTES = (BM / (BN >= 64 ? 2 : 1)) * CS_LD * 4 + 2 * MAXBT * BN * 4;
   constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   constexpr int MK = Frag<T>::MK;
   typedef typename VT<T>::vec vec;
@@ -253,7 +252,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
 
   // ---- epilogue: accumulators → LDS (fp32) → row-contiguous vectors, in two passes of BM/2 rows so that the
   // staging buffer (not the K-loop buffers) never decides how many workgroups fit on a CU
-  constexpr int HR = BM / 2;  // rows per pass
+  constexpr int NPASS = BN >= 64 ? 2 : 1;
+  constexpr int HR = BM / NPASS;  // rows per pass
   float* Cs = reinterpret_cast<float*>(smem);
   float* red = Cs + HR * CS_LD;  // [2][MAXBT][BN]
   constexpr int NCH = BN / VN;        // column chunks per row
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
   }
 
 #pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < NPASS; ++half) {
     __syncthreads();  // K-loop buffers / previous pass no longer read
     if ((wm * FM * 16) / HR == half) {
 #pragma unroll
@@ -419,21 +419,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
   }
 }
 
-template <typename T, int BM, int BN, int WM_, int WN_>
+template <typename T, int BM, int BN, int WM_, int WN_, int BK>
 static int launch_nt(const VsxGemm* p, hipStream_t s) {
   int tiles = vsx_cdiv(p->M, BM) * vsx_cdiv(p->N, BN);
   dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM_, WN_>), grid, dim3(256), 0, s, *p);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM_, WN_, BK>), grid, dim3(256), 0, s, *p);
   VSX_LAUNCH_CHECK();
   return 0;
 }
 
 template <typename T>
 static int dispatch_nt(const VsxGemm* p, hipStream_t s) {
-  if (p->N > 64) return launch_nt<T, 128, 128, 2, 2>(p, s);
-  if (p->N > 32) return launch_nt<T, 128, 64, 2, 2>(p, s);
-  if (p->N > 16) return launch_nt<T, 128, 32, 4, 1>(p, s);
-  return launch_nt<T, 128, 16, 4, 1>(p, s);
+  if (p->N > 64) {
+    // few workgroups (< 2 per CU) and a long K loop: the loop is bound by global-load latency, not by MFMA
+    // or bandwidth — stage 4x more K per barrier so 4x more bytes are in flight per workgroup
+    long tiles = (long)vsx_cdiv(p->M, 128) * vsx_cdiv(p->N, 128) * (p->nz > 0 ? p->nz : 1);
+    if constexpr (sizeof(T) == 2) {
+      if (tiles < 512 && p->K >= 256) return launch_nt<T, 128, 128, 2, 2, 128>(p, s);
+    }
+    return launch_nt<T, 128, 128, 2, 2, 32>(p, s);
+  }
+  if (p->N > 32) return launch_nt<T, 128, 64, 2, 2, 32>(p, s);
+  if (p->N > 16) return launch_nt<T, 128, 32, 4, 1, 32>(p, s);
+  return launch_nt<T, 128, 16, 4, 1, 32>(p, s);
 }
 
 static int check_common(const VsxGemm* p, int dtype, const char* who) {

@@ -1,0 +1,164 @@
+// viscy-transforms hot-path pieces and the predict-time Z blend:
+// HBM-bound elementwise kernels over (B, C, Z, Y, X) fp32 stacks, 16-byte accesses along the
+// contiguous X axis, per-sample parameters broadcast from small device arrays.
+#include "vsx_common.h"
+#include "../../include/vsx.h"
+
+// y = (x - sub[b]) / (div[b] + 1e-8)
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ sub, const float* __restrict__ dv,
+                                                        long per_sample, long total) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
+    const int b = (int)(i / per_sample);
+    const float s = sub[b], d = dv[b] + 1e-8f;
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    v.x = (v.x - s) / d; v.y = (v.y - s) / d; v.z = (v.z - s) / d; v.w = (v.w - s) / d;
+    *reinterpret_cast<float4*>(y + i) = v;
+  }
+}
+
+// y = clamp(x, lo, hi) → 2 (x - lo) / (hi - lo + 1e-8) - 1
+__global__ __launch_bounds__(256) void minmax_norm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ lo, const float* __restrict__ hi,
+                                                          long per_sample, long total) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
+    const int b = (int)(i / per_sample);
+    const float l = lo[b], h = hi[b];
+    const float inv = 1.f / (h - l + 1e-8f);
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    float* p = &v.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = 2.f * (fminf(fmaxf(p[j], l), h) - l) * inv - 1.f;
+    *reinterpret_cast<float4*>(y + i) = v;
+  }
+}
+
+__device__ __forceinline__ void atomic_minmax(float* mn, float* mx, float lo, float hi) {
+  // order-preserving int mapping of floats
+  if (lo >= 0.f) atomicMin(reinterpret_cast<int*>(mn), __float_as_int(lo));
+  else atomicMax(reinterpret_cast<unsigned int*>(mn), __float_as_uint(lo));
+  if (hi >= 0.f) atomicMax(reinterpret_cast<int*>(mx), __float_as_int(hi));
+  else atomicMin(reinterpret_cast<unsigned int*>(mx), __float_as_uint(hi));
+}
+
+// per-sample min / max (mn pre-set to +inf, mx to -inf); gridDim.y = B, <= 64 blocks per sample
+__global__ __launch_bounds__(256) void sample_minmax_kernel(const float* __restrict__ x, float* __restrict__ mn,
+                                                            float* __restrict__ mx, long per_sample) {
+  const int b = blockIdx.y;
+  const float* xs = x + (size_t)b * per_sample;
+  float lo = INFINITY, hi = -INFINITY;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * 256 * 4) {
+    float4 v = *reinterpret_cast<const float4*>(xs + i);
+    lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
+    hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+  }
+  lo = -wave_max(-lo);
+  hi = wave_max(hi);
+  if ((threadIdx.x & 63) == 0 && hi >= lo) atomic_minmax(mn + b, mx + b, lo, hi);
+}
+
+// fused intensity augmentation (BatchedRandAdjustContrast → BatchedRandScaleIntensity → BatchedRandGaussianNoise):
+//   gamma[b] > 0 : x = ((x - m)/(r + 1e-7))^gamma * r + m     (MONAI AdjustContrast, m = min, r = max - min)
+//   x *= (1 + factor[b])
+//   nstd[b] >= 0 (applied): x += nmean + noise[i mod per_sample] * nstd[b]   (one field shared by the batch)
+__global__ __launch_bounds__(256) void intensity_aug_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ mn, const float* __restrict__ mx,
+                                                            const float* __restrict__ gamma, const float* __restrict__ factor,
+                                                            const float* __restrict__ noise, const float* __restrict__ nstd,
+                                                            float nmean, long per_sample, long total) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
+    const int b = (int)(i / per_sample);
+    const long off = i - (long)b * per_sample;
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    float* p = &v.x;
+    const float g = gamma ? gamma[b] : 0.f;
+    if (g > 0.f) {
+      const float m = mn[b], r = mx[b] - m;
+      const float inv = 1.f / (r + 1e-7f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] = __powf((p[j] - m) * inv, g) * r + m;
+    }
+    if (factor) {
+      const float f = 1.f + factor[b];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] *= f;
+    }
+    if (noise && nstd[b] >= 0.f) {
+      const float4 nz = *reinterpret_cast<const float4*>(noise + off);
+      const float s = nstd[b];
+      p[0] += nmean + nz.x * s; p[1] += nmean + nz.y * s; p[2] += nmean + nz.z * s; p[3] += nmean + nz.w * s;
+    }
+    *reinterpret_cast<float4*>(y + i) = v;
+  }
+}
+
+// out[b,c,z,y,x] = old * (f_z - 1) / f_z + new / f_z    (prediction_writer._blend_in, Z feathering)
+__global__ __launch_bounds__(256) void blend_in_kernel(const float* __restrict__ oldp, const float* __restrict__ newp,
+                                                       float* __restrict__ out, const float* __restrict__ fz, int Z, long plane,
+                                                       long total) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
+    const int z = (int)((i / plane) % Z);
+    const float f = fz[z];
+    const float a = (f - 1.f) / f, bq = 1.f / f;
+    const float4 o = *reinterpret_cast<const float4*>(oldp + i);
+    const float4 n = *reinterpret_cast<const float4*>(newp + i);
+    *reinterpret_cast<float4*>(out + i) = make_float4(o.x * a + n.x * bq, o.y * a + n.y * bq, o.z * a + n.z * bq, o.w * a + n.w * bq);
+  }
+}
+
+static int ew_grid(long total) {
+  int g = vsx_cdiv(total, 256L * 4 * 4);
+  return g > 8192 ? 8192 : (g < 1 ? 1 : g);
+}
+
+/* K17 NormalizeSampled.__call__ (viscy_transforms/_normalize.py:72-80) on a (B, ...) fp32 batch with (B,) statistics. */
+extern "C" int32_t vsx_normalize(const float* x, float* y, const float* sub, const float* div, int32_t B, int64_t per_sample,
+                                 vsx_stream_t stream) {
+  VSX_CHECK(x && y && sub && div && B > 0 && per_sample > 0 && per_sample % 4 == 0, "vsx_normalize: bad arguments (per-sample size must be a multiple of 4)");
+  long total = (long)B * per_sample;
+  hipLaunchKernelGGL(normalize_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, sub, div, (long)per_sample, total);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+/* MinMaxSampled.__call__ (viscy_transforms/_normalize.py:124-134). */
+extern "C" int32_t vsx_minmax_norm(const float* x, float* y, const float* lo, const float* hi, int32_t B, int64_t per_sample,
+                                   vsx_stream_t stream) {
+  VSX_CHECK(x && y && lo && hi && B > 0 && per_sample > 0 && per_sample % 4 == 0, "vsx_minmax_norm: bad arguments");
+  long total = (long)B * per_sample;
+  hipLaunchKernelGGL(minmax_norm_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, lo, hi, (long)per_sample, total);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+/* per-sample min / max needed by MONAI AdjustContrast (K19); mn/mx must be pre-set to +inf / -inf. */
+extern "C" int32_t vsx_sample_minmax(const float* x, float* mn, float* mx, int32_t B, int64_t per_sample, vsx_stream_t stream) {
+  VSX_CHECK(x && mn && mx && B > 0 && per_sample > 0 && per_sample % 4 == 0, "vsx_sample_minmax: bad arguments");
+  int gx = vsx_cdiv(per_sample, 256L * 4 * 8);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(sample_minmax_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, mn, mx, (long)per_sample);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+/* K19-K21 fused: BatchedRandAdjustContrast (_adjust_contrast.py:54-86) → BatchedRandScaleIntensity
+ * (_scale_intensity.py:59-77) → BatchedRandGaussianNoise (_noise.py:158-204) with injected per-sample parameters;
+ * any of gamma / factor / noise may be NULL (stage skipped); gamma[b] <= 0 or nstd[b] < 0 = sample not selected. */
+extern "C" int32_t vsx_intensity_aug(const float* x, float* y, const float* mn, const float* mx, const float* gamma,
+                                     const float* factor, const float* noise, const float* nstd, float nmean, int32_t B,
+                                     int64_t per_sample, vsx_stream_t stream) {
+  VSX_CHECK(x && y && B > 0 && per_sample > 0 && per_sample % 4 == 0, "vsx_intensity_aug: bad arguments");
+  VSX_CHECK(!gamma || (mn && mx), "vsx_intensity_aug: gamma needs per-sample min/max");
+  VSX_CHECK((noise == nullptr) == (nstd == nullptr), "vsx_intensity_aug: noise and nstd come together");
+  long total = (long)B * per_sample;
+  hipLaunchKernelGGL(intensity_aug_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, mn, mx, gamma, factor,
+                     noise, nstd, nmean, (long)per_sample, total);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+/* K25 _blend_in (viscy_utils/callbacks/prediction_writer.py:74-111): fz[Z] = per-slice blend factor. */
+extern "C" int32_t vsx_blend_in(const float* oldp, const float* newp, float* out, const float* fz, int32_t Z, int64_t plane,
+                                int64_t total, vsx_stream_t stream) {
+  VSX_CHECK(oldp && newp && out && fz && Z > 0 && plane > 0 && plane % 4 == 0 && total % 4 == 0, "vsx_blend_in: bad arguments");
+  hipLaunchKernelGGL(blend_in_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, oldp, newp, out, fz, Z, (long)plane,
+                     (long)total);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,262 @@
+"""``HCSDataModule`` / ``SlidingWindowDataset`` — the data-module surface of the Cytoland pipeline
+(/root/reference/packages/viscy-data/src/viscy_data/hcs.py:124-829, sliding_window.py:21-286), kept so
+that ``VSUNet`` + the HIP path drop in behind the same batch contract:
+
+  Sample = {"source": (B,Cs,Z,Y,X) f32, "target": (B,Ct,Z,Y,X) f32,
+            "index": (list["/row/col/fov/0"], t, z), "norm_meta": {channel: {level: {stat: Tensor}}}}
+
+Covered: fit / predict / test set-up, seeded FOV train/val split, Z-sliding windows over T, CPU
+normalisations + augmentations composed per sample in the workers, collation of multi-sample crops,
+``on_after_batch_transfer`` GPU augmentations + spatial-shape validation + ``target_2d`` slicing,
+``DistributedSampler`` sharding under DP.  Not built: mmap preload, foreground masks, non-zero
+rejection sampling (marked NotImplemented when requested).  I/O is plain host code.
+"""
+
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Callable, Iterable, Sequence
+
+import numpy as np
+import torch
+from torch import Tensor
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.distributed import DistributedSampler
+
+from .ome_zarr import open_ome_zarr
+
+try:  # pragma: no cover
+    from lightning.pytorch import LightningDataModule as _DMBase
+except Exception:  # noqa: BLE001
+    _DMBase = object
+
+
+def _ensure_channel_list(x) -> list[str]:
+    return [x] if isinstance(x, str) else list(x)
+
+
+def _read_norm_meta(fov) -> dict | None:
+    """viscy_data/_utils.py:139-165: zattrs["normalization"] → float32 0-d tensors."""
+    meta = fov.zattrs.get("normalization")
+    if meta is None:
+        return None
+    out = {}
+    for ch, levels in meta.items():
+        out[ch] = {}
+        for level, stats in levels.items():
+            if level == "timepoint_statistics":
+                out[ch][level] = {t: {k: torch.tensor(v, dtype=torch.float32) for k, v in s.items()} for t, s in stats.items()}
+            else:
+                out[ch][level] = {k: torch.tensor(v, dtype=torch.float32) for k, v in stats.items()}
+    return out
+
+
+class Compose:
+    def __init__(self, transforms: Sequence[Callable]):
+        self.transforms = list(transforms)
+
+    def __call__(self, sample):
+        for t in self.transforms:
+            if isinstance(sample, list):
+                sample = [t(s) for s in sample]
+            else:
+                sample = t(sample)
+        return sample
+
+
+class SlidingWindowDataset(Dataset):
+    """All (FOV, t, z-window) positions of an HCS plate; see sliding_window.py:21-286."""
+
+    def __init__(self, positions, channels: dict[str, list[str]], z_window_size: int, array_key: str = "0",
+                 transform: Callable | None = None, load_normalization_metadata: bool = True):
+        self.positions, self.channels = list(positions), {k: list(v) for k, v in channels.items()}
+        self.z_window_size, self.array_key, self.transform = z_window_size, array_key, transform
+        self.load_normalization_metadata = load_normalization_metadata
+        names = self.channels["source"] + [c for c in self.channels.get("target", []) if c not in self.channels["source"]]
+        self._all_ch_names = names
+        self._windows = []  # cumulative window counts
+        self._arrays, self._ch_idx, self._norm = [], [], []
+        total = 0
+        for fov in self.positions:
+            img = fov[array_key]
+            zs = img.slices - z_window_size + 1
+            if zs < 1:
+                raise ValueError(f"z_window_size {z_window_size} exceeds the {img.slices} slices of {fov.name}")
+            total += img.frames * zs
+            self._windows.append(total)
+            self._arrays.append(img)
+            self._ch_idx.append([fov.get_channel_index(c) for c in names])
+            self._norm.append(_read_norm_meta(fov))
+        self._max_window = total
+
+    def __len__(self) -> int:
+        return self._max_window
+
+    def _find_window(self, index: int):
+        i = int(np.searchsorted(self._windows, index, side="right"))
+        tz = index - (self._windows[i - 1] if i else 0)
+        return i, tz
+
+    def __getitem__(self, index: int):
+        i, tz = self._find_window(index)
+        img = self._arrays[i]
+        zs = img.slices - self.z_window_size + 1
+        t, z = tz // zs, tz % zs
+        data = img.oindex[slice(t, t + 1), self._ch_idx[i], slice(z, z + self.z_window_size)].astype(np.float32)
+        images = dict(zip(self._all_ch_names, torch.from_numpy(data).unbind(dim=1)))  # each (1, Z, Y, X)
+        sample_index = (f"/{img.path}", t, z)
+        norm_meta = self._norm[i]
+        if norm_meta is not None:
+            nm = {}
+            for ch, levels in norm_meta.items():  # resolve timepoint statistics (sliding_window.py:148-164)
+                nm[ch] = {lv: (st.get(str(t), next(iter(st.values()))) if lv == "timepoint_statistics" else st)
+                          for lv, st in levels.items()}
+            images["norm_meta"] = norm_meta = nm
+        if "target" in self.channels:
+            images["weight"] = images[self.channels["target"][0]]
+        if self.transform:
+            images = self.transform(images)
+
+        def build(im):
+            im.pop("weight", None)
+            s = {"index": sample_index, "source": torch.stack([im[c][0] for c in self.channels["source"]])}
+            if "target" in self.channels:
+                s["target"] = torch.stack([im[c][0] for c in self.channels["target"]])
+            if self.load_normalization_metadata and norm_meta is not None:
+                s["norm_meta"] = norm_meta
+            return s
+
+        return [build(im) for im in images] if isinstance(images, list) else build(images)
+
+
+def _collate_samples(batch):
+    """viscy_data/_utils.py:112-136: flatten per-stack lists of patches, stack tensors, keep indices as lists."""
+    flat = []
+    for b in batch:
+        flat.extend(b if isinstance(b, list) else [b])
+    out = {}
+    for k in flat[0]:
+        vals = [s[k] for s in flat]
+        if torch.is_tensor(vals[0]):
+            out[k] = torch.stack(vals)
+        elif k == "index":
+            out[k] = ([v[0] for v in vals], torch.tensor([v[1] for v in vals]), torch.tensor([v[2] for v in vals]))
+        elif k == "norm_meta":
+            out[k] = {ch: {lv: {st: torch.stack([v[ch][lv][st] for v in vals]) for st in vals[0][ch][lv]}
+                           for lv in vals[0][ch]} for ch in vals[0]}
+        else:
+            out[k] = vals
+    return out
+
+
+class HCSDataModule(_DMBase):
+    def __init__(self, data_path: str, source_channel, target_channel, z_window_size: int, split_ratio: float = 0.8,
+                 batch_size: int = 16, num_workers: int = 8, target_2d: bool = False, yx_patch_size=(256, 256),
+                 normalizations: list | None = None, augmentations: list | None = None, mmap_preload: bool = False,
+                 scratch_dir=None, ground_truth_masks=None, persistent_workers=False, prefetch_factor=None,
+                 array_key: str = "0", pin_memory=True, min_nonzero_fraction: float = 0.0, nonzero_threshold: float = 0.0,
+                 nonzero_channel=None, max_nonzero_retries: int = 100, fg_mask_key=None, gpu_augmentations: list | None = None,
+                 val_augmentations: list | None = None, val_gpu_augmentations: list | None = None,
+                 include_fov_names: Iterable[str] | None = None, exclude_fov_names: Iterable[str] | None = None, seed: int = 42):
+        if _DMBase is not object:  # pragma: no cover
+            super().__init__()
+        if mmap_preload or fg_mask_key is not None or ground_truth_masks is not None or min_nonzero_fraction > 0:
+            raise NotImplementedError("mmap_preload / fg_mask_key / ground_truth_masks / min_nonzero_fraction are not built")
+        self.data_path = Path(data_path)
+        self.source_channel, self.target_channel = _ensure_channel_list(source_channel), _ensure_channel_list(target_channel)
+        self.batch_size, self.num_workers, self.target_2d = batch_size, num_workers, target_2d
+        self.z_window_size, self.split_ratio, self.yx_patch_size = z_window_size, split_ratio, tuple(yx_patch_size)
+        self.normalizations, self.augmentations = normalizations or [], augmentations or []
+        self.val_augmentations = val_augmentations or []
+        self.array_key, self.pin_memory = array_key, pin_memory
+        self.persistent_workers, self.prefetch_factor = persistent_workers, prefetch_factor
+        self.include_fov_names = set(include_fov_names) if include_fov_names is not None else None
+        self.exclude_fov_names = set(exclude_fov_names) if exclude_fov_names is not None else None
+        self._gpu_augmentations = Compose(gpu_augmentations) if gpu_augmentations else None
+        self._val_gpu_augmentations = Compose(val_gpu_augmentations) if val_gpu_augmentations else None
+        self.prepare_data_per_node = True
+        self.seed = seed
+        self.training = True  # set by the trainer loop (Lightning: trainer.training / trainer.validating)
+        self.train_patches_per_stack = 1
+        for aug in self.augmentations:
+            n = getattr(getattr(aug, "cropper", None), "num_samples", None) or getattr(aug, "num_samples", None)
+            if n:
+                if batch_size % n:
+                    raise ValueError(f"Batch size must be divisible by `num_samples` per stack. Got batch size {batch_size} "
+                                     f"and number of samples {n} for transform type {type(aug)}.")
+                self.train_patches_per_stack = n
+
+    def prepare_data(self):
+        pass
+
+    def _filtered_positions(self, plate):
+        pos = [p for name, p in plate.positions()
+               if (self.include_fov_names is None or name in self.include_fov_names)
+               and (self.exclude_fov_names is None or name not in self.exclude_fov_names)]
+        if not pos:
+            raise ValueError(f"No positions left in {self.data_path} after applying include_fov_names / exclude_fov_names filters")
+        return pos
+
+    def setup(self, stage: str):
+        settings = dict(channels={"source": self.source_channel}, z_window_size=self.z_window_size, array_key=self.array_key)
+        plate = open_ome_zarr(self.data_path, mode="r")
+        positions = self._filtered_positions(plate)
+        if stage in ("fit", "validate"):
+            settings["channels"]["target"] = self.target_channel
+            g = torch.Generator().manual_seed(self.seed)
+            idx = torch.randperm(len(positions), generator=g).tolist()  # hcs.py:490-494,566-569
+            positions = [positions[i] for i in idx]
+            n_train = int(len(positions) * self.split_ratio)
+            self.train_dataset = SlidingWindowDataset(positions[:n_train], transform=Compose(self.normalizations + self.augmentations), **settings)
+            self.val_dataset = SlidingWindowDataset(positions[n_train:], transform=Compose(self.normalizations + self.val_augmentations), **settings)
+        elif stage == "test":
+            settings["channels"]["target"] = self.target_channel
+            self.test_dataset = SlidingWindowDataset(positions, transform=Compose(self.normalizations), **settings)
+        elif stage == "predict":
+            self.predict_dataset = SlidingWindowDataset(positions, transform=Compose(self.normalizations), **settings)
+        else:
+            raise NotImplementedError(f"{stage} stage not supported")
+
+    def _loader(self, ds, batch_size, shuffle, drop_last=False):
+        sampler = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # what Lightning injects for plain HCSDataModule (hcs.py:723-735): stock DistributedSampler
+            sampler = DistributedSampler(ds, shuffle=shuffle, seed=self.seed, drop_last=drop_last)
+            shuffle = False
+        return DataLoader(ds, batch_size=batch_size, num_workers=self.num_workers, shuffle=shuffle, sampler=sampler,
+                          drop_last=drop_last, collate_fn=_collate_samples, pin_memory=self.pin_memory and torch.cuda.is_available(),
+                          persistent_workers=self.persistent_workers and self.num_workers > 0,
+                          prefetch_factor=self.prefetch_factor if self.num_workers else None)
+
+    def train_dataloader(self):
+        return self._loader(self.train_dataset, self.batch_size // self.train_patches_per_stack, shuffle=True, drop_last=True)
+
+    def val_dataloader(self):
+        return self._loader(self.val_dataset, self.batch_size, shuffle=False)
+
+    def test_dataloader(self):
+        return self._loader(self.test_dataset, 1, shuffle=False)
+
+    def predict_dataloader(self):
+        return self._loader(self.predict_dataset, self.batch_size, shuffle=False)
+
+    @torch.no_grad()
+    def on_after_batch_transfer(self, batch, dataloader_idx: int):
+        """hcs.py:679-721: GPU augmentations, target_2d slicing, training-shape validation."""
+        if isinstance(batch, Tensor):
+            return batch
+        if self.training and self._gpu_augmentations is not None:
+            batch = self._gpu_augmentations(batch)
+        elif not self.training and self._val_gpu_augmentations is not None:
+            batch = self._val_gpu_augmentations(batch)
+        if self.target_2d and "target" in batch:
+            z_index = self.z_window_size // 2
+            batch["target"] = batch["target"][:, :, slice(z_index, z_index + 1)]
+        if self.training and self._gpu_augmentations is None and "source" in batch:
+            expected = (self.z_window_size, self.yx_patch_size[0], self.yx_patch_size[1])
+            actual = tuple(batch["source"].shape[2:])
+            if actual != expected:
+                raise ValueError(f"Source spatial shape {actual} does not match expected {expected} "
+                                 f"(z_window_size={self.z_window_size}, yx_patch_size={list(self.yx_patch_size)}). "
+                                 f"Configure gpu_augmentations with a spatial crop to match yx_patch_size.")
+        return batch

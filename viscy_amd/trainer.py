@@ -1,0 +1,83 @@
+"""Minimal trainer for ``viscy_amd.VSUNet`` + ``viscy_amd.data.HCSDataModule`` reproducing the Lightning
+automatic-optimisation semantics the reference relies on: per batch
+``zero_grad → autocast(bf16){training_step} → backward → optimizer.step → scheduler step``;
+``on_after_batch_transfer`` runs on the device batch; ``fast_dev_run`` = 1 train + 1 val batch;
+validation logs the mean of per-dataloader mean losses as ``loss/validate``; DDP = one process per GPU,
+gradient all-reduce through ``viscy_amd.parallel.FlatDataParallel`` (RCCL), index sharding with
+``DistributedSampler`` semantics, ``sync_dist`` → mean all-reduce of logged scalars.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .parallel import FlatDataParallel
+
+
+class Trainer:
+    def __init__(self, max_epochs: int = 1, fast_dev_run: bool = False, precision: str = "bf16-mixed",
+                 accelerator: str = "gpu", seed: int | None = 42, limit_train_batches: int | None = None):
+        self.max_epochs, self.fast_dev_run, self.precision = max_epochs, fast_dev_run, precision
+        self.limit_train_batches = limit_train_batches
+        self.finished = False
+        self.global_step = 0
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+    def _to_device(self, batch):
+        if isinstance(batch, dict):
+            return {k: self._to_device(v) for k, v in batch.items()}
+        if isinstance(batch, (list, tuple)):
+            return type(batch)(self._to_device(v) for v in batch)
+        if torch.is_tensor(batch):
+            return batch.to(self.device, non_blocking=True)
+        return batch
+
+    def fit(self, module, datamodule) -> None:
+        module.to(self.device)
+        datamodule.setup("fit")
+        train_dl = datamodule.train_dataloader()
+        steps_per_epoch = 1 if self.fast_dev_run else min(len(train_dl), self.limit_train_batches or len(train_dl))
+        opt = module.configure_optimizers(t_total=steps_per_epoch * (1 if self.fast_dev_run else self.max_epochs))
+        ddp = FlatDataParallel(module.model.engine(), opt) if dist.is_initialized() else None
+        use_bf16 = self.precision.startswith("bf16")
+        for epoch in range(1 if self.fast_dev_run else self.max_epochs):
+            module.train()
+            if hasattr(train_dl, "sampler") and hasattr(train_dl.sampler, "set_epoch"):
+                train_dl.sampler.set_epoch(epoch)
+            for i, batch in enumerate(train_dl):
+                if i >= steps_per_epoch:
+                    break
+                batch = datamodule.on_after_batch_transfer(self._to_device(batch), 0)
+                opt.zero_grad()
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+                    loss = module.training_step(batch, i)
+                loss.backward()
+                if ddp is not None:
+                    ddp.finish()
+                opt.step()
+                self.global_step += 1
+            module.on_train_epoch_end()
+            module.eval()
+            with torch.no_grad():
+                for j, batch in enumerate(datamodule.val_dataloader()):
+                    batch = datamodule.on_after_batch_transfer(self._to_device(batch), 0)
+                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+                        module.validation_step(batch, j, 0)
+                    if self.fast_dev_run:
+                        break
+            module.on_validation_epoch_end()
+        torch.cuda.synchronize()
+        self.finished = True
+
+    def predict(self, module, datamodule) -> list[torch.Tensor]:
+        module.to(self.device).eval()
+        datamodule.setup("predict")
+        module.on_predict_start()
+        outs = []
+        with torch.no_grad():
+            for j, batch in enumerate(datamodule.predict_dataloader()):
+                outs.append(module.predict_step(self._to_device(batch), j))
+        return outs

@@ -1,0 +1,244 @@
+"""viscy-transforms surface used by the UNeXt2 recipes, on MI355X.
+
+Same class names / constructor keywords / dict-in-dict-out call convention as
+``viscy_transforms`` (/root/reference/packages/viscy-transforms/src/viscy_transforms):
+``NormalizeSampled``, ``MinMaxSampled`` (_normalize.py:27-134), ``BatchedRandScaleIntensityd``
+(_scale_intensity.py), ``BatchedRandAdjustContrastd`` (_adjust_contrast.py),
+``BatchedRandGaussianNoised`` (_noise.py), ``BatchedRandFlipd`` (_flip.py),
+``BatchedCenterSpatialCropd`` (_crop.py:164-213).
+
+Tensors on the GPU go through the fused HIP kernels of csrc/transforms.hip (one pass for the whole
+contrast → scale → noise chain).  ``NormalizeSampled`` / ``MinMaxSampled`` are also applied by the
+reference inside DataLoader *worker processes* on CPU tensors (hcs.py:783); workers must never touch
+the GPU library, so CPU inputs use the identical two-line arithmetic in torch — that is host-side
+data preparation, not a fallback for a GPU kernel.  Random parameters are sampled on the host with
+torch's generator (RNG streams of kornia / MONAI cannot be reproduced); every transform accepts
+``params=`` to inject them, which is how the parity tests drive it.
+"""
+
+from __future__ import annotations
+
+from typing import Iterable, Sequence
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from ._lib import check, lib, ptr, stream
+
+_DATA_RANGE_KEYS = {"min_max": ("min", "max"), "p1_p99": ("p1", "p99"), "p5_p95": ("p5", "p95")}
+
+
+def _keys(keys) -> tuple[str, ...]:
+    return (keys,) if isinstance(keys, str) else tuple(keys)
+
+
+def _stat(t, B: int, dev) -> Tensor:
+    t = torch.as_tensor(t, dtype=torch.float32)
+    if t.ndim == 0:
+        t = t.expand(B)
+    return t.reshape(B).to(dev, non_blocking=True).contiguous()
+
+
+def _match(t: Tensor, target: Tensor) -> Tensor:
+    return t.reshape(t.shape + (1,) * (target.ndim - t.ndim)).to(device=target.device)
+
+
+def _gpu_ok(x: Tensor) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and (x[0].numel() % 4 == 0)
+
+
+class NormalizeSampled:
+    """(x - subtrahend) / (divisor + 1e-8) with precomputed statistics from ``sample["norm_meta"]``."""
+
+    is_spatial = False
+
+    def __init__(self, keys, level, subtrahend="mean", divisor="std", remove_meta: bool = False):
+        self.keys, self.level = _keys(keys), level
+        self.subtrahend, self.divisor, self.remove_meta = subtrahend, divisor, remove_meta
+
+    def __call__(self, sample: dict) -> dict:
+        for key in self.keys:
+            meta = sample["norm_meta"][key][self.level]
+            x = sample[key]
+            sub, div = meta[self.subtrahend], meta[self.divisor]
+            if _gpu_ok(x) and x.ndim >= 2:
+                B = x.shape[0]
+                y = torch.empty_like(x)
+                sub_d, div_d = _stat(sub, B, x.device), _stat(div, B, x.device)  # keep alive across the launch
+                check(lib().vsx_normalize(ptr(x), ptr(y), ptr(sub_d), ptr(div_d), B, x[0].numel(), stream()), "normalize")
+                sample[key] = y
+            else:  # DataLoader worker / CPU tensor
+                sample[key] = (x - _match(torch.as_tensor(sub), x)) / (_match(torch.as_tensor(div), x) + 1e-8)
+        if self.remove_meta:
+            sample.pop("norm_meta")
+        return sample
+
+
+class MinMaxSampled:
+    """clamp to [low, high] then rescale to [-1, 1]."""
+
+    is_spatial = False
+
+    def __init__(self, keys, level, data_range="p1_p99", remove_meta: bool = False):
+        if data_range not in _DATA_RANGE_KEYS:
+            raise ValueError(f"Invalid data_range: {data_range}")
+        self.keys, self.level, self.remove_meta = _keys(keys), level, remove_meta
+        self._low_key, self._high_key = _DATA_RANGE_KEYS[data_range]
+
+    def __call__(self, sample: dict) -> dict:
+        for key in self.keys:
+            meta = sample["norm_meta"][key][self.level]
+            x = sample[key]
+            lo, hi = meta[self._low_key], meta[self._high_key]
+            if _gpu_ok(x) and x.ndim >= 2:
+                B = x.shape[0]
+                y = torch.empty_like(x)
+                lo_d, hi_d = _stat(lo, B, x.device), _stat(hi, B, x.device)
+                check(lib().vsx_minmax_norm(ptr(x), ptr(y), ptr(lo_d), ptr(hi_d), B, x[0].numel(), stream()), "minmax_norm")
+                sample[key] = y
+            else:
+                lo_t, hi_t = _match(torch.as_tensor(lo), x), _match(torch.as_tensor(hi), x)
+                xc = x.clamp(lo_t, hi_t)
+                sample[key] = 2.0 * (xc - lo_t) / (hi_t - lo_t + 1e-8) - 1.0
+        if self.remove_meta:
+            sample.pop("norm_meta")
+        return sample
+
+
+def intensity_augment(x: Tensor, *, gamma: Tensor | None = None, factor: Tensor | None = None,
+                      noise: Tensor | None = None, noise_std: Tensor | None = None, noise_mean: float = 0.0) -> Tensor:
+    """Fused contrast → scale → noise pass on a (B, ...) fp32 GPU batch (csrc/transforms.hip).
+    gamma[b] <= 0: no contrast change; factor[b] = 0: no scaling; noise_std[b] < 0: no noise."""
+    if not _gpu_ok(x):
+        raise RuntimeError("viscy_amd GPU augmentations need a contiguous float32 batch on the HIP device (no CPU fallback)")
+    B, per = x.shape[0], x[0].numel()
+    dev = x.device
+    mn = mx = None
+    if gamma is not None:
+        mm = torch.empty(2, B, dtype=torch.float32, device=dev)
+        mm[0].fill_(float("inf"))
+        mm[1].fill_(float("-inf"))
+        check(lib().vsx_sample_minmax(ptr(x), ptr(mm[0]), ptr(mm[1]), B, per, stream()), "sample_minmax")
+        mn, mx = mm[0], mm[1]
+    y = torch.empty_like(x)
+    f32 = lambda t: None if t is None else t.to(dev, torch.float32).contiguous()  # noqa: E731
+    g_d, f_d, n_d, s_d = f32(gamma), f32(factor), f32(noise), f32(noise_std)  # named: ptr() does not keep a tensor alive
+    check(lib().vsx_intensity_aug(ptr(x), ptr(y), ptr(mn), ptr(mx), ptr(g_d), ptr(f_d), ptr(n_d), ptr(s_d),
+                                  float(noise_mean), B, per, stream()), "intensity_aug")
+    return y
+
+
+class _BatchedRand:
+    def __init__(self, keys, prob: float):
+        self.keys, self.prob = _keys(keys), prob
+        self.generator: torch.Generator | None = None
+
+    def _rand(self, n):
+        return torch.rand(n, generator=self.generator)
+
+
+class BatchedRandScaleIntensityd(_BatchedRand):
+    """x * (1 + f_b), f_b ~ U(factors) for selected samples (same factor for every key)."""
+
+    def __init__(self, keys, factors=0.1, prob: float = 0.1, channel_wise: bool = False, allow_missing_keys: bool = False):
+        super().__init__(keys, prob)
+        if channel_wise:
+            raise NotImplementedError("channel_wise scaling is not built")
+        self.range = (-abs(factors), abs(factors)) if isinstance(factors, (int, float)) else (min(factors), max(factors))
+
+    def randomize(self, B: int) -> Tensor:
+        f = torch.empty(B).uniform_(*self.range, generator=self.generator)
+        f[~(self._rand(B) < self.prob)] = 0.0
+        return f
+
+    def __call__(self, sample: dict, params: Tensor | None = None) -> dict:
+        f = params if params is not None else self.randomize(sample[self.keys[0]].shape[0])
+        for k in self.keys:
+            sample[k] = intensity_augment(sample[k], factor=f)
+        return sample
+
+
+class BatchedRandAdjustContrastd(_BatchedRand):
+    """per-sample gamma contrast (MONAI AdjustContrast), gamma_b ~ U(gamma) for selected samples."""
+
+    def __init__(self, keys, gamma=(0.5, 4.5), prob: float = 0.1, invert_image: bool = False, retain_stats: bool = False,
+                 allow_missing_keys: bool = False):
+        super().__init__(keys, prob)
+        if invert_image or retain_stats:
+            raise NotImplementedError("invert_image / retain_stats are not built")
+        self.gamma_range = (gamma, gamma) if isinstance(gamma, (int, float)) else (min(gamma), max(gamma))
+        if self.gamma_range[0] <= 0.0:
+            raise ValueError("Gamma must be a positive value.")
+
+    def randomize(self, B: int) -> Tensor:
+        g = torch.empty(B).uniform_(*self.gamma_range, generator=self.generator)
+        g[~(self._rand(B) < self.prob)] = 0.0  # 0 = not selected
+        return g
+
+    def __call__(self, sample: dict, params: Tensor | None = None) -> dict:
+        g = params if params is not None else self.randomize(sample[self.keys[0]].shape[0])
+        for k in self.keys:
+            sample[k] = intensity_augment(sample[k], gamma=g)
+        return sample
+
+
+class BatchedRandGaussianNoised(_BatchedRand):
+    """one N(0,1) field shared by the batch, scaled by a per-sample std (selected samples only)."""
+
+    def __init__(self, keys, prob: float = 0.1, mean: float = 0.0, std: float = 0.1, sample_std: bool = True,
+                 allow_missing_keys: bool = False, dtype=None):
+        super().__init__(keys, prob)
+        self.mean, self.std, self.sample_std = mean, std, sample_std
+
+    def randomize(self, x: Tensor):
+        B = x.shape[0]
+        do = self._rand(B) < self.prob
+        std = self._rand(B) * self.std if self.sample_std else torch.full((B,), float(self.std))
+        std[~do] = -1.0  # negative = not selected
+        noise = torch.randn(x.shape[1:], device=x.device, dtype=torch.float32)
+        return noise, std
+
+    def __call__(self, sample: dict, params=None) -> dict:
+        for k in self.keys:
+            noise, std = params if params is not None else self.randomize(sample[k])
+            sample[k] = intensity_augment(sample[k], noise=noise, noise_std=std, noise_mean=self.mean)
+        return sample
+
+
+class BatchedRandFlipd(_BatchedRand):
+    """per-sample random flips along the given spatial axes (pure data movement: torch.flip)."""
+
+    def __init__(self, keys, spatial_axes: Sequence[int] = (0, 1, 2), prob: float = 0.5, allow_missing_keys: bool = False):
+        super().__init__(keys, prob)
+        self.spatial_axes = tuple(spatial_axes)
+
+    def __call__(self, sample: dict, params: Tensor | None = None) -> dict:
+        B = sample[self.keys[0]].shape[0]
+        flips = params if params is not None else (torch.rand(B, len(self.spatial_axes), generator=self.generator) < self.prob)
+        for k in self.keys:
+            x = sample[k]
+            out = x.clone()
+            for b in range(B):
+                dims = [a + 1 for a, f in zip(self.spatial_axes, flips[b]) if bool(f)]  # +1: channel dim of x[b]
+                if dims:
+                    out[b] = torch.flip(x[b], dims)
+            sample[k] = out
+        return sample
+
+
+class BatchedCenterSpatialCropd:
+    """centre crop of the trailing spatial dims to ``roi_size`` (slicing only)."""
+
+    def __init__(self, keys, roi_size: Sequence[int], allow_missing_keys: bool = False):
+        self.keys, self.roi_size = _keys(keys), tuple(roi_size)
+
+    def __call__(self, sample: dict) -> dict:
+        for k in self.keys:
+            x = sample[k]
+            sl = [slice(None)] * x.ndim
+            for d, size in zip(range(x.ndim - len(self.roi_size), x.ndim), self.roi_size):
+                start = (x.shape[d] - size) // 2
+                sl[d] = slice(start, start + size)
+            sample[k] = x[tuple(sl)].contiguous()
+        return sample

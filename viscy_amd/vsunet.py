@@ -1,0 +1,252 @@
+"""``VSUNet`` on MI355X — same surface as ``cytoland.engine.VSUNet``
+(/root/reference/applications/cytoland/src/cytoland/engine.py:167-560): constructor keywords,
+``forward / training_step / validation_step / predict_step / on_predict_start /
+on_validation_epoch_end / configure_optimizers``, logged keys ``loss/train``, ``loss/val/{i}``,
+``loss/validate``, ``example_input_array``, divisible padding + centre crop at predict time, 90-degree
+rotation TTA and the Z-sliding-window prediction with ``_blend_in`` feathering
+(engine.py:432-501,760-805; viscy_utils/callbacks/prediction_writer.py:74-111).
+
+When ``lightning`` is importable the class IS a ``LightningModule`` and drops into
+``python -m cytoland fit -c …`` through ``class_path``; here (no Lightning in the image) it derives
+from ``nn.Module`` and is driven by ``viscy_amd.trainer.Trainer``, which reproduces the automatic-
+optimisation semantics the reference relies on.
+"""
+
+from __future__ import annotations
+
+import inspect
+from typing import Callable, Literal, Sequence
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+from ._lib import check, lib, ptr, stream
+from .unext2 import UNeXt2
+
+try:  # pragma: no cover - lightning is not installed in the build image
+    from lightning.pytorch import LightningModule as _Base
+
+    _HAVE_LIGHTNING = True
+except Exception:  # noqa: BLE001
+    _Base = nn.Module
+    _HAVE_LIGHTNING = False
+
+_UNET_ARCHITECTURE = {"UNeXt2": UNeXt2}
+
+
+def _divisible_pad_amounts(shape_yx: Sequence[int], k: int) -> list[tuple[int, int]]:
+    """MONAI DivisiblePad: symmetric zero padding of each dim to the next multiple of k."""
+    out = []
+    for s in shape_yx:
+        tot = (-s) % k
+        out.append((tot // 2, tot - tot // 2))
+    return out
+
+
+def _center_crop_to_shape(tensor: Tensor, spatial_shape: Sequence[int]) -> Tensor:
+    """engine.py:61-71."""
+    slices = [slice(None)] * tensor.ndim
+    start_dim = tensor.ndim - len(spatial_shape)
+    for dim, size in enumerate(spatial_shape, start=start_dim):
+        current = tensor.shape[dim]
+        if current < size:
+            raise ValueError(f"Cannot crop dimension {dim} from {current} to {size}")
+        start = (current - size) // 2
+        slices[dim] = slice(start, start + size)
+    return tensor[tuple(slices)]
+
+
+def blend_in(old_stack: Tensor, new_stack: Tensor, z_slice: slice) -> Tensor:
+    """prediction_writer._blend_in on the device: linear Z feathering of overlapping windows."""
+    if z_slice.start == 0:
+        return new_stack
+    depth = z_slice.stop - z_slice.start
+    samples = min(z_slice.start + 1, depth)
+    factors = [float(min(i + 1, samples)) for i in reversed(range(depth))]
+    old_c, new_c = old_stack.contiguous().float(), new_stack.contiguous().float()
+    if not old_c.is_cuda or (old_c.shape[-1] * old_c.shape[-2]) % 4:
+        raise RuntimeError("viscy_amd.blend_in runs on the HIP device only (plane size must be a multiple of 4)")
+    fz = torch.tensor(factors, dtype=torch.float32).to(old_c.device)
+    out = torch.empty_like(old_c)
+    plane = old_c.shape[-1] * old_c.shape[-2]
+    check(lib().vsx_blend_in(ptr(old_c), ptr(new_c), ptr(out), ptr(fz), depth, plane, old_c.numel(), stream()), "blend_in")
+    return out
+
+
+class VSUNet(_Base):
+    def __init__(
+        self,
+        architecture: Literal["UNeXt2"] = "UNeXt2",
+        model_config: dict | None = None,
+        loss_function: nn.Module | None = None,
+        lr: float = 1e-3,
+        schedule: Literal["WarmupCosine", "Constant"] = "Constant",
+        warmup_steps: int = 3,
+        warmup_multiplier: float = 1e-3,
+        freeze_encoder: bool = False,
+        ckpt_path: str | None = None,
+        log_batches_per_epoch: int = 8,
+        log_samples_per_batch: int = 1,
+        example_input_yx_shape: Sequence[int] = (256, 256),
+        test_cellpose_model_path: str | None = None,
+        test_cellpose_diameter: float | None = None,
+        test_evaluate_cellpose: bool | None = False,
+        test_time_augmentations: bool | None = False,
+        tta_type: Literal["mean", "median", "product"] = "mean",
+    ) -> None:
+        super().__init__()
+        if _HAVE_LIGHTNING:  # pragma: no cover
+            self.save_hyperparameters(ignore=["loss_function", "ckpt_path"])
+        model_config = model_config or {}
+        net_class = _UNET_ARCHITECTURE.get(architecture)
+        if not net_class:
+            raise ValueError(f"Architecture {architecture} not in {_UNET_ARCHITECTURE.keys()} (this build accelerates the "
+                             "UNeXt2 path only)")
+        if freeze_encoder:
+            raise ValueError("freeze_encoder=True requires a model with an 'encoder' attribute (FCMAE); UNeXt2 has none")
+        self.model = net_class(**model_config)
+        if loss_function is None:
+            from .losses import MixedLoss
+
+            loss_function = MixedLoss(l1_alpha=0.0, l2_alpha=1.0, ms_dssim_alpha=0.0)  # == nn.MSELoss() (engine.py:197)
+        self.loss_function = loss_function
+        self.lr, self.schedule = lr, schedule
+        self.warmup_steps, self.warmup_multiplier = warmup_steps, warmup_multiplier
+        self.log_batches_per_epoch, self.log_samples_per_batch = log_batches_per_epoch, log_samples_per_batch
+        self.training_step_outputs, self.validation_losses, self.validation_step_outputs = [], [], []
+        self.example_input_array = torch.rand(1, model_config.get("in_channels") or 1, model_config.get("in_stack_depth") or 5,
+                                              *example_input_yx_shape)
+        sig = inspect.signature(self.loss_function.forward)
+        self._loss_accepts_fg_mask = "fg_mask" in sig.parameters or any(
+            p.kind == inspect.Parameter.VAR_KEYWORD for p in sig.parameters.values())
+        self.test_time_augmentations, self.tta_type = test_time_augmentations, tta_type
+        self._predict_pad_k = None
+        self.logged: dict[str, list[float]] = {}
+        if ckpt_path is not None:
+            self.load_state_dict(torch.load(ckpt_path, weights_only=True, map_location="cpu")["state_dict"])
+
+    # ---- logging shim (LightningModule.log when available)
+    def _log(self, key: str, value: Tensor, **kw) -> None:
+        if _HAVE_LIGHTNING:  # pragma: no cover
+            self.log(key, value, **kw)
+        else:
+            self.logged.setdefault(key, []).append(value.detach())
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.model(x)
+
+    def _compute_loss(self, pred: Tensor, target: Tensor, batch: dict) -> Tensor:
+        if "fg_mask" in batch:
+            if not self._loss_accepts_fg_mask:
+                raise TypeError(f"{type(self.loss_function).__name__} does not accept 'fg_mask'. "
+                                f"Use SpotlightLoss or remove fg_mask_key from the data config.")
+            return self.loss_function(pred, target, fg_mask=batch["fg_mask"])
+        return self.loss_function(pred, target)
+
+    def training_step(self, batch, batch_idx: int):
+        losses, batch_size = [], 0
+        if not isinstance(batch, Sequence):
+            batch = [batch]
+        for b in batch:
+            pred = self.forward(b["source"])
+            losses.append(self._compute_loss(pred, b["target"], b))
+            batch_size += b["source"].shape[0]
+        loss_step = torch.stack(losses).mean()
+        self._log("loss/train", loss_step, on_step=True, on_epoch=True, prog_bar=True, logger=True, sync_dist=True,
+                  batch_size=batch_size)
+        return loss_step
+
+    def validation_step(self, batch, batch_idx: int, dataloader_idx: int = 0):
+        pred = self.forward(batch["source"])
+        loss = self._compute_loss(pred, batch["target"], batch)
+        if dataloader_idx + 1 > len(self.validation_losses):
+            self.validation_losses.append([])
+        self.validation_losses[dataloader_idx].append(loss.detach())
+        self._log(f"loss/val/{dataloader_idx}", loss, sync_dist=True, batch_size=batch["source"].shape[0])
+
+    def on_validation_epoch_end(self):
+        loss_means = [torch.stack(l).mean() for l in self.validation_losses]
+        if loss_means:
+            self._log("loss/validate", torch.stack(loss_means).mean(), sync_dist=True)
+        self.validation_step_outputs.clear()
+        self.validation_losses.clear()
+
+    def on_train_epoch_end(self):
+        self.training_step_outputs = []
+
+    # ---- predict path
+    def on_predict_start(self):
+        self._predict_pad_k = 2 ** self.model.num_blocks  # _make_divisible_pad (engine.py:48-53); UNeXt2 does not downsample Z
+
+    def _pad_forward_crop(self, source: Tensor) -> Tensor:
+        if self._predict_pad_k is None:
+            self.on_predict_start()
+        original_shape = source.shape[2:]
+        (py0, py1), (px0, px1) = _divisible_pad_amounts(source.shape[-2:], self._predict_pad_k)
+        if py0 or py1 or px0 or px1:
+            source = torch.nn.functional.pad(source, (px0, px1, py0, py1))
+        prediction = self.forward(source.contiguous())
+        return _center_crop_to_shape(prediction, original_shape)
+
+    def predict_step(self, batch, batch_idx: int, dataloader_idx: int = 0):
+        source = batch["source"]
+        if self.test_time_augmentations:
+            return self.perform_test_time_augmentations(source)
+        return self._pad_forward_crop(source)
+
+    def perform_test_time_augmentations(self, source: Tensor) -> Tensor:
+        """4x rot90 TTA with mean / median / product aggregation (engine.py:464-501)."""
+        yx = source.shape[-2:]
+        preds = []
+        for i in range(4):
+            aug = torch.rot90(source, k=i, dims=(-2, -1))
+            p = self._pad_forward_crop(aug)
+            p = torch.rot90(p, k=4 - i, dims=(-2, -1))
+            preds.append(_center_crop_to_shape(p, yx))
+        st = torch.stack(preds)
+        if self.tta_type == "mean":
+            return st.mean(dim=0)
+        if self.tta_type == "median":
+            return st.median(dim=0).values
+        if self.tta_type == "product":
+            return torch.exp(torch.log(st + 1e-9).sum(dim=0))
+        raise ValueError(f"unknown tta_type {self.tta_type}")
+
+    def predict_sliding_windows(self, x: Tensor, out_channel: int = 2, step: int = 1) -> Tensor:
+        """Z sliding-window inference with linear feathering (engine.py:760-805)."""
+        if x.ndim != 5:
+            raise ValueError(f"Expected input with 5 dimensions (B, C, Z, Y, X), got {x.shape}")
+        batch_size, _, depth, height, width = x.shape
+        in_stack_depth = getattr(self.model, "out_stack_depth", None)
+        if in_stack_depth is None:
+            raise ValueError(f"Model {type(self.model).__name__} does not support sliding window prediction "
+                             "(missing out_stack_depth attribute).")
+        if in_stack_depth > depth:
+            raise ValueError(f"in_stack_depth {in_stack_depth} > input depth {depth}")
+        out_tensor = x.new_zeros((batch_size, out_channel, depth, height, width))
+        for start in range(0, depth - in_stack_depth + 1, step):
+            end = start + in_stack_depth
+            pred = self.predict_step({"source": x[:, :, start:end].contiguous()}, 0)
+            z_slice = slice(start, end)
+            out_tensor[:, :, z_slice] = blend_in(out_tensor[:, :, z_slice], pred, z_slice)
+        return out_tensor
+
+    # ---- optimiser (viscy_utils/optimizers.py:10-62)
+    def configure_optimizers(self, t_total: int | None = None):
+        """Returns the fused flat-buffer AdamW (+ WarmupCosine) used by viscy_amd.trainer; under Lightning
+        the standard ``([optimizer], [scheduler])`` pair over ``model.parameters()`` with the same hyper-parameters."""
+        if _HAVE_LIGHTNING:  # pragma: no cover
+            from .optim import warmup_cosine_lambda
+
+            opt = torch.optim.AdamW(self.model.parameters(), lr=self.lr)
+            if self.schedule == "WarmupCosine":
+                tt = t_total or self.trainer.estimated_stepping_batches
+                sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: warmup_cosine_lambda(s, self.warmup_steps, tt, self.warmup_multiplier))
+                return [opt], [{"scheduler": sch, "interval": "step"}]
+            return [opt], [torch.optim.lr_scheduler.ConstantLR(opt, factor=1, total_iters=1)]
+        from .optim import FlatAdamW
+
+        self.model.grad_mode = "flat"
+        return FlatAdamW(self.model.engine(), lr=self.lr, schedule=self.schedule, warmup_steps=self.warmup_steps,
+                         t_total=t_total or 0, warmup_multiplier=self.warmup_multiplier)
