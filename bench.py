@@ -119,14 +119,16 @@ def _cpu_baseline_child():
     """Runs in a child process; prints one JSON line per completed measurement (the parent keeps the last)."""
     from oracle import loss_ref, unext2_ref
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch's CPU kernels stop scaling (and then regress) well below the 256 hardware threads of the GPU host:
+    # 32 threads measured fastest there (tools/cpu_probe.py); `cores` in the JSON is the thread count actually used
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     kw = dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True)
     model = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=0)
     opt = torch.optim.AdamW(model.parameters(), lr=2e-4)
     B = 2
     x, tgt = make_batch(B, 256, 256, "cpu")
     times = []
-    for i in range(6):
+    for i in range(12):
         t0 = time.perf_counter()
         opt.zero_grad()
         loss = loss_ref.mixed_loss(model(x), tgt, 0.5, 0.0, 0.5)
@@ -142,7 +144,7 @@ def _cpu_baseline_child():
                                         f"(pure-torch restatement of the reference) at B={B}, Z=5, 256x256, median"}), flush=True)
 
 
-def cpu_baseline(budget_s: float = 45.0):
+def cpu_baseline(budget_s: float = 75.0):
     """The oracle timed on the host cores over a bounded sample (child process, hard time limit)."""
     import subprocess
 
@@ -167,7 +169,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("VSX_BENCH_BATCH", 32)), help="patches per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("VSX_BENCH_BATCH", 128)), help="patches per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
