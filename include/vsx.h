@@ -251,6 +251,16 @@ int32_t vsx_intensity_aug(const float* x, float* y, const float* mn, const float
 int32_t vsx_blend_in(const float* oldp, const float* newp, float* out, const float* fz, int32_t Z, int64_t plane,
     int64_t total, vsx_stream_t stream);
 
+/* K18 kornia warp_affine3d as used by BatchedRandAffined (viscy_transforms/_affine.py:33-47,358-393): trilinear (or
+ * nearest) resampling, zero padding; Minv[B][3][4] maps output-voxel to input-voxel coordinates (x, y, z order). */
+int32_t vsx_warp_affine3d(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,
+    int32_t W, int32_t nearest, vsx_stream_t stream);
+
+/* K22 one pass of the separable Gaussian of BatchedRandGaussianSmooth (viscy_transforms/_gaussian_smooth.py:141-167):
+ * per-sample 1-D taps along the axis with element stride `stride` and length L, zero border. */
+int32_t vsx_conv1d_axis(const float* x, float* y, const float* taps, int32_t k, int32_t B, int64_t per_sample,
+    int64_t stride, int32_t L, vsx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,3 +60,91 @@ def gaussian_noise(x: Tensor, noise: Tensor, std: Tensor, apply: Tensor, mean: f
     ``x + (mean + noise * std_b)`` (``addcmul`` then ``index_add``), others are untouched."""
     add = mean + noise.unsqueeze(0) * _match(std, x)
     return torch.where(_match(apply.bool(), x), x + add, x)
+
+
+def gaussian_erf_kernel1d(kernel_size: int, sigma: Tensor) -> Tensor:
+    """kornia 0.8.3 ``get_gaussian_erf_kernel1d`` (called at _gaussian_smooth.py:139; kornia is not installed here —
+    restated from its published source): pixel-integrated Gaussian taps
+    ``0.5*(erf((i+0.5)/(σ√2)) - erf((i-0.5)/(σ√2)))``, i = -r..r, normalised to sum 1; σ is (B, 1)."""
+    r = kernel_size // 2
+    i = torch.arange(-r, r + 1, dtype=torch.float32).view(1, -1)
+    t = 0.70710678 / sigma.float().abs().clamp_min(0.0)
+    t = torch.where(torch.isfinite(t), t, torch.full_like(t, float("inf")))
+    g = 0.5 * (torch.erf((i + 0.5) * t) - torch.erf((i - 0.5) * t))
+    g = torch.nan_to_num(g, nan=0.0)
+    g = g.clamp_min(0)
+    return g / g.sum(-1, keepdim=True)
+
+
+def estimate_kernel_size(sigma: float, truncated: float = 4.0) -> int:
+    """_gaussian_smooth.py:119-122."""
+    tail = int(max(float(sigma) * truncated, 0.5) + 0.5)
+    return 2 * tail + 1
+
+
+def gaussian_smooth(x: Tensor, sigma: Tensor, apply: Tensor, truncated: float = 4.0) -> Tensor:
+    """BatchedRandGaussianSmooth.__call__, _gaussian_smooth.py:141-167, with injected per-sample sigma (B, 3) in
+    (Z, Y, X) order: separable filter3d with zero ("constant") border; kernel size from the max sigma of the
+    selected samples per axis."""
+    import torch.nn.functional as F
+
+    out = x.clone()
+    idx = torch.where(apply.bool())[0]
+    if len(idx) == 0:
+        return out
+    data = x[idx].float()
+    sg = sigma[idx].float()
+    B, C = data.shape[:2]
+    for axis in range(3):
+        s = sg[:, axis]
+        if not (s > 0).any():
+            continue
+        k = estimate_kernel_size(s.max().item(), truncated)
+        taps = gaussian_erf_kernel1d(k, s.view(-1, 1))  # (B, k)
+        shape = [1, 1, 1]
+        shape[axis] = k
+        pad = [0, 0, 0]
+        pad[axis] = k // 2
+        w = taps.repeat_interleave(C, 0).view(B * C, 1, *shape)
+        data = F.conv3d(data.reshape(1, B * C, *data.shape[2:]), w, padding=pad, groups=B * C).view_as(data)
+    out[idx] = data.to(x.dtype)
+    return out
+
+
+def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear") -> Tensor:
+    """What kornia ``warp_affine3d(..., padding_mode="zeros", align_corners=True)`` (called at _affine.py:33-47)
+    computes, stated with torch's own ``affine_grid`` / ``grid_sample``: output voxel (x, y, z) samples the input at
+    ``Minv · (x, y, z, 1)`` (voxel coordinates)."""
+    import torch.nn.functional as F
+
+    B, C, D, H, W = x.shape
+
+    def norm_mat(d, h, w):  # voxel → [-1, 1] (align_corners=True)
+        return torch.tensor([[2.0 / max(w - 1, 1), 0, 0, -1.0], [0, 2.0 / max(h - 1, 1), 0, -1.0],
+                             [0, 0, 2.0 / max(d - 1, 1), -1.0], [0, 0, 0, 1.0]])
+
+    N = norm_mat(D, H, W)
+    M4 = torch.cat([Minv.float(), torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(B, 1, 4)], dim=1)
+    theta = (N @ M4 @ torch.linalg.inv(N))[:, :3]
+    grid = F.affine_grid(theta, (B, C, D, H, W), align_corners=True)
+    return F.grid_sample(x.float(), grid, mode=mode, padding_mode="zeros", align_corners=True)
+
+
+def affine_matrix_zyx(angle_z_deg: Tensor, scale_xyz: Tensor, shape_dhw, shear_xy: Tensor | None = None) -> Tensor:
+    """Output→input voxel matrix for a rotation about the Z axis (in the YX plane) by ``angle`` degrees, per-axis
+    scale and optional XY shear about the volume centre — the parameterisation the UNeXt2 recipes use
+    (rotate_range only about Z, _affine.py:248-276; applications/dynacell/.../unext2_fit.yml)."""
+    D, H, W = shape_dhw
+    B = angle_z_deg.shape[0]
+    th = torch.deg2rad(angle_z_deg.float())
+    c, s = th.cos(), th.sin()
+    A = torch.zeros(B, 4, 4)
+    A[:, 0, 0], A[:, 0, 1], A[:, 1, 0], A[:, 1, 1], A[:, 2, 2], A[:, 3, 3] = c, -s, s, c, 1.0, 1.0
+    S = torch.diag_embed(torch.cat([scale_xyz.float(), torch.ones(B, 1)], dim=1))
+    Sh = torch.eye(4).repeat(B, 1, 1)
+    if shear_xy is not None:
+        Sh[:, 0, 1] = shear_xy.float()
+    ctr = torch.eye(4).repeat(B, 1, 1)
+    ctr[:, 0, 3], ctr[:, 1, 3], ctr[:, 2, 3] = (W - 1) / 2.0, (H - 1) / 2.0, (D - 1) / 2.0
+    fwd = ctr @ A @ Sh @ S @ torch.linalg.inv(ctr)  # input → output
+    return torch.linalg.inv(fwd)[:, :3]

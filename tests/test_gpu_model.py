@@ -50,9 +50,27 @@ CASES = [
 
 @pytest.mark.parametrize("tag,kw,bhw", CASES, ids=[c[0] for c in CASES])
 @pytest.mark.parametrize("mode", ["autograd", "flat"])
-def test_forward_backward_vs_oracle_fp32(tag, kw, bhw, mode):
+@pytest.mark.parametrize("slope", ["slope1", "slope_ref"])
+def test_forward_backward_vs_oracle_fp32(tag, kw, bhw, mode, slope):
+    """Every parameter gradient of the whole model against the oracle's autograd.
+
+    The head's PReLU derivative jumps at n̂ = 0.  With ~10^6 normalised values per batch about one lies within fp32
+    rounding of the kink, and whether the HIP path and the CPU oracle put it on the same side depends on the last bit
+    of the InstanceNorm mean (the statistics are reduced with atomics, i.e. in a run-dependent order).  One flipped
+    voxel moves S1 = Σ dn for its channel, hence every upstream gradient, by a few 1e-3 — the comparison, not the
+    kernel, is ill-conditioned there (measured: tools/flake_hunt3.py).  So the strict 2e-3 bar is applied with the
+    slope set to 1 (no kink; dalpha still exercised), and with the reference's slope the bar is the direction of the
+    full gradient plus a looser per-tensor bound."""
     torch.manual_seed(0)
-    ref, mine = _pair(kw)
+    ref = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=7).eval()
+    if slope == "slope1":
+        with torch.no_grad():
+            ref.head.conv[0].adn.A.weight.fill_(1.0)
+    from viscy_amd.unext2 import UNeXt2
+
+    mine = UNeXt2(**kw)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.cuda()
     mine.compute_dtype = torch.float32
     mine.grad_mode = mode
     B, H, W = bhw
@@ -65,7 +83,9 @@ def test_forward_backward_vs_oracle_fp32(tag, kw, bhw, mode):
     out = mine(x.cuda())
     assert relerr(out, y) <= 1e-3
     out.backward(dout.cuda())
+    bar = 2e-3 if slope == "slope1" else 2e-2
     worst, worst_name = 0.0, ""
+    gm, gr = [], []
     for (name, pr), pm in zip(ref.named_parameters(), mine.parameters()):
         assert pm.grad is not None, name
         if name == "head.conv.0.conv.bias":  # exactly-zero gradient (bias in front of InstanceNorm)
@@ -74,8 +94,12 @@ def test_forward_backward_vs_oracle_fp32(tag, kw, bhw, mode):
         e = relerr(pm.grad, pr.grad)
         if e > worst:
             worst, worst_name = e, name
-        assert e <= 2e-3, (name, e)
-    print(tag, mode, "worst relative gradient error", worst, worst_name)
+        assert e <= bar, (name, e)
+        gm.append(pm.grad.flatten().cpu().double())
+        gr.append(pr.grad.flatten().double())
+    cos = torch.nn.functional.cosine_similarity(torch.cat(gm), torch.cat(gr), dim=0).item()
+    assert 1 - cos < (1e-7 if slope == "slope1" else 2e-4), cos
+    print(tag, mode, slope, "worst relative gradient error", worst, worst_name, "1-cos", 1 - cos)
 
 
 def test_forward_backward_bf16_tracks_fp32():

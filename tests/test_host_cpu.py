@@ -50,7 +50,9 @@ def test_zarr_roundtrip(compress, chunks):
 def test_datamodule_fit_contract(tiny_hcs_zarr):
     path, pos = tiny_hcs_zarr
     dm = HCSDataModule(path, "Phase3D", "Nuclei", z_window_size=5, batch_size=2, num_workers=0, yx_patch_size=(128, 128),
-                       normalizations=[NormalizeSampled(["Phase3D", "Nuclei"], "fov_statistics")], split_ratio=0.5)
+                       normalizations=[NormalizeSampled(["Phase3D", "Nuclei"], "fov_statistics")], split_ratio=0.5,
+                       normalize_on_device=False)  # the reference's worker-side order (hcs.py:783)
+    assert HCSDataModule(path, "Phase3D", "Nuclei", 5, normalizations=[NormalizeSampled(["Phase3D"], "fov_statistics")]).normalize_on_device
     dm.setup("fit")
     assert len(dm.train_dataset) == 2 and len(dm.val_dataset) == 2
     b = next(iter(dm.train_dataloader()))

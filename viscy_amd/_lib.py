@@ -80,6 +80,8 @@ _SIGS = {
     "vsx_sample_minmax": (_I32, [_P, _P, _P, _I32, _I64, _P]),
     "vsx_intensity_aug": (_I32, [_P] * 8 + [_F32, _I32, _I64, _P]),
     "vsx_blend_in": (_I32, [_P, _P, _P, _P, _I32, _I64, _I64, _P]),
+    "vsx_warp_affine3d": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "vsx_conv1d_axis": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
 }
 
 _lib = None

@@ -680,7 +680,7 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
   int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
   // few tiles (skinny weight matrices, e.g. the head's 8x32): the atomics spread over few addresses anyway,
   // parallelism matters more
-  int cap = tiles * nz <= 4 ? 384 : (tiles * nz <= 16 ? 96 : 48);
+  int cap = tiles * nz <= 4 ? 384 : (tiles * nz <= 24 ? 96 : 48);
   if (splits > cap) splits = cap;
   int rpb = 0;
   if (splits > vsx_cdiv(p->M, 32)) splits = vsx_cdiv(p->M, 32);
@@ -694,8 +694,10 @@ extern "C" int32_t vsx_gemm_tn(const VsxGemm* p, int32_t dtype, vsx_stream_t str
   if (int e = check_common(p, dtype, "vsx_gemm_tn")) return e;
   VSX_CHECK(p->epi == VSX_EPI_NONE && p->c_mode == VSX_A_ROWS, "vsx_gemm_tn: no epilogue / scatter modes");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // 64x64 tiles unless the 128x128 grid alone already yields >= 24 tiles
-  bool small = (long)vsx_cdiv(p->N, 128) * vsx_cdiv(p->K, 128) < 24;
+  // 128x128 tiles (4x the MFMA work per barrier of a 64x64 tile) whenever the output is at least one such tile
+  // and there are enough pixel rows to split; 64x64 only for genuinely small weight matrices
+  long t128 = (long)vsx_cdiv(p->N, 128) * vsx_cdiv(p->K, 128);
+  bool small = (p->N < 96 || p->K < 96) || (t128 < 24 && p->M < 65536);
   if (dtype == VSX_BF16) {
     if (g_vsx_tn_tr) return small ? launch_tn<bf16_t, 64, true>(p, s) : launch_tn<bf16_t, 128, true>(p, s);
     return small ? launch_tn<bf16_t, 64, false>(p, s) : launch_tn<bf16_t, 128, false>(p, s);

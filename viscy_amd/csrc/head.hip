@@ -93,12 +93,11 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
                                                             HeadDims d, float eps, int vox_per_thread) {
   constexpr int VN = VT<T>::N;
   __shared__ float mu[HEAD_MAX_CMID], rs[HEAD_MAX_CMID], w2s[HEAD_MAX_CO4 * HEAD_MAX_CMID];
-  __shared__ float red[2 * HEAD_MAX_CMID + 1];
+  __shared__ float part[4][2 * HEAD_MAX_CMID + 1];  // per-wave partials (no LDS atomics: plain stores, fixed order)
   const int b = blockIdx.y;
   constexpr int co4 = CO4;
   head_load_stats(ssum, ssq, b, CMID, (float)d.Z * d.H2 * d.W2, eps, mu, rs);
   for (int i = threadIdx.x; i < co4 * CMID; i += 256) w2s[i] = w2[i];
-  for (int i = threadIdx.x; i < 2 * CMID + 1; i += 256) red[i] = 0.f;
   __syncthreads();
   const float alpha = alpha_p[0];
   const int nvox = d.H2 * d.W2 * d.Z;
@@ -134,18 +133,19 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
       s2[c] += dn * nh[c];
     }
   }
+  const int wv = threadIdx.x >> 6;
   _Pragma("unroll") for (int c = 0; c < CMID; ++c) {
     float t1 = wave_sum(s1[c]), t2 = wave_sum(s2[c]);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&red[c], t1); atomicAdd(&red[CMID + c], t2); }
+    if ((threadIdx.x & 63) == 0) { part[wv][c] = t1; part[wv][CMID + c] = t2; }
   }
   da = wave_sum(da);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&red[2 * CMID], da);
+  if ((threadIdx.x & 63) == 0) part[wv][2 * CMID] = da;
   __syncthreads();
-  for (int i = threadIdx.x; i < CMID; i += 256) {
-    atomicAdd(S1 + b * CMID + i, red[i]);
-    atomicAdd(S2 + b * CMID + i, red[CMID + i]);
+  for (int i = threadIdx.x; i < 2 * CMID + 1; i += 256) {
+    const float v = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+    float* dst = i < CMID ? S1 + b * CMID + i : (i < 2 * CMID ? S2 + b * CMID + (i - CMID) : dalpha);
+    atomicAdd(dst, v);
   }
-  if (threadIdx.x == 0) atomicAdd(dalpha, red[2 * CMID]);
 }
 
 // backward pass 2: dU = rstd * (dn - S1/cnt - n̂ * S2/cnt)

@@ -268,17 +268,20 @@ __global__ __launch_bounds__(256) void ssim_bwd_in_kernel(const float* __restric
 // ------------------------------------------------------------------ scalar finalisation
 // vals[s][b] = clamp(mean cs (s<4) or mean ssim (s=4), 1e-4); ms = mean_b Π_s vals^beta_s
 // loss = a1*l1 + a2*l2 + a3*(1 - ms);  coef[s][b] = {d loss / d ssim_pixel, d loss / d cs_pixel} (already / Npix_s)
-__global__ void loss_finalize_kernel(const float* __restrict__ sum_ssim, const float* __restrict__ sum_cs,
-                                     const float* __restrict__ l1sum, const float* __restrict__ l2sum,
-                                     const float* __restrict__ npix, float nelem, int B, int nscale, float a1, float a2,
-                                     float a3, const float* __restrict__ gout_p, float* __restrict__ loss,
-                                     float* __restrict__ coef, float* __restrict__ ms_out) {
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ sum_ssim,
+                                                            const float* __restrict__ sum_cs,
+                                                            const float* __restrict__ l1sum, const float* __restrict__ l2sum,
+                                                            const float* __restrict__ npix, float nelem, int B, int nscale,
+                                                            float a1, float a2, float a3,
+                                                            const float* __restrict__ gout_p, float* __restrict__ loss,
+                                                            float* __restrict__ coef, float* __restrict__ ms_out) {
+  // one thread per batch sample (strided), block reduction of the per-sample MS-SSIM products
+  __shared__ float sh[4];
   const float betas[5] = {0.0448f, 0.2856f, 0.3001f, 0.2363f, 0.1333f};
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float gout = gout_p ? gout_p[0] : 1.f;
-  float ms_mean = 0.f;
+  float acc = 0.f;
   if (a3 != 0.f) {
-    for (int b = 0; b < B; ++b) {
+    for (int b = threadIdx.x; b < B; b += 256) {
       float v[5];
       bool clamped[5];
       float prod = 1.f;
@@ -288,21 +291,24 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sum_ssim, const f
         v[s] = clamped[s] ? 1e-4f : raw;
         prod *= powf(v[s], betas[s]);
       }
-      ms_mean += prod;
+      acc += prod;
       for (int s = 0; s < nscale; ++s) {
         float g = clamped[s] ? 0.f : -a3 * gout / (float)B * betas[s] * prod / v[s] / npix[s];
         coef[(s * B + b) * 2 + 0] = (s == nscale - 1) ? g : 0.f;
         coef[(s * B + b) * 2 + 1] = (s == nscale - 1) ? 0.f : g;
       }
     }
-    ms_mean /= (float)B;
   }
-  float l = 0.f;
-  if (a1 != 0.f) l += a1 * l1sum[0] / nelem;
-  if (a2 != 0.f) l += a2 * l2sum[0] / nelem;
-  if (a3 != 0.f) l += a3 * (1.f - ms_mean);
-  loss[0] = l;
-  if (ms_out) ms_out[0] = ms_mean;
+  const float tot = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) {
+    const float ms_mean = a3 != 0.f ? tot / (float)B : 0.f;
+    float l = 0.f;
+    if (a1 != 0.f) l += a1 * l1sum[0] / nelem;
+    if (a2 != 0.f) l += a2 * l2sum[0] / nelem;
+    if (a3 != 0.f) l += a3 * (1.f - ms_mean);
+    loss[0] = l;
+    if (ms_out) ms_out[0] = ms_mean;
+  }
 }
 
 /* avg_pool3d(·,(1,2,2)) of preds/target (metrics.py:340-341), target.max() of the INPUT planes
@@ -363,7 +369,7 @@ extern "C" int32_t vsx_loss_finalize(const float* sum_ssim, const float* sum_cs,
                                      float a3, const float* gout, float* loss, float* coef, float* ms_out,
                                      vsx_stream_t stream) {
   VSX_CHECK(loss && B > 0 && nscale >= 1 && nscale <= 5, "vsx_loss_finalize: bad arguments");
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sum_ssim, sum_cs, l1sum, l2sum,
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sum_ssim, sum_cs, l1sum, l2sum,
                      npix, nelem, B, nscale, a1, a2, a3, gout, loss, coef, ms_out);
   VSX_LAUNCH_CHECK();
   return 0;

@@ -162,3 +162,95 @@ extern "C" int32_t vsx_blend_in(const float* oldp, const float* newp, float* out
   VSX_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------ K18: batched 3-D affine warp
+// y[b,c,z,y,x] = trilinear( x[b,c], Minv[b] · (x,y,z,1) ), zero padding outside the volume.
+// Minv [B][3][4] maps OUTPUT voxel coordinates (x, y, z) to INPUT voxel coordinates (x, y, z).
+__global__ __launch_bounds__(256) void warp_affine3d_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ Minv, int B, int C, int D, int H, int W,
+                                                            int nearest) {
+  const long vol = (long)D * H * W;
+  const long total = (long)B * vol;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / vol);
+    long r = i - (long)b * vol;
+    const int ox = (int)(r % W); r /= W;
+    const int oy = (int)(r % H);
+    const int oz = (int)(r / H);
+    const float* m = Minv + (size_t)b * 12;
+    const float sx = m[0] * ox + m[1] * oy + m[2] * oz + m[3];
+    const float sy = m[4] * ox + m[5] * oy + m[6] * oz + m[7];
+    const float sz = m[8] * ox + m[9] * oy + m[10] * oz + m[11];
+    for (int c = 0; c < C; ++c) {
+      const float* xc = x + ((size_t)b * C + c) * vol;
+      float v = 0.f;
+      if (nearest) {
+        const int ix = (int)nearbyintf(sx), iy = (int)nearbyintf(sy), iz = (int)nearbyintf(sz);
+        if (ix >= 0 && ix < W && iy >= 0 && iy < H && iz >= 0 && iz < D) v = xc[((size_t)iz * H + iy) * W + ix];
+      } else {
+        const float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
+        const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+        const float tx = sx - fx, ty = sy - fy, tz = sz - fz;
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+              const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+              if (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D) {
+                const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
+                v += wgt * xc[((size_t)zz * H + yy) * W + xx];
+              }
+            }
+      }
+      y[((size_t)b * C + c) * vol + (i - (long)b * vol)] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K22: one axis of a separable filter
+// y[i] = Σ_t taps[b][t] · x[i + (t - r)·stride]   (zero outside the axis; taps per sample; r = (k-1)/2)
+__global__ __launch_bounds__(256) void conv1d_axis_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ taps, int k, long per_sample, long stride,
+                                                          int L, long total) {
+  const int r = (k - 1) / 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int b = (int)(i / per_sample);
+    const int pos = (int)((i / stride) % L);
+    const float* tb = taps + (size_t)b * k;
+    float acc = 0.f;
+    for (int t = 0; t < k; ++t) {
+      const int p = pos + t - r;
+      if (p >= 0 && p < L) acc = fmaf(tb[t], x[i + (long)(t - r) * stride], acc);
+    }
+    y[i] = acc;
+  }
+}
+
+/* K18 kornia warp_affine3d as used by BatchedRandAffined (viscy_transforms/_affine.py:33-47,358-393): trilinear (or
+ * nearest) resampling with zero padding; Minv[B][3][4] = output-voxel → input-voxel coordinates (x, y, z order). */
+extern "C" int32_t vsx_warp_affine3d(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,
+                                     int32_t W, int32_t nearest, vsx_stream_t stream) {
+  VSX_CHECK(x && y && Minv && B > 0 && C > 0 && D > 0 && H > 0 && W > 0, "vsx_warp_affine3d: bad arguments");
+  long total = (long)B * D * H * W;
+  int g = vsx_cdiv(total, 256);
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(warp_affine3d_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, Minv, B, C, D, H, W, nearest);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+/* K22 one pass of kornia filter3d's separable form as used by BatchedRandGaussianSmooth
+ * (viscy_transforms/_gaussian_smooth.py:141-167): per-sample 1-D taps along the axis with element stride `stride`
+ * and length L, constant (zero) border. */
+extern "C" int32_t vsx_conv1d_axis(const float* x, float* y, const float* taps, int32_t k, int32_t B, int64_t per_sample,
+                                   int64_t stride, int32_t L, vsx_stream_t stream) {
+  VSX_CHECK(x && y && taps && k > 0 && (k & 1) && B > 0 && per_sample > 0 && stride > 0 && L > 0, "vsx_conv1d_axis: bad arguments");
+  long total = (long)B * per_sample;
+  int g = vsx_cdiv(total, 256);
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(conv1d_axis_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, taps, k, (long)per_sample,
+                     (long)stride, L, total);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

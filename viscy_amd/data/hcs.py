@@ -157,7 +157,8 @@ class HCSDataModule(_DMBase):
                  array_key: str = "0", pin_memory=True, min_nonzero_fraction: float = 0.0, nonzero_threshold: float = 0.0,
                  nonzero_channel=None, max_nonzero_retries: int = 100, fg_mask_key=None, gpu_augmentations: list | None = None,
                  val_augmentations: list | None = None, val_gpu_augmentations: list | None = None,
-                 include_fov_names: Iterable[str] | None = None, exclude_fov_names: Iterable[str] | None = None, seed: int = 42):
+                 include_fov_names: Iterable[str] | None = None, exclude_fov_names: Iterable[str] | None = None, seed: int = 42,
+                 normalize_on_device: bool = True):
         if _DMBase is not object:  # pragma: no cover
             super().__init__()
         if mmap_preload or fg_mask_key is not None or ground_truth_masks is not None or min_nonzero_fraction > 0:
@@ -178,6 +179,12 @@ class HCSDataModule(_DMBase):
         self.seed = seed
         self.training = True  # set by the trainer loop (Lightning: trainer.training / trainer.validating)
         self.train_patches_per_stack = 1
+        # MI355X-first: when nothing intensity-dependent runs in the workers, ship raw patches + statistics and normalise
+        # in HBM right after the transfer (one vsx_normalize launch per stacked key) instead of per sample on host cores.
+        from ..transforms import NormalizeSampled
+        self.normalize_on_device = bool(normalize_on_device and self.normalizations and not self.augmentations
+                                        and not self.val_augmentations
+                                        and all(type(n) is NormalizeSampled for n in self.normalizations))
         for aug in self.augmentations:
             n = getattr(getattr(aug, "cropper", None), "num_samples", None) or getattr(aug, "num_samples", None)
             if n:
@@ -207,13 +214,14 @@ class HCSDataModule(_DMBase):
             idx = torch.randperm(len(positions), generator=g).tolist()  # hcs.py:490-494,566-569
             positions = [positions[i] for i in idx]
             n_train = int(len(positions) * self.split_ratio)
-            self.train_dataset = SlidingWindowDataset(positions[:n_train], transform=Compose(self.normalizations + self.augmentations), **settings)
-            self.val_dataset = SlidingWindowDataset(positions[n_train:], transform=Compose(self.normalizations + self.val_augmentations), **settings)
+            norms = [] if self.normalize_on_device else self.normalizations
+            self.train_dataset = SlidingWindowDataset(positions[:n_train], transform=Compose(norms + self.augmentations), **settings)
+            self.val_dataset = SlidingWindowDataset(positions[n_train:], transform=Compose(norms + self.val_augmentations), **settings)
         elif stage == "test":
             settings["channels"]["target"] = self.target_channel
-            self.test_dataset = SlidingWindowDataset(positions, transform=Compose(self.normalizations), **settings)
+            self.test_dataset = SlidingWindowDataset(positions, transform=Compose([] if self.normalize_on_device else self.normalizations), **settings)
         elif stage == "predict":
-            self.predict_dataset = SlidingWindowDataset(positions, transform=Compose(self.normalizations), **settings)
+            self.predict_dataset = SlidingWindowDataset(positions, transform=Compose([] if self.normalize_on_device else self.normalizations), **settings)
         else:
             raise NotImplementedError(f"{stage} stage not supported")
 
@@ -240,11 +248,43 @@ class HCSDataModule(_DMBase):
     def predict_dataloader(self):
         return self._loader(self.predict_dataset, self.batch_size, shuffle=False)
 
+    def _device_normalize(self, batch):
+        """NormalizeSampled (_normalize.py:27-81) for the stacked ``source`` / ``target`` keys: per-(sample, channel)
+        subtrahend / divisor gathered from the collated ``norm_meta`` and applied by ONE kernel launch per key."""
+        from ..transforms import normalize_stacked
+        meta = batch.get("norm_meta")
+        if meta is None:
+            raise ValueError("normalize_on_device needs `norm_meta` in the batch (load_normalization_metadata=True)")
+        for key, channels in (("source", self.source_channel), ("target", self.target_channel)):
+            x = batch.get(key)
+            if x is None:
+                continue
+            B, C = x.shape[:2]
+            sub, div = torch.zeros(B, C), torch.ones(B, C)
+            touched = False
+            for n in self.normalizations:
+                for ch in n.keys:
+                    if ch in channels:
+                        c = channels.index(ch)
+                        st = meta[ch][n.level]
+                        # composition of successive normalisations of one channel is not affine-foldable in general
+                        if (sub[:, c] != 0).any() or (div[:, c] != 1).any():
+                            raise NotImplementedError(f"two normalisations of channel {ch}: set normalize_on_device=False")
+                        sub[:, c], div[:, c] = st[n.subtrahend].float().cpu(), st[n.divisor].float().cpu()
+                        touched = True
+            if touched:
+                batch[key] = normalize_stacked(x, sub, div)
+        if any(n.remove_meta for n in self.normalizations):
+            batch.pop("norm_meta", None)
+        return batch
+
     @torch.no_grad()
     def on_after_batch_transfer(self, batch, dataloader_idx: int):
         """hcs.py:679-721: GPU augmentations, target_2d slicing, training-shape validation."""
         if isinstance(batch, Tensor):
             return batch
+        if self.normalize_on_device:
+            batch = self._device_normalize(batch)
         if self.training and self._gpu_augmentations is not None:
             batch = self._gpu_augmentations(batch)
         elif not self.training and self._val_gpu_augmentations is not None:

@@ -158,7 +158,7 @@ def write_hcs_plate(path, positions: dict[str, np.ndarray], channel_names: list[
             {"path": "0", "coordinateTransformations": [{"type": "scale", "scale": [1.0] * 5}]}]}],
             "omero": {"channels": [{"label": c} for c in channel_names]}}
         if norm_meta is not None:
-            attrs["normalization"] = norm_meta
+            attrs["normalization"] = norm_meta.get(name, norm_meta)  # per-position dict or one dict for all
         (pos / ".zattrs").write_text(json.dumps(attrs))
         ck = chunks or (1, 1, arr.shape[2], arr.shape[3], arr.shape[4])
         (pos / "0" / ".zarray").write_text(json.dumps({

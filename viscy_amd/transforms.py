@@ -75,6 +75,18 @@ class NormalizeSampled:
         return sample
 
 
+def normalize_stacked(x: Tensor, sub: Tensor, div: Tensor) -> Tensor:
+    """(x - sub[b, c]) / (div[b, c] + 1e-8) for a stacked (B, C, ...) batch on the device — the data module's
+    on-device form of ``NormalizeSampled`` (identity channels: sub 0, div 1)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x[0, 0].numel() % 4 == 0):
+        raise RuntimeError("normalize_stacked needs a contiguous float32 (B,C,...) batch on the HIP device (no CPU fallback)")
+    B, C = x.shape[:2]
+    y = torch.empty_like(x)
+    sub_d, div_d = _stat(sub, B * C, x.device), _stat(div, B * C, x.device)
+    check(lib().vsx_normalize(ptr(x), ptr(y), ptr(sub_d), ptr(div_d), B * C, x[0, 0].numel(), stream()), "normalize")
+    return y
+
+
 class MinMaxSampled:
     """clamp to [low, high] then rescale to [-1, 1]."""
 
@@ -241,4 +253,140 @@ class BatchedCenterSpatialCropd:
                 start = (x.shape[d] - size) // 2
                 sl[d] = slice(start, start + size)
             sample[k] = x[tuple(sl)].contiguous()
+        return sample
+
+
+# ------------------------------------------------------------------------------------------------
+# K22 BatchedRandGaussianSmooth / K18 BatchedRandAffined
+# ------------------------------------------------------------------------------------------------
+def _erf_taps(kernel_size: int, sigma: Tensor) -> Tensor:
+    """pixel-integrated Gaussian taps (kornia get_gaussian_erf_kernel1d), σ = 0 → identity; (B, k) on the host."""
+    r = kernel_size // 2
+    i = torch.arange(-r, r + 1, dtype=torch.float64).view(1, -1)
+    sg = sigma.double().abs().view(-1, 1)
+    t = torch.where(sg > 0, 0.7071067811865476 / sg.clamp_min(1e-30), torch.full_like(sg, float("inf")))
+    g = 0.5 * (torch.erf((i + 0.5) * t) - torch.erf((i - 0.5) * t))
+    g = torch.nan_to_num(g, nan=0.0).clamp_min(0)
+    return (g / g.sum(-1, keepdim=True)).float()
+
+
+def gaussian_smooth(x: Tensor, sigma_zyx: Tensor, apply: Tensor, truncated: float = 4.0) -> Tensor:
+    """separable 3-D Gaussian with per-sample sigma (B, 3) in (Z, Y, X) order, zero border (csrc/transforms.hip)."""
+    if not _gpu_ok(x) or x.ndim != 5:
+        raise RuntimeError("viscy_amd GPU augmentations need a contiguous float32 (B,C,Z,Y,X) batch on the HIP device (no CPU fallback)")
+    B, C, D, H, W = x.shape
+    sel = apply.bool().cpu()
+    if not sel.any():
+        return x
+    sg = torch.where(sel.view(-1, 1), sigma_zyx.float().cpu(), torch.zeros(B, 3))
+    cur = x
+    per = C * D * H * W
+    for axis, (stride, L) in enumerate(((H * W, D), (W, H), (1, W))):
+        s = sg[:, axis]
+        if not (s[sel] > 0).any():
+            continue
+        tail = int(max(float(s[sel].max()) * truncated, 0.5) + 0.5)
+        k = 2 * tail + 1
+        taps = _erf_taps(k, s).to(x.device).contiguous()  # unselected samples (σ = 0) get the identity kernel
+        out = torch.empty_like(cur)
+        check(lib().vsx_conv1d_axis(ptr(cur), ptr(out), ptr(taps), k, B, per, stride, L, stream()), "conv1d_axis")
+        cur = out
+    return cur
+
+
+class BatchedRandGaussianSmoothd(_BatchedRand):
+    def __init__(self, keys, sigma_x=(0.25, 1.5), sigma_y=(0.25, 1.5), sigma_z=(0.25, 1.5), truncated: float = 4.0,
+                 approx: str = "erf", prob: float = 0.1, allow_missing_keys: bool = False):
+        super().__init__(keys, prob)
+        self.ranges = [self._rng(sigma_z), self._rng(sigma_y), self._rng(sigma_x)]  # (Z, Y, X)
+        self.truncated = truncated
+
+    @staticmethod
+    def _rng(s):
+        if isinstance(s, (int, float)):
+            return (float(s), float(s))
+        if len(s) != 2:
+            raise ValueError(f"sigma must be float or tuple of 2 values, got {s}")
+        return (float(s[0]), float(s[1]))
+
+    def randomize(self, B: int):
+        do = self._rand(B) < self.prob
+        sig = torch.stack([self._rand(B) * (hi - lo) + lo for lo, hi in self.ranges], dim=1)
+        return sig, do
+
+    def __call__(self, sample: dict, params=None) -> dict:
+        sig, do = params if params is not None else self.randomize(sample[self.keys[0]].shape[0])
+        for k in self.keys:
+            sample[k] = gaussian_smooth(sample[k], sig, do, self.truncated)
+        return sample
+
+
+def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear") -> Tensor:
+    """resample (B,C,D,H,W) with the output→input voxel matrices Minv (B,3,4), zero padding (csrc/transforms.hip)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 5):
+        raise RuntimeError("viscy_amd GPU augmentations need a contiguous float32 (B,C,Z,Y,X) batch on the HIP device (no CPU fallback)")
+    B, C, D, H, W = x.shape
+    m = Minv.to(x.device, torch.float32).contiguous()
+    y = torch.empty_like(x)
+    check(lib().vsx_warp_affine3d(ptr(x), ptr(y), ptr(m), B, C, D, H, W, int(mode == "nearest"), stream()), "warp_affine3d")
+    return y
+
+
+class BatchedRandAffined(_BatchedRand):
+    """One random 3-D affine per sample (rotation about Z in degrees-space of the recipes: ``rotate_range`` in radians
+    as in the reference signature, per-axis / isotropic scale, XY shear), same matrix for every key, trilinear
+    resampling with zero padding.  The matrix composition is this package's own (kornia's parameter sampling cannot
+    be reproduced bit-for-bit — SURVEY §7); inject ``params=Minv`` (B,3,4) for exact control."""
+
+    def __init__(self, keys, prob: float = 0.1, rotate_range=None, shear_range=None, translate_range=None, scale_range=None,
+                 mode: str = "bilinear", padding_mode: str = "zeros", isotropic_scale: bool = False,
+                 safe_crop_size=None, safe_crop_coverage: float = 1.0, scale_z_shear: bool = False,
+                 allow_missing_keys: bool = False):
+        super().__init__(keys, prob)
+        if padding_mode != "zeros":
+            raise NotImplementedError("only zero padding is built")
+        if translate_range is not None:
+            raise NotImplementedError("translate_range is not built")
+        rr = rotate_range if rotate_range is not None else (0.0, 0.0, 0.0)
+        if isinstance(rr, (int, float)):
+            rr = (rr, 0.0, 0.0)
+        self.rot_z = float(rr[0])  # reference recipes: rotate_range: [3.14, 0.0, 0.0] → about Z (first entry)
+        if any(float(v) != 0.0 for v in list(rr)[1:]):
+            raise NotImplementedError("rotation about Y / X is not built (the UNeXt2 recipes rotate about Z only)")
+        sr = scale_range if scale_range is not None else 0.0
+        self.scale_rng = [float(sr)] * 3 if isinstance(sr, (int, float)) else [float(v) for v in sr]  # (Z, Y, X) deltas
+        sh = shear_range if shear_range is not None else 0.0
+        self.shear = float(sh if isinstance(sh, (int, float)) else sh[0])
+        self.mode, self.isotropic = mode, isotropic_scale
+
+    def randomize(self, shape) -> Tensor:
+        B, _, D, H, W = shape
+        do = self._rand(B) < self.prob
+        u = lambda: self._rand(B) * 2 - 1  # noqa: E731
+        ang = u() * self.rot_z
+        sc = torch.stack([1 + u() * self.scale_rng[2], 1 + u() * self.scale_rng[1], 1 + u() * self.scale_rng[0]], dim=1)  # x,y,z
+        if self.isotropic:
+            sc = sc[:, :1].expand(-1, 3).clone()
+        shr = u() * self.shear
+        ang, shr = torch.where(do, ang, torch.zeros(B)), torch.where(do, shr, torch.zeros(B))
+        sc = torch.where(do.view(-1, 1), sc, torch.ones(B, 3))
+        c, s = ang.cos(), ang.sin()
+        A = torch.zeros(B, 4, 4)
+        A[:, 0, 0], A[:, 0, 1], A[:, 1, 0], A[:, 1, 1], A[:, 2, 2], A[:, 3, 3] = c, -s, s, c, 1.0, 1.0
+        S = torch.diag_embed(torch.cat([sc, torch.ones(B, 1)], dim=1))
+        Sh = torch.eye(4).repeat(B, 1, 1)
+        Sh[:, 0, 1] = shr
+        ctr = torch.eye(4).repeat(B, 1, 1)
+        ctr[:, 0, 3], ctr[:, 1, 3], ctr[:, 2, 3] = (W - 1) / 2.0, (H - 1) / 2.0, (D - 1) / 2.0
+        fwd = ctr @ A @ Sh @ S @ torch.linalg.inv(ctr)
+        return torch.linalg.inv(fwd)[:, :3].contiguous()
+
+    def __call__(self, sample: dict, params: Tensor | None = None) -> dict:
+        first = next((k for k in self.keys if k in sample), None)
+        if first is None:
+            return sample
+        Minv = params if params is not None else self.randomize(sample[first].shape)
+        for k in self.keys:
+            if k in sample:
+                sample[k] = warp_affine3d(sample[k], Minv, self.mode)
         return sample
