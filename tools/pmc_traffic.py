@@ -1,0 +1,52 @@
+"""Turn the two rocprofv3 counter_collection.csv files (FETCH_SIZE pass, WRITE_SIZE pass) of tools/pmc_workload.py
+into per-kernel HBM traffic per launch, calibrated on the known-byte-count launches (MI355X_MICROARCH.md, HBM section:
+gfx950's FETCH_SIZE needs a correction, WRITE_SIZE is uncalibrated → calibrate in the own access pattern)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def load(path, counter):
+    rows = []
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            rows.append((re.sub(r"[<(].*", "", r["Kernel_Name"]).replace("void ", "").strip(), float(r["Counter_Value"])))
+    return rows
+
+
+def main(fetch_csv, write_csv, steps, batch, out):
+    f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    cal = {}
+    for name, rows, key in (("FETCH_SIZE", f, "read"), ("WRITE_SIZE", w, "write")):
+        vals = [v for k, v in rows if k == "normalize_kernel"]
+        # launches: 2 x 256 MiB, 2 x 1024 MiB
+        assert len(vals) == 4, (name, len(vals))
+        per_mib = [vals[0] / 256, vals[1] / 256, vals[2] / 1024, vals[3] / 1024]
+        cal[key] = {"counter_per_MiB": per_mib, "bytes_per_count": (1 << 20) / (sum(per_mib[2:]) / 2)}
+    agg = collections.defaultdict(lambda: {"launches": 0, "read": 0.0, "write": 0.0})
+    for k, v in f:
+        agg[k]["launches"] += 1
+        agg[k]["read"] += v * cal["read"]["bytes_per_count"]
+    for k, v in w:
+        agg[k]["write"] += v * cal["write"]["bytes_per_count"]
+    res = {"steps": steps, "batch": batch, "calibration": cal, "kernels": {}}
+    for k, d in sorted(agg.items(), key=lambda kv: -(kv[1]["read"] + kv[1]["write"])):
+        if k == "normalize_kernel":
+            continue
+        n = d["launches"]
+        res["kernels"][k] = {"launches_per_step": n / steps, "read_GB_per_step": d["read"] / steps / 1e9, "write_GB_per_step": d["write"] / steps / 1e9,
+                             "traffic_bytes_per_launch": (d["read"] + d["write"]) / n}
+    tot = sum(v["read_GB_per_step"] + v["write_GB_per_step"] for v in res["kernels"].values())
+    res["total_GB_per_step"] = tot
+    res["total_MB_per_patch"] = tot * 1e3 / batch
+    json.dump(res, open(out, "w"), indent=1)
+    print("calibration", json.dumps(cal))
+    print(f"total {tot:.2f} GB/step = {tot * 1e3 / batch:.1f} MB/patch")
+    for k, v in list(res["kernels"].items())[:25]:
+        print(f"{k:40s} {v['launches_per_step']:6.1f}/step  R {v['read_GB_per_step']:7.3f} GB  W {v['write_GB_per_step']:7.3f} GB  {v['traffic_bytes_per_launch'] / 1e6:9.2f} MB/launch")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvsx.so")
+LIB_PATH = os.environ.get("VSX_LIB", os.path.join(_HERE, "libvsx.so"))  # VSX_LIB: A/B-test another build
 
 VSX_F32, VSX_BF16 = 0, 1
 A_ROWS, A_PATCH2, A_CONV3 = 0, 1, 2

@@ -18,6 +18,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 extern int g_vsx_tn_tr;
+extern int g_vsx_nt_wide;
+extern int g_vsx_nt_fast;
 
 // ------------------------------------------------------------------------------------------------
 // operand gather: returns the 16-byte chunk holding A(m, k .. k+VN-1) after the prologue
@@ -132,15 +134,15 @@ __device__ __forceinline__ float lds_frag_rk<float>(const char* tile, int row, i
 // ------------------------------------------------------------------------------------------------
 // gemm_nt
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM_, int WN_, int BK>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
+template <typename T, int BM, int BN, int WM_, int WN_, int BK, int NBUF = 2>
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 1) void gemm_nt_kernel(const VsxGemm p) {
   constexpr int ES = sizeof(T);
   constexpr int RS = BK * ES + (ES == 2 ? 32 : 16);
   constexpr int CPR = BK * ES / 16;
   constexpr int VN = VT<T>::N;
   constexpr int FM = BM / WM_ / 16, FN = BN / WN_ / 16;
   constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
-  constexpr int MAIN_BYTES = 2 * (BM + BN) * RS;
+  constexpr int MAIN_BYTES = NBUF * (BM + BN) * RS;
   constexpr int CS_LD = BN + 4;
   constexpr int MAXBT = 8;  // batch samples one tile may span on the LDS reduction path
   constexpr int EPI_BYTES = (BM / (BN >= 64 ? 2 : 1)) * CS_LD * 4 + 2 * MAXBT * BN * 4;
@@ -241,13 +243,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
 
   const int nk = (p.K + BK - 1) / BK;
   load_tiles(0, areg[0], breg[0]);
-  store_tiles(0, 0, areg[0], breg[0]);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tiles(kt + 1, areg[0], breg[0]);   // in flight across the MFMA phase
-    compute(kt & 1);
-    if (kt + 1 < nk) store_tiles(kt + 1, (kt + 1) & 1, areg[0], breg[0]);  // prologue math happens here
+  if constexpr (NBUF == 2) {
+    store_tiles(0, 0, areg[0], breg[0]);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) load_tiles(kt + 1, areg[0], breg[0]);   // in flight across the MFMA phase
+      compute(kt & 1);
+      if (kt + 1 < nk) store_tiles(kt + 1, (kt + 1) & 1, areg[0], breg[0]);  // prologue math happens here
+      __syncthreads();
+    }
+  } else {
+    // one LDS buffer, twice the K per slab: the registers carry a whole 2x-wide slab in flight across the MFMA
+    // phase (bytes in flight per workgroup double at the same LDS footprint -> same workgroups per CU)
+    for (int kt = 0; kt < nk; ++kt) {
+      store_tiles(kt, 0, areg[0], breg[0]);
+      __syncthreads();
+      if (kt + 1 < nk) load_tiles(kt + 1, areg[0], breg[0]);
+      compute(0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: accumulators → LDS (fp32) → row-contiguous vectors, in two passes of BM/2 rows so that the
@@ -419,11 +433,296 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const VsxGemm p) {
   }
 }
 
-template <typename T, int BM, int BN, int WM_, int WN_, int BK>
+// a = g * s[k..] + beta[k..] on one 16-byte chunk (GRN prologue of the lean kernels)
+template <typename T>
+__device__ __forceinline__ typename VT<T>::vec grn_apply(typename VT<T>::vec v, const float* grn_s, const float* grn_b, int k) {
+  constexpr int VN = VT<T>::N;
+  float f[VN];
+  unpack<T>(v, f);
+#pragma unroll
+  for (int j = 0; j < VN; j += 4) {
+    const float4 sv = *reinterpret_cast<const float4*>(grn_s + k + j);
+    const float4 bv = *reinterpret_cast<const float4*>(grn_b + k + j);
+    f[j] = fmaf(f[j], sv.x, bv.x); f[j + 1] = fmaf(f[j + 1], sv.y, bv.y);
+    f[j + 2] = fmaf(f[j + 2], sv.z, bv.z); f[j + 3] = fmaf(f[j + 3], sv.w, bv.w);
+  }
+  return pack<T>(f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt, lean instantiation for the shapes that carry the step: plain row operands, 128x128 tile, K a multiple
+// of 32, tile inside one batch sample.  Same math and LDS layout as gemm_nt_kernel; what changes is the
+// instruction count (PMC on the generic kernel: 1443 VALU + 1021 SALU instructions per wave for 16-112 MFMAs —
+// issue-bound, not memory-bound): the epilogue kind and the prologue are template parameters, operand addresses
+// are one scalar base per K-slab plus a per-lane 32-bit offset computed once, out-of-range rows / columns are
+// clamped at load time (their results are never stored) instead of predicated per chunk per slab.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int EPI, bool PRO>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void gemm_nt_fast_kernel(const VsxGemm p) {
+  constexpr int BM = 128, BN = 128, BK = 32, WN_ = 2, FM = 4, FN = 4;
+  constexpr int ES = sizeof(T);
+  constexpr int RS = BK * ES + (ES == 2 ? 32 : 16);
+  constexpr int CPR = BK * ES / 16;
+  constexpr int VN = VT<T>::N;
+  constexpr int NA = BM * CPR / 256, NB = BN * CPR / 256;
+  constexpr int STAGE = (BM + BN) * RS;
+  constexpr int CS_LD = BN + 4;
+  constexpr int HR = BM / 2;
+  constexpr int EPI_BYTES = HR * CS_LD * 4;
+  constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  constexpr int MK = Frag<T>::MK;
+  constexpr bool REDUCE = (EPI == VSX_EPI_BIAS_GELU_SQ || EPI == VSX_EPI_DZ);
+  typedef typename VT<T>::vec vec;
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN_, wn = wave % WN_;
+  const int p16 = lane & 15, kq = lane >> 4;
+  const int z = blockIdx.z;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);  // XCD-aware (see gemm_nt_kernel)
+  const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const char* Abase = reinterpret_cast<const char*>(p.A) + (size_t)p.a_coff[z] * ES;
+  const char* Bbase = reinterpret_cast<const char*>(p.B) + (size_t)p.b_off[z] * ES;
+  uint32_t offA[NA], offB[NB];
+  int ldsA[NA], ldsB[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int cid = tid + i * 256, row = cid / CPR, ch = cid % CPR;
+    int m = m0 + row;
+    m = m < p.M ? m : p.M - 1;
+    offA[i] = (uint32_t)m * (uint32_t)(p.lda * ES) + ch * 16;
+    ldsA[i] = row * RS + ch * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int cid = tid + i * 256, row = cid / CPR, ch = cid % CPR;
+    int n = n0 + row;
+    n = n < p.N ? n : p.N - 1;
+    offB[i] = (uint32_t)n * (uint32_t)(p.ldb * ES) + ch * 16;
+    ldsB[i] = BM * RS + row * RS + ch * 16;
+  }
+  const int b_tile = p.hw > 0 ? m0 / p.hw : 0;  // the tile lies inside one sample (dispatch guarantees it)
+  const float* grn_s = PRO ? p.grn_s + (size_t)b_tile * p.K : nullptr;
+
+  vec ar[NA], br[NB];
+  auto gload = [&](int kt, vec* ar, vec* br) {
+    const char* Ak = Abase + (size_t)kt * (BK * ES);
+    const char* Bk = Bbase + (size_t)kt * (BK * ES);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ar[i] = *reinterpret_cast<const vec*>(Ak + offA[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) br[i] = *reinterpret_cast<const vec*>(Bk + offB[i]);
+  };
+  auto lstore = [&](int kt, int buf, const vec* ar, const vec* br) {
+    char* S = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      vec v = ar[i];
+      if constexpr (PRO) {  // a = g * s[b, k] + beta[k]
+        const int k = kt * BK + ((tid + i * 256) % CPR) * VN;
+        float f[VN];
+        unpack<T>(v, f);
+#pragma unroll
+        for (int j = 0; j < VN; j += 4) {
+          const float4 sv = *reinterpret_cast<const float4*>(grn_s + k + j);
+          const float4 bv = *reinterpret_cast<const float4*>(p.grn_b + k + j);
+          f[j] = fmaf(f[j], sv.x, bv.x); f[j + 1] = fmaf(f[j + 1], sv.y, bv.y);
+          f[j + 2] = fmaf(f[j + 2], sv.z, bv.z); f[j + 3] = fmaf(f[j + 3], sv.w, bv.w);
+        }
+        v = pack<T>(f);
+      }
+      *reinterpret_cast<vec*>(S + ldsA[i]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const vec vb = br[i];  // through a value: a direct array -> LDS aggregate copy keeps the array in scratch
+      *reinterpret_cast<vec*>(S + ldsB[i]) = vb;
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fragA = (wm * FM * 16 + p16) * RS, fragB = BM * RS + (wn * FN * 16 + p16) * RS;
+  auto compute = [&](int buf) {
+    const char* S = smem + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < BK / MK; ++kk) {
+      frag_t af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = lds_frag_rk<T>(S + fragA, i * 16, RS, kk, kq);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[j] = lds_frag_rk<T>(S + fragB, j * 16, RS, kk, kq);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+    }
+  };
+
+  // register staging runs TWO K-slabs ahead of the MFMA work (two named stages, statically indexed), the LDS
+  // double buffer one slab ahead: up to 32 KB per workgroup are in flight, which is what an operand streamed
+  // from HBM needs (one slab in flight measured ~2 us per K-step per workgroup round = latency-bound)
+  const int nk = p.K / BK;
+  vec ar1[NA], br1[NB];
+  gload(0, ar, br);
+  if (nk > 1) gload(1, ar1, br1);
+  lstore(0, 0, ar, br);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) gload(kt + 2, ar, br);
+    compute(0);
+    if (kt + 1 < nk) lstore(kt + 1, 1, ar1, br1);
+    __syncthreads();
+    if (kt + 1 < nk) {  // (uniform)
+      if (kt + 3 < nk) gload(kt + 3, ar1, br1);
+      compute(1);
+      if (kt + 2 < nk) lstore(kt + 2, 0, ar, br);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (two passes of 64 rows through a fp32 staging tile, row-contiguous 16-byte stores)
+  float* Cs = reinterpret_cast<float*>(smem);
+  constexpr int NCH = BN / VN;
+  constexpr int RSTEP = 256 / NCH;
+  const int cc = tid % NCH, rr = tid / NCH;
+  const int n = n0 + cc * VN;
+  const bool ncol_ok = n < p.N;
+  float bias[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) bias[j] = 0.f;
+  if constexpr (EPI != VSX_EPI_NONE && EPI != VSX_EPI_DZ) {
+    if (ncol_ok && p.bias != nullptr) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) bias[j] = p.bias[n + j];
+    }
+  }
+  float r0[VN], r1[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) { r0[j] = 0.f; r1[j] = 0.f; }
+  const size_t ccol = (size_t)p.c_coff[z] + n;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cs[(i * 16 + kq * 4 + r) * CS_LD + (wn * FN + j) * 16 + p16] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (ncol_ok) {
+#pragma unroll
+      for (int it = 0; it < HR / RSTEP; ++it) {
+        const int row = rr + it * RSTEP;
+        const int m = m0 + half * HR + row;
+        if (m < p.M) {
+          float v[VN];
+#pragma unroll
+          for (int j = 0; j < VN; j += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(Cs + row * CS_LD + cc * VN + j);
+            v[j] = t.x + bias[j]; v[j + 1] = t.y + bias[j + 1]; v[j + 2] = t.z + bias[j + 2]; v[j + 3] = t.w + bias[j + 3];
+          }
+          if constexpr (EPI == VSX_EPI_BIAS_RES) {
+            float rf[VN];
+            unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n), rf);
+#pragma unroll
+            for (int j = 0; j < VN; ++j) v[j] += rf[j];
+          } else if constexpr (EPI == VSX_EPI_BIAS_GELU_SQ) {
+            float gv[VN];
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+              gv[j] = round_to<T>(gelu_f(round_to<T>(v[j])));
+              r0[j] += gv[j] * gv[j];
+            }
+            stvec<T>(reinterpret_cast<T*>(p.C2) + (size_t)m * p.ldc + ccol, pack<T>(gv));
+          } else if constexpr (EPI == VSX_EPI_DZ) {
+            float gf[VN];
+            unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldx + n), gf);
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+              const float dz = round_to<T>(v[j]);
+              r0[j] += dz * gf[j];
+              r1[j] += dz;
+            }
+          }
+          stvec<T>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + ccol, pack<T>(v));
+        }
+      }
+    }
+  }
+  if constexpr (REDUCE) {
+    // column sums of the tile: park the per-thread partials in the (dead) staging rows, then BN threads add them
+    __syncthreads();
+    if (ncol_ok) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) {
+        Cs[rr * CS_LD + cc * VN + j] = r0[j];
+        Cs[(rr + RSTEP) * CS_LD + cc * VN + j] = r1[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+      for (int r = 0; r < RSTEP; ++r) {
+        a0 += Cs[r * CS_LD + tid];
+        a1 += Cs[(r + RSTEP) * CS_LD + tid];
+      }
+      atomicAdd(p.red0 + (size_t)b_tile * p.N + n0 + tid, a0);
+      if constexpr (EPI == VSX_EPI_DZ) atomicAdd(p.red1 + (size_t)b_tile * p.N + n0 + tid, a1);
+    }
+  }
+}
+
+template <typename T, int EPI, bool PRO>
+static int launch_nt_fast(const VsxGemm* p, hipStream_t s) {
+  int tiles = vsx_cdiv(p->M, 128) * vsx_cdiv(p->N, 128);
+  dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
+  hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO>), grid, dim3(256), 0, s, *p);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+static bool nt_fast_ok(const VsxGemm* p, int es) {
+  if (!g_vsx_nt_fast || p->N <= 64 || p->a_mode != VSX_A_ROWS || p->c_mode != VSX_A_ROWS || p->K % 32 != 0) return false;
+  if (p->epi == VSX_EPI_BIAS_STATS) return false;
+  const bool reduce = p->epi == VSX_EPI_BIAS_GELU_SQ || p->epi == VSX_EPI_DZ;
+  if ((reduce || p->pro == VSX_PRO_GRN) && (p->hw <= 0 || p->hw % 128 != 0)) return false;
+  if ((unsigned long long)p->M * p->lda * es >= (1ull << 32) || (unsigned long long)p->N * p->ldb * es >= (1ull << 32)) return false;
+  return true;
+}
+
+template <typename T>
+static int dispatch_nt_fast(const VsxGemm* p, hipStream_t s) {
+  const bool pro = p->pro == VSX_PRO_GRN;
+  switch (p->epi) {
+    case VSX_EPI_NONE: return pro ? launch_nt_fast<T, VSX_EPI_NONE, true>(p, s) : launch_nt_fast<T, VSX_EPI_NONE, false>(p, s);
+    case VSX_EPI_BIAS: return pro ? launch_nt_fast<T, VSX_EPI_BIAS, true>(p, s) : launch_nt_fast<T, VSX_EPI_BIAS, false>(p, s);
+    case VSX_EPI_BIAS_GELU_SQ: return pro ? launch_nt_fast<T, VSX_EPI_BIAS_GELU_SQ, true>(p, s) : launch_nt_fast<T, VSX_EPI_BIAS_GELU_SQ, false>(p, s);
+    case VSX_EPI_BIAS_RES: return pro ? launch_nt_fast<T, VSX_EPI_BIAS_RES, true>(p, s) : launch_nt_fast<T, VSX_EPI_BIAS_RES, false>(p, s);
+    default: return pro ? launch_nt_fast<T, VSX_EPI_DZ, true>(p, s) : launch_nt_fast<T, VSX_EPI_DZ, false>(p, s);
+  }
+}
+
+template <typename T, int BM, int BN, int WM_, int WN_, int BK, int NBUF = 2>
 static int launch_nt(const VsxGemm* p, hipStream_t s) {
   int tiles = vsx_cdiv(p->M, BM) * vsx_cdiv(p->N, BN);
   dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM_, WN_, BK>), grid, dim3(256), 0, s, *p);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM_, WN_, BK, NBUF>), grid, dim3(256), 0, s, *p);
   VSX_LAUNCH_CHECK();
   return 0;
 }
@@ -437,6 +736,10 @@ static int dispatch_nt(const VsxGemm* p, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
       if (tiles < 512 && p->K >= 256) return launch_nt<T, 128, 128, 2, 2, 128>(p, s);
     }
+    if constexpr (sizeof(T) == 2) {
+      if (g_vsx_nt_wide && p->K >= 64) return launch_nt<T, 128, 128, 2, 2, 64, 1>(p, s);
+    }
+    if (nt_fast_ok(p, (int)sizeof(T))) return dispatch_nt_fast<T>(p, s);
     return launch_nt<T, 128, 128, 2, 2, 32>(p, s);
   }
   if (p->N > 32) return launch_nt<T, 128, 64, 2, 2, 32>(p, s);
@@ -562,7 +865,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
   const int z = blockIdx.z;
 
   const int tiles_k = (p.K + BT - 1) / BT;
-  const int tile_k = blockIdx.x % tiles_k, tile_n = blockIdx.x / tiles_k;
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest); all output tiles of
+  // one split stream the SAME 32-row windows of X / Y, so they are placed on one XCD (one L2) and adjacent in time —
+  // measured with FETCH_SIZE: without this every tile re-fetched its operands through the fabric
+  int bx = blockIdx.x, by = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int L = bx + gridDim.x * by;
+    const int j = L >> 3;
+    bx = j % gridDim.x;
+    by = (j / gridDim.x) * 8 + (L & 7);
+  }
+  const int tile_k = bx % tiles_k, tile_n = bx / tiles_k;
   const int n0 = tile_n * BT, k0 = tile_k * BT;
   // the 32-row contraction steps are dealt round-robin to the gridDim.y splits: at any instant the
   // splits stream one contiguous window of X / Y (blocked ranges would camp on a few HBM channels)
@@ -570,7 +883,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
   const int mend = p.M;
   const int total_steps = (p.M + BMS - 1) / BMS;
   const int nsplit = gridDim.y;
-  if ((int)blockIdx.y >= total_steps) return;
+  if (by >= total_steps) return;
 
   const T* X = reinterpret_cast<const T*>(p.B);
   const int x_coff = p.b_off[z];
@@ -627,12 +940,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
   float csum = 0.f;  // bias-gradient partial for column n0 + tid (tile_k == 0 blocks only)
   const bool do_colsum = p.colsum != nullptr && tile_k == 0 && tid < BT;
 
-  const int nsteps = (total_steps - (int)blockIdx.y + nsplit - 1) / nsplit;
-  load_tiles((int)blockIdx.y * BMS);
+  const int nsteps = (total_steps - by + nsplit - 1) / nsplit;
+  load_tiles(by * BMS);
   store_tiles(0);
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
-    if (st + 1 < nsteps) load_tiles(((st + 1) * nsplit + (int)blockIdx.y) * BMS);
+    if (st + 1 < nsteps) load_tiles(((st + 1) * nsplit + by) * BMS);
     const char* Xs = smem + (st & 1) * 2 * TILE_BYTES;
     const char* Ys = Xs + TILE_BYTES;
 #pragma unroll
@@ -669,6 +982,145 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
   if (do_colsum && n0 + tid < p.N) atomicAdd(p.colsum + n0 + tid, csum);
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_tn, lean instantiation: plain row operands, M a multiple of 32, a 32-row step inside one sample.
+// Same tiles / fragment reads / split order as gemm_tn_kernel; the operand addresses are a scalar base per step
+// plus a per-lane offset computed once, column tails are clamped at load time (a clamped column only feeds
+// outputs that are never written), the GRN prologue is a template parameter.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BT, bool TR, bool PRO>
+__global__ __launch_bounds__(256) void gemm_tn_fast_kernel(const VsxGemm p) {
+  constexpr int BMS = 32;
+  constexpr int ES = sizeof(T);
+  constexpr int VN = VT<T>::N;
+  constexpr int LD = BT + 16;
+  constexpr int LDB = LD * ES;
+  constexpr int CPR = BT / VN;
+  constexpr int NCH = (BMS * CPR + 255) / 256;
+  constexpr int TILE_BYTES = BMS * LDB;
+  constexpr int F = BT / 2 / 16;
+  constexpr int MK = Frag<T>::MK;
+  typedef typename VT<T>::vec vec;
+  typedef typename Frag<T>::type frag_t;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int p16 = lane & 15, kq = lane >> 4;
+  const int z = blockIdx.z;
+  const int tiles_k = (p.K + BT - 1) / BT;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {  // XCD-aware (see gemm_tn_kernel)
+    const int L = bx + gridDim.x * by;
+    const int j = L >> 3;
+    bx = j % gridDim.x;
+    by = (j / gridDim.x) * 8 + (L & 7);
+  }
+  const int tile_k = bx % tiles_k, tile_n = bx / tiles_k;
+  const int n0 = tile_n * BT, k0 = tile_k * BT;
+  const int total_steps = p.M / BMS;
+  const int nsplit = gridDim.y;
+  if (by >= total_steps) return;
+
+  const char* Xb = reinterpret_cast<const char*>(p.B) + (size_t)p.b_off[z] * ES;
+  const char* Yb = reinterpret_cast<const char*>(p.A) + (size_t)p.a_coff[z] * ES;
+  const size_t xstep = (size_t)BMS * p.ldb * ES, ystep = (size_t)BMS * p.lda * ES;
+  uint32_t xoff[NCH], yoff[NCH];
+  int lds_o[NCH], kcol[NCH];
+  bool live[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int cid = tid + i * 256, crow = cid / CPR, cch = cid % CPR;
+    live[i] = cid < BMS * CPR;
+    int nn = n0 + cch * VN, kk = k0 + cch * VN;
+    nn = nn < p.N ? nn : p.N - VN;
+    kk = kk < p.K ? kk : p.K - VN;
+    kcol[i] = kk;
+    xoff[i] = (uint32_t)(crow * p.ldb + nn) * ES;
+    yoff[i] = (uint32_t)(crow * p.lda + kk) * ES;
+    lds_o[i] = crow * LDB + cch * 16;
+  }
+
+  vec xreg[NCH], yreg[NCH];
+  auto load_tiles = [&](int step, vec* xr, vec* yr) {
+    const char* Xs = Xb + (size_t)step * xstep;
+    const char* Ys = Yb + (size_t)step * ystep;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (live[i]) {
+        xr[i] = *reinterpret_cast<const vec*>(Xs + xoff[i]);
+        yr[i] = *reinterpret_cast<const vec*>(Ys + yoff[i]);
+      }
+    }
+  };
+  auto store_tiles = [&](int step, int buf, const vec* xr, const vec* yr) {
+    char* Xs = smem + buf * 2 * TILE_BYTES;
+    char* Ys = Xs + TILE_BYTES;
+    const float* gs = PRO ? p.grn_s + (size_t)((step * BMS) / p.hw) * p.K : nullptr;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (live[i]) {
+        const vec xv = xr[i];
+        vec yv = yr[i];
+        if constexpr (PRO) yv = grn_apply<T>(yv, gs, p.grn_b, kcol[i]);
+        *reinterpret_cast<vec*>(Xs + lds_o[i]) = xv;
+        *reinterpret_cast<vec*>(Ys + lds_o[i]) = yv;
+      }
+    }
+  };
+
+  f32x4 acc[F][F];
+#pragma unroll
+  for (int i = 0; i < F; ++i)
+#pragma unroll
+    for (int j = 0; j < F; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;
+  const bool do_colsum = p.colsum != nullptr && tile_k == 0 && tid < BT;
+
+  const int nsteps = (total_steps - by + nsplit - 1) / nsplit;
+  load_tiles(by, xreg, yreg);
+  store_tiles(by, 0, xreg, yreg);
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int nxt = (st + 1) * nsplit + by;
+    if (st + 1 < nsteps) load_tiles(nxt, xreg, yreg);
+    const char* Xs = smem + (st & 1) * 2 * TILE_BYTES;
+    const char* Ys = Xs + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BMS / MK; ++kk) {
+      frag_t xf[F], yf[F];
+#pragma unroll
+      for (int i = 0; i < F; ++i) xf[i] = lds_frag_mn<T, TR>(Xs, LDB, (wn * F + i) * 16, p16, kq, kk);
+#pragma unroll
+      for (int j = 0; j < F; ++j) yf[j] = lds_frag_mn<T, TR>(Ys, LDB, (wk * F + j) * 16, p16, kq, kk);
+#pragma unroll
+      for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < F; ++j) acc[i][j] = mfma16(xf[i], yf[j], acc[i][j]);
+    }
+    if (do_colsum) {
+#pragma unroll 8
+      for (int r = 0; r < BMS; ++r) csum += to_f32<T>(*reinterpret_cast<const T*>(Xs + r * LDB + tid * ES));
+    }
+    if (st + 1 < nsteps) store_tiles(nxt, (st + 1) & 1, xreg, yreg);
+    __syncthreads();
+  }
+
+  float* W = reinterpret_cast<float*>(p.C) + p.c_coff[z];
+#pragma unroll
+  for (int i = 0; i < F; ++i)
+#pragma unroll
+    for (int j = 0; j < F; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (wn * F + i) * 16 + kq * 4 + r;
+        const int k = k0 + (wk * F + j) * 16 + p16;
+        if (n < p.N && k < p.K) atomicAdd(W + (size_t)n * p.ldc + k, acc[i][j][r]);
+      }
+  if (do_colsum && n0 + tid < p.N) atomicAdd(p.colsum + n0 + tid, csum);
+}
+
 template <typename T, int BT, bool TR>
 static int launch_tn(const VsxGemm* p, hipStream_t s) {
   int tiles = vsx_cdiv(p->N, BT) * vsx_cdiv(p->K, BT);
@@ -684,7 +1136,19 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
   if (splits > cap) splits = cap;
   int rpb = 0;
   if (splits > vsx_cdiv(p->M, 32)) splits = vsx_cdiv(p->M, 32);
+  if (splits >= 8) splits &= ~7;  // multiple of 8: the kernel maps whole splits onto XCDs
   dim3 grid(tiles, splits, nz);
+  const bool fast = g_vsx_nt_fast && p->a_mode == VSX_A_ROWS && p->M % 32 == 0 && p->N >= VT<T>::N && p->K >= VT<T>::N &&
+                    (p->pro == VSX_PRO_NONE || (p->pro == VSX_PRO_GRN && p->hw > 0 && p->hw % 32 == 0)) &&
+                    (unsigned long long)32 * (p->lda > p->ldb ? p->lda : p->ldb) * sizeof(T) < (1ull << 31);
+  if (fast) {
+    if (p->pro == VSX_PRO_GRN)
+      hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, true>), grid, dim3(256), 0, s, *p);
+    else
+      hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, false>), grid, dim3(256), 0, s, *p);
+    VSX_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL((gemm_tn_kernel<T, BT, TR>), grid, dim3(256), 0, s, *p, rpb);
   VSX_LAUNCH_CHECK();
   return 0;
