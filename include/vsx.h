@@ -116,6 +116,21 @@ int32_t vsx_dwconv7_bwd_data(const void* dy, const float* w, const void* add, vo
 int32_t vsx_dwconv7_bwd_weight(const void* dy, const void* x, float* dw, float* db, float* ws,
     int32_t ws_rows, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, vsx_stream_t stream);
 
+/* K12 direct: the head's 3x3x3 Conv3d (MONAI Convolution conv, viscy_models/components/heads.py:607-616) as LDS-tiled MFMA
+ * kernels for the production shape — bf16, C3 = 8 -> Cmid = 32, 5 output planes, H2 and W2 multiples of 16
+ * (vsx_head_conv_supported tells; everything else runs through vsx_gemm_nt / vsx_gemm_tn with VSX_A_CONV3).
+ * hin [B*H2*W2, 7*8], U / dU [B*H2*W2, 5*32], Wc [32][27*8] (k = ((dy*3+dx)*3+dz)*8 + c, the prepared conv weight),
+ * ssum / ssq [B,32] += InstanceNorm statistics of the stored U, dW fp32 [32][216] += , db fp32 [32] += (may be NULL),
+ * Wp: 45*2*64*8 bf16 packed by vsx_head_conv_dgrad_prep from Wc. */
+int32_t vsx_head_conv_supported(int32_t H2, int32_t W2, int32_t c3, int32_t cmid, int32_t zo, int32_t dtype);
+int32_t vsx_head_conv_fwd(const void* hin, const void* Wc, const float* bias, void* U, float* ssum, float* ssq,
+    int32_t B, int32_t H2, int32_t W2, int32_t c3, int32_t cmid, int32_t zo, int32_t dtype, vsx_stream_t stream);
+int32_t vsx_head_conv_wgrad(const void* hin, const void* dU, float* dW, float* db, int32_t B, int32_t H2, int32_t W2,
+    int32_t c3, int32_t cmid, int32_t zo, int32_t dtype, vsx_stream_t stream);
+int32_t vsx_head_conv_dgrad_prep(const void* Wc, void* Wp, int32_t dtype, vsx_stream_t stream);
+int32_t vsx_head_conv_dgrad(const void* dU, const void* Wp, void* dhin, int32_t B, int32_t H2, int32_t W2, int32_t c3,
+    int32_t cmid, int32_t zo, int32_t dtype, vsx_stream_t stream);
+
 /* K13 (norm+act) + K14: MONAI Convolution ADN (InstanceNorm3d eps 1e-5 → PReLU) → nn.Conv3d(mid, 4*out, 1) → transpose /
  * nn.PixelShuffle(2) / transpose (viscy_models/components/heads.py:617-625,638-641).  U: [B,H2,W2,Z,Cmid] conv output;
  * ssum/ssq: [B,Cmid] from the conv GEMM epilogue (VSX_EPI_BIAS_STATS); out: (B, Cout, Z, 2*H2, 2*W2) fp32. */

@@ -211,6 +211,57 @@ def test_gemm_conv3_z_batched(dt):
         close(g[4], x5.grad.permute(0, 3, 4, 2, 1).reshape(Mh, D7 * c3), dt, "dhin vs conv3d")
 
 
+@pytest.mark.parametrize("B,gh,gw", [(2, 32, 48), (1, 16, 16)])
+def test_head_conv_direct_bf16(B, gh, gw):
+    """csrc/headconv.hip (LDS-tiled direct 3x3x3 conv, bf16 8 -> 32 channels, 5 planes) against F.conv3d autograd on
+    the same bf16-rounded operands, and against the z-batched implicit-GEMM path it replaces."""
+    H = _hip()
+    dt = torch.bfloat16
+    c3, cmid, Zo = 8, 32, 5
+    D7 = Zo + 2
+    Mh = B * gh * gw
+    assert H.head_conv_supported(gh, gw, c3, cmid, Zo, dt) and not H.head_conv_supported(gh + 8, gw, c3, cmid, Zo, dt)
+    assert not H.head_conv_supported(gh, gw, c3, cmid, Zo, torch.float32)
+    hin = rnd(Mh, D7 * c3, dt=dt, seed=1)
+    Wc = rnd(cmid, c3, 3, 3, 3, seed=2, scale=0.1)
+    bias = rnd(cmid, seed=3)
+    dU = rnd(Mh, Zo * cmid, dt=dt, seed=4)
+    Wg, _ = H.prep_weight(Wc.to(DEV), cmid, c3, 27, dt, tapmode=1)
+    st = torch.zeros(2, B, cmid, device=DEV)
+    U = H.head_conv_fwd(hin.to(DEV), Wg, bias.to(DEV), st[0], st[1], B, gh, gw, c3, cmid, Zo)
+    dWc = torch.zeros(cmid, 27 * c3, device=DEV)
+    db = torch.zeros(cmid, device=DEV)
+    H.head_conv_wgrad(hin.to(DEV), dU.to(DEV), dWc, db, B, gh, gw, c3, cmid, Zo)
+    dWp = torch.zeros(cmid, c3, 3, 3, 3, device=DEV)
+    H.unprep_grad(dWc, dWp, cmid, c3, 27, tapmode=1)
+    dhin = H.head_conv_dgrad(dU.to(DEV), H.head_conv_dgrad_prep(Wg), B, gh, gw, c3, cmid, Zo)
+    assert U.dtype == dt and dhin.dtype == dt and dhin.shape == (Mh, D7 * c3)
+
+    # reference: fp32 conv3d on the bf16-rounded operands (what both device paths see)
+    x5 = hin.float().view(B, gh, gw, D7, c3).permute(0, 4, 3, 1, 2).clone().requires_grad_(True)
+    w = Wc.to(dt).float().clone().requires_grad_(True)
+    bb = bias.clone().requires_grad_(True)
+    y = torch.nn.functional.conv3d(x5, w, bb, padding=(0, 1, 1))
+    Uref = y.permute(0, 3, 4, 2, 1).reshape(Mh, Zo * cmid)
+    y.backward(dU.float().view(B, gh, gw, Zo, cmid).permute(0, 4, 3, 1, 2))
+    close(U, Uref, dt, "U vs conv3d")
+    ur = Uref.detach().to(dt).float().view(B, gh * gw * Zo, cmid)
+    close(st[0], ur.sum(1), dt, "sum")
+    close(st[1], (ur * ur).sum(1), dt, "sumsq")
+    close(dWp, w.grad, dt, "dW vs conv3d")
+    close(db, bb.grad, dt, "db vs conv3d")
+    close(dhin, x5.grad.permute(0, 3, 4, 2, 1).reshape(Mh, D7 * c3), dt, "dhin vs conv3d")
+
+    # the generic path on the same inputs (same rounding points: fp32 accumulation of bf16 products, one final rounding)
+    U2 = torch.zeros(Mh, Zo * cmid, dtype=dt, device=DEV)
+    st2 = torch.zeros(2, B, cmid, device=DEV)
+    H.gemm_z("nt", hin.to(DEV), Wg, U2, Mh, cmid, 27 * c3, D7 * c3, 27 * c3, Zo * cmid, dtype=dt, a_mode=R.A_CONV3, gh=gh,
+             gw=gw, cs=3 * c3, nz=Zo, a_coff=[z * c3 for z in range(Zo)], b_off=[0] * Zo,
+             c_coff=[z * cmid for z in range(Zo)], epi=R.EPI_BIAS_STATS, bias=bias.to(DEV), red0=st2[0], red1=st2[1], hw=gh * gw)
+    assert (U.float() - U2.float()).abs().max().item() <= 2.0 ** -7 * U2.float().abs().max().item()  # <= 1 bf16 ulp (sum order)
+    torch.testing.assert_close(st, st2, rtol=2e-3, atol=2e-2)
+
+
 # ------------------------------------------------------------------ GEMM tn
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("tr", [1, 0], ids=["tr_read", "scalar_read"])

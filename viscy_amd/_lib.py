@@ -80,6 +80,11 @@ _SIGS = {
     "vsx_sample_minmax": (_I32, [_P, _P, _P, _I32, _I64, _P]),
     "vsx_intensity_aug": (_I32, [_P] * 8 + [_F32, _I32, _I64, _P]),
     "vsx_blend_in": (_I32, [_P, _P, _P, _P, _I32, _I64, _I64, _P]),
+    "vsx_head_conv_supported": (_I32, [_I32] * 6),
+    "vsx_head_conv_fwd": (_I32, [_P] * 6 + [_I32] * 7 + [_P]),
+    "vsx_head_conv_wgrad": (_I32, [_P] * 4 + [_I32] * 7 + [_P]),
+    "vsx_head_conv_dgrad_prep": (_I32, [_P, _P, _I32, _P]),
+    "vsx_head_conv_dgrad": (_I32, [_P] * 3 + [_I32] * 7 + [_P]),
     "vsx_warp_affine3d": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_conv1d_axis": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
 }

@@ -178,6 +178,8 @@ class Engine:
         cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
         W["head_Wc"], _ = o.prep_weight(hc.weight, cmid, c3, 27, dt, tapmode=1)
         if need_bwd:
+            if dt == torch.bfloat16 and c3 == 8 and cmid == 32 and cfg["out_stack_depth"] == 5:
+                W["head_Wp"] = o.head_conv_dgrad_prep(W["head_Wc"])  # direct LDS-tiled dgrad (csrc/headconv.hip)
             W["head_Wd"] = o.prep_head_dgrad(hc.weight, cmid, c3, cfg["out_stack_depth"], dt)
         self.W = W
         self._prepared_for = key
@@ -311,12 +313,16 @@ class Engine:
         hin = o.head_shuffle_fwd(feat, B, fh, fw, c3, D7, cfg["head_pool"])
         H2, W2 = 2 * fh, 2 * fw
         Mh = B * H2 * W2
-        U = torch.empty((Mh, Zo * cmid), dtype=dt, device=x.device)
         stats = torch.zeros((2, B, cmid), dtype=torch.float32, device=x.device)
-        o.gemm_z("nt", hin, W["head_Wc"], U, Mh, cmid, 27 * c3, D7 * c3, 27 * c3, Zo * cmid, dtype=dt,
-                 a_mode=L.A_CONV3, gh=H2, gw=W2, cs=3 * c3, nz=Zo, a_coff=[z * c3 for z in range(Zo)],
-                 b_off=[0] * Zo, c_coff=[z * cmid for z in range(Zo)], epi=L.EPI_BIAS_STATS, bias=hc.bias,
-                 red0=stats[0], red1=stats[1], hw=H2 * W2)
+        direct = o.head_conv_supported(H2, W2, c3, cmid, Zo, dt)
+        if direct:
+            U = o.head_conv_fwd(hin, W["head_Wc"], hc.bias, stats[0], stats[1], B, H2, W2, c3, cmid, Zo)
+        else:
+            U = torch.empty((Mh, Zo * cmid), dtype=dt, device=x.device)
+            o.gemm_z("nt", hin, W["head_Wc"], U, Mh, cmid, 27 * c3, D7 * c3, 27 * c3, Zo * cmid, dtype=dt,
+                     a_mode=L.A_CONV3, gh=H2, gw=W2, cs=3 * c3, nz=Zo, a_coff=[z * c3 for z in range(Zo)],
+                     b_off=[0] * Zo, c_coff=[z * cmid for z in range(Zo)], epi=L.EPI_BIAS_STATS, bias=hc.bias,
+                     red0=stats[0], red1=stats[1], hw=H2 * W2)
         w2 = m.head.conv[1].weight.view(4 * cout, cmid)
         out = o.head_out_fwd(U, stats[0], stats[1], w2, m.head.conv[1].bias, m.head.conv[0].adn.A.weight, B, H2, W2, Zo,
                              cmid, cout)
@@ -354,15 +360,22 @@ class Engine:
         dU = o.head_out_bwd2(U, stats[0], stats[1], w2, alpha, dv, S[0], S[1], B, H2, W2, Zo, cmid, cout)
         del dv
         dWc = torch.zeros((cmid, 27 * c3), dtype=torch.float32, device=dev)
-        o.gemm_z("tn", hin, dU, dWc, Mh, cmid, 27 * c3, D7 * c3, Zo * cmid, 27 * c3, dtype=dt, a_mode=L.A_CONV3, gh=H2,
-                 gw=W2, cs=3 * c3, nz=Zo, a_coff=[z * c3 for z in range(Zo)], b_off=[z * cmid for z in range(Zo)],
-                 c_coff=[0] * Zo, colsum=g(hc.bias))
+        direct = "head_Wp" in W and o.head_conv_supported(H2, W2, c3, cmid, Zo, dt)
+        if direct:
+            o.head_conv_wgrad(hin, dU, dWc, g(hc.bias), B, H2, W2, c3, cmid, Zo)
+        else:
+            o.gemm_z("tn", hin, dU, dWc, Mh, cmid, 27 * c3, D7 * c3, Zo * cmid, 27 * c3, dtype=dt, a_mode=L.A_CONV3, gh=H2,
+                     gw=W2, cs=3 * c3, nz=Zo, a_coff=[z * c3 for z in range(Zo)], b_off=[z * cmid for z in range(Zo)],
+                     c_coff=[0] * Zo, colsum=g(hc.bias))
         o.unprep_grad(dWc, g(hc.weight), cmid, c3, 27, tapmode=1)
-        dhin = torch.empty((Mh, D7 * c3), dtype=dt, device=dev)
-        zs = [min(max(zp - 2, 0), Zo - 3) for zp in range(D7)]
-        o.gemm_z("nt", dU, W["head_Wd"], dhin, Mh, c3, 27 * cmid, Zo * cmid, 27 * cmid, D7 * c3, dtype=dt,
-                 a_mode=L.A_CONV3, gh=H2, gw=W2, cs=3 * cmid, nz=D7, a_coff=[z * cmid for z in zs],
-                 b_off=[zp * c3 * 27 * cmid for zp in range(D7)], c_coff=[zp * c3 for zp in range(D7)])
+        if direct:
+            dhin = o.head_conv_dgrad(dU, W["head_Wp"], B, H2, W2, c3, cmid, Zo)
+        else:
+            dhin = torch.empty((Mh, D7 * c3), dtype=dt, device=dev)
+            zs = [min(max(zp - 2, 0), Zo - 3) for zp in range(D7)]
+            o.gemm_z("nt", dU, W["head_Wd"], dhin, Mh, c3, 27 * cmid, Zo * cmid, 27 * cmid, D7 * c3, dtype=dt,
+                     a_mode=L.A_CONV3, gh=H2, gw=W2, cs=3 * cmid, nz=D7, a_coff=[z * cmid for z in zs],
+                     b_off=[zp * c3 * 27 * cmid for zp in range(D7)], c_coff=[zp * c3 for zp in range(D7)])
         del dU
         d = o.head_shuffle_bwd(dhin, B, fh, fw, c3, D7, cfg["head_pool"])
         del dhin

@@ -269,3 +269,35 @@ def prep_head_dgrad(W: Tensor, Cmid: int, C3: int, Zout: int, dtype: torch.dtype
 
 def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor) -> None:
     check(lib().vsx_adamw(ptr(p), ptr(g), ptr(m), ptr(v), ptr(hyper), p.numel(), stream()), "adamw")
+
+
+# ------------------------------------------------------------------ direct head convolution (csrc/headconv.hip)
+def head_conv_supported(H2: int, W2: int, c3: int, cmid: int, zo: int, dtype: torch.dtype) -> bool:
+    return bool(lib().vsx_head_conv_supported(H2, W2, c3, cmid, zo, dtype_code(dtype)))
+
+
+def head_conv_fwd(hin: Tensor, Wc: Tensor, bias: Tensor | None, ssum: Tensor, ssq: Tensor, B: int, H2: int, W2: int, c3: int,
+                  cmid: int, zo: int) -> Tensor:
+    U = torch.empty((B * H2 * W2, zo * cmid), dtype=hin.dtype, device=hin.device)
+    check(lib().vsx_head_conv_fwd(ptr(hin), ptr(Wc), ptr(bias), ptr(U), ptr(ssum), ptr(ssq), B, H2, W2, c3, cmid, zo,
+                                  dtype_code(hin.dtype), stream()), "head_conv_fwd")
+    return U
+
+
+def head_conv_wgrad(hin: Tensor, dU: Tensor, dW: Tensor, db: Tensor | None, B: int, H2: int, W2: int, c3: int, cmid: int,
+                    zo: int) -> None:
+    check(lib().vsx_head_conv_wgrad(ptr(hin), ptr(dU), ptr(dW), ptr(db), B, H2, W2, c3, cmid, zo, dtype_code(hin.dtype),
+                                    stream()), "head_conv_wgrad")
+
+
+def head_conv_dgrad_prep(Wc: Tensor) -> Tensor:
+    Wp = torch.empty(45 * 2 * 64 * 8, dtype=Wc.dtype, device=Wc.device)
+    check(lib().vsx_head_conv_dgrad_prep(ptr(Wc), ptr(Wp), dtype_code(Wc.dtype), stream()), "head_conv_dgrad_prep")
+    return Wp
+
+
+def head_conv_dgrad(dU: Tensor, Wp: Tensor, B: int, H2: int, W2: int, c3: int, cmid: int, zo: int) -> Tensor:
+    dhin = torch.empty((B * H2 * W2, (zo + 2) * c3), dtype=dU.dtype, device=dU.device)
+    check(lib().vsx_head_conv_dgrad(ptr(dU), ptr(Wp), ptr(dhin), B, H2, W2, c3, cmid, zo, dtype_code(dU.dtype), stream()),
+          "head_conv_dgrad")
+    return dhin
