@@ -281,6 +281,21 @@ def main():
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 5),
                         "launches": dom["launches"]}
+        if roof is not None:
+            # HBM traffic of the dominant kernel class: PMC counters cannot be read from inside this process, so the
+            # figure comes from the committed rocprofv3 --pmc passes of the SAME configuration
+            # (scripts/pmc_traffic.sh -> profiles/r01_pmc_traffic_b<batch>.json: FETCH_SIZE / WRITE_SIZE in separate
+            # passes, calibrated on a launch with a known byte count as MI355X_MICROARCH.md prescribes)
+            tf_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_traffic_b{B}.json")
+            if args.size == 256 and args.dtype == "bf16" and os.path.exists(tf_path):
+                try:
+                    cls = json.load(open(tf_path)).get("classes", {}).get(dominant)
+                    if cls:
+                        roof["traffic"] = round(cls["traffic_bytes_per_launch"])
+                        roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / dom["launches"])
+                        roof["traffic_source"] = os.path.relpath(tf_path, os.path.dirname(os.path.abspath(__file__)))
+                except (OSError, ValueError, KeyError):
+                    pass
         res = {
             "metric": "training patches/sec (Z=5, 256x256, 1->2ch UNeXt2)",
             "value": round(value, 2),

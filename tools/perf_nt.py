@@ -10,7 +10,7 @@ from viscy_amd import ops  # noqa: E402
 
 dt, dev = torch.bfloat16, "cuda"
 from viscy_amd._lib import lib  # noqa: E402
-lib().vsx_set_flag(b"nt_wide", int(os.environ.get("NTW", 1)))
+lib().vsx_set_flag(b"nt_wide", int(os.environ.get("NTW", 0)))
 B = int(os.environ.get("B", 128))
 
 

@@ -38,12 +38,25 @@ def main(fetch_csv, write_csv, steps, batch, out):
         n = d["launches"]
         res["kernels"][k] = {"launches_per_step": n / steps, "read_GB_per_step": d["read"] / steps / 1e9, "write_GB_per_step": d["write"] / steps / 1e9,
                              "traffic_bytes_per_launch": (d["read"] + d["write"]) / n}
+    # op classes as bench.py's OpTimer names them (all instantiations of one kernel family together)
+    cls = collections.defaultdict(lambda: {"launches_per_step": 0.0, "read_GB_per_step": 0.0, "write_GB_per_step": 0.0})
+    for k, v in res["kernels"].items():
+        base = re.sub(r"^_Z\d+", "", k)
+        base = re.sub(r"_kernel.*", "", base)
+        base = {"gemm_nt_fast": "gemm_nt", "gemm_tn_fast": "gemm_tn"}.get(base, base)
+        for f in ("launches_per_step", "read_GB_per_step", "write_GB_per_step"):
+            cls[base][f] += v[f]
+    for c in cls.values():
+        c["traffic_bytes_per_launch"] = (c["read_GB_per_step"] + c["write_GB_per_step"]) * 1e9 / max(c["launches_per_step"], 1e-9)
+    res["classes"] = dict(cls)
     tot = sum(v["read_GB_per_step"] + v["write_GB_per_step"] for v in res["kernels"].values())
     res["total_GB_per_step"] = tot
     res["total_MB_per_patch"] = tot * 1e3 / batch
     json.dump(res, open(out, "w"), indent=1)
     print("calibration", json.dumps(cal))
     print(f"total {tot:.2f} GB/step = {tot * 1e3 / batch:.1f} MB/patch")
+    for k, v in sorted(res["classes"].items(), key=lambda kv: -(kv[1]["read_GB_per_step"] + kv[1]["write_GB_per_step"])):
+        print(f"[class] {k:28s} {v['launches_per_step']:6.1f}/step  R {v['read_GB_per_step']:7.3f} GB  W {v['write_GB_per_step']:7.3f} GB  {v['traffic_bytes_per_launch'] / 1e6:9.2f} MB/launch")
     for k, v in list(res["kernels"].items())[:25]:
         print(f"{k:40s} {v['launches_per_step']:6.1f}/step  R {v['read_GB_per_step']:7.3f} GB  W {v['write_GB_per_step']:7.3f} GB  {v['traffic_bytes_per_launch'] / 1e6:9.2f} MB/launch")
 

@@ -7,7 +7,7 @@
 
 static thread_local char g_err[512] = "";
 int g_vsx_tn_tr = 1;
-int g_vsx_nt_wide = 0;
+int g_vsx_nt_wide = 1;
 int g_vsx_nt_fast = 1;
 
 void vsx_set_error(const char* fmt, ...) {

@@ -457,9 +457,9 @@ __device__ __forceinline__ typename VT<T>::vec grn_apply(typename VT<T>::vec v, 
 // are one scalar base per K-slab plus a per-lane 32-bit offset computed once, out-of-range rows / columns are
 // clamped at load time (their results are never stored) instead of predicated per chunk per slab.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int EPI, bool PRO>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void gemm_nt_fast_kernel(const VsxGemm p) {
-  constexpr int BM = 128, BN = 128, BK = 32, WN_ = 2, FM = 4, FN = 4;
+template <typename T, int EPI, bool PRO, int BK = 32, int NBUF = 2>
+__global__ __launch_bounds__(256, (BK == 64 && NBUF == 1) ? 3 : 1) void gemm_nt_fast_kernel(const VsxGemm p) {
+  constexpr int BM = 128, BN = 128, WN_ = 2, FM = 4, FN = 4;
   constexpr int ES = sizeof(T);
   constexpr int RS = BK * ES + (ES == 2 ? 32 : 16);
   constexpr int CPR = BK * ES / 16;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void gemm_nt_fast_kern
   constexpr int CS_LD = BN + 4;
   constexpr int HR = BM / 2;
   constexpr int EPI_BYTES = HR * CS_LD * 4;
-  constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  constexpr int LDS_BYTES = NBUF * STAGE > EPI_BYTES ? NBUF * STAGE : EPI_BYTES;
   constexpr int MK = Frag<T>::MK;
   constexpr bool REDUCE = (EPI == VSX_EPI_BIAS_GELU_SQ || EPI == VSX_EPI_DZ);
   typedef typename VT<T>::vec vec;
@@ -570,24 +570,28 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void gemm_nt_fast_kern
     }
   };
 
-  // register staging runs TWO K-slabs ahead of the MFMA work (two named stages, statically indexed), the LDS
-  // double buffer one slab ahead: up to 32 KB per workgroup are in flight, which is what an operand streamed
-  // from HBM needs (one slab in flight measured ~2 us per K-step per workgroup round = latency-bound)
+  // one K-slab of register staging ahead of the MFMA work, LDS double buffer.  (Measured: staging two slabs ahead —
+  // with unconditional loads so that the compiler really keeps `s_waitcnt vmcnt(4)` — changes nothing: the loop is
+  // bound by LDS bandwidth (48 KB of LDS traffic per 16 MFMAs per wave tile of 64x64), not by load latency.)
   const int nk = p.K / BK;
-  vec ar1[NA], br1[NB];
   gload(0, ar, br);
-  if (nk > 1) gload(1, ar1, br1);
-  lstore(0, 0, ar, br);
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) gload(kt + 2, ar, br);
-    compute(0);
-    if (kt + 1 < nk) lstore(kt + 1, 1, ar1, br1);
+  if constexpr (NBUF == 2) {
+    lstore(0, 0, ar, br);
     __syncthreads();
-    if (kt + 1 < nk) {  // (uniform)
-      if (kt + 3 < nk) gload(kt + 3, ar1, br1);
-      compute(1);
-      if (kt + 2 < nk) lstore(kt + 2, 0, ar, br);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) gload(kt + 1, ar, br);  // in flight across the MFMA phase
+      compute(kt & 1);
+      if (kt + 1 < nk) lstore(kt + 1, (kt + 1) & 1, ar, br);
+      __syncthreads();
+    }
+  } else {
+    // one LDS buffer of twice the K depth (128-byte row pieces: full cache lines through L1 — measured +25 % L2-hit
+    // throughput over 64-byte pieces, tools/micro/stream_tiles.hip) at the same LDS footprint
+    for (int kt = 0; kt < nk; ++kt) {
+      lstore(kt, 0, ar, br);
+      __syncthreads();
+      if (kt + 1 < nk) gload(kt + 1, ar, br);
+      compute(0);
       __syncthreads();
     }
   }
@@ -692,6 +696,18 @@ template <typename T, int EPI, bool PRO>
 static int launch_nt_fast(const VsxGemm* p, hipStream_t s) {
   int tiles = vsx_cdiv(p->M, 128) * vsx_cdiv(p->N, 128);
   dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
+  if constexpr (sizeof(T) == 2) {
+    if (g_vsx_nt_wide == 1 && p->K % 64 == 0 && p->K >= 256) {
+      hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 64, 1>), grid, dim3(256), 0, s, *p);
+      VSX_LAUNCH_CHECK();
+      return 0;
+    }
+    if (g_vsx_nt_wide == 2 && p->K % 64 == 0 && p->K >= 256) {
+      hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 64, 2>), grid, dim3(256), 0, s, *p);
+      VSX_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO>), grid, dim3(256), 0, s, *p);
   VSX_LAUNCH_CHECK();
   return 0;
@@ -735,9 +751,6 @@ static int dispatch_nt(const VsxGemm* p, hipStream_t s) {
     long tiles = (long)vsx_cdiv(p->M, 128) * vsx_cdiv(p->N, 128) * (p->nz > 0 ? p->nz : 1);
     if constexpr (sizeof(T) == 2) {
       if (tiles < 512 && p->K >= 256) return launch_nt<T, 128, 128, 2, 2, 128>(p, s);
-    }
-    if constexpr (sizeof(T) == 2) {
-      if (g_vsx_nt_wide && p->K >= 64) return launch_nt<T, 128, 128, 2, 2, 64, 1>(p, s);
     }
     if (nt_fast_ok(p, (int)sizeof(T))) return dispatch_nt_fast<T>(p, s);
     return launch_nt<T, 128, 128, 2, 2, 32>(p, s);
