@@ -9,6 +9,7 @@ static thread_local char g_err[512] = "";
 int g_vsx_tn_tr = 1;
 int g_vsx_nt_wide = 1;
 int g_vsx_nt_fast = 1;
+int g_vsx_tn_wide = 1;
 
 void vsx_set_error(const char* fmt, ...) {
   va_list ap;
@@ -23,6 +24,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "tn_tr")) { g_vsx_tn_tr = value; return 0; }
   if (name && !strcmp(name, "nt_wide")) { g_vsx_nt_wide = value; return 0; }
   if (name && !strcmp(name, "nt_fast")) { g_vsx_nt_fast = value; return 0; }
+  if (name && !strcmp(name, "tn_wide")) { g_vsx_tn_wide = value; return 0; }
   vsx_set_error("vsx_set_flag: unknown flag '%s'", name ? name : "(null)");
   return 1;
 }
@@ -30,5 +32,6 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "tn_tr")) return g_vsx_tn_tr;
   if (name && !strcmp(name, "nt_wide")) return g_vsx_nt_wide;
   if (name && !strcmp(name, "nt_fast")) return g_vsx_nt_fast;
+  if (name && !strcmp(name, "tn_wide")) return g_vsx_tn_wide;
   return -1;
 }

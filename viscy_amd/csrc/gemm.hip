@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 extern int g_vsx_tn_tr;
 extern int g_vsx_nt_wide;
 extern int g_vsx_nt_fast;
+extern int g_vsx_tn_wide;
 
 // ------------------------------------------------------------------------------------------------
 // operand gather: returns the 16-byte chunk holding A(m, k .. k+VN-1) after the prologue
@@ -1001,9 +1002,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
 // plus a per-lane offset computed once, column tails are clamped at load time (a clamped column only feeds
 // outputs that are never written), the GRN prologue is a template parameter.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BT, bool TR, bool PRO>
+template <typename T, int BT, bool TR, bool PRO, int BMS = 32, int NBUF = 2>
 __global__ __launch_bounds__(256) void gemm_tn_fast_kernel(const VsxGemm p) {
-  constexpr int BMS = 32;
   constexpr int ES = sizeof(T);
   constexpr int VN = VT<T>::N;
   constexpr int LD = BT + 16;
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(256) void gemm_tn_fast_kernel(const VsxGemm p) {
   constexpr int MK = Frag<T>::MK;
   typedef typename VT<T>::vec vec;
   typedef typename Frag<T>::type frag_t;
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * NBUF * TILE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1092,21 +1092,17 @@ __global__ __launch_bounds__(256) void gemm_tn_fast_kernel(const VsxGemm p) {
   const bool do_colsum = p.colsum != nullptr && tile_k == 0 && tid < BT;
 
   const int nsteps = (total_steps - by + nsplit - 1) / nsplit;
-  load_tiles(by, xreg, yreg);
-  store_tiles(by, 0, xreg, yreg);
-  __syncthreads();
-  for (int st = 0; st < nsteps; ++st) {
-    const int nxt = (st + 1) * nsplit + by;
-    if (st + 1 < nsteps) load_tiles(nxt, xreg, yreg);
-    const char* Xs = smem + (st & 1) * 2 * TILE_BYTES;
-    const char* Ys = Xs + TILE_BYTES;
+  auto mma_step = [&](const char* Xs, const char* Ys) {
 #pragma unroll
     for (int kk = 0; kk < BMS / MK; ++kk) {
+      // bf16: one MFMA contraction step = 32 tile rows (the transposing read addresses rows r, r + 16 of them)
+      const char* Xk = Xs + (sizeof(T) == 2 ? kk * 32 * LDB : 0);
+      const char* Yk = Ys + (sizeof(T) == 2 ? kk * 32 * LDB : 0);
       frag_t xf[F], yf[F];
 #pragma unroll
-      for (int i = 0; i < F; ++i) xf[i] = lds_frag_mn<T, TR>(Xs, LDB, (wn * F + i) * 16, p16, kq, kk);
+      for (int i = 0; i < F; ++i) xf[i] = lds_frag_mn<T, TR>(Xk, LDB, (wn * F + i) * 16, p16, kq, kk);
 #pragma unroll
-      for (int j = 0; j < F; ++j) yf[j] = lds_frag_mn<T, TR>(Ys, LDB, (wk * F + j) * 16, p16, kq, kk);
+      for (int j = 0; j < F; ++j) yf[j] = lds_frag_mn<T, TR>(Yk, LDB, (wk * F + j) * 16, p16, kq, kk);
 #pragma unroll
       for (int i = 0; i < F; ++i)
 #pragma unroll
@@ -1116,8 +1112,27 @@ __global__ __launch_bounds__(256) void gemm_tn_fast_kernel(const VsxGemm p) {
 #pragma unroll 8
       for (int r = 0; r < BMS; ++r) csum += to_f32<T>(*reinterpret_cast<const T*>(Xs + r * LDB + tid * ES));
     }
-    if (st + 1 < nsteps) store_tiles(nxt, (st + 1) & 1, xreg, yreg);
+  };
+  load_tiles(by, xreg, yreg);
+  if constexpr (NBUF == 2) {
+    store_tiles(by, 0, xreg, yreg);
     __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+      const int nxt = (st + 1) * nsplit + by;
+      if (st + 1 < nsteps) load_tiles(nxt, xreg, yreg);
+      const char* Xs = smem + (st & 1) * 2 * TILE_BYTES;
+      mma_step(Xs, Xs + TILE_BYTES);
+      if (st + 1 < nsteps) store_tiles(nxt, (st + 1) & 1, xreg, yreg);
+      __syncthreads();
+    }
+  } else {
+    for (int st = 0; st < nsteps; ++st) {
+      store_tiles(st * nsplit + by, 0, xreg, yreg);
+      __syncthreads();
+      if (st + 1 < nsteps) load_tiles((st + 1) * nsplit + by, xreg, yreg);
+      mma_step(smem, smem + TILE_BYTES);
+      __syncthreads();
+    }
   }
 
   float* W = reinterpret_cast<float*>(p.C) + p.c_coff[z];
@@ -1155,6 +1170,16 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
                     (p->pro == VSX_PRO_NONE || (p->pro == VSX_PRO_GRN && p->hw > 0 && p->hw % 32 == 0)) &&
                     (unsigned long long)32 * (p->lda > p->ldb ? p->lda : p->ldb) * sizeof(T) < (1ull << 31);
   if (fast) {
+    if constexpr (sizeof(T) == 2 && BT == 128) {
+      if (g_vsx_tn_wide && p->M % 64 == 0 && (p->pro == VSX_PRO_NONE || p->hw % 64 == 0) && p->M / 64 >= 2 * splits) {
+        if (p->pro == VSX_PRO_GRN)
+          hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, true, 64, 1>), grid, dim3(256), 0, s, *p);
+        else
+          hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, false, 64, 1>), grid, dim3(256), 0, s, *p);
+        VSX_LAUNCH_CHECK();
+        return 0;
+      }
+    }
     if (p->pro == VSX_PRO_GRN)
       hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, true>), grid, dim3(256), 0, s, *p);
     else
