@@ -102,19 +102,19 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
   const float alpha = alpha_p[0];
   const int nvox = d.H2 * d.W2 * d.Z;
   const int H = 2 * d.H2, W = 2 * d.W2;
-  float s1[CMID], s2[CMID];
-  _Pragma("unroll") for (int c = 0; c < CMID; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
-  float da = 0.f;
+  const int wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * (2 * HEAD_MAX_CMID + 1); i += 256) (&part[0][0])[i] = 0.f;
+  __syncthreads();
+  // Channels are processed 8 at a time and every partial sum is reduced across the wave immediately: keeping
+  // 2 x CMID running sums per thread (the first version) cost 256 VGPRs + 230 AGPRs = one wave per SIMD, 2.07 ms.
   for (int it = 0; it < vox_per_thread; ++it) {
     const int vox = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-    if (vox >= nvox) break;
-    const int z = vox % d.Z;
-    const int px = vox / d.Z;
+    const bool live = vox < nvox;
+    const int vv = live ? vox : nvox - 1;
+    const int z = vv % d.Z;
+    const int px = vv / d.Z;
     const int x = px % d.W2, y = px / d.W2;
-    float nh[CMID], a[CMID];
-    const size_t row = (size_t)b * nvox + vox;
-    head_norm_act<T, CMID>(U + row * CMID, mu, rs, alpha, nh, a);
-    _Pragma("unroll") for (int c = 0; c < CMID; c += VN) stvec<T>(act + row * CMID + c, pack<T>(a + c));
+    const size_t row = (size_t)b * nvox + vv;
     float dv[CO4];
     _Pragma("unroll") for (int co = 0; co < CO4 / 4; ++co) {
       const float* o = dout + ((((size_t)b * d.Cout + co) * d.Z + z) * H + 2 * y) * W + 2 * x;
@@ -123,23 +123,46 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
       dv[co * 4 + 0] = round_to<T>(t0.x); dv[co * 4 + 1] = round_to<T>(t0.y);
       dv[co * 4 + 2] = round_to<T>(t1.x); dv[co * 4 + 3] = round_to<T>(t1.y);
     }
-    _Pragma("unroll") for (int k = 0; k < CO4; k += VN) stvec<T>(dvout + row * co4 + k, pack<T>(dv + k));
-    _Pragma("unroll") for (int c = 0; c < CMID; ++c) {
-      float dA = 0.f;
-      _Pragma("unroll") for (int k = 0; k < CO4; ++k) dA = fmaf(w2s[k * CMID + c], dv[k], dA);
-      float dn = nh[c] > 0.f ? dA : alpha * dA;
-      if (nh[c] <= 0.f) da += dA * nh[c];
-      s1[c] += dn;
-      s2[c] += dn * nh[c];
+    if (live) {
+      _Pragma("unroll") for (int k = 0; k < CO4; k += VN) stvec<T>(dvout + row * co4 + k, pack<T>(dv + k));
     }
+    float da = 0.f;
+    _Pragma("unroll 1") for (int c0 = 0; c0 < CMID; c0 += 8) {
+      float u[8], nh[8], a[8];
+      _Pragma("unroll") for (int c = 0; c < 8; c += VN) unpack<T>(ldvec<T>(U + row * CMID + c0 + c), u + c);
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {
+        nh[j] = (u[j] - mu[c0 + j]) * rs[c0 + j];
+        a[j] = nh[j] > 0.f ? nh[j] : alpha * nh[j];
+      }
+      if (live) {
+        _Pragma("unroll") for (int c = 0; c < 8; c += VN) stvec<T>(act + row * CMID + c0 + c, pack<T>(a + c));
+      }
+      float dA[8];
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) dA[j] = 0.f;
+      _Pragma("unroll") for (int k = 0; k < CO4; ++k) {
+        const float4 wa = *reinterpret_cast<const float4*>(w2s + k * CMID + c0);  // same address in every lane: LDS broadcast
+        const float4 wb = *reinterpret_cast<const float4*>(w2s + k * CMID + c0 + 4);
+        dA[0] = fmaf(wa.x, dv[k], dA[0]); dA[1] = fmaf(wa.y, dv[k], dA[1]);
+        dA[2] = fmaf(wa.z, dv[k], dA[2]); dA[3] = fmaf(wa.w, dv[k], dA[3]);
+        dA[4] = fmaf(wb.x, dv[k], dA[4]); dA[5] = fmaf(wb.y, dv[k], dA[5]);
+        dA[6] = fmaf(wb.z, dv[k], dA[6]); dA[7] = fmaf(wb.w, dv[k], dA[7]);
+      }
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {
+        float dn = nh[j] > 0.f ? dA[j] : alpha * dA[j];
+        float dnn = dn * nh[j];
+        if (nh[j] <= 0.f) da += dA[j] * nh[j];
+        if (!live) { dn = 0.f; dnn = 0.f; }
+        const float t1 = wave_sum(dn), t2 = wave_sum(dnn);
+        if ((threadIdx.x & 63) == 0) {
+          part[wv][c0 + j] += t1;
+          part[wv][CMID + c0 + j] += t2;
+        }
+      }
+    }
+    if (!live) da = 0.f;
+    da = wave_sum(da);
+    if ((threadIdx.x & 63) == 0) part[wv][2 * CMID] += da;
   }
-  const int wv = threadIdx.x >> 6;
-  _Pragma("unroll") for (int c = 0; c < CMID; ++c) {
-    float t1 = wave_sum(s1[c]), t2 = wave_sum(s2[c]);
-    if ((threadIdx.x & 63) == 0) { part[wv][c] = t1; part[wv][CMID + c] = t2; }
-  }
-  da = wave_sum(da);
-  if ((threadIdx.x & 63) == 0) part[wv][2 * CMID] = da;
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * CMID + 1; i += 256) {
     const float v = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
