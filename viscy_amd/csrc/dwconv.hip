@@ -27,7 +27,11 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, c
 
   const int ncb = (C + CB - 1) / CB;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; give each XCD one contiguous range of
+  // (tile, channel-slab) ids so that the slabs of one pixel tile (which split 128-byte lines between them) and the
+  // halo-sharing neighbour tiles meet in ONE L2 instead of being fetched through the fabric once per XCD
   int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
   const int cb = bid % ncb; bid /= ncb;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y;
@@ -131,7 +135,9 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
   char* dt = smem + XT_BYTES;
 
   const int ncb = (C + CB - 1) / CB;
-  const int cb = blockIdx.x % ncb, group = blockIdx.x / ncb;
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);  // XCD-aware (see dwconv7_kernel)
+  const int cb = bid % ncb, group = bid / ncb;
   const int c_base = cb * CB;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int ntiles = B * tiles_y * tiles_x;

@@ -87,6 +87,20 @@ struct SsimPix {
   float ssim, cs, dmx, dmxx, dmxy;
 };
 
+// XCD-aware tile order for the 3-D grids of the SSIM kernels: workgroups are dealt round-robin to the 8 XCDs in
+// launch order (x fastest); remap so that each XCD owns a contiguous range of tiles = halo-sharing neighbours hit ONE L2
+struct TileId { int x, y, z; };
+__device__ __forceinline__ TileId xcd_tile() {
+  const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+  unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  if ((total & 7u) == 0u) L = (L & 7u) * (total >> 3) + (L >> 3);
+  TileId t;
+  t.x = (int)(L % gx);
+  t.y = (int)((L / gx) % gy);
+  t.z = (int)(L / (gx * gy));
+  return t;
+}
+
 template <bool BWD>
 __device__ __forceinline__ SsimPix ssim_pixel(float mx, float my, float mxx, float myy, float mxy, float c1, float c2,
                                               float gs, float gc) {
@@ -118,9 +132,10 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
   __shared__ float S[5][SI][SLD];
   __shared__ float R[5][SI][ST];
   __shared__ float sh[4];
-  const int bc = blockIdx.z;
+  const TileId tl = xcd_tile();
+  const int bc = tl.z;
   const int b = bc / C;
-  const int oy0 = blockIdx.y * ST, ox0 = blockIdx.x * ST;
+  const int oy0 = tl.y * ST, ox0 = tl.x * ST;
   const int Ho = H - 10, Wo = W - 10;
   const float kb = round_bf16(1.0f / (float)(D * 121));
   const float dr = tmax_p[0];
@@ -202,8 +217,9 @@ __global__ __launch_bounds__(256) void ssim_bwd_in_kernel(const float* __restric
                                                           float l2c_, const float* __restrict__ gout_p, int has_ssim) {
   __shared__ float S[3][SI][SLD];
   __shared__ float R[3][SI][ST];
-  const int bc = blockIdx.z;
-  const int iy0 = blockIdx.y * ST, ix0 = blockIdx.x * ST;
+  const TileId tl = xcd_tile();
+  const int bc = tl.z;
+  const int iy0 = tl.y * ST, ix0 = tl.x * ST;
   const int Ho = H - 10, Wo = W - 10;
   const float kb = round_bf16(1.0f / (float)(D * 121));
   const float gsc = gout_p ? gout_p[0] : 1.f;
