@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("VSX_BENCH_BATCH", 128)), help="patches per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("VSX_BENCH_BATCH", 256)), help="patches per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

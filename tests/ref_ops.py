@@ -348,3 +348,9 @@ def adamw(p, g, m, v, hyper):
     m.mul_(b1).add_(gr, alpha=1 - b1)
     v.mul_(b2).addcmul_(gr, gr, value=1 - b2)
     p.addcdiv_(m, v.sqrt() / (bc2**0.5) + eps, value=-lr / bc1)
+
+
+def head_conv_supported(H2, W2, c3, cmid, zo, dtype) -> bool:
+    """the direct LDS-tiled head convolution exists only as a HIP kernel; the schedule falls back to the z-batched
+    implicit GEMMs, which this backend states"""
+    return False

@@ -41,6 +41,31 @@ def _views(flat: Tensor, shapes):
     return out
 
 
+class _ZeroArena:
+    """One zero-filled fp32 allocation per pass, handed out as views: the ~130 small reduction targets of a step
+    (GRN sums, bias / weight gradient staging, InstanceNorm sums) used to cost one fill launch each (154 launches,
+    0.74 ms per step in the kernel trace).  Sized from the previous pass with the same key; a pass that needs more than
+    was recorded falls back to individual allocations (and records the new size)."""
+
+    def __init__(self, dev, numel: int):
+        self.dev = dev
+        self.buf = torch.zeros(numel, dtype=torch.float32, device=dev) if numel > 0 else None
+        self.off = 0
+        self.used = 0
+
+    def take(self, *shape) -> Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) // 64 * 64  # 256-byte granules: every view stays 16-byte aligned
+        self.used += n_al
+        if self.buf is not None and self.off + n_al <= self.buf.numel():
+            v = self.buf[self.off:self.off + n].view(*shape)
+            self.off += n_al
+            return v
+        return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+
+
 class Engine:
     def __init__(self, model, ops=None):
         if ops is None:
@@ -50,6 +75,8 @@ class Engine:
         self.ops = ops
         self.model = model
         self.cfg = model.cfg
+        self._za = None          # zero arena of the pass in flight
+        self._za_need = {}       # (pass, B, H, W) -> fp32 elements the pass took last time
         params = list(model.parameters())
         self.device = params[0].device
         # ---- flat parameter / gradient buffers, reverse forward order (head first, stem last)
@@ -193,7 +220,7 @@ class Engine:
         y = o.dwconv7_fwd(x, w.dw_w, blk.conv_dw.bias, B, H, Wd, C)
         xh, _, rstd = o.ln_fwd(y, None, None, M, C, 1e-6, need_mean=False)
         del y
-        colsq = torch.zeros((B, 4 * C), dtype=torch.float32, device=x.device)
+        colsq = self._za.take(B, 4 * C)
         # fc1 writes the pre-activation h (needed for gelu' in backward) AND the activation g = gelu(h):
         # fc2, the fc2 weight gradient and the GRN statistics path all consume g, so GELU is evaluated once
         h = torch.empty((M, 4 * C), dtype=dt, device=x.device)
@@ -218,16 +245,16 @@ class Engine:
         o.gemm("tn", gact, dout, g(blk.mlp.fc2.weight), M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
                grn_b=blk.mlp.grn.bias, hw=H * Wd, colsum=g(blk.mlp.fc2.bias))
         # fc2 data gradient dZ, with Σ dZ·gelu(h) (GRN statistics path) and Σ dZ (GRN beta gradient)
-        PS = torch.zeros((2, B, 4 * C), dtype=torch.float32, device=dev)
+        PS = self._za.take(2, B, 4 * C)
         dz = torch.empty((M, 4 * C), dtype=dt, device=dev)
         o.gemm("nt", dout, w.W2T, dz, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_DZ, aux=gact, ldx=4 * C, red0=PS[0],
                red1=PS[1], hw=H * Wd)
         t = o.grn_bwd_stats(colsq, PS[0], blk.mlp.grn.weight, g(blk.mlp.grn.weight), Sb=PS[1], dbeta=g(blk.mlp.grn.bias))
-        db1f = torch.zeros(4 * C, dtype=torch.float32, device=dev)
+        db1f = self._za.take(4 * C)
         o.grn_gelu_bwd(dz, h, s, t, db1f, M, 4 * C, H * Wd)  # dz now holds dH
         dxh = torch.empty((M, C), dtype=dt, device=dev)
         o.gemm("nt", dz, w.W1fT, dxh, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt)
-        dW1f = torch.zeros((4 * C, C), dtype=torch.float32, device=dev)
+        dW1f = self._za.take(4 * C, C)
         o.gemm("tn", xh, dz, dW1f, M, 4 * C, C, C, 4 * C, C, dtype=dt)
         del dz
         # unfold the LayerNorm affine: dW1 = dW1f·diag(γ) + db1f ⊗ β, dγ = Σ_r dW1f ⊙ W1, dβ = W1ᵀ db1f, db1 = db1f
@@ -238,7 +265,7 @@ class Engine:
         dy = o.ln_bwd(dxh, xh, None, rstd, None, None, None, None, M, C)
         del dxh
         dx = o.dwconv7_bwd_data(dy, w.dw_w, dout, B, H, Wd, C)
-        ddw = torch.zeros((49, C), dtype=torch.float32, device=dev)
+        ddw = self._za.take(49, C)
         o.dwconv7_bwd_weight(dy, x, ddw, g(blk.conv_dw.bias), B, H, Wd, C)
         o.transpose_f32(ddw, g(blk.conv_dw.weight), 49, C, True)
         return dx
@@ -248,6 +275,8 @@ class Engine:
         o, cfg, m = self.ops, self.cfg, self.model
         W = self.prepare(dt, need_bwd)
         B, Cin, Z, H, Wd = x.shape
+        za_key = ("fwd", B, H, Wd)
+        self._za = za = _ZeroArena(x.device, self._za_need.get(za_key, 0))
         if Cin != cfg["in_channels"] or Z != cfg["in_stack_depth"]:
             raise ValueError(f"expected input (B,{cfg['in_channels']},{cfg['in_stack_depth']},Y,X), got {tuple(x.shape)}")
         if H % 32 or Wd % 32:
@@ -313,7 +342,7 @@ class Engine:
         hin = o.head_shuffle_fwd(feat, B, fh, fw, c3, D7, cfg["head_pool"])
         H2, W2 = 2 * fh, 2 * fw
         Mh = B * H2 * W2
-        stats = torch.zeros((2, B, cmid), dtype=torch.float32, device=x.device)
+        stats = self._za.take(2, B, cmid)
         direct = o.head_conv_supported(H2, W2, c3, cmid, Zo, dt)
         if direct:
             U = o.head_conv_fwd(hin, W["head_Wc"], hc.bias, stats[0], stats[1], B, H2, W2, c3, cmid, Zo)
@@ -330,6 +359,7 @@ class Engine:
             sv["enc"], sv["dec"] = enc_sv, dec_sv
             sv["feat_dims"] = [(a, b_, c) for (_, a, b_, c) in feats]
             sv["head"] = (hin, U, stats, fh, fw)
+        self._za_need[za_key] = za.used
         return out, sv
 
     # ------------------------------------------------------------------ backward
@@ -340,6 +370,8 @@ class Engine:
         dt = sv["dt"]
         B, H, Wd = sv["shape"]
         dev = dout.device
+        za_key = ("bwd", B, H, Wd)
+        self._za = za = _ZeroArena(dev, self._za_need.get(za_key, 0))
         Zo, D7 = cfg["out_stack_depth"], cfg["out_stack_depth"] + 2
         hc = m.head.conv[0].conv
         cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
@@ -350,7 +382,7 @@ class Engine:
         alpha = m.head.conv[0].adn.A.weight
         w2 = m.head.conv[1].weight.view(4 * cout, cmid)
         # ---- head
-        S = torch.zeros((2, B, cmid), dtype=torch.float32, device=dev)
+        S = self._za.take(2, B, cmid)
         act, dv = o.head_out_bwd1(U, stats[0], stats[1], w2, alpha, dout.contiguous().float(), S[0], S[1], g(alpha), B, H2,
                                   W2, Zo, cmid, cout)
         M5 = Mh * Zo
@@ -359,7 +391,7 @@ class Engine:
         del act
         dU = o.head_out_bwd2(U, stats[0], stats[1], w2, alpha, dv, S[0], S[1], B, H2, W2, Zo, cmid, cout)
         del dv
-        dWc = torch.zeros((cmid, 27 * c3), dtype=torch.float32, device=dev)
+        dWc = self._za.take(cmid, 27 * c3)
         direct = "head_Wp" in W and o.head_conv_supported(H2, W2, c3, cmid, Zo, dt)
         if direct:
             o.head_conv_wgrad(hin, dU, dWc, g(hc.bias), B, H2, W2, c3, cmid, Zo)
@@ -410,7 +442,7 @@ class Engine:
                 prev, xn, mean, rstd = st_sv["proj"]
                 cin = proj.cin
                 Mo = B * ch * cw
-                dWg = torch.zeros((proj.cout, 4 * cin), dtype=torch.float32, device=dev)
+                dWg = self._za.take(proj.cout, 4 * cin)
                 o.gemm("tn", xn, d, dWg, Mo, proj.cout, 4 * cin, cin, proj.cout, 4 * cin, dtype=dt, a_mode=L.A_PATCH2,
                        gh=ch, gw=cw, cs=cin, colsum=g(proj.conv.bias))
                 o.unprep_grad(dWg, g(proj.conv.weight), proj.cout, cin, 4)
@@ -433,12 +465,13 @@ class Engine:
         else:
             co3 = C0 // Dp
             K = K0 // Dp
-            dWe = torch.zeros((C0, K0), dtype=torch.float32, device=dev)
-            dbe = torch.zeros(C0, dtype=torch.float32, device=dev)
+            dWe = self._za.take(C0, K0)
+            dbe = self._za.take(C0)
             o.gemm("tn", P, df, dWe, M0, C0, K0, K0, C0, K0, dtype=dt, colsum=dbe)
             dWe = dWe.view(co3, Dp, Dp, K)
             g(m.stem.conv.weight).add_(torch.stack([dWe[:, dd, dd] for dd in range(Dp)], 0).sum(0).view_as(m.stem.conv.weight))
             g(m.stem.conv.bias).add_(dbe.view(co3, Dp).sum(1))
+        self._za_need[za_key] = za.used
         if self.on_bucket_ready:
             self.on_bucket_ready(2)
 
