@@ -21,6 +21,7 @@ extern int g_vsx_tn_tr;
 extern int g_vsx_nt_wide;
 extern int g_vsx_nt_fast;
 extern int g_vsx_tn_wide;
+extern int g_vsx_nt_tall;
 
 // ------------------------------------------------------------------------------------------------
 // operand gather: returns the 16-byte chunk holding A(m, k .. k+VN-1) after the prologue
@@ -458,9 +459,12 @@ __device__ __forceinline__ typename VT<T>::vec grn_apply(typename VT<T>::vec v, 
 // are one scalar base per K-slab plus a per-lane 32-bit offset computed once, out-of-range rows / columns are
 // clamped at load time (their results are never stored) instead of predicated per chunk per slab.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int EPI, bool PRO, int BK = 32, int NBUF = 2>
-__global__ __launch_bounds__(256, (BK == 64 && NBUF == 1) ? 3 : 1) void gemm_nt_fast_kernel(const VsxGemm p) {
-  constexpr int BM = 128, BN = 128, WN_ = 2, FM = 4, FN = 4;
+template <typename T, int EPI, bool PRO, int BK = 32, int NBUF = 2, int BM = 128>
+__global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 : 1)) void gemm_nt_fast_kernel(const VsxGemm p) {
+  // BM = 256: each wave owns a 128x64 sub-tile (8x4 fragments, 128 accumulator registers): 12 fragment reads per 32
+  // MFMAs instead of 8 per 16, half the weight (B) traffic and half the per-tile fixed cost (launch, first-slab
+  // latency, store drain) per output — used for the M >= 65536 launches
+  constexpr int BN = 128, WN_ = 2, FM = BM / 32, FN = 4;
   constexpr int ES = sizeof(T);
   constexpr int RS = BK * ES + (ES == 2 ? 32 : 16);
   constexpr int CPR = BK * ES / 16;
@@ -468,7 +472,8 @@ __global__ __launch_bounds__(256, (BK == 64 && NBUF == 1) ? 3 : 1) void gemm_nt_
   constexpr int NA = BM * CPR / 256, NB = BN * CPR / 256;
   constexpr int STAGE = (BM + BN) * RS;
   constexpr int CS_LD = BN + 4;
-  constexpr int HR = BM / 2;
+  constexpr int HR = 64;               // rows per epilogue pass
+  constexpr int NPASS = BM / HR;
   constexpr int EPI_BYTES = HR * CS_LD * 4;
   constexpr int LDS_BYTES = NBUF * STAGE > EPI_BYTES ? NBUF * STAGE : EPI_BYTES;
   constexpr int MK = Frag<T>::MK;
@@ -618,15 +623,23 @@ __global__ __launch_bounds__(256, (BK == 64 && NBUF == 1) ? 3 : 1) void gemm_nt_
   for (int j = 0; j < VN; ++j) { r0[j] = 0.f; r1[j] = 0.f; }
   const size_t ccol = (size_t)p.c_coff[z] + n;
 #pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < NPASS; ++half) {
     __syncthreads();
-    if (wm == half) {
+    // pass `half` = tile rows [64*half, 64*half + 64): owned by wave row wm = half / (NPASS/2), its fragments
+    // (half % (NPASS/2)) * 4 .. + 4
+    if (wm == half / (NPASS / 2)) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+      for (int ip = 0; ip < NPASS / 2; ++ip) {
+        if (ip == half % (NPASS / 2)) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Cs[(i * 16 + kq * 4 + r) * CS_LD + (wn * FN + j) * 16 + p16] = acc[i][j][r];
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                Cs[(i * 16 + kq * 4 + r) * CS_LD + (wn * FN + j) * 16 + p16] = acc[ip * 4 + i][j][r];
+        }
+      }
     }
     __syncthreads();
     if (ncol_ok) {
@@ -698,6 +711,18 @@ static int launch_nt_fast(const VsxGemm* p, hipStream_t s) {
   int tiles = vsx_cdiv(p->M, 128) * vsx_cdiv(p->N, 128);
   dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
   if constexpr (sizeof(T) == 2) {
+    // measured (tools/perf_nt.py): -5..-9 % on the wide-output launches (N >= 384: fc1, fc2 data gradient), +5..+10 % on
+    // the GRN-prologue / two-N-tile launches -> only the former
+    const bool tall = g_vsx_nt_tall && !PRO && p->N >= 384 && p->M >= 65536 && p->M % 256 == 0 && (p->hw <= 0 || p->hw % 256 == 0);
+    if (tall) {
+      dim3 g2(vsx_cdiv(p->M, 256) * vsx_cdiv(p->N, 128), 1, p->nz > 0 ? p->nz : 1);
+      if (p->K % 64 == 0 && p->K >= 128)
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 64, 1, 256>), g2, dim3(256), 0, s, *p);
+      else
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 32, 2, 256>), g2, dim3(256), 0, s, *p);
+      VSX_LAUNCH_CHECK();
+      return 0;
+    }
     if (g_vsx_nt_wide == 1 && p->K % 64 == 0 && p->K >= 256) {
       hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 64, 1>), grid, dim3(256), 0, s, *p);
       VSX_LAUNCH_CHECK();
