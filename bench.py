@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured step")
     ap.add_argument("--profile-ops", action="store_true", help="print the per-op-class event-timing table to stderr")
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel collective path even with one rank (RCCL smoke test on a single GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,10 +185,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from viscy_amd import ops
@@ -205,7 +209,7 @@ def main():
     eng = model.engine()
     total_steps = args.steps + args.warmup
     opt = FlatAdamW(eng, lr=2e-4, schedule="WarmupCosine", warmup_steps=3, t_total=max(total_steps, 4), warmup_multiplier=1e-3)
-    ddp = FlatDataParallel(eng, opt)
+    ddp = FlatDataParallel(eng, opt, force=args.force_dp)
     crit = MixedLoss(0.5, 0.0, 0.5)
     B = args.batch
     x, tgt = make_batch(B, args.size, args.size, dev, seed=42 + rank)
@@ -320,10 +324,12 @@ def main():
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dp:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)  # the ONE JSON line, after every library banner (RCCL prints its own at init)
 
 
 if __name__ == "__main__":

@@ -11,57 +11,71 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      int rows, int C, float eps) {
+  // A lane group owns R rows per block and requests all of them before the first reduction: one row per group
+  // (first version) meant one 16-byte load in flight per lane and 6 KB blocks -> 2.2 TB/s.
   constexpr int VN = VT<T>::N;
+  constexpr int R = CPL == 1 ? 4 : (CPL == 2 ? 2 : 1);
+  constexpr int RPI = 256 / G;  // rows per sweep of the block
   const int nch = C / VN;
-  const int row = blockIdx.x * (256 / G) + threadIdx.x / G;
   const int gl = threadIdx.x % G;
-  if (row >= rows) return;  // whole groups exit together
-  const T* xr = x + (size_t)row * C;
-  float v[CPL][VN];
-  float s = 0.f;
+  const int row0 = blockIdx.x * (RPI * R) + threadIdx.x / G;
+  float v[R][CPL][VN];
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    int c = gl + i * G;
-    if (c < nch) {
-      unpack<T>(ldvec<T>(xr + c * VN), v[i]);
+  for (int r = 0; r < R; ++r) {
+    const int row = row0 + r * RPI;
+    const T* xr = x + (size_t)(row < rows ? row : rows - 1) * C;
 #pragma unroll
-      for (int j = 0; j < VN; ++j) s += v[i][j];
-    } else {
+    for (int i = 0; i < CPL; ++i) {
+      const int c = gl + i * G;
+      if (c < nch) {
+        unpack<T>(ldvec<T>(xr + c * VN), v[r][i]);
+      } else {
 #pragma unroll
-      for (int j = 0; j < VN; ++j) v[i][j] = 0.f;
-    }
-  }
-  const float mean = group_sum<G>(s) / (float)C;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    int c = gl + i * G;
-    if (c < nch) {
-#pragma unroll
-      for (int j = 0; j < VN; ++j) {
-        float d = v[i][j] - mean;
-        q += d * d;
+        for (int j = 0; j < VN; ++j) v[r][i][j] = 0.f;
       }
     }
   }
-  const float rstd = rsqrtf(group_sum<G>(q) / (float)C + eps);
-  T* yr = y + (size_t)row * C;
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    int c = gl + i * G;
-    if (c < nch) {
-      float o[VN];
+  for (int r = 0; r < R; ++r) {
+    const int row = row0 + r * RPI;
+    float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < VN; ++j) {
-        float xh = (v[i][j] - mean) * rstd;
-        o[j] = gamma ? xh * gamma[c * VN + j] + beta[c * VN + j] : xh;
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int j = 0; j < VN; ++j) s += v[r][i][j];
+    const float mean = group_sum<G>(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      if (gl + i * G < nch) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+          const float d = v[r][i][j] - mean;
+          q += d * d;
+        }
       }
-      stvec<T>(yr + c * VN, pack<T>(o));
     }
-  }
-  if (gl == 0) {
-    if (mean_out) mean_out[row] = mean;
-    rstd_out[row] = rstd;
+    const float rstd = rsqrtf(group_sum<G>(q) / (float)C + eps);
+    if (row < rows) {  // (uniform per group; the shuffles above ran for every lane)
+      T* yr = y + (size_t)row * C;
+#pragma unroll
+      for (int i = 0; i < CPL; ++i) {
+        const int c = gl + i * G;
+        if (c < nch) {
+          float o[VN];
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            const float xh = (v[r][i][j] - mean) * rstd;
+            o[j] = gamma ? xh * gamma[c * VN + j] + beta[c * VN + j] : xh;
+          }
+          stvec<T>(yr + c * VN, pack<T>(o));
+        }
+      }
+      if (gl == 0) {
+        if (mean_out) mean_out[row] = mean;
+        rstd_out[row] = rstd;
+      }
+    }
   }
 }
 
@@ -94,50 +108,74 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       gam[i][j] = (gamma && c < nch) ? gamma[c * VN + j] : 1.f;
     }
   }
-  for (int it = 0; it < iters; ++it) {
-    const int row = (it * gridDim.x + blockIdx.x) * RPI + rslot;  // interleaved: the grid sweeps a contiguous window
-    if (row >= rows) break;
-    const float mu = mean ? mean[row] : 0.f;
-    const float rs = rstd[row];
-    float xh[CPL][VN], g[CPL][VN];
-    float s1 = 0.f, s2 = 0.f;
+  typedef typename VT<T>::vec vec;
+  constexpr int R = CPL == 1 ? 2 : 1;  // rows requested together per lane group (loads of both rows in flight)
+  for (int it0 = 0; it0 < iters; it0 += R) {
+    vec xr[R][CPL], dr[R][CPL], ar[R][CPL];
+    int rowr[R];
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      int c = gl + i * G;
-      if (c < nch) {
-        float xv[VN], dv[VN];
-        unpack<T>(ldvec<T>(x + (size_t)row * C + c * VN), xv);
-        unpack<T>(ldvec<T>(dy + (size_t)row * C + c * VN), dv);
+    for (int r = 0; r < R; ++r) {
+      const int row = ((it0 + r) * gridDim.x + blockIdx.x) * RPI + rslot;  // interleaved: the grid sweeps a contiguous window
+      rowr[r] = (it0 + r < iters && row < rows) ? row : -1;
+      const size_t ro = (size_t)(rowr[r] >= 0 ? row : 0) * C;
 #pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          xh[i][j] = mean ? (xv[j] - mu) * rs : xv[j];
-          g[i][j] = dv[j] * gam[i][j];
-          s1 += g[i][j];
-          s2 += g[i][j] * xh[i][j];
-          dg[i][j] += dv[j] * xh[i][j];
-          db[i][j] += dv[j];
+      for (int i = 0; i < CPL; ++i) {
+        const int c = gl + i * G;
+        if (c < nch) {
+          xr[r][i] = ldvec<T>(x + ro + c * VN);
+          dr[r][i] = ldvec<T>(dy + ro + c * VN);
+          if (add) ar[r][i] = ldvec<T>(add + ro + c * VN);
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < VN; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
       }
     }
-    s1 = group_sum<G>(s1) / (float)C;
-    s2 = group_sum<G>(s2) / (float)C;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-      int c = gl + i * G;
-      if (c < nch) {
-        float o[VN];
+    for (int r = 0; r < R; ++r) {
+      const int row = rowr[r];
+      const bool live = row >= 0;  // uniform per lane group; dead groups still take part in the shuffles
+      const float mu = (mean && live) ? mean[row] : 0.f;
+      const float rs = live ? rstd[row] : 0.f;
+      float xh[CPL][VN], g[CPL][VN];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < VN; ++j) o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
-        if (add) {
-          float a[VN];
-          unpack<T>(ldvec<T>(add + (size_t)row * C + c * VN), a);
+      for (int i = 0; i < CPL; ++i) {
+        const int c = gl + i * G;
+        if (c < nch && live) {
+          float xv[VN], dv[VN];
+          unpack<T>(xr[r][i], xv);
+          unpack<T>(dr[r][i], dv);
 #pragma unroll
-          for (int j = 0; j < VN; ++j) o[j] += a[j];
+          for (int j = 0; j < VN; ++j) {
+            xh[i][j] = mean ? (xv[j] - mu) * rs : xv[j];
+            g[i][j] = dv[j] * gam[i][j];
+            s1 += g[i][j];
+            s2 += g[i][j] * xh[i][j];
+            dg[i][j] += dv[j] * xh[i][j];
+            db[i][j] += dv[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < VN; ++j) { xh[i][j] = 0.f; g[i][j] = 0.f; }
         }
-        stvec<T>(dx + (size_t)row * C + c * VN, pack<T>(o));
+      }
+      s1 = group_sum<G>(s1) / (float)C;
+      s2 = group_sum<G>(s2) / (float)C;
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+          const int c = gl + i * G;
+          if (c < nch) {
+            float o[VN];
+#pragma unroll
+            for (int j = 0; j < VN; ++j) o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
+            if (add) {
+              float a[VN];
+              unpack<T>(ar[r][i], a);
+#pragma unroll
+              for (int j = 0; j < VN; ++j) o[j] += a[j];
+            }
+            stvec<T>(dx + (size_t)row * C + c * VN, pack<T>(o));
+          }
+        }
       }
     }
   }
@@ -167,7 +205,8 @@ static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float*
                      int C, float eps, hipStream_t s) {
   constexpr int RPI = 256 / G;
   if (fwd) {
-    hipLaunchKernelGGL((ln_fwd_kernel<T, G, CPL>), dim3(vsx_cdiv(rows, RPI)), dim3(256), 0, s, (const T*)a0, (T*)out,
+    constexpr int R = CPL == 1 ? 4 : (CPL == 2 ? 2 : 1);  // rows per lane group (see the kernel)
+    hipLaunchKernelGGL((ln_fwd_kernel<T, G, CPL>), dim3(vsx_cdiv(rows, RPI * R)), dim3(256), 0, s, (const T*)a0, (T*)out,
                        mean, rstd, gamma, beta, rows, C, eps);
   } else {
     int iters = vsx_cdiv(rows, RPI * 512);  // <= 512 blocks → <= 512 same-address atomics on dgamma / dbeta

@@ -17,12 +17,15 @@ import torch.distributed as dist
 
 
 class FlatDataParallel:
-    def __init__(self, engine, optimizer=None, process_group=None, broadcast: bool = True):
+    def __init__(self, engine, optimizer=None, process_group=None, broadcast: bool = True, force: bool = False):
+        """``force``: run the collective path even in a 1-rank group (exercises RCCL init, the bucket hooks and the
+        graph + collective ordering on a single GPU; numerically a no-op)."""
         self.engine = engine
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.works = []
-        if self.world > 1:
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        if self.active:
             if broadcast:  # DDP-style: rank 0's parameters win
                 dist.broadcast(engine.flat, src=0, group=process_group)
             engine.on_bucket_ready = self._bucket_ready
@@ -41,7 +44,7 @@ class FlatDataParallel:
 
     def all_reduce_mean(self, t: torch.Tensor) -> torch.Tensor:
         """``self.log(..., sync_dist=True)`` equivalent for scalars (engine.py:294-303 of the reference)."""
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
             t = t / self.world
         return t

@@ -25,6 +25,7 @@ class TrainStep:
         self.graph = None
         self.x = self.t = self.loss = None
         self.world = ddp.world if ddp is not None else 1
+        self.dist = bool(ddp is not None and getattr(ddp, "active", self.world > 1))  # collectives outside the graph
 
     # ---- the captured body
     def _fwd_bwd(self):
@@ -43,7 +44,7 @@ class TrainStep:
             for _ in range(2):
                 self.opt.host_prepare()
                 self._fwd_bwd()
-                if self.world == 1:
+                if not self.dist:
                     self.opt.device_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -51,7 +52,7 @@ class TrainStep:
         self.opt.host_prepare()
         with torch.cuda.graph(g):
             self.loss = self._fwd_bwd()
-            if self.world == 1:
+            if not self.dist:
                 self.opt.device_step()
         self.opt.t -= 1  # the capture pass records but does not execute: it is not an optimisation step
         self.graph = g
@@ -73,7 +74,7 @@ class TrainStep:
             self.t.copy_(t, non_blocking=True)
         self.opt.host_prepare()
         self.graph.replay()
-        if self.world > 1:
+        if self.dist:
             import torch.distributed as dist
 
             dist.all_reduce(self.model.engine().flat_grad, op=dist.ReduceOp.SUM, group=self.ddp.pg)
