@@ -73,6 +73,9 @@ GEMM_CASES = [
     (640, 224, 144, 320),
     (384, 32, 216, 384),
     (130, 8, 64, 130),
+    (512, 384, 256, 256),   # lean instantiation, 128-byte K slabs (BK = 64, single LDS buffer), 3 N tiles
+    (1024, 224, 512, 512),  # lean, BK = 64, ragged last N tile
+    (384, 192, 224, 128),   # lean, BK = 32 (K % 64 != 0)
 ]
 
 
@@ -119,11 +122,12 @@ def test_gemm_nt_rows(dt, M, N, K, hw, epi):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
-def test_gemm_nt_grn_prologue(dt):
+@pytest.mark.parametrize("M,N,K,hw", [(192, 40, 160, 64), (768, 224, 384, 256), (512, 128, 96, 128)],
+                         ids=["generic", "lean_bk64", "lean_bk32"])
+def test_gemm_nt_grn_prologue(dt, M, N, K, hw):
     H = _hip()
-    M, N, K, hw = 192, 40, 160, 64
     A, Bw = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, seed=2, scale=K**-0.5)
-    s, beta = 1 + 0.3 * rnd(3, K, seed=3), 0.1 * rnd(K, seed=4)
+    s, beta = 1 + 0.3 * rnd(M // hw, K, seed=3), 0.1 * rnd(K, seed=4)
     res, bias = rnd(M, N, dt=dt, seed=5), rnd(N, seed=6)
 
     def run(ops, dev):
@@ -265,7 +269,8 @@ def test_head_conv_direct_bf16(B, gh, gw):
 # ------------------------------------------------------------------ GEMM tn
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("tr", [1, 0], ids=["tr_read", "scalar_read"])
-@pytest.mark.parametrize("M,N,K", [(512, 160, 40), (1000, 96, 384), (70, 8, 32), (9000, 384, 96), (4100, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(512, 160, 40), (1000, 96, 384), (70, 8, 32), (9000, 384, 96), (4100, 768, 3072),
+                                   (4096, 384, 128), (8192, 224, 896), (2048, 96, 384)])  # lean (M % 64 == 0): 64-row steps
 def test_gemm_tn(dt, tr, M, N, K):
     from viscy_amd import _lib
 
@@ -293,11 +298,12 @@ def test_gemm_tn(dt, tr, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
-def test_gemm_tn_grn_and_patch2(dt):
+@pytest.mark.parametrize("M,N,K,hw", [(300, 40, 160, 100), (4096, 224, 896, 1024), (1024, 96, 384, 256)],
+                         ids=["generic", "lean_wide", "lean"])
+def test_gemm_tn_grn_and_patch2(dt, M, N, K, hw):
     H = _hip()
-    M, N, K, hw = 300, 40, 160, 100
     X, Hh = rnd(M, N, dt=dt, seed=1), rnd(M, K, dt=dt, seed=2)
-    s, beta = 1 + 0.3 * rnd(3, K, seed=3), 0.1 * rnd(K, seed=4)
+    s, beta = 1 + 0.3 * rnd(M // hw, K, seed=3), 0.1 * rnd(K, seed=4)
     B, gh, gw, cin, cout = 2, 6, 5, 16, 24
     Mp = B * gh * gw
     src, d = rnd(B * 4 * gh * gw, cin, dt=dt, seed=5), rnd(Mp, cout, dt=dt, seed=6)
