@@ -86,6 +86,9 @@ typedef struct VsxGemm {
   float* red1;
   float* colsum;        /* TN only: [N] += sum_m X[m, n] (bias gradient), may be NULL */
   void* C2;             /* NT, EPI_BIAS_GELU_SQ: second output g = gelu(h), same layout as C */
+  int64_t b_bstride;    /* NT: element stride between PER-SAMPLE weight matrices B[b] (b = m / hw); 0 = one shared B.
+                         * Needs hw % 128 == 0, plain row operands, N > 64, K % 32 == 0 (the lean instantiation). Used to
+                         * fold the GRN scale into fc2: a·W2^T with a = g·s[b] + beta  ==  g·(W2·diag(s[b]))^T + W2·beta */
 } VsxGemm;
 
 /* K5/K8/K9/K11/K13 (pointwise / patch / 3x3 convolutions as MFMA GEMMs) — replaces
@@ -205,6 +208,11 @@ int32_t vsx_prep_weight(const float* src, void* dst, void* dstT, const float* ga
 /* inverse of vsx_prep_weight for gradients: dparam[r][c][t] += g[r][k]*gamma[c] + u[r]*beta[c]; dgamma[c] += Σ g*W. */
 int32_t vsx_unprep_grad(const float* g, float* dparam, const float* gamma, const float* W, float* dgamma,
     const float* u, const float* beta, int32_t R, int32_t Cs, int32_t Tn, int32_t tapmode, vsx_stream_t stream);
+
+/* fold of the GRN affine into the fc2 weights (timm GlobalResponseNorm inside GlobalResponseNormMlp, between act and fc2):
+ * out[b][r][k] = dtype(W[r][k] * s[b][k]) for b < B; W fp32 [R][K], s fp32 [B][K].  Pairs with VsxGemm.b_bstride = R*K. */
+int32_t vsx_scale_weight_samples(const float* W, const float* s, void* out, int32_t B, int32_t R, int32_t K,
+    int32_t dtype, vsx_stream_t stream);
 
 /* out[r] = (b ? b[r] : 0) + Σ_c W[r][c]*v[c]   (fold LayerNorm beta into the fc1 bias). */
 int32_t vsx_matvec(const float* W, const float* v, const float* b, float* out, int32_t R, int32_t C,

@@ -45,7 +45,7 @@ def _gather(A: Tensor, M, K, lda, a_mode, gh, gw, cs, coff, pro, grn_s, grn_b, h
 
 def gemm(kind, A, B, Cout, M, N, K, lda, ldb, ldc, *, dtype, a_mode=A_ROWS, gh=0, gw=0, cs=0, nz=1, a_coff=None,
          b_off=None, c_coff=None, c_mode=A_ROWS, c_cs=0, pro=PRO_NONE, grn_s=None, grn_b=None, hw=0, epi=EPI_NONE,
-         bias=None, res=None, ldr=0, aux=None, ldx=0, red0=None, red1=None, colsum=None, C2=None):
+         bias=None, res=None, ldr=0, aux=None, ldx=0, red0=None, red1=None, colsum=None, C2=None, b_bstride=0):
     a_coff = list(a_coff) if a_coff else [0] * nz
     b_off = list(b_off) if b_off else [0] * nz
     c_coff = list(c_coff) if c_coff else [0] * nz
@@ -59,9 +59,15 @@ def gemm(kind, A, B, Cout, M, N, K, lda, ldb, ldc, *, dtype, a_mode=A_ROWS, gh=0
             if colsum is not None:
                 colsum += X.sum(0)
             continue
-        Bw = B.reshape(-1)[b_off[z] : b_off[z] + N * ldb].view(N, ldb)[:, :K].float()
-        acc = a @ Bw.t()
-        bidx = torch.arange(M, device=acc.device) // (hw if hw > 0 else M)
+        bidx = torch.arange(M, device=a.device) // (hw if hw > 0 else M)
+        if b_bstride:  # one weight matrix per batch sample
+            acc = torch.empty(M, N)
+            for bb in range(int(bidx.max().item()) + 1):
+                Bw = B.reshape(-1)[b_off[z] + bb * b_bstride : b_off[z] + bb * b_bstride + N * ldb].view(N, ldb)[:, :K].float()
+                acc[bidx == bb] = a[bidx == bb] @ Bw.t()
+        else:
+            Bw = B.reshape(-1)[b_off[z] : b_off[z] + N * ldb].view(N, ldb)[:, :K].float()
+            acc = a @ Bw.t()
         nb = int(bidx.max().item()) + 1
         if epi in (EPI_BIAS, EPI_BIAS_GELU_SQ, EPI_BIAS_RES, EPI_BIAS_STATS) and bias is not None:
             acc = acc + bias[None, :]
@@ -354,3 +360,7 @@ def head_conv_supported(H2, W2, c3, cmid, zo, dtype) -> bool:
     """the direct LDS-tiled head convolution exists only as a HIP kernel; the schedule falls back to the z-batched
     implicit GEMMs, which this backend states"""
     return False
+
+
+def scale_weight_samples(W, s, dtype):
+    return (W.detach().float().reshape(W.shape[0], -1)[None, :, :] * s.float()[:, None, :]).to(dtype)

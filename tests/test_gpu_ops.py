@@ -140,6 +140,38 @@ def test_gemm_nt_grn_prologue(dt, M, N, K, hw):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_gemm_nt_per_sample_weights_fold_grn(dt):
+    """VsxGemm.b_bstride + vsx_scale_weight_samples: (g·s_b + β)·W2ᵀ as a plain GEMM with per-sample weights
+    W2·diag(s_b) and bias b2 + W2·β — against the ref backend AND against the GRN-prologue formulation it replaces."""
+    H = _hip()
+    M, N, K, hw = 768, 96, 384, 256
+    nb = M // hw
+    A = rnd(M, K, dt=dt, seed=1)
+    W2 = rnd(N, K, seed=2, scale=K**-0.5)            # fp32 master weights
+    s, beta = 1 + 0.3 * rnd(nb, K, seed=3), 0.1 * rnd(K, seed=4)
+    res, bias = rnd(M, N, dt=dt, seed=5), rnd(N, seed=6)
+
+    def run(ops, dev):
+        Ws = ops.scale_weight_samples(W2.to(dev), s.to(dev), dt)
+        b2 = ops.matvec(W2.to(dev), beta.to(dev), bias.to(dev), N, K)
+        C = torch.zeros(M, N, dtype=dt, device=dev)
+        ops.gemm("nt", A.to(dev), Ws, C, M, N, K, K, K, N, dtype=dt, hw=hw, b_bstride=N * K, epi=R.EPI_BIAS_RES, bias=b2,
+                 res=res.to(dev), ldr=N)
+        return Ws, C
+
+    (Wg, Cg), (Wr, Cr) = run(H, DEV), run(R, "cpu")
+    assert Wg.shape == (nb, N, K) and Wg.dtype == dt
+    close(Wg, Wr, dt, "scaled weights")
+    close(Cg, Cr, dt, "folded fc2")
+    C2 = torch.zeros(M, N, dtype=dt, device=DEV)
+    H.gemm("nt", A.to(DEV), W2.to(dt).to(DEV), C2, M, N, K, K, K, N, dtype=dt, pro=R.PRO_GRN, grn_s=s.to(DEV), grn_b=beta.to(DEV),
+           hw=hw, epi=R.EPI_BIAS_RES, bias=bias.to(DEV), res=res.to(DEV), ldr=N)
+    close(Cg, C2, dt, "fold == prologue")
+    with pytest.raises(RuntimeError, match="per-sample weights"):
+        H.gemm("nt", A.to(DEV), Wg, C2, M, 40, K, K, K, 40, dtype=dt, hw=hw, b_bstride=N * K)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 def test_gemm_nt_patch2_gather_and_scatter(dt):
     H = _hip()
     B, gh, gw, cin, cout = 2, 6, 5, 16, 24

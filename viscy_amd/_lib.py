@@ -38,6 +38,7 @@ class VsxGemm(C.Structure):
         ("bias", _P), ("res", _P), ("ldr", _I32),
         ("aux", _P), ("ldx", _I32),
         ("red0", _P), ("red1", _P), ("colsum", _P), ("C2", _P),
+        ("b_bstride", _I64),
     ]
 
 
@@ -80,6 +81,7 @@ _SIGS = {
     "vsx_sample_minmax": (_I32, [_P, _P, _P, _I32, _I64, _P]),
     "vsx_intensity_aug": (_I32, [_P] * 8 + [_F32, _I32, _I64, _P]),
     "vsx_blend_in": (_I32, [_P, _P, _P, _P, _I32, _I64, _I64, _P]),
+    "vsx_scale_weight_samples": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_head_conv_supported": (_I32, [_I32] * 6),
     "vsx_head_conv_fwd": (_I32, [_P] * 6 + [_I32] * 7 + [_P]),
     "vsx_head_conv_wgrad": (_I32, [_P] * 4 + [_I32] * 7 + [_P]),

@@ -495,8 +495,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
   const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+  const int b_tile = p.hw > 0 ? m0 / p.hw : 0;  // the tile lies inside one sample (dispatch guarantees it)
   const char* Abase = reinterpret_cast<const char*>(p.A) + (size_t)p.a_coff[z] * ES;
-  const char* Bbase = reinterpret_cast<const char*>(p.B) + (size_t)p.b_off[z] * ES;
+  const char* Bbase = reinterpret_cast<const char*>(p.B) + ((size_t)p.b_off[z] + (size_t)b_tile * (size_t)p.b_bstride) * ES;
   uint32_t offA[NA], offB[NB];
   int ldsA[NA], ldsB[NB];
 #pragma unroll
@@ -515,7 +516,6 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
     offB[i] = (uint32_t)n * (uint32_t)(p.ldb * ES) + ch * 16;
     ldsB[i] = BM * RS + row * RS + ch * 16;
   }
-  const int b_tile = p.hw > 0 ? m0 / p.hw : 0;  // the tile lies inside one sample (dispatch guarantees it)
   const float* grn_s = PRO ? p.grn_s + (size_t)b_tile * p.K : nullptr;
 
   vec ar[NA], br[NB];
@@ -743,7 +743,7 @@ static bool nt_fast_ok(const VsxGemm* p, int es) {
   if (!g_vsx_nt_fast || p->N <= 64 || p->a_mode != VSX_A_ROWS || p->c_mode != VSX_A_ROWS || p->K % 32 != 0) return false;
   if (p->epi == VSX_EPI_BIAS_STATS) return false;
   const bool reduce = p->epi == VSX_EPI_BIAS_GELU_SQ || p->epi == VSX_EPI_DZ;
-  if ((reduce || p->pro == VSX_PRO_GRN) && (p->hw <= 0 || p->hw % 128 != 0)) return false;
+  if ((reduce || p->pro == VSX_PRO_GRN || p->b_bstride != 0) && (p->hw <= 0 || p->hw % 128 != 0)) return false;
   if ((unsigned long long)p->M * p->lda * es >= (1ull << 32) || (unsigned long long)p->N * p->ldb * es >= (1ull << 32)) return false;
   return true;
 }
@@ -771,6 +771,13 @@ static int launch_nt(const VsxGemm* p, hipStream_t s) {
 
 template <typename T>
 static int dispatch_nt(const VsxGemm* p, hipStream_t s) {
+  if (p->b_bstride != 0) {
+    if (!nt_fast_ok(p, (int)sizeof(T))) {
+      vsx_set_error("vsx_gemm_nt: per-sample weights (b_bstride) need plain row operands, N > 64, K %% 32 == 0, hw %% 128 == 0");
+      return 1;
+    }
+    return dispatch_nt_fast<T>(p, s);
+  }
   if (p->N > 64) {
     // few workgroups (< 2 per CU) and a long K loop: the loop is bound by global-load latency, not by MFMA
     // or bandwidth — stage 4x more K per barrier so 4x more bytes are in flight per workgroup

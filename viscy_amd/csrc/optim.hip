@@ -254,3 +254,39 @@ extern "C" int32_t vsx_prep_head_dgrad(const float* W, void* dst, int32_t Cmid, 
   VSX_LAUNCH_CHECK();
   return 0;
 }
+
+// out[b][r][k] = T(W[r][k] * s[b][k])   (GRN scale folded into per-sample fc2 weights; one 16-byte vector per thread)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_weight_samples_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                                   T* __restrict__ out, int B, int R, int K) {
+  constexpr int VN = VT<T>::N;
+  const int kv = K / VN;
+  const long total = (long)B * R * kv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % kv);
+    const long br = i / kv;
+    const int r = (int)(br % R), b = (int)(br / R);
+    float f[VN];
+#pragma unroll
+    for (int j = 0; j < VN; j += 4) {
+      const float4 w = *reinterpret_cast<const float4*>(W + (size_t)r * K + c * VN + j);
+      const float4 sv = *reinterpret_cast<const float4*>(s + (size_t)b * K + c * VN + j);
+      f[j] = w.x * sv.x; f[j + 1] = w.y * sv.y; f[j + 2] = w.z * sv.z; f[j + 3] = w.w * sv.w;
+    }
+    stvec<T>(out + ((size_t)b * R + r) * K + c * VN, pack<T>(f));
+  }
+}
+extern "C" int32_t vsx_scale_weight_samples(const float* W, const float* s, void* out, int32_t B, int32_t R, int32_t K,
+                                            int32_t dtype, vsx_stream_t stream) {
+  int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(W && s && out && B > 0 && R > 0 && K > 0 && K % vn == 0, "vsx_scale_weight_samples: bad arguments (K=%d)", K);
+  long total = (long)B * R * (K / vn);
+  int g = vsx_cdiv(total, 256);
+  if (g > 8192) g = 8192;
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(scale_weight_samples_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, W, s, (bf16_t*)out, B, R, K);
+  else
+    hipLaunchKernelGGL(scale_weight_samples_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, W, s, (float*)out, B, R, K);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

@@ -229,8 +229,19 @@ class Engine:
                hw=H * Wd, C2=gact)
         s = o.grn_scale(colsq, blk.mlp.grn.weight)
         out = torch.empty((M, C), dtype=dt, device=x.device)
-        o.gemm("nt", gact, w.W2, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
-               grn_b=blk.mlp.grn.bias, hw=H * Wd, epi=L.EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=x, ldr=C)
+        hw = H * Wd
+        if dt == torch.bfloat16 and C > 64 and hw % 128 == 0 and hw // 128 >= 8:
+            # large feature maps: fold the GRN affine into per-sample fc2 weights,
+            #   (g·s_b + β)·W2ᵀ = g·(W2·diag(s_b))ᵀ + W2·β,
+            # so fc2 is a plain GEMM (the operand prologue costs +60 % on these launches); B·C·4C extra weight bytes
+            # are small next to the M·4C activation bytes when a sample spans >= 8 row tiles
+            Ws = o.scale_weight_samples(blk.mlp.fc2.weight, s, dt)
+            b2 = o.matvec(blk.mlp.fc2.weight, blk.mlp.grn.bias, blk.mlp.fc2.bias, C, 4 * C)
+            o.gemm("nt", gact, Ws, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, hw=hw, b_bstride=C * 4 * C,
+                   epi=L.EPI_BIAS_RES, bias=b2, res=x, ldr=C)
+        else:
+            o.gemm("nt", gact, w.W2, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
+                   grn_b=blk.mlp.grn.bias, hw=hw, epi=L.EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=x, ldr=C)
         if save is not None:
             save.append((x, xh, rstd, h, gact, colsq, s))
         return out

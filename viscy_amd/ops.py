@@ -71,6 +71,7 @@ def gemm(
     red1: Tensor | None = None,
     colsum: Tensor | None = None,
     C2: Tensor | None = None,
+    b_bstride: int = 0,
 ) -> None:
     """kind='nt': C[M,N] = pro(A)[M,K]·B[N,K]^T (+epilogue);  kind='tn': C[N,K](fp32) += B[M,N]^T·pro(A)[M,K]."""
     for t in (bias, grn_s, grn_b, red0, red1, colsum):
@@ -94,6 +95,7 @@ def gemm(
     p.aux, p.ldx = ptr(aux), ldx
     p.red0, p.red1, p.colsum = ptr(red0), ptr(red1), ptr(colsum)
     p.C2 = ptr(C2)
+    p.b_bstride = b_bstride
     fn = lib().vsx_gemm_nt if kind == "nt" else lib().vsx_gemm_tn
     check(fn(C.byref(p), dtype_code(dtype), stream()), f"gemm_{kind}")
 
@@ -301,3 +303,13 @@ def head_conv_dgrad(dU: Tensor, Wp: Tensor, B: int, H2: int, W2: int, c3: int, c
     check(lib().vsx_head_conv_dgrad(ptr(dU), ptr(Wp), ptr(dhin), B, H2, W2, c3, cmid, zo, dtype_code(dU.dtype), stream()),
           "head_conv_dgrad")
     return dhin
+
+
+def scale_weight_samples(W: Tensor, s: Tensor, dtype: torch.dtype) -> Tensor:
+    """out[b] = dtype(W * s[b][None, :]) — the GRN scale folded into the fc2 weights, one matrix per batch sample"""
+    R = W.shape[0]
+    K = W.numel() // R  # nn.Linear [R, K] or 1x1 nn.Conv2d [R, K, 1, 1] (timm conv_mlp backbones)
+    B = s.shape[0]
+    out = torch.empty((B, R, K), dtype=dtype, device=W.device)
+    check(lib().vsx_scale_weight_samples(ptr(W), ptr(s), ptr(out), B, R, K, dtype_code(dtype), stream()), "scale_weight_samples")
+    return out
