@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
 // outputs that are never written), the GRN prologue is a template parameter.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BT, bool TR, bool PRO, int BMS = 32, int NBUF = 2>
-__global__ __launch_bounds__(256) void gemm_tn_fast_kernel(const VsxGemm p) {
+__global__ __launch_bounds__(256, (BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1) void gemm_tn_fast_kernel(const VsxGemm p) {
   constexpr int ES = sizeof(T);
   constexpr int VN = VT<T>::N;
   constexpr int LD = BT + 16;
@@ -1099,16 +1099,39 @@ __global__ __launch_bounds__(256) void gemm_tn_fast_kernel(const VsxGemm p) {
       }
     }
   };
+  // GRN prologue operands: every chunk of this thread covers the SAME 8 (4) columns (256 % CPR == 0), and the sample
+  // index changes only every hw / BMS steps -> s[b, k..] and beta[k..] live in registers, reloaded on a sample change
+  // (the first version re-read them from global memory for every chunk of every step)
+  float gsr[VN], gbr[VN];
+  int gcur = -1;
+  if constexpr (PRO) {
+#pragma unroll
+    for (int j = 0; j < VN; ++j) gbr[j] = p.grn_b[kcol[0] + j];
+  }
   auto store_tiles = [&](int step, int buf, const vec* xr, const vec* yr) {
     char* Xs = smem + buf * 2 * TILE_BYTES;
     char* Ys = Xs + TILE_BYTES;
-    const float* gs = PRO ? p.grn_s + (size_t)((step * BMS) / p.hw) * p.K : nullptr;
+    if constexpr (PRO) {
+      const int bnow = (step * BMS) / p.hw;  // (uniform)
+      if (bnow != gcur) {
+        gcur = bnow;
+        const float* gs = p.grn_s + (size_t)bnow * p.K + kcol[0];
+#pragma unroll
+        for (int j = 0; j < VN; ++j) gsr[j] = gs[j];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       if (live[i]) {
         const vec xv = xr[i];
         vec yv = yr[i];
-        if constexpr (PRO) yv = grn_apply<T>(yv, gs, p.grn_b, kcol[i]);
+        if constexpr (PRO) {
+          float f[VN];
+          unpack<T>(yv, f);
+#pragma unroll
+          for (int j = 0; j < VN; ++j) f[j] = fmaf(f[j], gsr[j], gbr[j]);
+          yv = pack<T>(f);
+        }
         *reinterpret_cast<vec*>(Xs + lds_o[i]) = xv;
         *reinterpret_cast<vec*>(Ys + lds_o[i]) = yv;
       }
