@@ -35,7 +35,10 @@ for name, hw, C in stages:
         us = timeit(lambda: ops.dwconv7_bwd_weight(dy, x, dw, db, B, hw, hw, C)); print(f"dwconv7_bwd_weight {name}: {us:8.1f} us  {2*M*C*2/us/1e3:8.1f} GB/s  {2*49*M*C/us/1e6:6.2f} TFLOP/s")
     if "ln" in which:
         x = rnd(M, C); g = torch.ones(C, device=dev); bb = torch.zeros(C, device=dev)
-        us = timeit(lambda: ops.ln_fwd(x, g, bb, M, C)); print(f"ln_fwd {name} C={C}: {us:8.1f} us  {2*M*C*2/us/1e3:8.1f} GB/s")
+        us = timeit(lambda: ops.ln_fwd(x, g, bb, M, C)); print(f"ln_fwd affine {name} C={C}: {us:8.1f} us  {2*M*C*2/us/1e3:8.1f} GB/s")
+        us = timeit(lambda: ops.ln_fwd(x, None, None, M, C, 1e-6, need_mean=False)); print(f"ln_fwd plain  {name} C={C}: {us:8.1f} us  {2*M*C*2/us/1e3:8.1f} GB/s")
+        xh, _, rstd = ops.ln_fwd(x, None, None, M, C, 1e-6, need_mean=False); dyy = rnd(M, C)
+        us = timeit(lambda: ops.ln_bwd(dyy, xh, None, rstd, None, None, None, None, M, C)); print(f"ln_bwd plain  {name} C={C}: {us:8.1f} us  {3*M*C*2/us/1e3:8.1f} GB/s")
     if "gemm" in which:
         xh, W1, hbuf = rnd(M, C), rnd(N4, C), torch.empty(M, N4, device=dev, dtype=dt)
         b1 = torch.zeros(N4, device=dev); colsq = torch.zeros(B, N4, device=dev)

@@ -10,7 +10,7 @@ template <typename T, int G, int CPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     int rows, int C, float eps) {
+                                                     int rows, int C, float eps, int iters) {
   // A lane group owns R rows per block and requests all of them before the first reduction: one row per group
   // (first version) meant one 16-byte load in flight per lane and 6 KB blocks -> 2.2 TB/s.
   constexpr int VN = VT<T>::N;
@@ -18,7 +18,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
   constexpr int RPI = 256 / G;  // rows per sweep of the block
   const int nch = C / VN;
   const int gl = threadIdx.x % G;
-  const int row0 = blockIdx.x * (RPI * R) + threadIdx.x / G;
+  float gam[CPL][VN], bet[CPL][VN];  // this lane's channels never change: the affine parameters live in registers
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = gl + i * G;
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      gam[i][j] = (gamma && c < nch) ? gamma[c * VN + j] : 1.f;
+      bet[i][j] = (gamma && c < nch) ? beta[c * VN + j] : 0.f;
+    }
+  }
+  // a bounded grid sweeps the rows in interleaved windows (like ln_bwd, which streamed 1.9x faster than one short-lived
+  // block per 64 rows): sweep `it` of the grid covers rows [it * gridDim.x * RPI * R, ...)
+  for (int it = 0; it < iters; ++it) {
+  const int row0 = (it * gridDim.x + blockIdx.x) * (RPI * R) + threadIdx.x / G;
   float v[R][CPL][VN];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -38,24 +51,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int row = row0 + r * RPI;
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < CPL; ++i)
-#pragma unroll
-      for (int j = 0; j < VN; ++j) s += v[r][i][j];
-    const float mean = group_sum<G>(s) / (float)C;
-    float q = 0.f;
+    // one reduction round: Σ(x - x0) and Σ(x - x0)² reduced together (two independent shuffle chains instead of two
+    // dependent rounds); the shift x0 = first element of the row keeps the single-pass variance well conditioned
+    const float x0 = __shfl(v[r][0][0], (threadIdx.x & 63) / G * G, 64);
+    float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       if (gl + i * G < nch) {
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
-          const float d = v[r][i][j] - mean;
-          q += d * d;
+          const float d = v[r][i][j] - x0;
+          s += d;
+          q = fmaf(d, d, q);
         }
       }
     }
-    const float rstd = rsqrtf(group_sum<G>(q) / (float)C + eps);
+    s = group_sum<G>(s) / (float)C;
+    q = group_sum<G>(q) / (float)C;
+    const float mean = x0 + s;
+    const float rstd = rsqrtf(fmaxf(q - s * s, 0.f) + eps);
     if (row < rows) {  // (uniform per group; the shuffles above ran for every lane)
       T* yr = y + (size_t)row * C;
 #pragma unroll
@@ -66,17 +80,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
 #pragma unroll
           for (int j = 0; j < VN; ++j) {
             const float xh = (v[r][i][j] - mean) * rstd;
-            o[j] = gamma ? xh * gamma[c * VN + j] + beta[c * VN + j] : xh;
+            o[j] = gamma ? fmaf(xh, gam[i][j], bet[i][j]) : xh;
           }
           stvec<T>(yr + c * VN, pack<T>(o));
         }
       }
+#ifndef LN_NO_RSTD
       if (gl == 0) {
         if (mean_out) mean_out[row] = mean;
         rstd_out[row] = rstd;
       }
+#endif
     }
   }
+  }  // sweeps
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -206,8 +223,10 @@ static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float*
   constexpr int RPI = 256 / G;
   if (fwd) {
     constexpr int R = CPL == 1 ? 4 : (CPL == 2 ? 2 : 1);  // rows per lane group (see the kernel)
-    hipLaunchKernelGGL((ln_fwd_kernel<T, G, CPL>), dim3(vsx_cdiv(rows, RPI * R)), dim3(256), 0, s, (const T*)a0, (T*)out,
-                       mean, rstd, gamma, beta, rows, C, eps);
+    int iters = vsx_cdiv(rows, RPI * R * 2048);           // <= 2048 workgroups, each sweeping `iters` windows
+    if (iters < 1) iters = 1;
+    hipLaunchKernelGGL((ln_fwd_kernel<T, G, CPL>), dim3(vsx_cdiv(rows, RPI * R * iters)), dim3(256), 0, s, (const T*)a0,
+                       (T*)out, mean, rstd, gamma, beta, rows, C, eps, iters);
   } else {
     int iters = vsx_cdiv(rows, RPI * 512);  // <= 512 blocks → <= 512 same-address atomics on dgamma / dbeta
     if (iters < 1) iters = 1;
