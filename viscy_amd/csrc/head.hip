@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
   constexpr int VN = VT<T>::N;
   __shared__ float mu[HEAD_MAX_CMID], rs[HEAD_MAX_CMID], w2s[HEAD_MAX_CO4 * HEAD_MAX_CMID];
   __shared__ float part[4][2 * HEAD_MAX_CMID + 1];  // per-wave partials (no LDS atomics: plain stores, fixed order)
+  __shared__ typename VT<T>::vec stage[CMID / VN][256];
   const int b = blockIdx.y;
   constexpr int co4 = CO4;
   head_load_stats(ssum, ssq, b, CMID, (float)d.Z * d.H2 * d.W2, eps, mu, rs);
@@ -127,6 +128,9 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
       _Pragma("unroll") for (int k = 0; k < CO4; k += VN) stvec<T>(dvout + row * co4 + k, pack<T>(dv + k));
     }
     float da = 0.f;
+    // the activation row is parked in this thread's LDS slots chunk by chunk and written to HBM in one go after the
+    // channel loop (stores issued between the reductions reached HBM as partial lines: 2.4x the write traffic; keeping
+    // the row in registers instead needs an unrolled channel loop = the 486-register version again)
     _Pragma("unroll 1") for (int c0 = 0; c0 < CMID; c0 += 8) {
       float u[8], nh[8], a[8];
       _Pragma("unroll") for (int c = 0; c < 8; c += VN) unpack<T>(ldvec<T>(U + row * CMID + c0 + c), u + c);
@@ -134,9 +138,7 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
         nh[j] = (u[j] - mu[c0 + j]) * rs[c0 + j];
         a[j] = nh[j] > 0.f ? nh[j] : alpha * nh[j];
       }
-      if (live) {
-        _Pragma("unroll") for (int c = 0; c < 8; c += VN) stvec<T>(act + row * CMID + c0 + c, pack<T>(a + c));
-      }
+      _Pragma("unroll") for (int c = 0; c < 8; c += VN) stage[(c0 + c) / VN][threadIdx.x] = pack<T>(a + c);
       float dA[8];
       _Pragma("unroll") for (int j = 0; j < 8; ++j) dA[j] = 0.f;
       _Pragma("unroll") for (int k = 0; k < CO4; ++k) {
@@ -158,6 +160,9 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
           part[wv][CMID + c0 + j] += t2;
         }
       }
+    }
+    if (live) {
+      _Pragma("unroll") for (int c = 0; c < CMID / VN; ++c) stvec<T>(act + row * CMID + c * VN, stage[c][threadIdx.x]);
     }
     if (!live) da = 0.f;
     da = wave_sum(da);

@@ -163,17 +163,25 @@ __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
 }
 
 // ------------------------------------------------------------------ wave helpers (wave64)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Butterfly sums.  The four steps inside a 16-lane row are DPP-modified VALU adds (quad_perm x2, row_half_mirror,
+// row_mirror: no LDS, no wait); only the row-crossing steps (xor 16 / 32) go through ds_bpermute.  The all-__shfl_xor
+// version was 6 ds_bpermute + 6 s_waitcnt per sum — head_out_bwd1 issued 408 of them per thread.
+template <int CTRL>
+__device__ __forceinline__ float dpp_xadd(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+  return v + __int_as_float(r);
 }
 template <int G>
-__device__ __forceinline__ float group_sum(float v) {  // sum over aligned groups of G lanes (G pow2 <= 64)
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+__device__ __forceinline__ float group_sum(float v) {  // sum over aligned groups of G lanes (G pow2 <= 64), result in every lane
+  if (G >= 2) v = dpp_xadd<0xB1>(v);    // quad_perm [1,0,3,2]  (xor 1)
+  if (G >= 4) v = dpp_xadd<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
+  if (G >= 8) v = dpp_xadd<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of each 8 (quads already hold their totals)
+  if (G >= 16) v = dpp_xadd<0x140>(v);  // row_mirror: lane i <-> 15 - i
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
