@@ -734,6 +734,15 @@ static int launch_nt_fast(const VsxGemm* p, hipStream_t s) {
       return 0;
     }
   }
+  if constexpr (sizeof(T) == 2) {
+    if (g_vsx_nt_wide) {
+      // short K (fc1, fc2 data gradient: epilogue-dominated): BK = 32 with ONE LDS buffer = 33.8 KB, 124 registers ->
+      // 4 workgroups per CU instead of 3 (measured -5..-10 % on these launches)
+      hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 32, 1>), grid, dim3(256), 0, s, *p);
+      VSX_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO>), grid, dim3(256), 0, s, *p);
   VSX_LAUNCH_CHECK();
   return 0;
