@@ -129,8 +129,11 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
                                                         const float* __restrict__ tmax_p, int C, int D, int H, int W,
                                                         float* __restrict__ sum_ssim, float* __restrict__ sum_cs,
                                                         const float* __restrict__ coef, float* __restrict__ dmu) {
-  __shared__ float S[5][SI][SLD];
-  __shared__ float R[5][SI][ST];
+  // The five window means are produced one quantity at a time through ONE pair of LDS planes (13 KB instead of 63 KB:
+  // the kernel ran at 2 workgroups per CU and was latency-bound); the plane sums of this thread's halo pixels and the
+  // finished means of its output pixels wait in registers.
+  __shared__ float S[SI][SLD];
+  __shared__ float R[SI][ST];
   __shared__ float sh[4];
   const TileId tl = xcd_tile();
   const int bc = tl.z;
@@ -141,11 +144,17 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
   const float dr = tmax_p[0];
   const float c1 = (0.01f * dr) * (0.01f * dr), c2 = (0.03f * dr) * (0.03f * dr);
 
-  for (int idx = threadIdx.x; idx < SI * SI; idx += 256) {
+  constexpr int NIN = (SI * SI + 255) / 256;   // halo pixels per thread
+  constexpr int NH = (SI * ST + 255) / 256;    // horizontal-pass outputs per thread
+  constexpr int NOUT = (ST * ST + 255) / 256;  // output pixels per thread
+  float sq[NIN][5];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int idx = threadIdx.x + i * 256;
     const int iy = idx / SI, ix = idx - iy * SI;
     const int gy = oy0 + iy, gx = ox0 + ix;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    if (gy < H && gx < W) {
+    if (idx < SI * SI && gy < H && gx < W) {
       for (int z = 0; z < D; ++z) {
         const size_t off = (((size_t)bc * D + z) * H + gy) * W + gx;
         const float p = P[off], t = T[off];
@@ -156,36 +165,52 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
         s4 += round_bf16(p * t);
       }
     }
-    S[0][iy][ix] = s0; S[1][iy][ix] = s1; S[2][iy][ix] = s2; S[3][iy][ix] = s3; S[4][iy][ix] = s4;
+    sq[i][0] = s0; sq[i][1] = s1; sq[i][2] = s2; sq[i][3] = s3; sq[i][4] = s4;
   }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < SI * ST; idx += 256) {
-    const int iy = idx / ST, ox = idx - iy * ST;
+  float m[NOUT][5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
+  for (int q = 0; q < 5; ++q) {
+    if (q) __syncthreads();  // previous quantity's vertical pass has finished reading R (and S)
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      if (idx < SI * SI) S[idx / SI][idx % SI] = sq[i][q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      if (idx < SI * ST) {
+        const int iy = idx / ST, ox = idx - iy * ST;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) a += S[iy][ox + k];
+        R[iy][ox] = a;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      const int oy = idx / ST, ox = idx - oy * ST;
       float a = 0.f;
+      if (idx < ST * ST) {
 #pragma unroll
-      for (int k = 0; k < 11; ++k) a += S[q][iy][ox + k];
-      R[q][iy][ox] = a;
+        for (int k = 0; k < 11; ++k) a += R[oy + k][ox];
+      }
+      m[i][q] = round_bf16(kb * a);
     }
   }
-  __syncthreads();
   float acc_s = 0.f, acc_c = 0.f;
   float gs = 0.f, gc = 0.f;
   if (BWD) { gs = coef[2 * b]; gc = coef[2 * b + 1]; }
-  for (int idx = threadIdx.x; idx < ST * ST; idx += 256) {
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const int idx = threadIdx.x + i * 256;
     const int oy = idx / ST, ox = idx - oy * ST;
     const int gy = oy0 + oy, gx = ox0 + ox;
-    if (gy >= Ho || gx >= Wo) continue;
-    float m[5];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-      float a = 0.f;
-#pragma unroll
-      for (int k = 0; k < 11; ++k) a += R[q][oy + k][ox];
-      m[q] = round_bf16(kb * a);
-    }
-    SsimPix px = ssim_pixel<BWD>(m[0], m[1], m[2], m[3], m[4], c1, c2, gs, gc);
+    if (idx >= ST * ST || gy >= Ho || gx >= Wo) continue;
+    SsimPix px = ssim_pixel<BWD>(m[i][0], m[i][1], m[i][2], m[i][3], m[i][4], c1, c2, gs, gc);
     if (BWD) {
       const size_t plane = (size_t)Ho * Wo;
       const size_t nbc = (size_t)gridDim.z;
