@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("VSX_BENCH_BATCH", 256)), help="patches per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("VSX_BENCH_BATCH", 512)), help="patches per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -319,6 +319,7 @@ def main():
                 "hbm_frac_of_algorithmic_floor": round(value * ALGO_MB_PER_PATCH * scale * 1e6 / (world * HBM_PEAK_GBS * 1e9), 4),
                 "mfma_frac": round(value * 3 * FWD_GFLOP_PER_PATCH * scale * 1e9 / (world * MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
                 "final_loss": round(float(loss.item()), 5), "first_loss": round(float(l0.item()), 5),
+                "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 1e9, 1),
             },
             "roofline": roof,
         }
