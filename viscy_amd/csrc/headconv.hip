@@ -279,16 +279,22 @@ __global__ void head_conv_dgrad_prep_kernel(const bf16_t* __restrict__ Wc, bf16_
 
 template <int Z>
 __device__ __forceinline__ void hd_step(const char* halo, int pb, const uint4* __restrict__ wp, int step, int lane,
-                                        f32x4 (&acc)[2][4]) {
+                                        f32x4 (&acc)[2][4], uint4& w0, uint4& w1) {
   constexpr int FA = (Z & 1) ? (Z - 1) / 2 : Z / 2;
-  union { uint4 u; bf16x8 v; } w0, w1;
-  w0.u = wp[(step * 2 + 0) * 64 + lane];
-  w1.u = wp[(step * 2 + 1) * 64 + lane];
+  // weights of THIS step arrive in (w0, w1); the next step's pair is requested before the MFMAs so that its L2 latency
+  // hides behind them (the loop is fully unrolled: `step` is a literal, the last prefetch is dropped by the compiler)
+  union { uint4 u; bf16x8 v; } a0, a1;
+  a0.u = w0;
+  a1.u = w1;
+  if (step + 1 < 45) {
+    w0 = wp[((step + 1) * 2 + 0) * 64 + lane];
+    w1 = wp[((step + 1) * 2 + 1) * 64 + lane];
+  }
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf) {
     const bf16x8 pf = *reinterpret_cast<const bf16x8*>(halo + pb + mf * 18 * HD_PS);
-    acc[mf][FA] = hc_mfma(w0.v, pf, acc[mf][FA]);
-    acc[mf][FA + 1] = hc_mfma(w1.v, pf, acc[mf][FA + 1]);
+    acc[mf][FA] = hc_mfma(a0.v, pf, acc[mf][FA]);
+    acc[mf][FA + 1] = hc_mfma(a1.v, pf, acc[mf][FA + 1]);
   }
 }
 
@@ -313,19 +319,20 @@ __global__ __launch_bounds__(256) void head_conv_dgrad_kernel(const bf16_t* __re
   for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[mf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
   const uint4* wp = reinterpret_cast<const uint4*>(Wp);
+  uint4 w0 = wp[0 * 64 + lane], w1 = wp[1 * 64 + lane];  // step 0, requested before the barrier
+  __syncthreads();
   // wave w: output pixel rows 2w, 2w + 1; lane: pixel x = p16, channel quarter kq (8 of the 32 n per plane)
   const int pb0 = ((wave * 2) * 18 + p16) * HD_PS + kq * 16;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int ey = tap / 3, ex = tap - ey * 3;
     const int pb = pb0 + (ey * 18 + ex) * HD_PS;
-    hd_step<0>(halo, pb + 0 * 64, wp, tap * 5 + 0, lane, acc);
-    hd_step<1>(halo, pb + 1 * 64, wp, tap * 5 + 1, lane, acc);
-    hd_step<2>(halo, pb + 2 * 64, wp, tap * 5 + 2, lane, acc);
-    hd_step<3>(halo, pb + 3 * 64, wp, tap * 5 + 3, lane, acc);
-    hd_step<4>(halo, pb + 4 * 64, wp, tap * 5 + 4, lane, acc);
+    hd_step<0>(halo, pb + 0 * 64, wp, tap * 5 + 0, lane, acc, w0, w1);
+    hd_step<1>(halo, pb + 1 * 64, wp, tap * 5 + 1, lane, acc, w0, w1);
+    hd_step<2>(halo, pb + 2 * 64, wp, tap * 5 + 2, lane, acc, w0, w1);
+    hd_step<3>(halo, pb + 3 * 64, wp, tap * 5 + 3, lane, acc, w0, w1);
+    hd_step<4>(halo, pb + 4 * 64, wp, tap * 5 + 4, lane, acc, w0, w1);
   }
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf) {
