@@ -160,3 +160,101 @@ def test_flat_data_parallel_gloo_world2():
     assert torch.equal(g0, expect) and torch.equal(g1, expect)   # SUM all-reduce of every bucket
     assert s0 == s1 == 0.5                           # averaging folded into the optimizer's grad_scale
     assert l0 == l1 == 1.5                           # sync_dist mean of a logged scalar
+
+
+# ------------------------------------------------------------------------------------------------ HCSPredictionWriter (§8 f1)
+def _expected_blend(preds, Z, zw):
+    """independent statement of the reference's out-of-core feathering (prediction_writer.py:74-111,300-326): windows
+    arrive in Z order; a window at offset z is merged into what is already stored there."""
+    C, _, Y, X = preds[0].shape
+    vol = np.zeros((C, Z, Y, X), np.float32)
+    for z, new in enumerate(preds):
+        if z == 0:
+            vol[:, :zw] = new
+            continue
+        samples = min(z + 1, zw)
+        f = np.array([min(i + 1, samples) for i in reversed(range(zw))], np.float64)[None, :, None, None]
+        vol[:, z : z + zw] = (vol[:, z : z + zw] * (f - 1) / f + new / f).astype(np.float32)
+    return vol
+
+
+class _StubTrainer:
+    def __init__(self, dm):
+        self.datamodule = dm
+
+
+def test_prediction_writer_blends_z_windows_and_appends_channels(tiny_hcs_zarr, tmp_path):
+    from viscy_amd.prediction_writer import HCSPredictionWriter
+
+    path, pos = tiny_hcs_zarr
+    zw = 3
+    dm = HCSDataModule(path, "Phase3D", ["Nuclei", "Membrane"], z_window_size=zw, batch_size=2, num_workers=0)
+    dm.setup("predict")
+    out = str(tmp_path / "pred.zarr")
+    w = HCSPredictionWriter(out)
+    assert w.interval == "batch"
+    w.on_predict_start(_StubTrainer(dm), None)
+    rng = np.random.default_rng(0)
+    sent = {}
+    for j, batch in enumerate(dm.predict_dataloader()):
+        B = batch["source"].shape[0]
+        pred = torch.from_numpy(rng.random((B, 2, zw, 128, 128), dtype=np.float32))
+        for i in range(B):
+            sent.setdefault(batch["index"][0][i], []).append(pred[i].numpy())
+        w.write_on_batch_end(None, None, pred, None, batch, j, 0)
+    w.on_predict_end(None, None)
+    plate = open_ome_zarr(out)
+    names = [n for n, _ in plate.positions()]
+    assert sorted(names) == sorted(n[1:-2] for n in sent)  # "/A/1/0/0" -> "A/1/0"
+    Z = 5
+    for n, p in plate.positions():
+        assert p.channel_names == ["Nuclei_prediction", "Membrane_prediction"]
+        img = p["0"]
+        assert img.shape == (1, 2, Z, 128, 128) and img.chunks == (1, 1, 1, 128, 128)
+        assert p.scale == [1.0] * 5
+        got = img.oindex[slice(0, 1), [0, 1], slice(0, Z)][0]
+        np.testing.assert_allclose(got, _expected_blend(sent["/" + n + "/0"], Z, zw), rtol=1e-6, atol=1e-7)
+    # an existing store: the same channels are refused, overwrite replaces, write_input is refused
+    with pytest.raises(FileExistsError, match="already exists"):
+        HCSPredictionWriter(out).on_predict_start(_StubTrainer(dm), None)
+    with pytest.raises(FileExistsError, match="existing store"):
+        HCSPredictionWriter(out, write_input=True).on_predict_start(_StubTrainer(dm), None)
+    HCSPredictionWriter(out, overwrite=True).on_predict_start(_StubTrainer(dm), None)
+    # appending prediction channels to a copy of the input plate (r+): arrays grow along C, existing data stays
+    import shutil
+
+    both = str(tmp_path / "both.zarr")
+    shutil.copytree(path, both)
+    w2 = HCSPredictionWriter(both)
+    w2.on_predict_start(_StubTrainer(dm), None)
+    for j, batch in enumerate(dm.predict_dataloader()):
+        w2.write_on_batch_end(None, None, torch.ones(batch["source"].shape[0], 2, zw, 128, 128), None, batch, j, 0)
+    p0 = next(iter(open_ome_zarr(both).positions()))[1]
+    assert p0.channel_names[-2:] == ["Nuclei_prediction", "Membrane_prediction"] and p0["0"].shape[1] == len(p0.channel_names)
+    raw = pos[next(iter(pos))]
+    np.testing.assert_array_equal(p0["0"].oindex[slice(0, 1), [0], slice(0, 5)][0, 0], raw[0, 0])
+    np.testing.assert_allclose(p0["0"].oindex[slice(0, 1), [len(p0.channel_names) - 1], slice(0, 5)], 1.0)
+
+
+def test_prediction_writer_2d_target_and_write_input(tiny_hcs_zarr, tmp_path):
+    """target_2d: one slice per window written at z + z_window // 2, no blending; write_input stores the centre slices."""
+    from viscy_amd.prediction_writer import HCSPredictionWriter
+
+    path, pos = tiny_hcs_zarr
+    dm = HCSDataModule(path, "Phase3D", "Nuclei", z_window_size=3, batch_size=3, num_workers=0, target_2d=True)
+    dm.setup("predict")
+    out = str(tmp_path / "p2d.zarr")
+    w = HCSPredictionWriter(out, write_input=True)
+    w.on_predict_start(_StubTrainer(dm), None)
+    assert w.z_padding == 1
+    for j, batch in enumerate(dm.predict_dataloader()):
+        z = batch["index"][2].float().view(-1, 1, 1, 1, 1)
+        w.write_on_batch_end(None, None, z + torch.zeros(len(z), 1, 1, 128, 128), None, batch, j, 0)
+    for n, p in open_ome_zarr(out).positions():
+        assert p.channel_names == ["Phase3D", "Nuclei", "Nuclei_prediction"]
+        img = p["0"]
+        assert img.shape == (1, 3, 4, 128, 128)  # windows z = 0..2 land on slices 1..3
+        got = img.oindex[slice(0, 1), [2], slice(0, 4)][0, 0]
+        for zi in range(3):
+            np.testing.assert_allclose(got[zi + 1], float(zi))
+        np.testing.assert_array_equal(img.oindex[slice(0, 1), [0], slice(1, 4)][0, 0], pos[n][0, 0][1:4])

@@ -5,7 +5,7 @@
 See DESIGN.md (what is built and why) and INTEGRATION.md (how it binds to the reference).
 """
 
-__all__ = ["UNeXt2", "MixedLoss", "VSUNet", "HCSDataModule", "FlatAdamW", "FlatDataParallel", "TrainStep"]
+__all__ = ["UNeXt2", "MixedLoss", "VSUNet", "HCSDataModule", "HCSPredictionWriter", "FlatAdamW", "FlatDataParallel", "TrainStep"]
 
 
 def __getattr__(name):
@@ -17,6 +17,8 @@ def __getattr__(name):
         from .vsunet import VSUNet as v
     elif name == "HCSDataModule":
         from .data import HCSDataModule as v
+    elif name == "HCSPredictionWriter":
+        from .prediction_writer import HCSPredictionWriter as v
     elif name == "FlatAdamW":
         from .optim import FlatAdamW as v
     elif name == "FlatDataParallel":

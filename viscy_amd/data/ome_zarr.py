@@ -35,6 +35,20 @@ class _OIndex:
         return out
 
 
+    def __setitem__(self, key, value):
+        """``img.oindex[t, [channels], z_slice] = array(C, Z, Y, X)`` (prediction_writer.py:323-326)."""
+        t, c, z = key[:3]
+        a = self.arr
+        cs = [int(i) for i in c] if not isinstance(c, slice) else list(range(*c.indices(a.shape[1])))
+        zs = range(*z.indices(a.shape[2])) if isinstance(z, slice) else [int(z)]
+        v = np.asarray(value, dtype=a.dtype)
+        if not isinstance(z, slice):
+            v = v[:, None]  # (C, Y, X) -> (C, 1, Y, X)
+        v = v.reshape(len(cs), len(zs), a.shape[3], a.shape[4])
+        for j, cc in enumerate(cs):
+            a.write_zrange(int(t), cc, zs[0], v[j])
+
+
 class ImageArray:
     """zarr v2 array, 5-D TCZYX."""
 
@@ -80,6 +94,44 @@ class ImageArray:
     def __getitem__(self, key):
         return self.oindex[key]
 
+    def __setitem__(self, key, value):
+        self.oindex[key] = value
+
+    # ---- writing (HCSPredictionWriter): chunk read-modify-write, shape changes are metadata-only
+    def _write_chunk(self, idx, data: np.ndarray) -> None:
+        f = self.fs_path / self.sep.join(str(i) for i in idx)
+        f.parent.mkdir(parents=True, exist_ok=True)
+        raw = np.ascontiguousarray(data, dtype=self.dtype).tobytes()
+        f.write_bytes(zlib.compress(raw, 1) if self.codec == "zlib" else raw)
+
+    def write_zrange(self, t: int, c: int, z0: int, data: np.ndarray) -> None:
+        """data: (Zn, Y, X) written at [t, c, z0:z0+Zn]."""
+        z1 = z0 + data.shape[0]
+        if t >= self.shape[0] or c >= self.shape[1] or z1 > self.shape[2]:
+            raise IndexError(f"write [{t}, {c}, {z0}:{z1}] outside array of shape {self.shape} (resize first)")
+        ct, cc, cz, cy, cx = self.chunks
+        for zc in range(z0 // cz, (z1 - 1) // cz + 1):
+            for yc in range((self.height + cy - 1) // cy):
+                for xc in range((self.width + cx - 1) // cx):
+                    idx = (t // ct, c // cc, zc, yc, xc)
+                    zs, ze = max(z0, zc * cz), min(z1, (zc + 1) * cz)
+                    ys, ye = yc * cy, min(self.height, (yc + 1) * cy)
+                    xs, xe = xc * cx, min(self.width, (xc + 1) * cx)
+                    whole = (ct == 1 and cc == 1 and zs == zc * cz and ze == (zc + 1) * cz and ye - ys == cy and xe - xs == cx)
+                    ch = np.empty(self.chunks, dtype=self.dtype) if whole else self._chunk(idx).copy()
+                    ch[t % ct, c % cc, zs - zc * cz : ze - zc * cz, : ye - ys, : xe - xs] = data[zs - z0 : ze - z0, ys:ye, xs:xe]
+                    self._write_chunk(idx, ch)
+
+    def resize(self, shape) -> None:
+        shape = tuple(int(v) for v in shape)
+        if shape[3:] != self.shape[3:]:
+            raise NotImplementedError("resize keeps Y and X")
+        meta = json.loads((self.fs_path / ".zarray").read_text())
+        meta["shape"] = list(shape)
+        (self.fs_path / ".zarray").write_text(json.dumps(meta))
+        self.shape = shape
+        self.frames, self.channels, self.slices, self.height, self.width = shape
+
 
 class Position:
     def __init__(self, root: Path, name: str):
@@ -91,7 +143,41 @@ class Position:
         return self.channel_names.index(name)
 
     def __getitem__(self, key: str) -> ImageArray:
+        if not (self.fs_path / key / ".zarray").exists():
+            raise KeyError(f"{self.name}/{key}")
         return ImageArray(self.fs_path / key, f"{self.name}/{key}")
+
+    def _save(self) -> None:
+        (self.fs_path / ".zattrs").write_text(json.dumps(self.zattrs))
+
+    def create_zeros(self, name: str, shape, dtype, chunks=None, transform=None) -> ImageArray:
+        """iohub ``Position.create_zeros`` (prediction_writer.py:353-362): a zero-filled 5-D TCZYX array; chunk files
+        appear only when written (fill_value 0)."""
+        shape = tuple(int(v) for v in shape)
+        chunks = tuple(int(v) for v in (chunks or (1, 1, 1) + shape[-2:]))
+        arr = self.fs_path / name
+        arr.mkdir(parents=True, exist_ok=True)
+        (arr / ".zarray").write_text(json.dumps({
+            "zarr_format": 2, "shape": list(shape), "chunks": list(chunks), "dtype": np.dtype(dtype).str, "order": "C",
+            "fill_value": 0, "filters": None, "dimension_separator": "/", "compressor": None}))
+        scale = list(transform[0]["scale"]) if transform else [1.0] * 5
+        ms = self.zattrs.setdefault("multiscales", [{"axes": [{"name": a} for a in "tczyx"], "version": "0.4", "datasets": []}])
+        if not any(d["path"] == name for d in ms[0]["datasets"]):
+            ms[0]["datasets"].append({"path": name, "coordinateTransformations": [{"type": "scale", "scale": scale}]})
+        self._save()
+        return self[name]
+
+    def append_channel(self, name: str, resize_arrays: bool = True) -> None:
+        """iohub ``Position.append_channel`` (prediction_writer.py:205-207)."""
+        if name in self.channel_names:
+            raise ValueError(f"channel {name!r} already exists")
+        self.channel_names.append(name)
+        self.zattrs["omero"]["channels"].append({"label": name})
+        self._save()
+        if resize_arrays:
+            for d in self.zattrs.get("multiscales", [{}])[0].get("datasets", []):
+                img = self[d["path"]]
+                img.resize((img.shape[0], len(self.channel_names)) + tuple(img.shape[2:]))
 
     @property
     def scale(self):
@@ -99,9 +185,61 @@ class Position:
 
 
 class Plate:
-    def __init__(self, path):
+    def __init__(self, path, channel_names=None):
         self.fs_path = Path(path)
         self.zattrs = json.loads((self.fs_path / ".zattrs").read_text())
+        self._channel_names = list(channel_names) if channel_names is not None else None
+
+    # ---- writing
+    @classmethod
+    def create(cls, path, channel_names):
+        root = Path(path)
+        root.mkdir(parents=True, exist_ok=True)
+        (root / ".zgroup").write_text(json.dumps({"zarr_format": 2}))
+        (root / ".zattrs").write_text(json.dumps({"plate": {"rows": [], "columns": [], "wells": [], "version": "0.4"}}))
+        return cls(root, channel_names)
+
+    @property
+    def channel_names(self):
+        if self._channel_names is None:
+            for _, pos in self.positions():
+                self._channel_names = list(pos.channel_names)
+                break
+        return self._channel_names or []
+
+    def get_channel_index(self, name: str) -> int:
+        return self.channel_names.index(name)
+
+    def create_position(self, row: str, col: str, fov: str) -> Position:
+        """iohub ``Plate.create_position``: registers row / column / well / field in the NGFF metadata."""
+        pl = self.zattrs["plate"]
+        if not any(r["name"] == row for r in pl["rows"]):
+            pl["rows"].append({"name": row})
+        if not any(c["name"] == col for c in pl["columns"]):
+            pl["columns"].append({"name": col})
+        wpath = f"{row}/{col}"
+        if not any(w["path"] == wpath for w in pl["wells"]):
+            pl["wells"].append({"path": wpath, "rowIndex": [r["name"] for r in pl["rows"]].index(row),
+                                "columnIndex": [c["name"] for c in pl["columns"]].index(col)})
+        (self.fs_path / ".zattrs").write_text(json.dumps(self.zattrs))
+        wdir = self.fs_path / row / col
+        wdir.mkdir(parents=True, exist_ok=True)
+        (self.fs_path / row / ".zgroup").write_text(json.dumps({"zarr_format": 2}))
+        (wdir / ".zgroup").write_text(json.dumps({"zarr_format": 2}))
+        wz = wdir / ".zattrs"
+        wattrs = json.loads(wz.read_text()) if wz.exists() else {"well": {"images": [], "version": "0.4"}}
+        if not any(i["path"] == fov for i in wattrs["well"]["images"]):
+            wattrs["well"]["images"].append({"path": fov})
+        wz.write_text(json.dumps(wattrs))
+        pdir = wdir / fov
+        pdir.mkdir(parents=True, exist_ok=True)
+        (pdir / ".zgroup").write_text(json.dumps({"zarr_format": 2}))
+        if not (pdir / ".zattrs").exists():
+            (pdir / ".zattrs").write_text(json.dumps({"omero": {"channels": [{"label": c} for c in self.channel_names]}}))
+        return Position(self.fs_path, f"{wpath}/{fov}")
+
+    def close(self) -> None:
+        pass
 
     def positions(self):
         for well in self.zattrs["plate"]["wells"]:
@@ -110,8 +248,19 @@ class Plate:
                 name = f"{well['path']}/{img['path']}"
                 yield name, Position(self.fs_path, name)
 
-    def __getitem__(self, name: str) -> Position:
-        return Position(self.fs_path, name)
+    def __getitem__(self, name: str):
+        """``plate["A/1/0"]`` -> Position; ``plate["/A/1/0/0"]`` -> ImageArray (how the writer looks up an image,
+        prediction_writer.py:345); KeyError when absent."""
+        parts = [p for p in str(name).split("/") if p]
+        if len(parts) == 3:
+            if not (self.fs_path / "/".join(parts) / ".zattrs").exists():
+                raise KeyError(name)
+            return Position(self.fs_path, "/".join(parts))
+        if len(parts) == 4:
+            if not (self.fs_path / "/".join(parts[:3]) / ".zattrs").exists():
+                raise KeyError(name)
+            return Position(self.fs_path, "/".join(parts[:3]))[parts[3]]
+        raise KeyError(name)
 
     def __enter__(self):
         return self
@@ -120,10 +269,18 @@ class Plate:
         return False
 
 
-def open_ome_zarr(path, mode: str = "r", layout: str = "hcs", **kw):
-    if mode != "r":
-        raise NotImplementedError("use write_hcs_plate() to create stores")
+def open_ome_zarr(path, mode: str = "r", layout: str = "hcs", channel_names=None, **kw):
+    """``iohub.open_ome_zarr`` for the modes the path uses: "r" / "r+" open an existing store; "a" / "w" create an HCS
+    plate with ``channel_names`` when the store does not exist ("w" refuses to clobber an existing one)."""
     p = Path(path)
+    if mode not in ("r", "r+", "a", "w", "w-"):
+        raise ValueError(f"mode {mode!r}")
+    if mode in ("a", "w", "w-") and not (p / ".zattrs").exists():
+        if layout != "hcs" or channel_names is None:
+            raise ValueError("creating a store needs layout='hcs' and channel_names")
+        return Plate.create(p, channel_names)
+    if mode in ("w", "w-"):
+        raise FileExistsError(f"{p} exists")
     if not (p / ".zattrs").exists():
         raise FileNotFoundError(f"{p} is not an OME-Zarr store")
     attrs = json.loads((p / ".zattrs").read_text())

@@ -80,3 +80,35 @@ class TrainStep:
             dist.all_reduce(self.model.engine().flat_grad, op=dist.ReduceOp.SUM, group=self.ddp.pg)
             self.opt.device_step()
         return self.loss
+
+
+class InferStep:
+    """Forward-only counterpart of ``TrainStep`` for tiled / sliding-window inference (BASELINE config 4): every window
+    of a FOV has the same shape, so the ~300 launches of one forward are captured once into a hipGraph and replayed per
+    window; the window is copied into a static input buffer, the output buffer is reused (clone it to keep it)."""
+
+    def __init__(self, model, use_graph: bool = True):
+        self.model, self.use_graph = model, use_graph
+        self.graph = None
+        self.x = self.y = None
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.use_graph:
+            return self.model(x)
+        if self.graph is None or self.x.shape != x.shape or self.x.dtype != x.dtype:
+            self.x = x.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):  # warm-up on a side stream (allocator, arena sizing, weight preparation)
+                for _ in range(2):
+                    self.model(self.x)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.y = self.model(self.x)
+            self.graph = g
+        self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.y

@@ -17,8 +17,10 @@ from .parallel import FlatDataParallel
 
 class Trainer:
     def __init__(self, max_epochs: int = 1, fast_dev_run: bool = False, precision: str = "bf16-mixed",
-                 accelerator: str = "gpu", seed: int | None = 42, limit_train_batches: int | None = None):
+                 accelerator: str = "gpu", seed: int | None = 42, limit_train_batches: int | None = None, callbacks=None):
         self.max_epochs, self.fast_dev_run, self.precision = max_epochs, fast_dev_run, precision
+        self.callbacks = list(callbacks or [])
+        self.datamodule = None
         self.limit_train_batches = limit_train_batches
         self.finished = False
         self.global_step = 0
@@ -73,11 +75,30 @@ class Trainer:
         self.finished = True
 
     def predict(self, module, datamodule) -> list[torch.Tensor]:
+        """Lightning's predict loop as the reference uses it: ``on_predict_start`` hooks, ``predict_step`` per batch,
+        prediction-writer callbacks (``write_on_batch_end``) after every batch, ``on_predict_end``."""
         module.to(self.device).eval()
+        self.datamodule = datamodule
         datamodule.setup("predict")
         module.on_predict_start()
+        for cb in self.callbacks:
+            if hasattr(cb, "on_predict_start"):
+                cb.on_predict_start(self, module)
         outs = []
         with torch.no_grad():
             for j, batch in enumerate(datamodule.predict_dataloader()):
-                outs.append(module.predict_step(self._to_device(batch), j))
+                batch = self._to_device(batch)
+                if hasattr(datamodule, "on_after_batch_transfer"):
+                    was = getattr(datamodule, "training", False)
+                    datamodule.training = False
+                    batch = datamodule.on_after_batch_transfer(batch, 0)
+                    datamodule.training = was
+                pred = module.predict_step(batch, j)
+                outs.append(pred)
+                for cb in self.callbacks:
+                    if hasattr(cb, "write_on_batch_end") and getattr(cb, "interval", "batch") in ("batch", "batch_and_epoch"):
+                        cb.write_on_batch_end(self, module, pred, None, batch, j, 0)
+        for cb in self.callbacks:
+            if hasattr(cb, "on_predict_end"):
+                cb.on_predict_end(self, module)
         return outs

@@ -122,6 +122,8 @@ class VSUNet(_Base):
             p.kind == inspect.Parameter.VAR_KEYWORD for p in sig.parameters.values())
         self.test_time_augmentations, self.tta_type = test_time_augmentations, tta_type
         self._predict_pad_k = None
+        self.predict_graph = False  # True: hipGraph-captured forward per window shape in predict (viscy_amd.step.InferStep)
+        self._infer_step = None
         self.logged: dict[str, list[float]] = {}
         if ckpt_path is not None:
             self.load_state_dict(torch.load(ckpt_path, weights_only=True, map_location="cpu")["state_dict"])
@@ -186,7 +188,15 @@ class VSUNet(_Base):
         (py0, py1), (px0, px1) = _divisible_pad_amounts(source.shape[-2:], self._predict_pad_k)
         if py0 or py1 or px0 or px1:
             source = torch.nn.functional.pad(source, (px0, px1, py0, py1))
-        prediction = self.forward(source.contiguous())
+        if self.predict_graph and source.is_cuda and not torch.is_grad_enabled():
+            # tiled inference: every window has the same padded shape -> replay one captured forward per window
+            from .step import InferStep
+
+            if self._infer_step is None:
+                self._infer_step = InferStep(self.model)
+            prediction = self._infer_step(source.contiguous()).clone()
+        else:
+            prediction = self.forward(source.contiguous())
         return _center_crop_to_shape(prediction, original_shape)
 
     def predict_step(self, batch, batch_idx: int, dataloader_idx: int = 0):
