@@ -134,6 +134,13 @@ int32_t vsx_head_conv_dgrad_prep(const void* Wc, void* Wp, int32_t dtype, vsx_st
 int32_t vsx_head_conv_dgrad(const void* dU, const void* Wp, void* dhin, int32_t B, int32_t H2, int32_t W2, int32_t c3,
     int32_t cmid, int32_t zo, int32_t dtype, vsx_stream_t stream);
 
+/* FCMAE head: viscy_models.components.heads.PixelToVoxelShuffleHead (heads.py:656-685) = MONAI UpSample(pixelshuffle, scale s,
+ * pre_conv None, apply_pad_pool) + reshape: feat [B*h*w, Cout*D*s*s] (dtype) <-> out / dout fp32 (B, Cout, D, s*h, s*w). */
+int32_t vsx_voxel_shuffle_fwd(const void* feat, float* out, int32_t B, int32_t h, int32_t w, int32_t Cout, int32_t D,
+    int32_t s, int32_t pool, int32_t dtype, vsx_stream_t stream);
+int32_t vsx_voxel_shuffle_bwd(const float* dout, void* dfeat, int32_t B, int32_t h, int32_t w, int32_t Cout, int32_t D,
+    int32_t s, int32_t pool, int32_t dtype, vsx_stream_t stream);
+
 /* K13 (norm+act) + K14: MONAI Convolution ADN (InstanceNorm3d eps 1e-5 → PReLU) → nn.Conv3d(mid, 4*out, 1) → transpose /
  * nn.PixelShuffle(2) / transpose (viscy_models/components/heads.py:617-625,638-641).  U: [B,H2,W2,Z,Cmid] conv output;
  * ssum/ssq: [B,Cmid] from the conv GEMM epilogue (VSX_EPI_BIAS_STATS); out: (B, Cout, Z, 2*H2, 2*W2) fp32. */

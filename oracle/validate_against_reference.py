@@ -297,6 +297,61 @@ def g8_wiring():
     torch.save(golden, os.path.join(GOLD, "unext2_forward.pt"))
 
 
+def g9_fcmae():
+    """Run the reference's own fcmae.py (dense path) on stubbed timm / monai modules == oracle/fcmae_ref.py."""
+    from oracle import fcmae_ref as F
+
+    R = unext2_ref
+
+    class _Downsample(nn.Module):  # never instantiated on the dense path inside a stage (in == out, stride 1)
+        def __init__(self, *a, **k):
+            raise AssertionError("timm Downsample is not on the dense FCMAE path")
+
+    def create_conv2d(in_channels, out_channels, kernel_size, stride=1, depthwise=False):
+        assert depthwise and stride == 1 and in_channels == out_channels
+        return nn.Conv2d(in_channels, out_channels, kernel_size, padding=kernel_size // 2, groups=out_channels)
+
+    def grn_mlp(in_features, hidden_features, out_features):
+        return R.GlobalResponseNormMlp(in_features, hidden_features, out_features, use_conv=False)
+
+    conv_mod = sys.modules["timm.models.convnext"]
+    conv_mod.Downsample = _Downsample
+    conv_mod.DropPath = lambda p: nn.Identity()
+    conv_mod.GlobalResponseNormMlp = grn_mlp
+    conv_mod.LayerNorm2d = R.LayerNorm2d
+    conv_mod.create_conv2d = create_conv2d
+    conv_mod.trunc_normal_ = nn.init.trunc_normal_
+    base = f"{REF}/viscy-models/src/viscy_models"
+    ref = _load("viscy_models.unet.fcmae", f"{base}/unet/fcmae.py")
+
+    golden = {}
+    for tag, kw, hw in [
+        ("small_z5", dict(in_channels=1, out_channels=2, encoder_blocks=[1, 1, 2, 1], dims=[16, 32, 64, 128], in_stack_depth=5,
+                          decoder_conv_blocks=1, pretraining=False), 64),
+        ("vscyto3d_z15", dict(in_channels=1, out_channels=2, encoder_blocks=[3, 3, 9, 3], dims=[96, 192, 384, 768],
+                              decoder_conv_blocks=2, stem_kernel_size=(5, 4, 4), in_stack_depth=15, pretraining=False), 64),
+        ("head_conv_z5", dict(in_channels=1, out_channels=2, encoder_blocks=[2, 2, 2, 2], dims=[48, 96, 192, 384], in_stack_depth=5,
+                              decoder_conv_blocks=2, pretraining=False, head_conv=True, head_conv_pool=True), 64),
+    ]:
+        r = ref.FullyConvolutionalMAE(**kw)
+        o = F.FullyConvolutionalMAE(**kw)
+        assert list(r.state_dict().keys()) == list(o.state_dict().keys()), tag
+        assert [tuple(v.shape) for v in r.state_dict().values()] == [tuple(v.shape) for v in o.state_dict().values()], tag
+        R.randomize_(o, seed=11)
+        r.load_state_dict(o.state_dict(), strict=True)
+        g = torch.Generator().manual_seed(43)
+        x = torch.randn((2, kw["in_channels"], kw["in_stack_depth"], hw, hw + 32), generator=g)
+        with torch.no_grad():
+            yr, yo = r(x), o(x)
+        d = maxrel(yo, yr)
+        assert d == 0.0, (tag, d)
+        golden[tag] = {"kwargs": kw, "seed": 11, "x_seed": 43, "x_shape": tuple(x.shape), "y": yo, "n_keys": len(o.state_dict()),
+                       "keys": list(o.state_dict().keys()),
+                       "param_checksum": sum(p.double().sum() for p in o.parameters()).item()}
+        print(f"G9 fcmae {tag}: reference dense forward on stubbed timm/monai == oracle (exact); keys={len(o.state_dict())}")
+    torch.save(golden, os.path.join(GOLD, "fcmae_forward.pt"))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -305,4 +360,5 @@ if __name__ == "__main__":
     g2_loss()
     g3_normalize()
     g8_wiring()
+    g9_fcmae()
     print("oracle pinned; fixtures written to tests/golden/")

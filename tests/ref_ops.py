@@ -364,3 +364,20 @@ def head_conv_supported(H2, W2, c3, cmid, zo, dtype) -> bool:
 
 def scale_weight_samples(W, s, dtype):
     return (W.detach().float().reshape(W.shape[0], -1)[None, :, :] * s.float()[:, None, :]).to(dtype)
+
+
+def voxel_shuffle_fwd(feat, B, h, w, Cout, D, s, pool):
+    import torch.nn.functional as F
+
+    x = feat.float().view(B, h, w, Cout * D * s * s).permute(0, 3, 1, 2)
+    x = F.pixel_shuffle(x, s)
+    if pool:
+        x = F.avg_pool2d(F.pad(x, (s - 1, 0, s - 1, 0)), kernel_size=s, stride=1)
+    return x.reshape(B, Cout, D, s * h, s * w).contiguous()
+
+
+@torch.enable_grad()
+def voxel_shuffle_bwd(dout, B, h, w, Cout, D, s, pool, dtype):
+    f = torch.zeros(B * h * w, Cout * D * s * s, requires_grad=True)
+    voxel_shuffle_fwd(f, B, h, w, Cout, D, s, pool).backward(dout.float())
+    return f.grad.to(dtype)

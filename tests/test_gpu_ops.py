@@ -473,6 +473,22 @@ def test_head_shuffle(dt, pool):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("pool", [True, False])
+def test_voxel_shuffle_head(dt, pool):
+    """PixelToVoxelShuffleHead (FCMAE): pixel shuffle x4 + MONAI pad-pool + reshape, forward and its transpose."""
+    H = _hip()
+    B, h, w, Cout, D, s = 2, 5, 7, 2, 3, 4
+    feat = rnd(B * h * w, Cout * D * s * s, dt=dt, seed=1)
+    dout = rnd(B, Cout, D, s * h, s * w, seed=2)
+    og = H.voxel_shuffle_fwd(feat.to(DEV), B, h, w, Cout, D, s, pool)
+    orf = R.voxel_shuffle_fwd(feat, B, h, w, Cout, D, s, pool)
+    assert og.shape == (B, Cout, D, s * h, s * w) and og.dtype == torch.float32
+    close(og, orf, dt, "voxel shuffle fwd")
+    close(H.voxel_shuffle_bwd(dout.to(DEV), B, h, w, Cout, D, s, pool, dt), R.voxel_shuffle_bwd(dout, B, h, w, Cout, D, s, pool, dt),
+          dt, "voxel shuffle bwd")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 def test_head_tail_fwd_bwd(dt):
     H = _hip()
     B, H2, W2, Z, Cmid, Cout = 2, 6, 10, 5, 32, 2

@@ -95,3 +95,32 @@ def test_normalize_golden():
     # clipping KAT (test_normalize.py:96-102)
     x = torch.full((1, 1, 8, 64, 64), 200.0)
     assert torch.allclose(transforms_ref.minmax_sampled(x, torch.tensor(5.0), torch.tensor(95.0)), torch.ones_like(x))
+
+
+# ------------------------------------------------------------------------------------------------ FCMAE dense path (§8 f2)
+@pytest.mark.parametrize("tag", ["small_z5", "vscyto3d_z15", "head_conv_z5"])
+def test_fcmae_forward_golden_and_key_compat(tag):
+    """oracle/fcmae_ref.py reproduces what the REFERENCE's fcmae.py produced (validate_against_reference.py::g9_fcmae), and
+    the MI355X parameter holder exposes exactly the reference's state-dict (keys, order, shapes) and loads it strictly."""
+    from oracle import fcmae_ref
+    from viscy_amd.fcmae import FullyConvolutionalMAE
+
+    g = load_golden("fcmae_forward.pt")[tag]
+    m = unext2_ref.randomize_(fcmae_ref.FullyConvolutionalMAE(**g["kwargs"]), seed=g["seed"]).eval()
+    assert list(m.state_dict().keys()) == g["keys"] and len(g["keys"]) == g["n_keys"]
+    cs = sum(p.double().sum() for p in m.parameters()).item()
+    assert abs(cs - g["param_checksum"]) <= 1e-6 * max(1.0, abs(g["param_checksum"]))
+    x = torch.randn(g["x_shape"], generator=torch.Generator().manual_seed(g["x_seed"]))
+    with torch.no_grad():
+        y = m(x)
+    torch.testing.assert_close(y, g["y"], rtol=1e-5, atol=1e-6)
+    mine = FullyConvolutionalMAE(**g["kwargs"])
+    sd = mine.state_dict()
+    assert list(sd.keys()) == g["keys"]
+    assert [tuple(v.shape) for v in sd.values()] == [tuple(v.shape) for v in m.state_dict().values()]
+    mine.load_state_dict(m.state_dict(), strict=True)
+    assert mine.out_stack_depth == m.out_stack_depth and mine.num_blocks == m.num_blocks
+    with pytest.raises(RuntimeError, match="HIP kernels only"):
+        mine(x)
+    with pytest.raises(NotImplementedError, match="dense"):
+        mine(x, mask_ratio=0.5)

@@ -82,6 +82,8 @@ _SIGS = {
     "vsx_intensity_aug": (_I32, [_P] * 8 + [_F32, _I32, _I64, _P]),
     "vsx_blend_in": (_I32, [_P, _P, _P, _P, _I32, _I64, _I64, _P]),
     "vsx_scale_weight_samples": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "vsx_voxel_shuffle_fwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),
+    "vsx_voxel_shuffle_bwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),
     "vsx_head_conv_supported": (_I32, [_I32] * 6),
     "vsx_head_conv_fwd": (_I32, [_P] * 6 + [_I32] * 7 + [_P]),
     "vsx_head_conv_wgrad": (_I32, [_P] * 4 + [_I32] * 7 + [_P]),

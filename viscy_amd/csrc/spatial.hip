@@ -413,3 +413,105 @@ extern "C" int32_t vsx_head_shuffle_bwd(const void* dhin, void* ddec, int32_t B,
   VSX_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------ PixelToVoxelShuffleHead (FCMAE head, heads.py:656-685)
+// out[b, co, z, Y, X] = pool(v)(Y, X),  v(Y, X) = feat[b, Y/s, X/s, ((co*D + z)*s + Y%s)*s + X%s]   (nn.PixelShuffle(s))
+// pool = MONAI SubpixelUpsample pad-pool: ConstantPad2d((s-1, 0, s-1, 0)) + AvgPool2d(s, stride 1)
+//      = mean of v over the s x s block ending at (Y, X), zeros outside.  feat: [B*h*w, Cout*D*s*s] (T), out: fp32 NCDHW.
+template <typename T>
+__global__ __launch_bounds__(256) void voxel_shuffle_fwd_kernel(const T* __restrict__ feat, float* __restrict__ out, int B, int h,
+                                                                int w, int Cout, int D, int s, int pool) {
+  const int H = h * s, W = w * s;
+  const int Cd = Cout * D * s * s;
+  const long total = (long)B * Cout * D * H * W;
+  const float inv = pool ? 1.f / (float)(s * s) : 1.f;
+  const int nt = pool ? s : 1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int X = (int)(i % W);
+    long r = i / W;
+    const int Y = (int)(r % H); r /= H;
+    const int z = (int)(r % D); r /= D;
+    const int co = (int)(r % Cout);
+    const int b = (int)(r / Cout);
+    const int cb = (co * D + z) * s * s;
+    float acc = 0.f;
+    for (int ty = 0; ty < nt; ++ty) {
+      const int yy = Y - ty;
+      if (yy < 0) break;
+      for (int tx = 0; tx < nt; ++tx) {
+        const int xx = X - tx;
+        if (xx < 0) break;
+        acc += to_f32<T>(feat[(((size_t)b * h + yy / s) * w + xx / s) * Cd + cb + (yy % s) * s + (xx % s)]);
+      }
+    }
+    out[i] = acc * inv;
+  }
+}
+// dfeat[b, y, x, (ch*s + dy)*s + dx] = inv * sum_{ty, tx < s} dout[b, ch, s*y + dy + ty, s*x + dx + tx]   (inside the image)
+template <typename T>
+__global__ __launch_bounds__(256) void voxel_shuffle_bwd_kernel(const float* __restrict__ dout, T* __restrict__ dfeat, int B,
+                                                                int h, int w, int Cout, int D, int s, int pool) {
+  constexpr int VN = VT<T>::N;
+  const int H = h * s, W = w * s;
+  const int Cd = Cout * D * s * s;
+  const int nch = Cd / VN;
+  const long total = (long)B * h * w * nch;
+  const float inv = pool ? 1.f / (float)(s * s) : 1.f;
+  const int nt = pool ? s : 1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    const long pix = i / nch;
+    const int x = (int)(pix % w);
+    const long r = pix / w;
+    const int y = (int)(r % h);
+    const int b = (int)(r / h);
+    float o[VN];
+#pragma unroll
+    for (int j = 0; j < VN; ++j) {
+      const int c = ch * VN + j;
+      const int dx = c % s, dy = (c / s) % s, cz = c / (s * s);  // cz = co*D + z
+      const float* plane = dout + ((size_t)b * Cout * D + cz) * H * W;
+      const int Y = y * s + dy, X = x * s + dx;
+      float acc = 0.f;
+      for (int ty = 0; ty < nt && Y + ty < H; ++ty)
+        for (int tx = 0; tx < nt && X + tx < W; ++tx) acc += plane[(size_t)(Y + ty) * W + X + tx];
+      o[j] = acc * inv;
+    }
+    stvec<T>(dfeat + (size_t)pix * Cd + ch * VN, pack<T>(o));
+  }
+}
+
+/* FCMAE head: viscy_models.components.heads.PixelToVoxelShuffleHead (heads.py:656-685) = MONAI UpSample(pixelshuffle,
+ * scale s, pre_conv None, apply_pad_pool) + reshape to (B, Cout, D, s*h, s*w).  feat [B*h*w, Cout*D*s*s] dtype -> out fp32. */
+extern "C" int32_t vsx_voxel_shuffle_fwd(const void* feat, float* out, int32_t B, int32_t h, int32_t w, int32_t Cout, int32_t D,
+                                         int32_t s, int32_t pool, int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(feat && out && B > 0 && h > 0 && w > 0 && Cout > 0 && D > 0 && s > 0, "vsx_voxel_shuffle_fwd: bad arguments");
+  long total = (long)B * Cout * D * h * s * w * s;
+  int g = vsx_cdiv(total, 256);
+  if (g > 65536) g = 65536;
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(voxel_shuffle_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)feat, out, B, h,
+                       w, Cout, D, s, pool);
+  else
+    hipLaunchKernelGGL(voxel_shuffle_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)feat, out, B, h, w,
+                       Cout, D, s, pool);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int32_t vsx_voxel_shuffle_bwd(const float* dout, void* dfeat, int32_t B, int32_t h, int32_t w, int32_t Cout, int32_t D,
+                                         int32_t s, int32_t pool, int32_t dtype, vsx_stream_t stream) {
+  int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(dout && dfeat && B > 0 && h > 0 && w > 0 && Cout > 0 && D > 0 && s > 0, "vsx_voxel_shuffle_bwd: bad arguments");
+  VSX_CHECK((Cout * D * s * s) % vn == 0, "vsx_voxel_shuffle_bwd: Cout*D*s*s=%d must be a multiple of %d", Cout * D * s * s, vn);
+  long total = (long)B * h * w * (Cout * D * s * s / vn);
+  int g = vsx_cdiv(total, 256);
+  if (g > 65536) g = 65536;
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(voxel_shuffle_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, dout, (bf16_t*)dfeat, B, h, w,
+                       Cout, D, s, pool);
+  else
+    hipLaunchKernelGGL(voxel_shuffle_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, dout, (float*)dfeat, B, h, w, Cout,
+                       D, s, pool);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

@@ -116,8 +116,10 @@ class Engine:
 
     def _param_order(self):
         m = self.model
-        ps = [m.head.conv[1].weight, m.head.conv[1].bias, m.head.conv[0].adn.A.weight, m.head.conv[0].conv.weight,
-              m.head.conv[0].conv.bias]
+        ps = []
+        if self.cfg.get("head", "conv") == "conv":
+            ps = [m.head.conv[1].weight, m.head.conv[1].bias, m.head.conv[0].adn.A.weight, m.head.conv[0].conv.weight,
+                  m.head.conv[0].conv.bias]
         self._bucket_marks = [0]
         for st in reversed(list(m.decoder.decoder_stages)):
             ps += self._stage_params_rev(st.conv)
@@ -201,13 +203,14 @@ class Engine:
             proj = self._prep_proj(st.downsample[0], st.downsample[1], dt, need_bwd)
             dec.append((proj, [self._prep_block(b, dt, need_bwd) for b in st.blocks]))
         W["dec"] = dec
-        hc = m.head.conv[0].conv
-        cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
-        W["head_Wc"], _ = o.prep_weight(hc.weight, cmid, c3, 27, dt, tapmode=1)
-        if need_bwd:
-            if dt == torch.bfloat16 and c3 == 8 and cmid == 32 and cfg["out_stack_depth"] == 5:
-                W["head_Wp"] = o.head_conv_dgrad_prep(W["head_Wc"])  # direct LDS-tiled dgrad (csrc/headconv.hip)
-            W["head_Wd"] = o.prep_head_dgrad(hc.weight, cmid, c3, cfg["out_stack_depth"], dt)
+        if cfg.get("head", "conv") == "conv":
+            hc = m.head.conv[0].conv
+            cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
+            W["head_Wc"], _ = o.prep_weight(hc.weight, cmid, c3, 27, dt, tapmode=1)
+            if need_bwd:
+                if dt == torch.bfloat16 and c3 == 8 and cmid == 32 and cfg["out_stack_depth"] == 5:
+                    W["head_Wp"] = o.head_conv_dgrad_prep(W["head_Wc"])  # direct LDS-tiled dgrad (csrc/headconv.hip)
+                W["head_Wd"] = o.prep_head_dgrad(hc.weight, cmid, c3, cfg["out_stack_depth"], dt)
         self.W = W
         self._prepared_for = key
         return W
@@ -346,6 +349,16 @@ class Engine:
             feat, fc = cur, proj.cout
             dec_sv.append(st_sv)
         # ---- head
+        if cfg.get("head", "conv") == "shuffle":
+            # PixelToVoxelShuffleHead (heads.py:656-685): pixel shuffle x s + pad-pool + reshape, parameter free
+            sxy = cfg["stem_kernel"][-1]
+            out = o.voxel_shuffle_fwd(feat, B, fh, fw, cfg["out_channels"], cfg["out_stack_depth"], sxy, True)
+            if need_bwd:
+                sv["enc"], sv["dec"] = enc_sv, dec_sv
+                sv["feat_dims"] = [(a, b_, c) for (_, a, b_, c) in feats]
+                sv["head"] = (fh, fw)
+            self._za_need[za_key] = za.used
+            return out, sv
         Zo, D7 = cfg["out_stack_depth"], cfg["out_stack_depth"] + 2
         hc = m.head.conv[0].conv
         cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
@@ -373,16 +386,9 @@ class Engine:
         self._za_need[za_key] = za.used
         return out, sv
 
-    # ------------------------------------------------------------------ backward
-    def backward(self, sv, dout: Tensor) -> None:
-        """Accumulates parameter gradients into the flat gradient buffer (no input gradient:
-        the image stack never requires grad on this path)."""
+    def _head_conv_bwd(self, sv, dout, dt, B, dev):
+        """PixelToVoxelHead backward; returns the gradient of the decoder feature map."""
         o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, self.W
-        dt = sv["dt"]
-        B, H, Wd = sv["shape"]
-        dev = dout.device
-        za_key = ("bwd", B, H, Wd)
-        self._za = za = _ZeroArena(dev, self._za_need.get(za_key, 0))
         Zo, D7 = cfg["out_stack_depth"], cfg["out_stack_depth"] + 2
         hc = m.head.conv[0].conv
         cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
@@ -422,6 +428,24 @@ class Engine:
         del dU
         d = o.head_shuffle_bwd(dhin, B, fh, fw, c3, D7, cfg["head_pool"])
         del dhin
+        return d
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, sv, dout: Tensor) -> None:
+        """Accumulates parameter gradients into the flat gradient buffer (no input gradient:
+        the image stack never requires grad on this path)."""
+        o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, self.W
+        dt = sv["dt"]
+        B, H, Wd = sv["shape"]
+        dev = dout.device
+        za_key = ("bwd", B, H, Wd)
+        self._za = za = _ZeroArena(dev, self._za_need.get(za_key, 0))
+        if cfg.get("head", "conv") == "shuffle":
+            fh, fw = sv["head"]
+            d = o.voxel_shuffle_bwd(dout.contiguous().float(), B, fh, fw, cfg["out_channels"], cfg["out_stack_depth"],
+                                    cfg["stem_kernel"][-1], True, dt)
+        else:
+            d = self._head_conv_bwd(sv, dout, dt, B, dev)
         # ---- decoder (reverse)
         dskips = {}
         for k in (2, 1, 0):

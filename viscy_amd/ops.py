@@ -313,3 +313,17 @@ def scale_weight_samples(W: Tensor, s: Tensor, dtype: torch.dtype) -> Tensor:
     out = torch.empty((B, R, K), dtype=dtype, device=W.device)
     check(lib().vsx_scale_weight_samples(ptr(W), ptr(s), ptr(out), B, R, K, dtype_code(dtype), stream()), "scale_weight_samples")
     return out
+
+
+def voxel_shuffle_fwd(feat: Tensor, B: int, h: int, w: int, Cout: int, D: int, s: int, pool: bool) -> Tensor:
+    out = torch.empty((B, Cout, D, s * h, s * w), dtype=torch.float32, device=feat.device)
+    check(lib().vsx_voxel_shuffle_fwd(ptr(feat), ptr(out), B, h, w, Cout, D, s, int(pool), dtype_code(feat.dtype), stream()),
+          "voxel_shuffle_fwd")
+    return out
+
+
+def voxel_shuffle_bwd(dout: Tensor, B: int, h: int, w: int, Cout: int, D: int, s: int, pool: bool, dtype: torch.dtype) -> Tensor:
+    dfeat = torch.empty((B * h * w, Cout * D * s * s), dtype=dtype, device=dout.device)
+    check(lib().vsx_voxel_shuffle_bwd(ptr(dout), ptr(dfeat), B, h, w, Cout, D, s, int(pool), dtype_code(dtype), stream()),
+          "voxel_shuffle_bwd")
+    return dfeat

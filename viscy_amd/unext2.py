@@ -142,6 +142,14 @@ class _HeadConv0(_Holder):
         self.adn = _ADN()
 
 
+class _ShuffleHead(_Holder):
+    """PixelToVoxelShuffleHead: parameter free (pixel shuffle + pad-pool + reshape)."""
+
+    def __init__(self):
+        super().__init__()
+        self.upsample = nn.Identity()
+
+
 class _Head(_Holder):
     def __init__(self, c3, cmid, co4):
         super().__init__()
@@ -163,7 +171,103 @@ def _icnr_(weight: Tensor, scale: int) -> None:
 
 
 # ------------------------------------------------------------------------------------------------
-class UNeXt2(nn.Module):
+class _Core(nn.Module):
+    """Shared machinery of the ConvNeXt-V2 U-Net family on this path (UNeXt2, the dense FCMAE U-Net): parameter tree in the
+    engine's naming, flat-buffer engine, HIP-only forward."""
+
+    def _build(self, *, in_channels, out_channels, in_stack_depth, out_stack_depth, depths, dims, conv_mlp, stem_kernel_size,
+               decoder_conv_blocks, head: str, head_channels_from: int, head_pool: bool, head_expansion_ratio: int) -> None:
+        stem_kernel_size = tuple(stem_kernel_size)
+        if stem_kernel_size[1] != 4 or stem_kernel_size[2] != 4:
+            raise NotImplementedError("stem_kernel_size must be (k, 4, 4)")
+        ratio = in_stack_depth // stem_kernel_size[0]
+        if dims[0] % ratio != 0:
+            raise ValueError(
+                f"out_channels ({dims[0]}) must be divisible by in_stack_depth // kernel_size[0] ({ratio})"
+            )
+        self.cfg = dict(
+            in_channels=in_channels, out_channels=out_channels, in_stack_depth=in_stack_depth,
+            out_stack_depth=out_stack_depth, depths=tuple(depths), dims=tuple(dims), conv_mlp=conv_mlp,
+            stem_kernel=stem_kernel_size, ratio=ratio, decoder_conv_blocks=decoder_conv_blocks,
+            head_pool=bool(head_pool), head_expansion_ratio=head_expansion_ratio, head=head,
+        )
+        self.encoder_stages = _Encoder(depths, dims, conv_mlp)
+        self.stem = _Stem(in_channels, dims[0] // ratio, stem_kernel_size)
+        dec = list(reversed(dims))
+        if head == "conv":  # PixelToVoxelHead: (D + 2) * C * 2^2 * expansion channels feed the 3-D convolution
+            dec[-1] = (out_stack_depth + 2) * head_channels_from * 4 * head_expansion_ratio
+        else:               # PixelToVoxelShuffleHead: C_out * D * s^2, s = stem XY kernel
+            dec[-1] = out_channels * out_stack_depth * stem_kernel_size[-1] ** 2
+        self.cfg["decoder_channels"] = dec
+        self.decoder = _Decoder(dec, decoder_conv_blocks)
+        if head == "conv":
+            c3 = dec[-1] // 4 // (out_stack_depth + 2)
+            cmid = out_channels * head_expansion_ratio * 4
+            self.head = _Head(c3, cmid, out_channels * 4)
+        else:
+            self.head = _ShuffleHead()
+        self.out_stack_depth = out_stack_depth
+        self.compute_dtype: torch.dtype | None = None
+        self.grad_mode = "autograd"  # or "flat": gradients are written straight into the flat buffer
+        self._engine = None
+        self.reset_parameters()
+
+    # ---- reference-compatible initialisation (timm _init_weights, MONAI normal_init, ICNR, torch Conv3d default)
+    def reset_parameters(self) -> None:
+        def tn(w):
+            nn.init.trunc_normal_(w, std=0.02)
+
+        for name, mod in self.named_modules():
+            if isinstance(mod, _Conv) and (name.startswith("encoder_stages") or name.startswith("decoder")):
+                tn(mod.weight)
+                nn.init.zeros_(mod.bias)
+        w = self.stem.conv.weight  # torch Conv3d default: kaiming_uniform(a=sqrt(5))
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        bound = 1 / math.sqrt(w[0].numel())
+        nn.init.uniform_(self.stem.conv.bias, -bound, bound)
+        for st in self.decoder.decoder_stages:
+            _icnr_(st.conv.blocks[-1].mlp.fc2.weight, 2)
+        if self.cfg["head"] == "conv":
+            nn.init.normal_(self.head.conv[0].conv.weight, 0.0, 0.02)
+            nn.init.zeros_(self.head.conv[0].conv.bias)
+            w = self.head.conv[1].weight
+            _icnr_(w, 2)
+            bound = 1 / math.sqrt(w[0].numel())
+            nn.init.uniform_(self.head.conv[1].bias, -bound, bound)
+
+    # ---- engine plumbing
+    def _resolve_dtype(self) -> torch.dtype:
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            return torch.bfloat16
+        return torch.float32
+
+    def engine(self, ops=None):
+        from .engine_unext2 import Engine
+
+        dev = self.stem.conv.weight.device
+        if self._engine is None or self._engine.device != dev or (ops is not None and self._engine.ops is not ops):
+            self._engine = Engine(self, ops)
+        return self._engine
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None  # parameter storage moves: flat views must be rebuilt
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, x: Tensor) -> Tensor:
+        if not x.is_cuda:
+            raise RuntimeError(
+                f"viscy_amd.{type(self).__name__} runs on MI355X HIP kernels only (no CPU / eager fallback): move the model "
+                "and the input to a 'cuda' (ROCm) device"
+            )
+        L.lib()  # raises loudly when libvsx.so is missing
+        from .engine_unext2 import unext2_apply
+
+        return unext2_apply(self, x)
+
+
+class UNeXt2(_Core):
     """MI355X-native UNeXt2 (see module docstring).  ``compute_dtype``: None → bf16 under
     ``torch.autocast(bfloat16)``, fp32 otherwise; or force ``torch.bfloat16`` / ``torch.float32``."""
 
@@ -200,91 +304,15 @@ class UNeXt2(nn.Module):
             raise NotImplementedError("pretrained timm weights cannot be downloaded here; load a state_dict instead")
         if drop_path_rate:
             raise NotImplementedError("drop_path_rate > 0 is not built")
-        if stem_kernel_size[1] != 4 or stem_kernel_size[2] != 4:
-            raise NotImplementedError("stem_kernel_size must be (k, 4, 4)")
         if out_stack_depth is None:
             out_stack_depth = in_stack_depth
         depths, dims, conv_mlp = CONVNEXTV2_CFGS[backbone]
-        ratio = in_stack_depth // stem_kernel_size[0]
-        if dims[0] % ratio != 0:
-            raise ValueError(
-                f"out_channels ({dims[0]}) must be divisible by in_stack_depth // kernel_size[0] ({ratio})"
-            )
-        self.cfg = dict(
-            in_channels=in_channels, out_channels=out_channels, in_stack_depth=in_stack_depth,
-            out_stack_depth=out_stack_depth, depths=depths, dims=dims, conv_mlp=conv_mlp,
-            stem_kernel=stem_kernel_size, ratio=ratio, decoder_conv_blocks=decoder_conv_blocks,
-            head_pool=bool(head_pool), head_expansion_ratio=head_expansion_ratio,
-        )
-        self.encoder_stages = _Encoder(depths, dims, conv_mlp)
-        self.stem = _Stem(in_channels, dims[0] // ratio, stem_kernel_size)
-        dec = list(reversed(dims))
-        dec[-1] = (out_stack_depth + 2) * out_channels * 4 * head_expansion_ratio
-        self.cfg["decoder_channels"] = dec
-        self.decoder = _Decoder(dec, decoder_conv_blocks)
-        c3 = dec[-1] // 4 // (out_stack_depth + 2)
-        cmid = out_channels * head_expansion_ratio * 4
-        self.head = _Head(c3, cmid, out_channels * 4)
-        self.out_stack_depth = out_stack_depth
-        self.compute_dtype: torch.dtype | None = None
-        self.grad_mode = "autograd"  # or "flat": gradients are written straight into the flat buffer
-        self._engine = None
-        self.reset_parameters()
-
-    # ---- reference-compatible initialisation (timm _init_weights, MONAI normal_init, ICNR, torch Conv3d default)
-    def reset_parameters(self) -> None:
-        def tn(w):
-            nn.init.trunc_normal_(w, std=0.02)
-
-        for name, mod in self.named_modules():
-            if isinstance(mod, _Conv) and (name.startswith("encoder_stages") or name.startswith("decoder")):
-                tn(mod.weight)
-                nn.init.zeros_(mod.bias)
-        w = self.stem.conv.weight  # torch Conv3d default: kaiming_uniform(a=sqrt(5))
-        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
-        bound = 1 / math.sqrt(w[0].numel())
-        nn.init.uniform_(self.stem.conv.bias, -bound, bound)
-        for st in self.decoder.decoder_stages:
-            _icnr_(st.conv.blocks[-1].mlp.fc2.weight, 2)
-        nn.init.normal_(self.head.conv[0].conv.weight, 0.0, 0.02)
-        nn.init.zeros_(self.head.conv[0].conv.bias)
-        w = self.head.conv[1].weight
-        _icnr_(w, 2)
-        bound = 1 / math.sqrt(w[0].numel())
-        nn.init.uniform_(self.head.conv[1].bias, -bound, bound)
+        self._build(in_channels=in_channels, out_channels=out_channels, in_stack_depth=in_stack_depth,
+                    out_stack_depth=out_stack_depth, depths=depths, dims=dims, conv_mlp=conv_mlp,
+                    stem_kernel_size=stem_kernel_size, decoder_conv_blocks=decoder_conv_blocks, head="conv",
+                    head_channels_from=out_channels, head_pool=head_pool, head_expansion_ratio=head_expansion_ratio)
 
     @property
     def num_blocks(self) -> int:
         """2-times downscaling factor of the smallest feature map (reference unext2.py:71-74)."""
         return 6
-
-    # ---- engine plumbing
-    def _resolve_dtype(self) -> torch.dtype:
-        if self.compute_dtype is not None:
-            return self.compute_dtype
-        if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
-            return torch.bfloat16
-        return torch.float32
-
-    def engine(self, ops=None):
-        from .engine_unext2 import Engine
-
-        dev = self.stem.conv.weight.device
-        if self._engine is None or self._engine.device != dev or (ops is not None and self._engine.ops is not ops):
-            self._engine = Engine(self, ops)
-        return self._engine
-
-    def _apply(self, fn, *a, **k):
-        self._engine = None  # parameter storage moves: flat views must be rebuilt
-        return super()._apply(fn, *a, **k)
-
-    def forward(self, x: Tensor) -> Tensor:
-        if not x.is_cuda:
-            raise RuntimeError(
-                "viscy_amd.UNeXt2 runs on MI355X HIP kernels only (no CPU / eager fallback): move the model and the "
-                "input to a 'cuda' (ROCm) device"
-            )
-        L.lib()  # raises loudly when libvsx.so is missing
-        from .engine_unext2 import unext2_apply
-
-        return unext2_apply(self, x)

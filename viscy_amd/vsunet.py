@@ -32,7 +32,10 @@ except Exception:  # noqa: BLE001
     _Base = nn.Module
     _HAVE_LIGHTNING = False
 
-_UNET_ARCHITECTURE = {"UNeXt2": UNeXt2}
+from .fcmae import FullyConvolutionalMAE  # noqa: E402
+
+# cytoland.engine._UNET_ARCHITECTURE (engine.py:36-43): the entries on the accelerated path
+_UNET_ARCHITECTURE = {"UNeXt2": UNeXt2, "fcmae": FullyConvolutionalMAE}
 
 
 def _divisible_pad_amounts(shape_yx: Sequence[int], k: int) -> list[tuple[int, int]]:
@@ -77,7 +80,7 @@ def blend_in(old_stack: Tensor, new_stack: Tensor, z_slice: slice) -> Tensor:
 class VSUNet(_Base):
     def __init__(
         self,
-        architecture: Literal["UNeXt2"] = "UNeXt2",
+        architecture: Literal["UNeXt2", "fcmae"] = "UNeXt2",
         model_config: dict | None = None,
         loss_function: nn.Module | None = None,
         lr: float = 1e-3,
@@ -104,7 +107,7 @@ class VSUNet(_Base):
             raise ValueError(f"Architecture {architecture} not in {_UNET_ARCHITECTURE.keys()} (this build accelerates the "
                              "UNeXt2 path only)")
         if freeze_encoder:
-            raise ValueError("freeze_encoder=True requires a model with an 'encoder' attribute (FCMAE); UNeXt2 has none")
+            raise ValueError("freeze_encoder=True is not built (the fused flat-buffer optimiser updates every parameter)")
         self.model = net_class(**model_config)
         if loss_function is None:
             from .losses import MixedLoss
