@@ -281,6 +281,16 @@ int32_t vsx_intensity_aug(const float* x, float* y, const float* mn, const float
 int32_t vsx_blend_in(const float* oldp, const float* newp, float* out, const float* fz, int32_t Z, int64_t plane,
     int64_t total, vsx_stream_t stream);
 
+/* K23 viscy_transforms.BatchedRandWeightedCropd (_crop.py:263-386): window weights = clamp(sum over (C, Z), 0) summed over
+ * every (cy, cx) window (stride 1) -> wpool [B, (Y-cy+1)*(X-cx+1)]; tmp = caller scratch of B*Y*X + B*Y*(X-cx+1) floats. */
+int32_t vsx_crop_weights(const float* w, float* wpool, float* tmp, int32_t B, int32_t CZ, int32_t Y, int32_t X,
+    int32_t cy, int32_t cx, vsx_stream_t stream);
+/* inverse-CDF draw: idx[b] = smallest i with sum_{j<=i} wpool[b,j] > u[b] * sum_j wpool[b,j]  (uniform when the sum is 0) */
+int32_t vsx_sample_index(const float* wpool, const float* u, int32_t* idx, int32_t B, int64_t n, vsx_stream_t stream);
+/* y[b,c,z,yy,xx] = x[b,c, starts[b][0]+z, starts[b][1]+yy, starts[b][2]+xx]   (starts int32 [B,3] on the device) */
+int32_t vsx_crop3d(const float* x, float* y, const int32_t* starts, int32_t B, int32_t C, int32_t Z, int32_t Y, int32_t X,
+    int32_t cz, int32_t cy, int32_t cx, vsx_stream_t stream);
+
 /* K18 kornia warp_affine3d as used by BatchedRandAffined (viscy_transforms/_affine.py:33-47,358-393): trilinear (or
  * nearest) resampling, zero padding; Minv[B][3][4] maps output-voxel to input-voxel coordinates (x, y, z order). */
 int32_t vsx_warp_affine3d(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,

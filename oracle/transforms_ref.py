@@ -148,3 +148,27 @@ def affine_matrix_zyx(angle_z_deg: Tensor, scale_xyz: Tensor, shape_dhw, shear_x
     ctr[:, 0, 3], ctr[:, 1, 3], ctr[:, 2, 3] = (W - 1) / 2.0, (H - 1) / 2.0, (D - 1) / 2.0
     fwd = ctr @ A @ Sh @ S @ torch.linalg.inv(ctr)  # input → output
     return torch.linalg.inv(fwd)[:, :3]
+
+
+def weighted_crop_window_weights(weight_map: Tensor, crop_yx) -> Tensor:
+    """BatchedRandWeightedCropd._sample_crop_starts, _crop.py:317-333: (B, vy*vx) pooled window weights, all-zero maps -> 1."""
+    import torch.nn.functional as F
+
+    w = weight_map.sum(dim=(1, 2)).clamp(min=0).float()
+    wp = F.avg_pool2d(w.unsqueeze(1), tuple(crop_yx), stride=1)
+    flat = wp.view(wp.shape[0], -1).clone()
+    flat[flat.sum(dim=1) == 0] = 1.0
+    return flat
+
+
+def inverse_cdf_index(weights: Tensor, u: Tensor) -> Tensor:
+    """the draw torch.multinomial(weights, 1) makes, written with explicit uniforms: smallest i with cdf_i > u * total"""
+    cdf = weights.double().cumsum(1)
+    target = u.double().view(-1, 1) * cdf[:, -1:]
+    return torch.searchsorted(cdf, target, right=True).squeeze(1).clamp_max(weights.shape[1] - 1)
+
+
+def crop3d(img: Tensor, z0, y0, x0, size) -> Tensor:
+    """_crop.py:368-384"""
+    cz, cy, cx = size
+    return torch.stack([img[b, :, z0[b] : z0[b] + cz, y0[b] : y0[b] + cy, x0[b] : x0[b] + cx] for b in range(img.shape[0])])

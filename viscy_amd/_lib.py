@@ -89,6 +89,9 @@ _SIGS = {
     "vsx_head_conv_wgrad": (_I32, [_P] * 4 + [_I32] * 7 + [_P]),
     "vsx_head_conv_dgrad_prep": (_I32, [_P, _P, _I32, _P]),
     "vsx_head_conv_dgrad": (_I32, [_P] * 3 + [_I32] * 7 + [_P]),
+    "vsx_crop_weights": (_I32, [_P, _P, _P] + [_I32] * 6 + [_P]),
+    "vsx_sample_index": (_I32, [_P, _P, _P, _I32, _I64, _P]),
+    "vsx_crop3d": (_I32, [_P, _P, _P] + [_I32] * 8 + [_P]),
     "vsx_warp_affine3d": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_conv1d_axis": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
 }

@@ -254,3 +254,137 @@ extern "C" int32_t vsx_conv1d_axis(const float* x, float* y, const float* taps, 
   VSX_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------ K23: BatchedRandWeightedCropd (_crop.py:263-386)
+// (1) w2[b, y, x] = max(sum_{c, z} w[b, c, z, y, x], 0)
+__global__ __launch_bounds__(256) void weight_map_yx_kernel(const float* __restrict__ w, float* __restrict__ out, int B, int CZ,
+                                                            long plane4) {
+  const long total = (long)B * plane4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / plane4, p = i - b * plane4;
+    const float4* src = reinterpret_cast<const float4*>(w) + (size_t)b * CZ * plane4 + p;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < CZ; ++k) {
+      const float4 v = src[(size_t)k * plane4];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+    reinterpret_cast<float4*>(out)[i] = a;
+  }
+}
+// (2) window sums, separable: rows (window cx along x) then columns (window cy along y); double running sums
+__global__ __launch_bounds__(256) void box_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int X, int cx) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const float* a = in + (size_t)r * X;
+  float* o = out + (size_t)r * (X - cx + 1);
+  double s = 0.0;
+  for (int x = 0; x < cx; ++x) s += a[x];
+  o[0] = (float)s;
+  for (int x = 1; x + cx <= X; ++x) {
+    s += (double)a[x + cx - 1] - (double)a[x - 1];
+    o[x] = (float)s;
+  }
+}
+__global__ __launch_bounds__(256) void box_cols_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int Y, int vx, int cy) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (b, x)
+  if (i >= (long)B * vx) return;
+  const int b = (int)(i / vx), x = (int)(i % vx);
+  const float* a = in + (size_t)b * Y * vx + x;
+  float* o = out + (size_t)b * (Y - cy + 1) * vx + x;
+  double s = 0.0;
+  for (int y = 0; y < cy; ++y) s += a[(size_t)y * vx];
+  o[0] = (float)s;
+  for (int y = 1; y + cy <= Y; ++y) {
+    s += (double)a[(size_t)(y + cy - 1) * vx] - (double)a[(size_t)(y - 1) * vx];
+    o[(size_t)y * vx] = (float)s;
+  }
+}
+// (3) inverse-CDF draw per sample: smallest i with sum_{j <= i} wp[b, j] > u[b] * total  (uniform over n when total == 0)
+__global__ __launch_bounds__(256) void sample_index_kernel(const float* __restrict__ wp, const float* __restrict__ u, int* __restrict__ idx,
+                                                           long n) {
+  __shared__ double part[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* a = wp + (size_t)b * n;
+  const long chunk = (n + 255) / 256;
+  const long lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  double s = 0.0;
+  for (long i = lo; i < hi; ++i) s += a[i];
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    double total = 0.0;
+    for (int k = 0; k < 256; ++k) total += part[k];
+    long pick;
+    if (total <= 0.0) {
+      pick = (long)((double)u[b] * (double)n);
+    } else {
+      const double target = (double)u[b] * total;
+      double c = 0.0;
+      int k = 0;
+      while (k < 255 && c + part[k] <= target) c += part[k++];
+      long i = k * chunk;
+      const long e = i + chunk < n ? i + chunk : n;
+      pick = e - 1;
+      for (; i < e; ++i) {
+        c += a[i];
+        if (c > target) { pick = i; break; }
+      }
+    }
+    if (pick >= n) pick = n - 1;
+    if (pick < 0) pick = 0;
+    idx[b] = (int)pick;
+  }
+}
+// (4) crop gather: y[b, c, z, yy, xx] = x[b, c, z0[b] + z, y0[b] + yy, x0[b] + xx]
+__global__ __launch_bounds__(256) void crop3d_kernel(const float* __restrict__ x, float* __restrict__ y, const int* __restrict__ starts,
+                                                     int B, int C, int Z, int Y, int X, int cz, int cy, int cx) {
+  const long total = (long)B * C * cz * cy * cx;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int xx = (int)(i % cx);
+    long r = i / cx;
+    const int yy = (int)(r % cy); r /= cy;
+    const int zz = (int)(r % cz); r /= cz;
+    const int c = (int)(r % C);
+    const int b = (int)(r / C);
+    const int z0 = starts[3 * b], y0 = starts[3 * b + 1], x0 = starts[3 * b + 2];
+    y[i] = x[((((size_t)b * C + c) * Z + z0 + zz) * Y + y0 + yy) * X + x0 + xx];
+  }
+}
+
+/* K23 pieces of viscy_transforms.BatchedRandWeightedCropd (_crop.py:263-386): the pooled window weights the reference
+ * computes with sum(dim=(1,2)).clamp(min=0) + F.avg_pool2d((cy, cx), stride 1) (here: window SUMS — the same distribution),
+ * an inverse-CDF draw per sample from caller-supplied uniforms (torch.multinomial's stream cannot be reproduced), and the
+ * crop gather.  wpool: [B, (Y-cy+1)*(X-cx+1)]; tmp: B*Y*(X-cx+1) + B*Y*X floats of caller-owned scratch. */
+extern "C" int32_t vsx_crop_weights(const float* w, float* wpool, float* tmp, int32_t B, int32_t CZ, int32_t Y, int32_t X,
+                                    int32_t cy, int32_t cx, vsx_stream_t stream) {
+  VSX_CHECK(w && wpool && tmp && B > 0 && CZ > 0 && Y >= cy && X >= cx && cy > 0 && cx > 0 && ((long)Y * X) % 4 == 0,
+            "vsx_crop_weights: bad arguments (Y*X must be a multiple of 4, crop inside the image)");
+  float* w2 = tmp;                              // [B, Y, X]
+  float* rows = tmp + (size_t)B * Y * X;        // [B, Y, X - cx + 1]
+  const long plane4 = (long)Y * X / 4;
+  int g = vsx_cdiv((long)B * plane4, 256);
+  if (g > 32768) g = 32768;
+  hipLaunchKernelGGL(weight_map_yx_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, w, w2, B, CZ, plane4);
+  hipLaunchKernelGGL(box_rows_kernel, dim3(vsx_cdiv((long)B * Y, 256)), dim3(256), 0, (hipStream_t)stream, w2, rows, B * Y, X, cx);
+  hipLaunchKernelGGL(box_cols_kernel, dim3(vsx_cdiv((long)B * (X - cx + 1), 256)), dim3(256), 0, (hipStream_t)stream, rows, wpool, B, Y,
+                     X - cx + 1, cy);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int32_t vsx_sample_index(const float* wpool, const float* u, int32_t* idx, int32_t B, int64_t n, vsx_stream_t stream) {
+  VSX_CHECK(wpool && u && idx && B > 0 && n > 0, "vsx_sample_index: bad arguments");
+  hipLaunchKernelGGL(sample_index_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, wpool, u, idx, (long)n);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int32_t vsx_crop3d(const float* x, float* y, const int32_t* starts, int32_t B, int32_t C, int32_t Z, int32_t Y, int32_t X,
+                              int32_t cz, int32_t cy, int32_t cx, vsx_stream_t stream) {
+  VSX_CHECK(x && y && starts && B > 0 && C > 0 && cz > 0 && cy > 0 && cx > 0 && cz <= Z && cy <= Y && cx <= X, "vsx_crop3d: bad arguments");
+  long total = (long)B * C * cz * cy * cx;
+  int g = vsx_cdiv(total, 256);
+  if (g > 65536) g = 65536;
+  hipLaunchKernelGGL(crop3d_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, starts, B, C, Z, Y, X, cz, cy, cx);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

@@ -390,3 +390,75 @@ class BatchedRandAffined(_BatchedRand):
             if k in sample:
                 sample[k] = warp_affine3d(sample[k], Minv, self.mode)
         return sample
+
+
+# ------------------------------------------------------------------------------------------------
+# K23 BatchedRandWeightedCropd (_crop.py:263-386)
+# ------------------------------------------------------------------------------------------------
+def crop3d(x: Tensor, starts: Tensor, size: Sequence[int]) -> Tensor:
+    """per-sample (Z, Y, X) crops of a (B, C, Z, Y, X) batch at ``starts`` (B, 3) — one gather launch"""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 5):
+        raise RuntimeError("viscy_amd GPU augmentations need a contiguous float32 (B,C,Z,Y,X) batch on the HIP device (no CPU fallback)")
+    B, C, Z, Y, X = x.shape
+    cz, cy, cx = (int(v) for v in size)
+    st = starts.to(x.device, torch.int32).contiguous()
+    y = torch.empty((B, C, cz, cy, cx), dtype=torch.float32, device=x.device)
+    check(lib().vsx_crop3d(ptr(x), ptr(y), ptr(st), B, C, Z, Y, X, cz, cy, cx, stream()), "crop3d")
+    return y
+
+
+class BatchedRandWeightedCropd(_BatchedRand):
+    """Crop positions drawn with probability proportional to the weight map summed over each candidate window; every key
+    is cropped at the same per-sample position.  ``params=(z_starts, y_starts, x_starts)`` injects the positions;
+    ``uniforms=(u_yx, u_z)`` injects the random numbers of the inverse-CDF draw (torch.multinomial's stream cannot be
+    reproduced)."""
+
+    is_spatial = True
+
+    def __init__(self, keys, w_key: str, spatial_size: Sequence[int], allow_missing_keys: bool = False):
+        super().__init__(keys, 1.0)
+        self.w_key, self._spatial_size = w_key, tuple(int(v) for v in spatial_size)
+        self.allow_missing_keys = allow_missing_keys
+
+    def sample_crop_starts(self, weight_map: Tensor, uniforms=None):
+        if not _gpu_ok(weight_map) or weight_map.ndim != 5:
+            raise RuntimeError("viscy_amd GPU augmentations need a contiguous float32 (B,C,Z,Y,X) batch on the HIP device (no CPU fallback)")
+        B, C, Z, Y, X = weight_map.shape
+        cz, cy, cx = self._spatial_size
+        dev = weight_map.device
+        vy, vx = Y - cy + 1, X - cx + 1
+        wpool = torch.empty((B, vy * vx), dtype=torch.float32, device=dev)
+        tmp = torch.empty(B * Y * X + B * Y * vx, dtype=torch.float32, device=dev)
+        check(lib().vsx_crop_weights(ptr(weight_map), ptr(wpool), ptr(tmp), B, C * Z, Y, X, cy, cx, stream()), "crop_weights")
+        u_yx, u_z = uniforms if uniforms is not None else (self._rand(B), self._rand(B))
+        u_d = u_yx.to(dev, torch.float32).contiguous()
+        idx = torch.empty(B, dtype=torch.int32, device=dev)
+        check(lib().vsx_sample_index(ptr(wpool), ptr(u_d), ptr(idx), B, vy * vx, stream()), "sample_index")
+        idx = idx.long()
+        y_starts, x_starts = idx // vx, idx % vx
+        if cz >= Z:
+            z_starts = torch.zeros(B, dtype=torch.long, device=dev)
+        else:
+            z_starts = (u_z.to(dev).double() * (Z - cz + 1)).long().clamp_(0, Z - cz)
+        return z_starts, y_starts, x_starts
+
+    def __call__(self, sample: dict, params=None, uniforms=None) -> dict:
+        d = dict(sample)
+        wm = d[self.w_key]
+        if wm.ndim != 5:
+            raise ValueError(f"BatchedRandWeightedCropd requires 5D input (B, C, Z, Y, X), got {wm.ndim}D.")
+        _, _, Z, Y, X = wm.shape
+        cz, cy, cx = self._spatial_size
+        if cz > Z:
+            raise ValueError(f"spatial_size Z ({cz}) exceeds input Z ({Z}).")
+        if cy > Y or cx > X:
+            raise ValueError(f"spatial_size YX ({cy}, {cx}) exceeds input YX ({Y}, {X}).")
+        z0, y0, x0 = params if params is not None else self.sample_crop_starts(wm, uniforms)
+        starts = torch.stack([torch.as_tensor(z0), torch.as_tensor(y0), torch.as_tensor(x0)], dim=1)
+        for k in self.keys:
+            if k not in d:
+                if self.allow_missing_keys:
+                    continue
+                raise KeyError(k)
+            d[k] = crop3d(d[k], starts, self._spatial_size)
+        return d
