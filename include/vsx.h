@@ -141,6 +141,21 @@ int32_t vsx_voxel_shuffle_fwd(const void* feat, float* out, int32_t B, int32_t h
 int32_t vsx_voxel_shuffle_bwd(const float* dout, void* dfeat, int32_t B, int32_t h, int32_t w, int32_t Cout, int32_t D,
     int32_t s, int32_t pool, int32_t dtype, vsx_stream_t stream);
 
+/* FCMAE masked pre-training.  masked_patchify / masked_unpatchify / `x *= unmasked`
+ * (viscy_models/unet/fcmae.py:95-141,216-226) on channels-last row matrices, as one row permutation:
+ *   dst[r,:] = map[r] >= 0 ? src[map[r],:] (+ add[r,:] when add != NULL) : 0        r < n_out; rows of C elements (dtype)
+ * gather: map = dense row per kept token; scatter: map = compact row per dense row or -1 (zero fill); mask: map[r] = r or -1. */
+int32_t vsx_rows_select(const void* src, const int32_t* map, const void* add, void* dst, int64_t n_out, int32_t C,
+    int32_t dtype, vsx_stream_t stream);
+
+/* cytoland.engine.MaskedMSELoss.forward (applications/cytoland/src/cytoland/engine.py:104-125):
+ *   loss = sum(mask * mean_z (pred - orig)^2) / sum(mask);  pred / orig fp32 (B,C,Z,H,W), mask uint8 (B,1,H,W), H*W % 4 == 0.
+ * acc: 2 floats of scratch kept for the backward {sum mask*(p-o)^2, sum(mask)}; dpred = gout * d loss / d pred. */
+int32_t vsx_masked_mse_fwd(const float* pred, const float* orig, const uint8_t* mask, float* acc, float* loss, int32_t B,
+    int32_t C, int32_t Z, int64_t HW, vsx_stream_t stream);
+int32_t vsx_masked_mse_bwd(const float* pred, const float* orig, const uint8_t* mask, const float* acc, const float* gout,
+    float* dpred, int32_t B, int32_t C, int32_t Z, int64_t HW, vsx_stream_t stream);
+
 /* K13 (norm+act) + K14: MONAI Convolution ADN (InstanceNorm3d eps 1e-5 → PReLU) → nn.Conv3d(mid, 4*out, 1) → transpose /
  * nn.PixelShuffle(2) / transpose (viscy_models/components/heads.py:617-625,638-641).  U: [B,H2,W2,Z,Cmid] conv output;
  * ssum/ssq: [B,Cmid] from the conv GEMM epilogue (VSX_EPI_BIAS_STATS); out: (B, Cout, Z, 2*H2, 2*W2) fp32. */

@@ -1,7 +1,8 @@
-"""TEST INFRASTRUCTURE — CPU restatement (plain torch, fp32) of the DENSE path of the reference's FCMAE U-Net:
-``viscy_models.unet.fcmae.FullyConvolutionalMAE`` with ``mask_ratio = 0`` (no sparse masking), i.e. the network behind
-``cytoland.engine.FcmaeUNet`` for fine-tuning / inference and the architecture of the published VSCyto3D checkpoint
-(/root/reference/applications/cytoland/tests/test_inference_reproducibility.py:55-64).
+"""TEST INFRASTRUCTURE — CPU restatement (plain torch, fp32) of the reference's FCMAE U-Net:
+``viscy_models.unet.fcmae.FullyConvolutionalMAE``, dense (``mask_ratio = 0``: the network behind
+``cytoland.engine.FcmaeUNet`` for fine-tuning / inference and the architecture of the published VSCyto3D checkpoint,
+/root/reference/applications/cytoland/tests/test_inference_reproducibility.py:55-64) and masked (``mask_ratio > 0``:
+self-supervised pre-training with ``MaskedMSELoss``, engine.py:104-125).
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this package.
 
@@ -16,8 +17,16 @@ Follows /root/reference/packages/viscy-models/src/viscy_models/unet/fcmae.py:
     ``UNeXt2Decoder`` (3 stages, pixel shuffle x2, ConvNeXt conv_mlp blocks) -> ``PixelToVoxelShuffleHead``
     (components/heads.py:656-685: pixel shuffle x xy_scaling + pad-pool, channels -> (C_out, D)) or ``PixelToVoxelHead``.
 
+  * masking (:40-141): ``generate_mask`` (one random low-resolution mask per sample with exactly ``int(n * ratio)`` masked
+    cells), ``upsample_mask`` (nearest, integer factor), ``masked_patchify`` / ``masked_unpatchify`` (keep only the
+    unmasked tokens, row-major; scatter back into zeros).  With a mask every block computes
+    ``x <- x * unmasked`` (in place — the identity shortcut aliases ``x``, so the shortcut is masked as well),
+    dwconv, LayerNorm + GRN-MLP **on the unmasked tokens only** (the GRN statistics see L = (1 - ratio)·HW tokens),
+    zero-filled scatter, + shortcut.
+
 Pinned by ``oracle/validate_against_reference.py::g9_fcmae`` (the reference's own fcmae.py executed on stubbed timm /
-monai modules == this file, exactly, incl. the state-dict key list) -> ``tests/golden/fcmae_forward.pt``.
+monai modules == this file, exactly, incl. the state-dict key list and the masked path with the reference's own
+``generate_mask`` draw) -> ``tests/golden/fcmae_forward.pt``, ``tests/golden/fcmae_masked.pt``.
 timm's ``GlobalResponseNormMlp`` / ``create_conv2d`` internals are not in /root/reference: restated as in unext2_ref.py.
 """
 
@@ -46,6 +55,50 @@ def _init_weights(module: nn.Module) -> None:
         nn.init.zeros_(module.bias)
 
 
+def generate_mask(target, stride: int, mask_ratio: float, device="cpu") -> Tensor:
+    """fcmae.py:40-66: (B, 1, H/stride, W/stride) bool, True = masked; exactly int(n * ratio) cells per sample."""
+    mh, mw = target[-2] // stride, target[-1] // stride
+    n = mh * mw
+    k = int(n * mask_ratio)
+    return (torch.rand(target[0], n, device=device).argsort(1) < k).reshape(target[0], 1, mh, mw)
+
+
+def upsample_mask(mask: Tensor, target) -> Tensor:
+    """fcmae.py:69-92: nearest-neighbour integer upsampling of a (B,1,h,w) mask to the (..., H, W) of ``target``."""
+    if tuple(target[-2:]) != tuple(mask.shape[-2:]):
+        if target[-2] % mask.shape[-2] or target[-1] % mask.shape[-1]:
+            raise ValueError(f"feature map shape {tuple(target)} must be divisible by mask shape {tuple(mask.shape)}.")
+        mask = mask.repeat_interleave(target[-2] // mask.shape[-2], dim=-2).repeat_interleave(target[-1] // mask.shape[-1], dim=-1)
+    return mask
+
+
+def _tokens(x: Tensor, unmasked: Tensor | None) -> Tensor:
+    """masked_patchify, fcmae.py:95-117: (B,C,H,W) -> (B, L, C), only the unmasked positions (row-major) when a mask is given."""
+    b, c = x.shape[:2]
+    t = x.permute(0, 2, 3, 1)
+    if unmasked is None:
+        return t.reshape(b, -1, c)
+    return t[unmasked[:, 0]].reshape(b, -1, c)
+
+
+def _untokens(t: Tensor, shape, unmasked: Tensor | None) -> Tensor:
+    """masked_unpatchify, fcmae.py:120-141: back to (B,C,H,W); masked positions are zero."""
+    b, c, h, w = shape
+    if unmasked is None:
+        return t.reshape(b, h, w, c).permute(0, 3, 1, 2)
+    out = torch.zeros((b, h, w, c), dtype=t.dtype, device=t.device)
+    out[unmasked[:, 0]] = t.reshape(-1, c)
+    return out.permute(0, 3, 1, 2)
+
+
+class MaskedMSELoss(nn.Module):
+    """cytoland engine.py:104-125: mean over Z of the squared error, summed over masked pixels / number of masked pixels."""
+
+    def forward(self, preds: Tensor, original: Tensor, mask: Tensor) -> Tensor:
+        se = (preds - original) ** 2
+        return (se.mean(2) * mask).sum() / mask.sum()
+
+
 class MaskedConvNeXtV2Block(nn.Module):
     def __init__(self, channels: int, kernel_size: int = 7, mlp_ratio: int = 4):
         super().__init__()
@@ -55,15 +108,15 @@ class MaskedConvNeXtV2Block(nn.Module):
         self.drop_path = nn.Identity()
         self.shortcut = nn.Identity()
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, unmasked: Tensor | None = None) -> Tensor:
+        if unmasked is not None:
+            x = x * unmasked                        # in place in the reference: the (identity) shortcut is masked too
         shortcut = x
         x = self.dwconv(x)
-        b, c, h, w = x.shape
-        x = x.flatten(2).permute(0, 2, 1)           # masked_patchify(unmasked=None): (B, HW, C)
-        x = self.layernorm(x)
-        x = self.mlp(x.unsqueeze(1)).squeeze(1)     # GRN statistics over the (1, HW) "spatial" axes = over all pixels
-        x = x.permute(0, 2, 1).reshape(b, c, h, w)  # masked_unpatchify
-        return x + shortcut
+        t = _tokens(x, unmasked)                    # (B, L, C); L = HW without a mask
+        t = self.layernorm(t)
+        t = self.mlp(t.unsqueeze(1)).squeeze(1)     # GRN statistics over the (1, L) "spatial" axes = over the kept tokens
+        return _untokens(t, x.shape, unmasked) + shortcut
 
 
 class MaskedConvNeXtV2Stage(nn.Module):
@@ -76,10 +129,12 @@ class MaskedConvNeXtV2Stage(nn.Module):
             self.downsample = nn.Identity()
         self.blocks = nn.ModuleList([MaskedConvNeXtV2Block(out_channels) for _ in range(num_blocks)])
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, unmasked: Tensor | None = None) -> Tensor:
         x = self.downsample(x)
+        if unmasked is not None:
+            unmasked = upsample_mask(unmasked, x.shape)
         for blk in self.blocks:
-            x = blk(x)
+            x = blk(x, unmasked)
         return x
 
 
@@ -92,16 +147,16 @@ class MaskedAdaptiveProjection(nn.Module):
         self.conv2d = nn.Conv2d(in_channels, out_channels, kernel_size_2d, stride=kernel_size_2d)
         self.norm = nn.LayerNorm(out_channels)
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, unmasked: Tensor | None = None) -> Tensor:
         if x.shape[2] > 1:
             x = self.conv3d(x)
             b, c, d, h, w = x.shape
             x = x.reshape(b, c * d, h, w)
         else:
             x = self.conv2d(x.squeeze(2))
-        b, c, h, w = x.shape
-        x = self.norm(x.flatten(2).permute(0, 2, 1))
-        return x.permute(0, 2, 1).reshape(b, c, h, w)
+        if unmasked is not None:
+            unmasked = upsample_mask(unmasked, x.shape)
+        return _untokens(self.norm(_tokens(x, unmasked)), x.shape, unmasked)
 
 
 class MaskedMultiscaleEncoder(nn.Module):
@@ -115,13 +170,21 @@ class MaskedMultiscaleEncoder(nn.Module):
         self.total_stride = stem_kernel_size[1] * 2 ** (len(self.stages) - 1)
         self.apply(_init_weights)
 
-    def forward(self, x: Tensor) -> list[Tensor]:
-        x = self.stem(x)
+    def forward(self, x: Tensor, mask_ratio: float = 0.0, mask: Tensor | None = None):
+        """``mask`` (B,1,H/stride,W/stride) injects the draw ``generate_mask`` would make (tests); returns (features, mask at
+        input resolution or None)."""
+        unmasked = None
+        if mask is None and mask_ratio > 0.0:
+            mask = generate_mask(x.shape, self.total_stride, mask_ratio, x.device)
+        if mask is not None:
+            unmasked = ~mask
+            mask = upsample_mask(mask, x.shape)
+        x = self.stem(x)  # fcmae.py:441: the stem is called WITHOUT the mask (its LayerNorm is per token; stage 0 masks next)
         feats = []
         for st in self.stages:
-            x = st(x)
+            x = st(x, unmasked)
             feats.append(x)
-        return feats
+        return feats, mask
 
 
 class PixelToVoxelShuffleHead(nn.Module):
@@ -162,10 +225,8 @@ class FullyConvolutionalMAE(nn.Module):
         self.num_blocks = len(dims) * int(math.log2(stem_kernel_size[-1]))
         self.pretraining = pretraining
 
-    def forward(self, x: Tensor, mask_ratio: float = 0.0):
-        if mask_ratio > 0.0:
-            raise NotImplementedError("the oracle restates the dense path only")
-        feats = self.encoder(x)
+    def forward(self, x: Tensor, mask_ratio: float = 0.0, mask: Tensor | None = None):
+        feats, mask = self.encoder(x, mask_ratio, mask)
         feats.reverse()
         x = self.head(self.decoder(feats))
-        return (x, None) if self.pretraining else x
+        return (x, mask) if self.pretraining else x

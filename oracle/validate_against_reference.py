@@ -351,6 +351,51 @@ def g9_fcmae():
         print(f"G9 fcmae {tag}: reference dense forward on stubbed timm/monai == oracle (exact); keys={len(o.state_dict())}")
     torch.save(golden, os.path.join(GOLD, "fcmae_forward.pt"))
 
+    # ---- masked pre-training path: the reference draws the mask (generate_mask, fcmae.py:40-66); the oracle gets the same
+    # low-resolution mask injected.  MaskedMSELoss is cut out of cytoland/engine.py (the module itself needs lightning).
+    import ast
+
+    eng_src = open(f"{os.path.dirname(REF)}/applications/cytoland/src/cytoland/engine.py").read()
+    node = next(n for n in ast.parse(eng_src).body if isinstance(n, ast.ClassDef) and n.name == "MaskedMSELoss")
+    ns = {"nn": nn, "F": torch.nn.functional, "torch": torch}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "cytoland/engine.py::MaskedMSELoss", "exec"), ns)
+    ref_loss = ns["MaskedMSELoss"]()
+    masked = {}
+    for tag, kw, hw, ratio in [
+        ("small_z5_r50", dict(in_channels=1, out_channels=1, encoder_blocks=[1, 1, 2, 1], dims=[16, 32, 64, 128], in_stack_depth=5,
+                              decoder_conv_blocks=1, pretraining=True), 96, 0.5),
+        ("two_ch_r75", dict(in_channels=2, out_channels=2, encoder_blocks=[2, 2, 2, 2], dims=[24, 48, 96, 192], in_stack_depth=5,
+                            decoder_conv_blocks=1, pretraining=True), 96, 0.75),
+    ]:
+        r = ref.FullyConvolutionalMAE(**kw)
+        o = F.FullyConvolutionalMAE(**kw)
+        R.randomize_(o, seed=12)
+        r.load_state_dict(o.state_dict(), strict=True)
+        g = torch.Generator().manual_seed(44)
+        x = torch.randn((2, kw["in_channels"], kw["in_stack_depth"], hw, hw + 32), generator=g)
+        torch.manual_seed(5)
+        yr, mask_r = r(x, mask_ratio=ratio)
+        lr_ = ref_loss(yr, x, mask_r)
+        lr_.backward()
+        stride = r.encoder.total_stride
+        low = mask_r[:, :, ::stride, ::stride].clone()
+        assert torch.equal(F.upsample_mask(low, x.shape), mask_r)
+        yo, mask_o = o(x, mask=low)
+        lo = F.MaskedMSELoss()(yo, x, mask_o)
+        lo.backward()
+        assert torch.equal(mask_o, mask_r) and maxrel(yo, yr) == 0.0 and lo.item() == lr_.item(), tag
+        gr = dict(r.named_parameters())
+        worst = max(maxrel(p.grad, gr[n].grad) for n, p in o.named_parameters() if n != "encoder.stem.conv2d.weight"
+                    and n != "encoder.stem.conv2d.bias")
+        assert worst < 1e-6, (tag, worst)
+        keep = ["encoder.stem.conv3d.weight", "encoder.stages.0.blocks.0.mlp.fc1.weight", "encoder.stages.2.blocks.1.mlp.grn.weight",
+                "encoder.stages.3.blocks.0.dwconv.weight", "decoder.decoder_stages.0.conv.blocks.0.mlp.fc2.weight"]
+        masked[tag] = {"kwargs": kw, "seed": 12, "x_seed": 44, "x_shape": tuple(x.shape), "mask_ratio": ratio, "mask_low": low,
+                       "y": yr.detach(), "loss": lr_.item(), "grads": {n: gr[n].grad.clone() for n in keep}}
+        print(f"G9 fcmae masked {tag}: reference masked forward / MaskedMSELoss == oracle (exact), grads {worst:.1e}; "
+              f"masked fraction {mask_r.float().mean():.3f}")
+    torch.save(masked, os.path.join(GOLD, "fcmae_masked.pt"))
+
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -366,6 +366,15 @@ def scale_weight_samples(W, s, dtype):
     return (W.detach().float().reshape(W.shape[0], -1)[None, :, :] * s.float()[:, None, :]).to(dtype)
 
 
+def rows_select(src, row_map, n_out, C, add=None):
+    m = row_map.long()
+    out = src[m.clamp_min(0)].clone()
+    if add is not None:
+        out = (out.float() + add.float()).to(src.dtype)
+    out[m < 0] = 0
+    return out
+
+
 def voxel_shuffle_fwd(feat, B, h, w, Cout, D, s, pool):
     import torch.nn.functional as F
 

@@ -400,3 +400,119 @@ def test_fcmae_vscyto3d_bf16_tracks_fp32_and_trains():
         opt.step()
         losses.append(loss.item())
     assert all(l == l for l in losses) and min(losses[5:]) < losses[0], losses
+
+
+# ------------------------------------------------------------------------------------------------ FCMAE masked pre-training (§8 f2)
+def _masked_pair(tag, dtype):
+    from oracle import fcmae_ref
+    from viscy_amd.fcmae import FullyConvolutionalMAE
+
+    g = load_golden("fcmae_masked.pt")[tag]
+    kw = g["kwargs"]
+    ref = unext2_ref.randomize_(fcmae_ref.FullyConvolutionalMAE(**kw), seed=g["seed"])
+    mine = FullyConvolutionalMAE(**kw)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.cuda()
+    mine.compute_dtype = dtype
+    x = torch.randn(g["x_shape"], generator=torch.Generator().manual_seed(g["x_seed"]))
+    return g, ref, mine, x
+
+
+@pytest.mark.parametrize("tag", ["small_z5_r50", "two_ch_r75"])
+def test_fcmae_masked_matches_reference_golden_fp32(tag):
+    """masked forward, MaskedMSELoss value and parameter gradients vs the REFERENCE's own run (generate_mask draw, fcmae.py
+    masked path, cytoland MaskedMSELoss; oracle/validate_against_reference.py G9) — the same mask is injected."""
+    from viscy_amd.losses import MaskedMSELoss
+
+    g, ref, mine, x = _masked_pair(tag, torch.float32)
+    xc = x.cuda()
+    y, mask = mine(xc, mask=g["mask_low"].cuda())
+    assert mask.dtype == torch.bool and tuple(mask.shape) == (x.shape[0], 1, x.shape[-2], x.shape[-1])
+    assert abs(mask.float().mean().item() - g["mask_ratio"]) < 1e-6
+    assert relerr(y, g["y"]) <= 1e-3
+    loss = MaskedMSELoss()(y, xc, mask)
+    assert abs(loss.item() - g["loss"]) <= 1e-4 * abs(g["loss"])
+    loss.backward()
+    named = dict(mine.named_parameters())
+    for name, gg in g["grads"].items():
+        assert relerr(named[name].grad, gg) <= 2e-3, name
+
+
+def test_fcmae_masked_all_gradients_vs_oracle_fp32():
+    from oracle import fcmae_ref
+    from viscy_amd.losses import MaskedMSELoss
+
+    g, ref, mine, x = _masked_pair("two_ch_r75", torch.float32)
+    low = g["mask_low"]
+    y, mask = ref(x, mask=low)
+    fcmae_ref.MaskedMSELoss()(y, x, mask).backward()
+    out, m2 = mine(x.cuda(), mask=low.cuda())
+    assert torch.equal(m2.cpu(), mask)
+    MaskedMSELoss()(out, x.cuda(), m2).backward()
+    worst = 0.0
+    for (name, pr), (n2, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert name == n2
+        if pr.grad is None:
+            continue
+        e = relerr(pm.grad, pr.grad)
+        worst = max(worst, e)
+        assert e <= 2e-3, (name, e)
+    print("fcmae masked worst relative gradient error", worst)
+
+
+def test_fcmae_generated_mask_properties_and_bf16():
+    """mask_ratio path: exactly int(n * ratio) cells hidden per sample at stride 32; the kept tokens of a bf16 run track the
+    fp32 oracle fed the same mask; masked encoder inputs do not influence the prediction (the encoder never sees them)."""
+    from oracle import fcmae_ref
+
+    g, ref, mine, x = _masked_pair("small_z5_r50", torch.bfloat16)
+    xc = x.cuda()
+    torch.manual_seed(3)
+    with torch.no_grad():
+        y, mask = mine(xc, mask_ratio=0.6)
+    B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+    n = (H // 32) * (W // 32)
+    cells = mask[:, 0, ::32, ::32]
+    assert torch.equal(cells.repeat_interleave(32, 1).repeat_interleave(32, 2), mask[:, 0])
+    assert cells.flatten(1).sum(1).tolist() == [int(n * 0.6)] * B
+    with torch.no_grad():
+        yr, mr = ref(x, mask=cells.unsqueeze(1).cpu())
+    assert torch.equal(mr, mask.cpu())
+    torch.testing.assert_close(y.cpu(), yr, rtol=2e-2, atol=0.03 * yr.abs().max().item())
+    # hidden voxels are invisible to the network
+    x2 = torch.where(mask.unsqueeze(2), torch.randn_like(xc), xc)
+    with torch.no_grad():
+        y2, _ = mine(x2, mask=cells.unsqueeze(1))
+    torch.testing.assert_close(y2, y, rtol=0, atol=0.01 * y.abs().max().item())  # run-to-run bf16 noise only
+
+
+def test_fcmae_unet_pretraining_steps_reduce_the_masked_loss():
+    """cytoland FcmaeUNet pre-training recipe: fit_mask_ratio 0.5, MaskedMSELoss, fused AdamW, bf16."""
+    from viscy_amd.losses import MaskedMSELoss, MixedLoss
+    from viscy_amd.vsunet import FcmaeUNet
+
+    kw = dict(in_channels=1, out_channels=1, encoder_blocks=[2, 2, 2, 2], dims=[32, 64, 128, 256], decoder_conv_blocks=1,
+              in_stack_depth=5, pretraining=True)
+    with pytest.raises(ValueError, match="requires ckpt_path"):
+        FcmaeUNet(encoder_only=True, model_config=kw)
+    bad = FcmaeUNet(fit_mask_ratio=0.5, model_config=kw, loss_function=MixedLoss())
+    with pytest.raises(ValueError, match="MaskedMSELoss is required"):
+        bad.on_fit_start()
+    vs = FcmaeUNet(fit_mask_ratio=0.5, model_config=kw, loss_function=MaskedMSELoss(), lr=1e-3).cuda()
+    vs.on_fit_start()
+    vs.model.compute_dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(4)
+    base = torch.nn.functional.avg_pool3d(torch.randn(4, 1, 5, 128, 128, generator=g), (1, 9, 9), 1, (0, 4, 4)).cuda() * 4
+    opt = vs.configure_optimizers(t_total=30)
+    losses = []
+    for i in range(30):
+        opt.zero_grad()
+        loss = vs.training_step([{"source": base[:2]}, {"source": base[2:]}], i)  # a CombinedLoader-style list of batches
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(l == l for l in losses)
+    assert sum(losses[-5:]) / 5 < 0.8 * sum(losses[:5]) / 5, losses
+    with torch.no_grad():
+        vs.validation_step({"source": base}, 0)
+    assert len(vs.validation_losses[0]) == 1

@@ -571,3 +571,48 @@ def test_prep_unprep_adamw():
         hyper = torch.tensor([1e-2, 0.9, 0.999, 1e-8, 0.01, 1 - 0.9**t, 1 - 0.999**t, 1.0]).to(DEV)
         H.adamw(p, gr.to(DEV), m, v, hyper)
     close(p, pt.detach(), torch.float32, "adamw")
+
+
+# ---------------------------------------------------------------- FCMAE masked pre-training pieces (csrc/mae.hip)
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("C", [96, 40, 6, 3])
+def test_rows_select_gather_scatter_mask(dt, C):
+    """masked_patchify / masked_unpatchify / `x *= unmasked` as one row permutation; every vector width (16/8/4/2-byte rows)."""
+    H = _hip()
+    n, k = 1000, 380
+    g = torch.Generator().manual_seed(C)
+    src = rnd(n, C, dt=dt, seed=1)
+    kept = torch.randperm(n, generator=g)[:k].sort().values.int()
+    inv = torch.full((n,), -1, dtype=torch.int32)
+    inv[kept.long()] = torch.arange(k, dtype=torch.int32)
+    keep = torch.where(inv >= 0, torch.arange(n, dtype=torch.int32), torch.tensor(-1, dtype=torch.int32))
+    comp = H.rows_select(src.to(DEV), kept.to(DEV), k, C)
+    assert torch.equal(comp.cpu(), src[kept.long()])                                   # bit-exact data movement
+    dense = H.rows_select(comp, inv.to(DEV), n, C)
+    assert torch.equal(dense.cpu(), R.rows_select(src[kept.long()], inv, n, C))
+    assert torch.equal(H.rows_select(src.to(DEV), keep.to(DEV), n, C).cpu(), dense.cpu())
+    if (C * src.element_size()) % 4 == 0:
+        add = rnd(k, C, dt=dt, seed=2)
+        close(H.rows_select(src.to(DEV), kept.to(DEV), k, C, add=add.to(DEV)), R.rows_select(src, kept, k, C, add=add), dt, "gather+add")
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 5, 64, 96), (3, 2, 3, 32, 36), (1, 2, 1, 256, 256)])
+def test_masked_mse_loss_vs_oracle(shape):
+    """cytoland MaskedMSELoss: value and gradient vs the oracle restatement (pinned on the reference's own class, G9)."""
+    from oracle.fcmae_ref import MaskedMSELoss as RefLoss
+    from viscy_amd.losses import MaskedMSELoss
+
+    B, C, Z, Hh, Ww = shape
+    g = torch.Generator().manual_seed(7)
+    p = torch.randn(shape, generator=g, requires_grad=True)
+    o = torch.randn(shape, generator=g)
+    m = torch.rand(B, 1, Hh, Ww, generator=g) < 0.4
+    lr = RefLoss()(p, o, m)
+    lr.backward()
+    pc = p.detach().to(DEV).requires_grad_(True)
+    lg = MaskedMSELoss()(pc, o.to(DEV), m.to(DEV))
+    (3.0 * lg).backward()
+    assert abs(lg.item() - lr.item()) <= 2e-6 * abs(lr.item())
+    torch.testing.assert_close(pc.grad.cpu(), 3.0 * p.grad, rtol=1e-5, atol=1e-9)
+    with pytest.raises(ValueError, match="mask must be"):
+        MaskedMSELoss()(pc, o.to(DEV), m[:, :, :-1].to(DEV))

@@ -122,5 +122,31 @@ def test_fcmae_forward_golden_and_key_compat(tag):
     assert mine.out_stack_depth == m.out_stack_depth and mine.num_blocks == m.num_blocks
     with pytest.raises(RuntimeError, match="HIP kernels only"):
         mine(x)
-    with pytest.raises(NotImplementedError, match="dense"):
+    with pytest.raises(RuntimeError, match="HIP kernels only"):  # the masked path has no CPU fallback either
         mine(x, mask_ratio=0.5)
+    with pytest.raises(ValueError, match="every cell"):
+        mine(x, mask_ratio=1.0)
+
+
+@pytest.mark.parametrize("tag", ["small_z5_r50", "two_ch_r75"])
+def test_fcmae_masked_oracle_matches_reference_golden(tag):
+    """masked pre-training path: the oracle fed the reference's own generate_mask draw reproduces the reference's output,
+    MaskedMSELoss value and gradients stored by oracle/validate_against_reference.py (G9)."""
+    from oracle import fcmae_ref, unext2_ref
+
+    g = load_golden("fcmae_masked.pt")[tag]
+    m = unext2_ref.randomize_(fcmae_ref.FullyConvolutionalMAE(**g["kwargs"]), seed=g["seed"])
+    x = torch.randn(g["x_shape"], generator=torch.Generator().manual_seed(g["x_seed"]))
+    y, mask = m(x, mask=g["mask_low"])
+    torch.testing.assert_close(y, g["y"], rtol=1e-5, atol=1e-6)
+    assert abs(mask.float().mean().item() - g["mask_ratio"]) < 1e-6
+    loss = fcmae_ref.MaskedMSELoss()(y, x, mask)
+    assert abs(loss.item() - g["loss"]) <= 1e-6 * abs(g["loss"])
+    loss.backward()
+    named = dict(m.named_parameters())
+    for name, gg in g["grads"].items():
+        torch.testing.assert_close(named[name].grad, gg, rtol=1e-4, atol=1e-7 + 1e-4 * gg.abs().max().item())
+    # generate_mask: exactly int(n * ratio) cells per sample
+    torch.manual_seed(0)
+    low = fcmae_ref.generate_mask((3, 1, 5, 128, 160), 32, 0.6)
+    assert low.shape == (3, 1, 4, 5) and low.flatten(1).sum(1).tolist() == [12, 12, 12]

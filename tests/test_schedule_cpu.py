@@ -76,3 +76,80 @@ def test_bad_depth_and_cpu_forward_raise():
     m = UNeXt2(backbone="convnextv2_atto")
     with pytest.raises(RuntimeError, match="no CPU"):
         m(torch.zeros(1, 1, 5, 64, 64))
+
+
+# ---------------------------------------------------------------- FCMAE masked pre-training schedule
+def _fcmae_masked_case(tag):
+    from oracle import fcmae_ref
+    from tests.conftest import load_golden
+    from viscy_amd.fcmae import FullyConvolutionalMAE
+
+    gold = load_golden("fcmae_masked.pt")[tag]
+    kw = gold["kwargs"]
+    ref = unext2_ref.randomize_(fcmae_ref.FullyConvolutionalMAE(**kw), seed=gold["seed"])
+    mine = FullyConvolutionalMAE(**kw)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(gold["x_seed"])
+    x = torch.randn(gold["x_shape"], generator=g)
+    return gold, ref, mine, x
+
+
+@pytest.mark.parametrize("tag", ["small_z5_r50", "two_ch_r75"])
+def test_row_maps_are_the_boolean_index_order(tag):
+    from oracle import fcmae_ref
+    from viscy_amd.fcmae import stage_row_maps
+
+    gold, _, _, x = _fcmae_masked_case(tag)
+    low = gold["mask_low"]
+    kept = int((~low).flatten(1).sum(1)[0])
+    B, H, W = x.shape[0], x.shape[-2] // 4, x.shape[-1] // 4
+    maps = stage_row_maps(~low, [(H >> i, W >> i) for i in range(4)], kept)
+    for i, (idx, inv, keep, L) in enumerate(maps):
+        h, w = H >> i, W >> i
+        u = fcmae_ref.upsample_mask(~low, (B, 1, h, w))[:, 0]
+        feat = torch.randn(B, 3, h, w)
+        tok = fcmae_ref._tokens(feat, u.unsqueeze(1)).reshape(-1, 3)      # reference order (boolean indexing)
+        rows = feat.permute(0, 2, 3, 1).reshape(-1, 3)
+        assert L * B == tok.shape[0] == idx.numel()
+        assert torch.equal(rows[idx.long()], tok)
+        assert torch.equal(ref_ops.rows_select(tok, inv, B * h * w, 3).view(B, h, w, 3).permute(0, 3, 1, 2),
+                           fcmae_ref._untokens(tok.view(B, -1, 3), feat.shape, u.unsqueeze(1)))
+        assert torch.equal(ref_ops.rows_select(rows, keep, B * h * w, 3), rows * u.reshape(-1, 1))
+
+
+@pytest.mark.parametrize("tag", ["small_z5_r50", "two_ch_r75"])
+def test_masked_schedule_matches_reference_golden(tag):
+    """forward + every parameter gradient of the masked path: engine schedule (kernels = plain torch) vs the reference's own
+    run stored in tests/golden/fcmae_masked.pt and vs autograd of the oracle."""
+    from oracle import fcmae_ref
+    from viscy_amd.fcmae import stage_row_maps
+
+    gold, ref, mine, x = _fcmae_masked_case(tag)
+    low = gold["mask_low"]
+    kept = int((~low).flatten(1).sum(1)[0])
+    H, W = x.shape[-2] // 4, x.shape[-1] // 4
+    masks = stage_row_maps(~low, [(H >> i, W >> i) for i in range(4)], kept)
+    eng = Engine(mine._core, ops=ref_ops)
+    with torch.no_grad():
+        out, sv = eng.forward(x, torch.float32, need_bwd=True, masks=masks)
+    torch.testing.assert_close(out, gold["y"], rtol=2e-4, atol=1e-4 * gold["y"].abs().max().item())
+    y, mask = ref(x, mask=low)
+    loss = fcmae_ref.MaskedMSELoss()(y, x, mask)
+    assert abs(loss.item() - gold["loss"]) < 1e-6 * max(1.0, abs(gold["loss"]))
+    (dy,) = torch.autograd.grad(loss, y, retain_graph=True)
+    loss.backward()
+    with torch.no_grad():
+        eng.backward(sv, dy)
+    mine_named = dict(mine.named_parameters())
+    worst = 0.0
+    for name, p_ref in ref.named_parameters():
+        if name.startswith("encoder.stem.conv2d"):
+            continue
+        gr = eng.g(mine_named[name])
+        err = ((gr - p_ref.grad).abs().max() / p_ref.grad.abs().max().clamp_min(1e-6)).item()
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err)
+    for name, gg in gold["grads"].items():
+        gr = eng.g(mine_named[name])
+        assert ((gr - gg).abs().max() / gg.abs().max().clamp_min(1e-6)).item() < 2e-3, name
+    print(tag, "masked max rel grad err", worst)

@@ -5,7 +5,7 @@
 See DESIGN.md (what is built and why) and INTEGRATION.md (how it binds to the reference).
 """
 
-__all__ = ["UNeXt2", "MixedLoss", "VSUNet", "HCSDataModule", "HCSPredictionWriter", "FlatAdamW", "FlatDataParallel", "TrainStep"]
+__all__ = ["UNeXt2", "MixedLoss", "VSUNet", "HCSDataModule", "HCSPredictionWriter", "FcmaeUNet", "FullyConvolutionalMAE", "MaskedMSELoss", "FlatAdamW", "FlatDataParallel", "TrainStep"]
 
 
 def __getattr__(name):
@@ -13,6 +13,12 @@ def __getattr__(name):
         from .unext2 import UNeXt2 as v
     elif name == "MixedLoss":
         from .losses import MixedLoss as v
+    elif name == "FcmaeUNet":
+        from .vsunet import FcmaeUNet as v
+    elif name == "FullyConvolutionalMAE":
+        from .fcmae import FullyConvolutionalMAE as v
+    elif name == "MaskedMSELoss":
+        from .losses import MaskedMSELoss as v
     elif name == "VSUNet":
         from .vsunet import VSUNet as v
     elif name == "HCSDataModule":

@@ -84,6 +84,9 @@ _SIGS = {
     "vsx_scale_weight_samples": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_voxel_shuffle_fwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),
     "vsx_voxel_shuffle_bwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),
+    "vsx_rows_select": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
+    "vsx_masked_mse_fwd": (_I32, [_P] * 5 + [_I32] * 3 + [_I64, _P]),
+    "vsx_masked_mse_bwd": (_I32, [_P] * 6 + [_I32] * 3 + [_I64, _P]),
     "vsx_head_conv_supported": (_I32, [_I32] * 6),
     "vsx_head_conv_fwd": (_I32, [_P] * 6 + [_I32] * 7 + [_P]),
     "vsx_head_conv_wgrad": (_I32, [_P] * 4 + [_I32] * 7 + [_P]),

@@ -216,11 +216,22 @@ class Engine:
         return W
 
     # ------------------------------------------------------------------ block forward / backward
-    def _block_fwd(self, x, w, B, H, Wd, dt, save):
+    def _block_fwd(self, x, w, B, H, Wd, dt, save, rows=None):
+        """One ConvNeXt-V2 block on a dense channels-last map [B*H*W, C].  ``rows = (idx, inv, keep, L)`` selects the FCMAE
+        masked path (fcmae.py:196-230): ``x`` arrives already multiplied by the mask, the depthwise convolution runs dense,
+        LayerNorm / GRN-MLP run on the L kept tokens per sample only (compact rows), and the result is scattered back into
+        zeros and added to the (masked) shortcut."""
         o = self.ops
         C, M = w.C, B * H * Wd
         blk = w.p
+        hw = H * Wd
         y = o.dwconv7_fwd(x, w.dw_w, blk.conv_dw.bias, B, H, Wd, C)
+        xres = x
+        if rows is not None:
+            idx, inv, _, Lr = rows
+            M, hw = B * Lr, Lr
+            y = o.rows_select(y, idx, M, C)      # masked_patchify
+            xres = o.rows_select(x, idx, M, C)   # the shortcut of the kept tokens
         xh, _, rstd = o.ln_fwd(y, None, None, M, C, 1e-6, need_mean=False)
         del y
         colsq = self._za.take(B, 4 * C)
@@ -229,10 +240,9 @@ class Engine:
         h = torch.empty((M, 4 * C), dtype=dt, device=x.device)
         gact = torch.empty((M, 4 * C), dtype=dt, device=x.device)
         o.gemm("nt", xh, w.W1f, h, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=w.b1f, red0=colsq,
-               hw=H * Wd, C2=gact)
+               hw=hw, C2=gact)
         s = o.grn_scale(colsq, blk.mlp.grn.weight)
         out = torch.empty((M, C), dtype=dt, device=x.device)
-        hw = H * Wd
         if dt == torch.bfloat16 and C > 64 and hw % 128 == 0 and hw // 128 >= 8:
             # large feature maps: fold the GRN affine into per-sample fc2 weights,
             #   (g·s_b + β)·W2ᵀ = g·(W2·diag(s_b))ᵀ + W2·β,
@@ -241,31 +251,39 @@ class Engine:
             Ws = o.scale_weight_samples(blk.mlp.fc2.weight, s, dt)
             b2 = o.matvec(blk.mlp.fc2.weight, blk.mlp.grn.bias, blk.mlp.fc2.bias, C, 4 * C)
             o.gemm("nt", gact, Ws, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, hw=hw, b_bstride=C * 4 * C,
-                   epi=L.EPI_BIAS_RES, bias=b2, res=x, ldr=C)
+                   epi=L.EPI_BIAS_RES, bias=b2, res=xres, ldr=C)
         else:
             o.gemm("nt", gact, w.W2, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
-                   grn_b=blk.mlp.grn.bias, hw=hw, epi=L.EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=x, ldr=C)
+                   grn_b=blk.mlp.grn.bias, hw=hw, epi=L.EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=xres, ldr=C)
+        if rows is not None:
+            out = o.rows_select(out, rows[1], B * H * Wd, C)  # masked_unpatchify: zero rows where masked (shortcut is 0 there)
         if save is not None:
-            save.append((x, xh, rstd, h, gact, colsq, s))
+            save.append((x, xh, rstd, h, gact, colsq, s, rows))
         return out
 
     def _block_bwd(self, dout, w, saved, B, H, Wd, dt):
         o, g = self.ops, self.g
         C, M = w.C, B * H * Wd
         blk = w.p
-        x, xh, rstd, h, gact, colsq, s = saved
+        x, xh, rstd, h, gact, colsq, s, rows = saved
         dev = dout.device
+        hw = H * Wd
+        dfull = dout
+        if rows is not None:  # masked path: the MLP branch only sees the gradient of the kept tokens
+            idx, inv, keep, Lr = rows
+            M, hw = B * Lr, Lr
+            dout = o.rows_select(dfull, idx, M, C)
         # fc2: weight gradient (Z recomputed in the operand prologue) + bias gradient
         o.gemm("tn", gact, dout, g(blk.mlp.fc2.weight), M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
-               grn_b=blk.mlp.grn.bias, hw=H * Wd, colsum=g(blk.mlp.fc2.bias))
+               grn_b=blk.mlp.grn.bias, hw=hw, colsum=g(blk.mlp.fc2.bias))
         # fc2 data gradient dZ, with Σ dZ·gelu(h) (GRN statistics path) and Σ dZ (GRN beta gradient)
         PS = self._za.take(2, B, 4 * C)
         dz = torch.empty((M, 4 * C), dtype=dt, device=dev)
         o.gemm("nt", dout, w.W2T, dz, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_DZ, aux=gact, ldx=4 * C, red0=PS[0],
-               red1=PS[1], hw=H * Wd)
+               red1=PS[1], hw=hw)
         t = o.grn_bwd_stats(colsq, PS[0], blk.mlp.grn.weight, g(blk.mlp.grn.weight), Sb=PS[1], dbeta=g(blk.mlp.grn.bias))
         db1f = self._za.take(4 * C)
-        o.grn_gelu_bwd(dz, h, s, t, db1f, M, 4 * C, H * Wd)  # dz now holds dH
+        o.grn_gelu_bwd(dz, h, s, t, db1f, M, 4 * C, hw)  # dz now holds dH
         dxh = torch.empty((M, C), dtype=dt, device=dev)
         o.gemm("nt", dz, w.W1fT, dxh, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt)
         dW1f = self._za.take(4 * C, C)
@@ -278,18 +296,24 @@ class Engine:
         g(blk.mlp.fc1.bias).add_(db1f)
         dy = o.ln_bwd(dxh, xh, None, rstd, None, None, None, None, M, C)
         del dxh
-        dx = o.dwconv7_bwd_data(dy, w.dw_w, dout, B, H, Wd, C)
+        if rows is not None:
+            dy = o.rows_select(dy, inv, B * H * Wd, C)  # adjoint of the gather: zero-filled scatter
+        dx = o.dwconv7_bwd_data(dy, w.dw_w, dfull, B, H, Wd, C)
         ddw = self._za.take(49, C)
         o.dwconv7_bwd_weight(dy, x, ddw, g(blk.conv_dw.bias), B, H, Wd, C)
         o.transpose_f32(ddw, g(blk.conv_dw.weight), 49, C, True)
+        if rows is not None:
+            dx = o.rows_select(dx, keep, B * H * Wd, C)  # adjoint of `x *= unmasked` (shortcut and dwconv input alike)
         return dx
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: Tensor, dt: torch.dtype, need_bwd: bool):
+    def forward(self, x: Tensor, dt: torch.dtype, need_bwd: bool, masks=None):
+        """``masks``: None (dense) or, per encoder stage, ``(idx, inv, keep, L)`` int32 row maps of the FCMAE mask at that
+        stage's resolution (see ``viscy_amd.fcmae.stage_row_maps``)."""
         o, cfg, m = self.ops, self.cfg, self.model
         W = self.prepare(dt, need_bwd)
         B, Cin, Z, H, Wd = x.shape
-        za_key = ("fwd", B, H, Wd)
+        za_key = ("fwd", B, H, Wd, masks is not None)
         self._za = za = _ZeroArena(x.device, self._za_need.get(za_key, 0))
         if Cin != cfg["in_channels"] or Z != cfg["in_stack_depth"]:
             raise ValueError(f"expected input (B,{cfg['in_channels']},{cfg['in_stack_depth']},Y,X), got {tuple(x.shape)}")
@@ -299,7 +323,7 @@ class Engine:
         h, w = H // ky, Wd // kx
         dims = cfg["dims"]
         C0 = dims[0]
-        sv = {"shape": (B, H, Wd), "dt": dt} if need_bwd else None
+        sv = {"shape": (B, H, Wd), "dt": dt, "masked": masks is not None} if need_bwd else None
         # ---- stem: patch gather + projection GEMM, then encoder stem_1 LayerNorm2d
         P = o.stem_im2col(x.contiguous(), (kz, ky, kx), dt)
         M0, K0 = B * h * w, P.shape[1]
@@ -325,8 +349,13 @@ class Engine:
                        a_mode=L.A_PATCH2, gh=ch, gw=cw, cs=cc, epi=L.EPI_BIAS, bias=proj.conv.bias)
                 st_sv["proj"] = (cur, xn, mean, rstd)
                 cur, cc = nxt, proj.cout
+            rows = None
+            if masks is not None:
+                rows = masks[i]
+                # first block of the stage: `x *= unmasked` (fcmae.py:216-217); later blocks receive masked maps already
+                cur = o.rows_select(cur, rows[2], B * ch * cw, cc)
             for bw in blocks:
-                cur = self._block_fwd(cur, bw, B, ch, cw, dt, st_sv["blocks"] if need_bwd else None)
+                cur = self._block_fwd(cur, bw, B, ch, cw, dt, st_sv["blocks"] if need_bwd else None, rows)
             feats.append((cur, ch, cw, cc))
             enc_sv.append(st_sv)
         # ---- decoder
@@ -438,7 +467,7 @@ class Engine:
         dt = sv["dt"]
         B, H, Wd = sv["shape"]
         dev = dout.device
-        za_key = ("bwd", B, H, Wd)
+        za_key = ("bwd", B, H, Wd, sv["masked"])
         self._za = za = _ZeroArena(dev, self._za_need.get(za_key, 0))
         if cfg.get("head", "conv") == "shuffle":
             fh, fw = sv["head"]
@@ -514,9 +543,9 @@ class Engine:
 # ------------------------------------------------------------------------------------------------
 class _UNeXt2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, model, dt, need_bwd, *params):
+    def forward(ctx, x, model, dt, need_bwd, masks, *params):
         eng = model.engine()
-        out, sv = eng.forward(x, dt, need_bwd)
+        out, sv = eng.forward(x, dt, need_bwd, masks)
         ctx.model, ctx.sv = model, sv
         return out
 
@@ -529,7 +558,7 @@ class _UNeXt2Fn(torch.autograd.Function):
         ctx.sv = None
         if model.grad_mode == "flat":
             eng.backward(sv, dout)
-            return (None, None, None, None) + tuple(None for _ in eng.order)
+            return (None, None, None, None, None) + tuple(None for _ in eng.order)
         # autograd mode: compute into a zeroed flat buffer and hand views back to autograd
         saved = eng.flat_grad
         eng.flat_grad = torch.zeros_like(saved)
@@ -542,14 +571,14 @@ class _UNeXt2Fn(torch.autograd.Function):
             grads = tuple(eng.grad_of[id(p)] for p in eng.order)
         finally:
             eng.flat_grad, eng.grad_of = saved, old
-        return (None, None, None, None) + grads
+        return (None, None, None, None, None) + grads
 
 
-def unext2_apply(model, x: Tensor) -> Tensor:
+def unext2_apply(model, x: Tensor, masks=None) -> Tensor:
     eng = model.engine()
     dt = model._resolve_dtype()
     if model.grad_mode == "flat":
         eng.attach_grads()
     need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in eng.order)
     with torch.autocast("cuda", enabled=False):
-        return _UNeXt2Fn.apply(x.float(), model, dt, need_bwd, *eng.order)
+        return _UNeXt2Fn.apply(x.float(), model, dt, need_bwd, masks, *eng.order)

@@ -1,9 +1,10 @@
-"""Dense path of the FCMAE U-Net on MI355X: drop-in for ``viscy_models.unet.fcmae.FullyConvolutionalMAE`` with
-``mask_ratio = 0`` (/root/reference/packages/viscy-models/src/viscy_models/unet/fcmae.py:451-560) — the network behind
-``cytoland.engine.FcmaeUNet`` fine-tuning / inference and the architecture of the published VSCyto3D checkpoint.
+"""The FCMAE U-Net on MI355X: drop-in for ``viscy_models.unet.fcmae.FullyConvolutionalMAE``
+(/root/reference/packages/viscy-models/src/viscy_models/unet/fcmae.py:451-560) — the network behind
+``cytoland.engine.FcmaeUNet`` (masked pre-training, fine-tuning, inference) and the architecture of the published VSCyto3D
+checkpoint.
 
-Same constructor keywords, ``forward(x, mask_ratio=0.0)`` (returns ``(y, None)`` when ``pretraining`` is set, like the
-reference with no mask), ``out_stack_depth`` / ``num_blocks`` / ``pretraining`` attributes and — so that published
+Same constructor keywords, ``forward(x, mask_ratio=0.0)`` (returns ``(y, mask)`` when ``pretraining`` is set — ``mask`` is
+None without masking, like the reference), ``out_stack_depth`` / ``num_blocks`` / ``pretraining`` attributes and — so that published
 checkpoints load with ``strict=True`` — the reference's ``state_dict()`` keys, order and shapes
 (``encoder.stem.{conv3d,conv2d,norm}``, ``encoder.stages.i.{downsample,blocks.j.{dwconv,layernorm,mlp}}``,
 ``decoder.*``, ``head.*``).
@@ -12,7 +13,8 @@ Arithmetic: the dense FCMAE network is the UNeXt2 schedule with a different para
 (``nn.Linear`` MLPs) and — unless ``head_conv`` — the parameter-free ``PixelToVoxelShuffleHead`` (``vsx_voxel_shuffle_*``).
 The reference-named tree below shares its ``nn.Parameter`` objects with the engine's own tree (``viscy_amd.unext2._Core``),
 so the flat-buffer engine, the fused AdamW and the data-parallel all-reduce work unchanged.  Sparse masked pre-training
-(``mask_ratio > 0``: masked patchify, mask generation) is not built.
+(``mask_ratio > 0``) runs the same kernel schedule with the kept tokens of every encoder block gathered into compact row
+matrices (``vsx_rows_select``; see ``stage_row_maps``).
 """
 
 from __future__ import annotations
@@ -63,6 +65,50 @@ class _StageView(_Holder):
         else:
             self.downsample = nn.Sequential(_share(st.downsample[0]), _share(st.downsample[1]))
         self.blocks = nn.ModuleList(_BlockView(b) for b in st.blocks)
+
+
+def generate_mask(target, stride: int, mask_ratio: float, device) -> Tensor:
+    """fcmae.py:40-66 — the same draw (``torch.rand(B, n).argsort(1) < int(n * ratio)`` on ``device``): (B,1,H/stride,W/stride)
+    bool, True = masked, exactly ``int(n * ratio)`` cells per sample."""
+    mh, mw = target[-2] // stride, target[-1] // stride
+    n = mh * mw
+    k = int(n * mask_ratio)
+    return (torch.rand(target[0], n, device=device).argsort(1) < k).reshape(target[0], 1, mh, mw)
+
+
+def upsample_mask(mask: Tensor, target) -> Tensor:
+    """fcmae.py:69-92"""
+    if tuple(target[-2:]) != tuple(mask.shape[-2:]):
+        if target[-2] % mask.shape[-2] or target[-1] % mask.shape[-1]:
+            raise ValueError(f"feature map shape {tuple(target)} must be divisible by mask shape {tuple(mask.shape)}.")
+        mask = mask.repeat_interleave(target[-2] // mask.shape[-2], dim=-2).repeat_interleave(target[-1] // mask.shape[-1], dim=-1)
+    return mask
+
+
+def stage_row_maps(unmasked: Tensor, shapes, kept_cells: int):
+    """Row maps that drive ``vsx_rows_select`` for each encoder stage: the boolean-index gather / zero-filled scatter of
+    ``masked_patchify`` / ``masked_unpatchify`` (fcmae.py:95-141) on channels-last row matrices.
+
+    ``unmasked``: (B,1,mh,mw) bool; ``shapes``: [(h_i, w_i)] per stage; ``kept_cells``: unmasked cells per sample (identical
+    for every sample by construction of ``generate_mask``, so every sample keeps the same token count L_i and the compact
+    matrix stays rectangular).  Index arithmetic only — static sizes, no host synchronisation (graph-capturable).
+    Returns per stage ``(idx [B*L] dense row of each kept token (row-major, as boolean indexing orders them),
+    inv [B*h*w] compact row or -1, keep [B*h*w] own row or -1, L)``."""
+    B, _, mh, mw = unmasked.shape
+    out = []
+    for h, w in shapes:
+        u = upsample_mask(unmasked, (B, 1, h, w)).reshape(-1)
+        n = B * h * w
+        L = kept_cells * (h // mh) * (w // mw)
+        ar = torch.arange(n, dtype=torch.int32, device=u.device)
+        pos = torch.cumsum(u, 0, dtype=torch.int32) - 1
+        neg = torch.full_like(ar, -1)
+        inv = torch.where(u, pos, neg)
+        keep = torch.where(u, ar, neg)
+        idx = torch.zeros(B * L + 1, dtype=torch.int32, device=u.device)
+        idx.scatter_(0, torch.where(u, pos, torch.full_like(pos, B * L)).long(), ar)  # masked rows land in the dump slot
+        out.append((idx[: B * L].contiguous(), inv, keep, L))
+    return out
 
 
 class FullyConvolutionalMAE(nn.Module):
@@ -126,10 +172,31 @@ class FullyConvolutionalMAE(nn.Module):
         self._core._engine = None  # parameter storage moves: flat views must be rebuilt
         return super()._apply(fn, *a, **k)
 
-    def forward(self, x: Tensor, mask_ratio: float = 0.0):
-        if mask_ratio > 0.0:
-            raise NotImplementedError("viscy_amd builds the dense FCMAE path (mask_ratio = 0); masked pre-training is not built")
+    @property
+    def total_stride(self) -> int:
+        """MaskedMultiscaleEncoder.total_stride, fcmae.py:422"""
+        return self._core.cfg["stem_kernel"][1] * 2 ** 3
+
+    def forward(self, x: Tensor, mask_ratio: float = 0.0, mask: Tensor | None = None):
+        """fcmae.py:541-560.  ``mask`` (B,1,H/stride,W/stride bool, True = masked) is an extension for tests: it injects the
+        draw ``generate_mask`` would make; every sample must mask the same number of cells."""
         if x.ndim == 5 and x.shape[2] == 1:
             raise NotImplementedError("the 2-D stem branch (Z == 1 inputs) is not built")
-        y = self._core(x)
-        return (y, None) if self.pretraining else y
+        masks = None
+        if mask is None and mask_ratio > 0.0:
+            mask = generate_mask(x.shape, self.total_stride, mask_ratio, x.device)
+            kept = mask.shape[-2] * mask.shape[-1] - int(mask.shape[-2] * mask.shape[-1] * mask_ratio)
+        elif mask is not None:
+            per = (~mask).flatten(1).sum(1)
+            kept = int(per[0])
+            if not bool((per == kept).all()):
+                raise ValueError("an injected mask must keep the same number of cells in every sample")
+        if mask is not None:
+            if kept == 0:
+                raise ValueError("mask_ratio masks every cell: nothing left to encode")
+            sk = self._core.cfg["stem_kernel"]
+            h, w = x.shape[-2] // sk[1], x.shape[-1] // sk[2]
+            masks = stage_row_maps(~mask, [(h >> i, w >> i) for i in range(4)], kept)
+            mask = upsample_mask(mask, (x.shape[0], 1, x.shape[-2], x.shape[-1]))
+        y = self._core(x, masks)
+        return (y, mask) if self.pretraining else y

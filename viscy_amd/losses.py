@@ -125,3 +125,41 @@ class MixedLoss(nn.Module):
             raise RuntimeError("viscy_amd.MixedLoss runs on MI355X HIP kernels only (no CPU / eager fallback)")
         L.lib()
         return _MixedLossFn.apply(preds, target, float(self.l1_alpha), float(self.l2_alpha), float(self.ms_dssim_alpha))
+
+
+class _MaskedMSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds: Tensor, original: Tensor, mask: Tensor):
+        from . import ops as O
+
+        p = preds.contiguous().float()
+        o = original.contiguous().float()
+        m = mask.contiguous().to(torch.uint8)
+        loss, acc = O.masked_mse_fwd(p, o, m)
+        ctx.save_for_backward(p, o, m, acc)
+        ctx.in_dtype = preds.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout: Tensor):
+        from . import ops as O
+
+        p, o, m, acc = ctx.saved_tensors
+        return O.masked_mse_bwd(p, o, m, acc, gout.contiguous().float()).to(ctx.in_dtype), None, None
+
+
+class MaskedMSELoss(nn.Module):
+    """``cytoland.engine.MaskedMSELoss`` (/root/reference/applications/cytoland/src/cytoland/engine.py:104-125), the FCMAE
+    pre-training loss: ``(mse(preds, original).mean(2) * mask).sum() / mask.sum()`` with ``preds`` / ``original``
+    (B,C,Z,Y,X) and ``mask`` (B,1,Y,X), True where the input was hidden from the encoder.  One reduction kernel forward,
+    one elementwise kernel backward (``vsx_masked_mse_*``)."""
+
+    def forward(self, preds: Tensor, original: Tensor, mask: Tensor) -> Tensor:
+        if not preds.is_cuda:
+            raise RuntimeError("viscy_amd.MaskedMSELoss runs on MI355X HIP kernels only (no CPU / eager fallback)")
+        if preds.shape != original.shape or preds.ndim != 5:
+            raise ValueError(f"preds {tuple(preds.shape)} and original {tuple(original.shape)} must be equal (B,C,Z,Y,X) shapes")
+        if tuple(mask.shape) != (preds.shape[0], 1, preds.shape[3], preds.shape[4]):
+            raise ValueError(f"mask must be (B,1,Y,X) = {(preds.shape[0], 1, preds.shape[3], preds.shape[4])}, got {tuple(mask.shape)}")
+        L.lib()
+        return _MaskedMSEFn.apply(preds, original, mask)

@@ -315,6 +315,31 @@ def scale_weight_samples(W: Tensor, s: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+def rows_select(src: Tensor, row_map: Tensor, n_out: int, C: int, add: Tensor | None = None) -> Tensor:
+    """dst[r] = map[r] >= 0 ? src[map[r]] (+ add[r]) : 0 — masked_patchify / masked_unpatchify / mask multiply of fcmae.py:95-141."""
+    assert row_map.dtype == torch.int32 and row_map.numel() == n_out
+    dst = torch.empty((n_out, C), dtype=src.dtype, device=src.device)
+    check(lib().vsx_rows_select(ptr(src), ptr(row_map), ptr(add) if add is not None else None, ptr(dst), n_out, C,
+                                dtype_code(src.dtype), stream()), "rows_select")
+    return dst
+
+
+def masked_mse_fwd(pred: Tensor, orig: Tensor, mask_u8: Tensor):
+    B, C, Z, H, W = pred.shape
+    acc = torch.empty(2, dtype=torch.float32, device=pred.device)
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    check(lib().vsx_masked_mse_fwd(ptr(pred), ptr(orig), ptr(mask_u8), ptr(acc), ptr(loss), B, C, Z, H * W, stream()), "masked_mse_fwd")
+    return loss, acc
+
+
+def masked_mse_bwd(pred: Tensor, orig: Tensor, mask_u8: Tensor, acc: Tensor, gout: Tensor) -> Tensor:
+    B, C, Z, H, W = pred.shape
+    dpred = torch.empty_like(pred)
+    check(lib().vsx_masked_mse_bwd(ptr(pred), ptr(orig), ptr(mask_u8), ptr(acc), ptr(gout), ptr(dpred), B, C, Z, H * W, stream()),
+          "masked_mse_bwd")
+    return dpred
+
+
 def voxel_shuffle_fwd(feat: Tensor, B: int, h: int, w: int, Cout: int, D: int, s: int, pool: bool) -> Tensor:
     out = torch.empty((B, Cout, D, s * h, s * w), dtype=torch.float32, device=feat.device)
     check(lib().vsx_voxel_shuffle_fwd(ptr(feat), ptr(out), B, h, w, Cout, D, s, int(pool), dtype_code(feat.dtype), stream()),

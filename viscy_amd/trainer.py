@@ -39,7 +39,11 @@ class Trainer:
 
     def fit(self, module, datamodule) -> None:
         module.to(self.device)
+        module.trainer = self
+        self.datamodule = datamodule
         datamodule.setup("fit")
+        if hasattr(module, "on_fit_start"):
+            module.on_fit_start()
         train_dl = datamodule.train_dataloader()
         steps_per_epoch = 1 if self.fast_dev_run else min(len(train_dl), self.limit_train_batches or len(train_dl))
         opt = module.configure_optimizers(t_total=steps_per_epoch * (1 if self.fast_dev_run else self.max_epochs))

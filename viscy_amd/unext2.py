@@ -255,7 +255,7 @@ class _Core(nn.Module):
         self._engine = None  # parameter storage moves: flat views must be rebuilt
         return super()._apply(fn, *a, **k)
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, masks=None) -> Tensor:
         if not x.is_cuda:
             raise RuntimeError(
                 f"viscy_amd.{type(self).__name__} runs on MI355X HIP kernels only (no CPU / eager fallback): move the model "
@@ -264,7 +264,7 @@ class _Core(nn.Module):
         L.lib()  # raises loudly when libvsx.so is missing
         from .engine_unext2 import unext2_apply
 
-        return unext2_apply(self, x)
+        return unext2_apply(self, x, masks)
 
 
 class UNeXt2(_Core):

@@ -263,3 +263,102 @@ class VSUNet(_Base):
         self.model.grad_mode = "flat"
         return FlatAdamW(self.model.engine(), lr=self.lr, schedule=self.schedule, warmup_steps=self.warmup_steps,
                          t_total=t_total or 0, warmup_multiplier=self.warmup_multiplier)
+
+
+class FcmaeUNet(VSUNet):
+    """``cytoland.engine.FcmaeUNet`` (/root/reference/applications/cytoland/src/cytoland/engine.py:808-1058): FCMAE
+    self-supervised pre-training (``fit_mask_ratio > 0`` with ``MaskedMSELoss`` and ``model_config["pretraining"] = True``)
+    and supervised fine-tuning (``pretraining = False``; ``encoder_only=True`` loads just the ``model.encoder.*`` weights of
+    a pre-trained checkpoint) on the MI355X FCMAE network (``viscy_amd.fcmae``).
+
+    Same constructor keywords, hooks and logged keys (``loss/train``, ``loss/val``).  Differences: ``freeze_encoder`` is not
+    built (see ``VSUNet``), and ``on_fit_start`` checks the loss type only — the reference additionally insists on its
+    ``CombinedDataModule`` / ``GPUTransformDataModule`` containers (engine.py:870-878), which are outside this build; any data
+    module that yields ``Sample`` dicts (or a list of them, merged like ``CombinedLoader`` batches) works."""
+
+    def __init__(self, fit_mask_ratio: float = 0.0, encoder_only: bool = False, **kwargs):
+        if encoder_only:
+            if "ckpt_path" not in kwargs or kwargs["ckpt_path"] is None:
+                raise ValueError("encoder_only=True requires ckpt_path")
+            ckpt_path = kwargs.pop("ckpt_path")
+        else:
+            ckpt_path = None
+        super().__init__(architecture="fcmae", **kwargs)
+        self.fit_mask_ratio = fit_mask_ratio
+        if ckpt_path is not None:
+            self._load_encoder_weights(ckpt_path)
+
+    def _load_encoder_weights(self, ckpt_path: str) -> None:
+        """engine.py:855-868"""
+        state_dict = torch.load(ckpt_path, weights_only=True, map_location="cpu")["state_dict"]
+        prefix = "model.encoder."
+        encoder_weights = {k.removeprefix(prefix): v for k, v in state_dict.items() if k.startswith(prefix)}
+        self.model.encoder.load_state_dict(encoder_weights, strict=True)
+
+    def on_fit_start(self):
+        from .losses import MaskedMSELoss
+
+        if self.model.pretraining and not isinstance(self.loss_function, MaskedMSELoss):
+            raise ValueError(f"MaskedMSELoss is required for FCMAE pre-training, got {type(self.loss_function)}")
+
+    def forward(self, x: Tensor, mask_ratio: float = 0.0):
+        return self.model(x, mask_ratio)
+
+    def forward_fit_fcmae(self, batch: dict, return_target: bool = False):
+        """engine.py:897-919: reconstruct the hidden patches of ``source`` itself."""
+        x = batch["source"]
+        pred, mask = self.forward(x, mask_ratio=self.fit_mask_ratio)
+        loss = self.loss_function(pred, x, mask)
+        target = x * mask.unsqueeze(2) if return_target else None
+        return pred, target, loss
+
+    def forward_fit_supervised(self, batch: dict):
+        """engine.py:921-939"""
+        x, target = batch["source"], batch["target"]
+        pred = self.forward(x)
+        return pred, target, self._compute_loss(pred, target, batch)
+
+    def forward_fit_task(self, batch: dict, batch_idx: int):
+        """engine.py:941-964"""
+        if self.model.pretraining:
+            return self.forward_fit_fcmae(batch, return_target=batch_idx < self.log_batches_per_epoch)
+        return self.forward_fit_supervised(batch)
+
+    @staticmethod
+    def _merge_batches(batch):
+        """engine.py:966-1004: concatenate the per-dataset batches a combined loader yields into one ``Sample``."""
+        if not isinstance(batch, list):
+            return batch
+        combined = {}
+        for key in batch[0]:
+            vals = [b[key] for b in batch if key in b]
+            if isinstance(vals[0], Tensor):
+                combined[key] = torch.cat(vals, dim=0)
+            elif isinstance(vals[0], tuple):
+                merged = []
+                for i in range(len(vals[0])):
+                    elems = [v[i] for v in vals]
+                    if isinstance(elems[0], Tensor):
+                        merged.append(torch.cat(elems, dim=0))
+                    elif isinstance(elems[0], list):
+                        merged.append([x for sub in elems for x in sub])
+                    else:
+                        merged.append(elems[0])
+                combined[key] = tuple(merged)
+            else:
+                combined[key] = vals[0]
+        return combined
+
+    def training_step(self, batch, batch_idx: int):
+        batch = self._merge_batches(batch)
+        pred, target, loss = self.forward_fit_task(batch, batch_idx)
+        self._log("loss/train", loss, on_step=True, on_epoch=True, prog_bar=True, logger=True, sync_dist=True,
+                  batch_size=pred.shape[0])
+        return loss
+
+    def validation_step(self, batch, batch_idx: int, dataloader_idx: int = 0):
+        pred, target, loss = self.forward_fit_task(batch, batch_idx)
+        if dataloader_idx + 1 > len(self.validation_losses):
+            self.validation_losses.append([])
+        self.validation_losses[dataloader_idx].append(loss.detach())
+        self._log("loss/val", loss, sync_dist=True, batch_size=pred.shape[0])
