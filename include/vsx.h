@@ -310,6 +310,10 @@ int32_t vsx_crop3d(const float* x, float* y, const int32_t* starts, int32_t B, i
  * nearest) resampling, zero padding; Minv[B][3][4] maps output-voxel to input-voxel coordinates (x, y, z order). */
 int32_t vsx_warp_affine3d(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,
     int32_t W, int32_t nearest, vsx_stream_t stream);
+/* the same warp restricted to the output window [z0,z0+Do) x [y0,y0+Ho) x [x0,x0+Wo) of the (D,H,W) frame: fuses the
+ * BatchedCenterSpatialCrop that follows the affine in the recipes (_crop.py:164-187); y: (B,C,Do,Ho,Wo). */
+int32_t vsx_warp_affine3d_roi(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,
+    int32_t W, int32_t z0, int32_t y0, int32_t x0, int32_t Do, int32_t Ho, int32_t Wo, int32_t nearest, vsx_stream_t stream);
 
 /* K22 one pass of the separable Gaussian of BatchedRandGaussianSmooth (viscy_transforms/_gaussian_smooth.py:141-167):
  * per-sample 1-D taps along the axis with element stride `stride` and length L, zero border. */

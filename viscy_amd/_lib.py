@@ -96,6 +96,7 @@ _SIGS = {
     "vsx_sample_index": (_I32, [_P, _P, _P, _I32, _I64, _P]),
     "vsx_crop3d": (_I32, [_P, _P, _P] + [_I32] * 8 + [_P]),
     "vsx_warp_affine3d": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "vsx_warp_affine3d_roi": (_I32, [_P, _P, _P] + [_I32] * 12 + [_P]),
     "vsx_conv1d_axis": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _P]),
 }
 

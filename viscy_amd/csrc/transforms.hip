@@ -166,46 +166,63 @@ extern "C" int32_t vsx_blend_in(const float* oldp, const float* newp, float* out
 // ------------------------------------------------------------------ K18: batched 3-D affine warp
 // y[b,c,z,y,x] = trilinear( x[b,c], Minv[b] · (x,y,z,1) ), zero padding outside the volume.
 // Minv [B][3][4] maps OUTPUT voxel coordinates (x, y, z) to INPUT voxel coordinates (x, y, z).
+// Only the output region of interest [z0,z0+Do) x [y0,y0+Ho) x [x0,x0+Wo) is produced (the recipes follow the warp with a
+// centre crop that keeps ~30 % of the voxels: viscy_data/hcs.py:694-695 chain, BatchedCenterSpatialCrop _crop.py:164-187).
+// A workgroup owns a 32 x 8 output tile of one z-slice: under an in-plane rotation its input footprint is a compact
+// ~30 x 30 patch per tap plane, so the 8 gathers per voxel hit L1 lines shared by the whole tile (a 256 x 1 row of outputs
+// would sweep up to 180 input rows).  The matrix is wave-uniform (scalar registers).
 __global__ __launch_bounds__(256) void warp_affine3d_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                            const float* __restrict__ Minv, int B, int C, int D, int H, int W,
-                                                            int nearest) {
-  const long vol = (long)D * H * W;
-  const long total = (long)B * vol;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int b = (int)(i / vol);
-    long r = i - (long)b * vol;
-    const int ox = (int)(r % W); r /= W;
-    const int oy = (int)(r % H);
-    const int oz = (int)(r / H);
-    const float* m = Minv + (size_t)b * 12;
-    const float sx = m[0] * ox + m[1] * oy + m[2] * oz + m[3];
-    const float sy = m[4] * ox + m[5] * oy + m[6] * oz + m[7];
-    const float sz = m[8] * ox + m[9] * oy + m[10] * oz + m[11];
-    for (int c = 0; c < C; ++c) {
-      const float* xc = x + ((size_t)b * C + c) * vol;
-      float v = 0.f;
-      if (nearest) {
-        const int ix = (int)nearbyintf(sx), iy = (int)nearbyintf(sy), iz = (int)nearbyintf(sz);
-        if (ix >= 0 && ix < W && iy >= 0 && iy < H && iz >= 0 && iz < D) v = xc[((size_t)iz * H + iy) * W + ix];
-      } else {
-        const float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
-        const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-        const float tx = sx - fx, ty = sy - fy, tz = sz - fz;
-#pragma unroll
-        for (int dz = 0; dz < 2; ++dz)
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-              const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
-              if (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D) {
-                const float wgt = (dx ? tx : 1.f - tx) * (dy ? ty : 1.f - ty) * (dz ? tz : 1.f - tz);
-                v += wgt * xc[((size_t)zz * H + yy) * W + xx];
-              }
-            }
-      }
-      y[((size_t)b * C + c) * vol + (i - (long)b * vol)] = v;
-    }
+                                                            const float* __restrict__ Minv, int C, int D, int H, int W, int z0,
+                                                            int y0, int x0, int Do, int Ho, int Wo, int tiles_x, int nearest) {
+  const int b = blockIdx.z, oz = blockIdx.y;
+  const int ty_ = blockIdx.x / tiles_x, tx_ = blockIdx.x - ty_ * tiles_x;
+  const int ox = tx_ * 32 + (threadIdx.x & 31), oy = ty_ * 8 + (threadIdx.x >> 5);
+  if (ox >= Wo || oy >= Ho) return;
+  const float* m = Minv + (size_t)b * 12;
+  const float fx_ = (float)(ox + x0), fy_ = (float)(oy + y0), fz_ = (float)(oz + z0);
+  const float sx = m[0] * fx_ + m[1] * fy_ + m[2] * fz_ + m[3];
+  const float sy = m[4] * fx_ + m[5] * fy_ + m[6] * fz_ + m[7];
+  const float sz = m[8] * fx_ + m[9] * fy_ + m[10] * fz_ + m[11];
+  const size_t vol = (size_t)D * H * W, ovol = (size_t)Do * Ho * Wo;
+  const float* xb = x + (size_t)b * C * vol;
+  float* yb = y + (size_t)b * C * ovol + ((size_t)oz * Ho + oy) * Wo + ox;
+  if (nearest) {
+    const int ix = (int)nearbyintf(sx), iy = (int)nearbyintf(sy), iz = (int)nearbyintf(sz);
+    const bool in = ix >= 0 && ix < W && iy >= 0 && iy < H && iz >= 0 && iz < D;
+    const size_t off = in ? ((size_t)iz * H + iy) * W + ix : 0;
+    for (int c = 0; c < C; ++c) yb[c * ovol] = in ? xb[c * vol + off] : 0.f;
+    return;
+  }
+  const float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
+  const int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+  const float tx = sx - fx, ty = sy - fy, tz = sz - fz;
+  // per-corner weights, zeroed outside the volume; clamped addresses keep every load legal and unconditional
+  const bool vx0 = ix >= 0 && ix < W, vx1 = ix + 1 >= 0 && ix + 1 < W;
+  const bool vy0 = iy >= 0 && iy < H, vy1 = iy + 1 >= 0 && iy + 1 < H;
+  const bool vz0 = iz >= 0 && iz < D, vz1 = iz + 1 >= 0 && iz + 1 < D;
+  const float wx0 = vx0 ? 1.f - tx : 0.f, wx1 = vx1 ? tx : 0.f;
+  const float wy0 = vy0 ? 1.f - ty : 0.f, wy1 = vy1 ? ty : 0.f;
+  const float wz0 = vz0 ? 1.f - tz : 0.f, wz1 = vz1 ? tz : 0.f;
+  const int cx0 = min(max(ix, 0), W - 1), cx1 = min(max(ix + 1, 0), W - 1);
+  const int cy0 = min(max(iy, 0), H - 1), cy1 = min(max(iy + 1, 0), H - 1);
+  const int cz0 = min(max(iz, 0), D - 1), cz1 = min(max(iz + 1, 0), D - 1);
+  const size_t r00 = ((size_t)cz0 * H + cy0) * W, r01 = ((size_t)cz0 * H + cy1) * W;
+  const size_t r10 = ((size_t)cz1 * H + cy0) * W, r11 = ((size_t)cz1 * H + cy1) * W;
+  // same association as the reference expression: sum over (dz, dy, dx) of wz*wy*wx * v, accumulated in that order
+  for (int c = 0; c < C; ++c) {
+    const float* xc = xb + c * vol;
+    const float a000 = xc[r00 + cx0], a001 = xc[r00 + cx1], a010 = xc[r01 + cx0], a011 = xc[r01 + cx1];
+    const float a100 = xc[r10 + cx0], a101 = xc[r10 + cx1], a110 = xc[r11 + cx0], a111 = xc[r11 + cx1];
+    float v = 0.f;
+    v += (wx0 * wy0 * wz0) * a000;
+    v += (wx1 * wy0 * wz0) * a001;
+    v += (wx0 * wy1 * wz0) * a010;
+    v += (wx1 * wy1 * wz0) * a011;
+    v += (wx0 * wy0 * wz1) * a100;
+    v += (wx1 * wy0 * wz1) * a101;
+    v += (wx0 * wy1 * wz1) * a110;
+    v += (wx1 * wy1 * wz1) * a111;
+    yb[c * ovol] = v;
   }
 }
 
@@ -229,16 +246,25 @@ __global__ __launch_bounds__(256) void conv1d_axis_kernel(const float* __restric
 }
 
 /* K18 kornia warp_affine3d as used by BatchedRandAffined (viscy_transforms/_affine.py:33-47,358-393): trilinear (or
- * nearest) resampling with zero padding; Minv[B][3][4] = output-voxel → input-voxel coordinates (x, y, z order). */
-extern "C" int32_t vsx_warp_affine3d(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,
-                                     int32_t W, int32_t nearest, vsx_stream_t stream) {
+ * nearest) resampling with zero padding; Minv[B][3][4] = output-voxel → input-voxel coordinates (x, y, z order).
+ * vsx_warp_affine3d_roi produces only the output window [z0,z0+Do) x [y0,y0+Ho) x [x0,x0+Wo) of the full (D,H,W) frame:
+ * the warp fused with the BatchedCenterSpatialCrop that follows it in the recipes (_crop.py:164-187). */
+extern "C" int32_t vsx_warp_affine3d_roi(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D,
+                                         int32_t H, int32_t W, int32_t z0, int32_t y0, int32_t x0, int32_t Do, int32_t Ho,
+                                         int32_t Wo, int32_t nearest, vsx_stream_t stream) {
   VSX_CHECK(x && y && Minv && B > 0 && C > 0 && D > 0 && H > 0 && W > 0, "vsx_warp_affine3d: bad arguments");
-  long total = (long)B * D * H * W;
-  int g = vsx_cdiv(total, 256);
-  if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(warp_affine3d_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, y, Minv, B, C, D, H, W, nearest);
+  VSX_CHECK(Do > 0 && Ho > 0 && Wo > 0 && z0 >= 0 && y0 >= 0 && x0 >= 0 && z0 + Do <= D && y0 + Ho <= H && x0 + Wo <= W,
+            "vsx_warp_affine3d: output window (%d,%d,%d)+(%d,%d,%d) outside the (%d,%d,%d) frame", z0, y0, x0, Do, Ho, Wo, D, H, W);
+  VSX_CHECK(B <= 65535 && Do <= 65535, "vsx_warp_affine3d: B and the output depth must be <= 65535");
+  const int tiles_x = vsx_cdiv(Wo, 32), tiles_y = vsx_cdiv(Ho, 8);
+  hipLaunchKernelGGL(warp_affine3d_kernel, dim3(tiles_x * tiles_y, Do, B), dim3(256), 0, (hipStream_t)stream, x, y, Minv, C, D, H, W,
+                     z0, y0, x0, Do, Ho, Wo, tiles_x, nearest);
   VSX_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int32_t vsx_warp_affine3d(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,
+                                     int32_t W, int32_t nearest, vsx_stream_t stream) {
+  return vsx_warp_affine3d_roi(x, y, Minv, B, C, D, H, W, 0, 0, 0, D, H, W, nearest, stream);
 }
 /* K22 one pass of kornia filter3d's separable form as used by BatchedRandGaussianSmooth
  * (viscy_transforms/_gaussian_smooth.py:141-167): per-sample 1-D taps along the axis with element stride `stride`

@@ -173,8 +173,10 @@ class HCSDataModule(_DMBase):
         self.persistent_workers, self.prefetch_factor = persistent_workers, prefetch_factor
         self.include_fov_names = set(include_fov_names) if include_fov_names is not None else None
         self.exclude_fov_names = set(exclude_fov_names) if exclude_fov_names is not None else None
-        self._gpu_augmentations = Compose(gpu_augmentations) if gpu_augmentations else None
-        self._val_gpu_augmentations = Compose(val_gpu_augmentations) if val_gpu_augmentations else None
+        from ..transforms import fuse_affine_crop
+
+        self._gpu_augmentations = Compose(fuse_affine_crop(gpu_augmentations)) if gpu_augmentations else None
+        self._val_gpu_augmentations = Compose(fuse_affine_crop(val_gpu_augmentations)) if val_gpu_augmentations else None
         self.prepare_data_per_node = True
         self.seed = seed
         self.training = True  # set by the trainer loop (Lightning: trainer.training / trainer.validating)

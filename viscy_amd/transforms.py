@@ -321,14 +321,24 @@ class BatchedRandGaussianSmoothd(_BatchedRand):
         return sample
 
 
-def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear") -> Tensor:
-    """resample (B,C,D,H,W) with the output→input voxel matrices Minv (B,3,4), zero padding (csrc/transforms.hip)."""
+def _center_window(shape, roi_size):
+    """(z0, y0, x0, Do, Ho, Wo) of BatchedCenterSpatialCrop on a (.., D, H, W) frame (start = (dim - size) // 2)."""
+    dims = list(shape[-3:])
+    size = [min(int(s), d) if int(s) > 0 else d for s, d in zip(roi_size, dims)]
+    return tuple((d - s) // 2 for d, s in zip(dims, size)) + tuple(size)
+
+
+def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear", window=None) -> Tensor:
+    """resample (B,C,D,H,W) with the output→input voxel matrices Minv (B,3,4), zero padding (csrc/transforms.hip).
+    ``window = (z0, y0, x0, Do, Ho, Wo)`` produces only that region of the output frame (warp + crop in one pass)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 5):
         raise RuntimeError("viscy_amd GPU augmentations need a contiguous float32 (B,C,Z,Y,X) batch on the HIP device (no CPU fallback)")
     B, C, D, H, W = x.shape
     m = Minv.to(x.device, torch.float32).contiguous()
-    y = torch.empty_like(x)
-    check(lib().vsx_warp_affine3d(ptr(x), ptr(y), ptr(m), B, C, D, H, W, int(mode == "nearest"), stream()), "warp_affine3d")
+    z0, y0, x0, Do, Ho, Wo = window if window is not None else (0, 0, 0, D, H, W)
+    y = torch.empty((B, C, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    check(lib().vsx_warp_affine3d_roi(ptr(x), ptr(y), ptr(m), B, C, D, H, W, z0, y0, x0, Do, Ho, Wo, int(mode == "nearest"),
+                                      stream()), "warp_affine3d")
     return y
 
 
@@ -381,15 +391,47 @@ class BatchedRandAffined(_BatchedRand):
         fwd = ctr @ A @ Sh @ S @ torch.linalg.inv(ctr)
         return torch.linalg.inv(fwd)[:, :3].contiguous()
 
-    def __call__(self, sample: dict, params: Tensor | None = None) -> dict:
+    def __call__(self, sample: dict, params: Tensor | None = None, crop_roi_size=None) -> dict:
+        """``crop_roi_size``: produce only the centre window a following ``BatchedCenterSpatialCropd(roi_size)`` would
+        keep (identical voxels, ~3x fewer of them in the recipes) — see ``fuse_affine_crop``."""
         first = next((k for k in self.keys if k in sample), None)
         if first is None:
             return sample
         Minv = params if params is not None else self.randomize(sample[first].shape)
         for k in self.keys:
             if k in sample:
-                sample[k] = warp_affine3d(sample[k], Minv, self.mode)
+                win = _center_window(sample[k].shape, crop_roi_size) if crop_roi_size is not None else None
+                sample[k] = warp_affine3d(sample[k], Minv, self.mode, win)
         return sample
+
+
+class _AffineThenCenterCrop:
+    """``BatchedRandAffined`` immediately followed by ``BatchedCenterSpatialCropd`` over the same keys, as one pass."""
+
+    def __init__(self, affine: "BatchedRandAffined", crop: "BatchedCenterSpatialCropd"):
+        self.affine, self.crop = affine, crop
+
+    def __call__(self, sample: dict) -> dict:
+        return self.affine(sample, crop_roi_size=self.crop.roi_size)
+
+
+def fuse_affine_crop(transforms: Sequence) -> list:
+    """Peephole over a GPU augmentation chain (viscy_data/hcs.py:694-695 applies it in order): an affine whose output is
+    centre-cropped next (every fit recipe: oversized patch -> affine -> crop to the training size) only computes the
+    voxels that survive the crop.  Same values, same RNG consumption; anything else passes through untouched."""
+    out, i = [], 0
+    ts = list(transforms)
+    while i < len(ts):
+        t = ts[i]
+        nxt = ts[i + 1] if i + 1 < len(ts) else None
+        if (isinstance(t, BatchedRandAffined) and isinstance(nxt, BatchedCenterSpatialCropd) and len(nxt.roi_size) == 3
+                and list(nxt.keys) == list(t.keys)):
+            out.append(_AffineThenCenterCrop(t, nxt))
+            i += 2
+        else:
+            out.append(t)
+            i += 1
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
