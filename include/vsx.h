@@ -85,7 +85,8 @@ typedef struct VsxGemm {
   float* red0;
   float* red1;
   float* colsum;        /* TN only: [N] += sum_m X[m, n] (bias gradient), may be NULL */
-  void* C2;             /* NT, EPI_BIAS_GELU_SQ: second output g = gelu(h), same layout as C */
+  void* C2;             /* NT, EPI_BIAS_GELU_SQ: second output g = gelu(h), same layout as C (C itself may be NULL then:
+                           inference keeps only the activation) */
   int64_t b_bstride;    /* NT: element stride between PER-SAMPLE weight matrices B[b] (b = m / hw); 0 = one shared B.
                          * Needs hw % 128 == 0, plain row operands, N > 64, K % 32 == 0 (the lean instantiation). Used to
                          * fold the GRN scale into fc2: a·W2^T with a = g·s[b] + beta  ==  g·(W2·diag(s[b]))^T + W2·beta */

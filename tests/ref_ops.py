@@ -92,7 +92,8 @@ def gemm(kind, A, B, Cout, M, N, K, lda, ldb, ldc, *, dtype, a_mode=A_ROWS, gh=0
             o = out.view(Bn, gh, gw, 2, 2, c_cs).permute(0, 1, 3, 2, 4, 5)
             Cv[..., c_coff[z] : c_coff[z] + c_cs] = o.to(Cout.dtype)
         else:
-            Cout.reshape(-1, ldc)[:M, c_coff[z] : c_coff[z] + N] = out.to(Cout.dtype)
+            if Cout is not None:  # EPI_BIAS_GELU_SQ in inference: only C2 (the activation) is kept
+                Cout.reshape(-1, ldc)[:M, c_coff[z] : c_coff[z] + N] = out.to(Cout.dtype)
 
 
 def gemm_z(kind, *args, nz, a_coff, b_off, c_coff, **kw):

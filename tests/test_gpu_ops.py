@@ -122,6 +122,25 @@ def test_gemm_nt_rows(dt, M, N, K, hw, epi):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K,hw", [(200, 40, 48, 100), (512, 384, 256, 256), (384, 192, 224, 128)],
+                         ids=["generic", "lean_bk64", "lean_bk32"])
+def test_gemm_nt_gelu_sq_without_preactivation_store(dt, M, N, K, hw):
+    """inference: C = NULL with EPI_BIAS_GELU_SQ keeps only the activation; bit-identical C2 / same statistics, C untouched"""
+    H = _hip()
+    nb = (M + hw - 1) // hw
+    A, Bw, bias = rnd(M, K, dt=dt, seed=1).to(DEV), rnd(N, K, dt=dt, seed=2, scale=K**-0.5).to(DEV), rnd(N, seed=3).to(DEV)
+    outs = []
+    for keep in (True, False):
+        C = torch.zeros(M, N, dtype=dt, device=DEV) if keep else None
+        C2 = torch.zeros(M, N, dtype=dt, device=DEV)
+        r0 = torch.zeros(nb, N, device=DEV)
+        H.gemm("nt", A, Bw, C, M, N, K, K, K, N, dtype=dt, hw=hw, epi=R.EPI_BIAS_GELU_SQ, bias=bias, red0=r0, C2=C2)
+        outs.append((C2, r0))
+    assert torch.equal(outs[0][0], outs[1][0])
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K,hw", [(192, 40, 160, 64), (768, 224, 384, 256), (512, 128, 96, 128)],
                          ids=["generic", "lean_bk64", "lean_bk32"])
 def test_gemm_nt_grn_prologue(dt, M, N, K, hw):

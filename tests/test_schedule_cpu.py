@@ -153,3 +153,15 @@ def test_masked_schedule_matches_reference_golden(tag):
         gr = eng.g(mine_named[name])
         assert ((gr - gg).abs().max() / gg.abs().max().clamp_min(1e-6)).item() < 2e-3, name
     print(tag, "masked max rel grad err", worst)
+
+
+def test_inference_schedule_skips_preactivation_store():
+    """need_bwd=False: fc1 keeps only gelu(h) (C = NULL); same output as the training-mode forward"""
+    torch.manual_seed(0)
+    ref, mine = _pair(CASES[0][1])
+    x = torch.randn(1, 1, 5, 64, 64)
+    eng = Engine(mine, ops=ref_ops)
+    with torch.no_grad():
+        a, sv = eng.forward(x, torch.float32, need_bwd=False)
+        b, _ = eng.forward(x, torch.float32, need_bwd=True)
+    assert sv is None and torch.equal(a, b)

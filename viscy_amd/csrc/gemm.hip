@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 1) void gemm_nt_kernel(const V
         } else {
           dst = Cg + (size_t)m * p.ldc + c_coff + n;
         }
-        stvec<T>(dst, pack<T>(v));
+        if (epi != VSX_EPI_BIAS_GELU_SQ || Cg != nullptr) stvec<T>(dst, pack<T>(v));
         if (reduce && !uniform) {
           // tile spans more than MAXBT batch samples (very small feature maps): direct atomics
 #pragma unroll
@@ -677,7 +677,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
               r1[j] += dz;
             }
           }
-          stvec<T>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + ccol, pack<T>(v));
+          // inference passes C = nullptr with EPI_BIAS_GELU_SQ: only the activation (C2) is kept, not the pre-activation
+          if (EPI != VSX_EPI_BIAS_GELU_SQ || p.C != nullptr)
+            stvec<T>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + ccol, pack<T>(v));
         }
       }
     }

@@ -237,7 +237,8 @@ class Engine:
         colsq = self._za.take(B, 4 * C)
         # fc1 writes the pre-activation h (needed for gelu' in backward) AND the activation g = gelu(h):
         # fc2, the fc2 weight gradient and the GRN statistics path all consume g, so GELU is evaluated once
-        h = torch.empty((M, 4 * C), dtype=dt, device=x.device)
+        # (inference keeps the activation only: C = NULL skips the pre-activation store, a third of the block's 4C-wide traffic)
+        h = torch.empty((M, 4 * C), dtype=dt, device=x.device) if save is not None else None
         gact = torch.empty((M, 4 * C), dtype=dt, device=x.device)
         o.gemm("nt", xh, w.W1f, h, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=w.b1f, red0=colsq,
                hw=hw, C2=gact)
