@@ -140,6 +140,7 @@ if __name__ == "__main__":
     want = sys.argv[1:] or ["augment", "fcmae", "fwd2048", "predict"]
     rows = {"augment": row_augment, "fcmae": row_fcmae, "fwd2048": row_fwd2048, "predict": row_predict}
     for w in want:
+        torch.cuda.reset_peak_memory_stats()
         try:
             r = rows[w]()
         except Exception as e:  # one failing row must not hide the others
