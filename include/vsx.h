@@ -157,6 +157,30 @@ int32_t vsx_masked_mse_fwd(const float* pred, const float* orig, const uint8_t* 
 int32_t vsx_masked_mse_bwd(const float* pred, const float* orig, const uint8_t* mask, const float* acc, const float* gout,
     float* dpred, int32_t B, int32_t C, int32_t Z, int64_t HW, vsx_stream_t stream);
 
+/* DynaCLR contrastive path: tail of viscy_models.contrastive.ContrastiveEncoder
+ * (packages/viscy-models/src/viscy_models/contrastive/encoder.py:93-154) behind the ConvNeXt trunk.
+ * Global average pool of a channels-last feature map x [B*hw, C] (dtype) -> out [B, C] fp32 (timm head.global_pool) and
+ * its transpose. */
+int32_t vsx_avgpool_rows_fwd(const void* x, float* out, int32_t B, int32_t hw, int32_t C, int32_t dtype, vsx_stream_t stream);
+int32_t vsx_avgpool_rows_bwd(const float* dout, void* dx, int32_t B, int32_t hw, int32_t C, int32_t dtype, vsx_stream_t stream);
+/* nn.BatchNorm1d on [B, F] fp32 (projection MLP, encoder.py:115-121), optional fused ReLU.  training != 0: batch
+ * statistics, running_{mean,var} updated in place (momentum, unbiased variance); else the running statistics normalise.
+ * save_{mean,rstd} [F] feed the backward, which ADDS into dw / db. */
+int32_t vsx_bn1d_fwd(const float* x, const float* w, const float* b, float* running_mean, float* running_var, float* y,
+    float* save_mean, float* save_rstd, int32_t B, int32_t F, float eps, float momentum, int32_t training, int32_t relu,
+    vsx_stream_t stream);
+int32_t vsx_bn1d_bwd(const float* dy, const float* x, const float* y, const float* w, const float* save_mean,
+    const float* save_rstd, float* dx, float* dw, float* db, int32_t B, int32_t F, int32_t training, int32_t relu,
+    vsx_stream_t stream);
+/* viscy_models.contrastive.loss.NTXentLoss / NTXentHCL (loss.py:20-186; pytorch-metric-learning pair semantics):
+ * E [N, D] fp32 embeddings, labels [N]; equal labels = positive pairs, different labels = negatives; cosine similarity;
+ * beta = 0: NT-Xent, beta > 0: hard-negative re-weighting.  Scratch owned by the caller: En [N,D], inv [N], S [N,N],
+ * dS [N,N], rows [2N]; acc [2] = {loss, number of positive pairs}.  vsx_ntxent_bwd: dE = gout * d loss / d E. */
+int32_t vsx_ntxent_fwd(const float* E, const int32_t* labels, float* En, float* inv, float* S, float* dS, float* rows, float* acc,
+    int32_t N, int32_t D, float temperature, float beta, vsx_stream_t stream);
+int32_t vsx_ntxent_bwd(const float* dS, const float* En, const float* inv, const float* acc, const float* gout, float* dE,
+    int32_t N, int32_t D, vsx_stream_t stream);
+
 /* K13 (norm+act) + K14: MONAI Convolution ADN (InstanceNorm3d eps 1e-5 → PReLU) → nn.Conv3d(mid, 4*out, 1) → transpose /
  * nn.PixelShuffle(2) / transpose (viscy_models/components/heads.py:617-625,638-641).  U: [B,H2,W2,Z,Cmid] conv output;
  * ssum/ssq: [B,Cmid] from the conv GEMM epilogue (VSX_EPI_BIAS_STATS); out: (B, Cout, Z, 2*H2, 2*W2) fp32. */

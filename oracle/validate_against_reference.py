@@ -397,13 +397,161 @@ def g9_fcmae():
     torch.save(masked, os.path.join(GOLD, "fcmae_masked.pt"))
 
 
+# ----------------------------------------------------------------------------------------------
+def g6b_hf_convnext_v1():
+    """ConvNeXt-V1 block (layer scale, plain MLP) and the whole pooled trunk vs `transformers`' independent implementation."""
+    from transformers import ConvNextConfig
+    from transformers.models.convnext.modeling_convnext import ConvNextLayer, ConvNextModel
+
+    from oracle import contrastive_ref as C
+
+    torch.manual_seed(4)
+    dim = 24
+    cfg = ConvNextConfig(hidden_act="gelu", layer_scale_init_value=0.3)
+    hf = ConvNextLayer(cfg, dim=dim, drop_path=0.0)
+    blk = C.ConvNeXtV1Block(dim)
+    with torch.no_grad():
+        for p_ in hf.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.2)
+        blk.gamma.copy_(hf.layer_scale_parameter)
+        blk.conv_dw.weight.copy_(hf.dwconv.weight); blk.conv_dw.bias.copy_(hf.dwconv.bias)
+        blk.norm.weight.copy_(hf.layernorm.weight); blk.norm.bias.copy_(hf.layernorm.bias)
+        blk.mlp.fc1.weight.copy_(hf.pwconv1.weight); blk.mlp.fc1.bias.copy_(hf.pwconv1.bias)
+        blk.mlp.fc2.weight.copy_(hf.pwconv2.weight); blk.mlp.fc2.bias.copy_(hf.pwconv2.bias)
+    x = torch.randn(2, dim, 12, 10)
+    d = maxrel(blk(x), hf(x))
+    assert d < 2e-6, d
+    print(f"G6b ConvNeXt-V1 block: max rel diff vs HF ConvNextLayer {d:.2e}")
+    # pooled trunk: stem (patchify conv + LN2d) -> 4 stages -> global average pool -> LayerNorm == HF pooler_output
+    cfg = ConvNextConfig(num_channels=3, hidden_sizes=[16, 32, 48, 64], depths=[1, 1, 2, 1], hidden_act="gelu", layer_scale_init_value=0.5)
+    hf = ConvNextModel(cfg).eval()
+    net = C.ConvNeXt("convnext_tiny", num_classes=0, depths=(1, 1, 2, 1), dims=(16, 32, 48, 64)).eval()
+    with torch.no_grad():
+        for p_ in hf.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.2)
+        emb = hf.embeddings
+        net.stem[0].weight.copy_(emb.patch_embeddings.weight); net.stem[0].bias.copy_(emb.patch_embeddings.bias)
+        net.stem[1].weight.copy_(emb.layernorm.weight); net.stem[1].bias.copy_(emb.layernorm.bias)
+        for st, hs in zip(net.stages, hf.encoder.stages):
+            if not isinstance(st.downsample, nn.Identity):
+                ds = hs.downsampling_layer
+                st.downsample[0].weight.copy_(ds[0].weight); st.downsample[0].bias.copy_(ds[0].bias)
+                st.downsample[1].weight.copy_(ds[1].weight); st.downsample[1].bias.copy_(ds[1].bias)
+            for b, h in zip(st.blocks, hs.layers):
+                b.gamma.copy_(h.layer_scale_parameter)
+                b.conv_dw.weight.copy_(h.dwconv.weight); b.conv_dw.bias.copy_(h.dwconv.bias)
+                b.norm.weight.copy_(h.layernorm.weight); b.norm.bias.copy_(h.layernorm.bias)
+                b.mlp.fc1.weight.copy_(h.pwconv1.weight); b.mlp.fc1.bias.copy_(h.pwconv1.bias)
+                b.mlp.fc2.weight.copy_(h.pwconv2.weight); b.mlp.fc2.bias.copy_(h.pwconv2.bias)
+        net.head.norm.weight.copy_(hf.layernorm.weight); net.head.norm.bias.copy_(hf.layernorm.bias)
+        x = torch.randn(2, 3, 64, 96)
+        d = maxrel(net(x), hf(x).pooler_output)
+    assert d < 5e-6, d
+    print(f"G6b ConvNeXt-V1 pooled trunk: max rel diff vs HF ConvNextModel.pooler_output {d:.2e}")
+
+
+def g10_contrastive():
+    """DynaCLR path: reference StemDepthtoChannels (direct import), the reference's own contrastive/encoder.py on a stub
+    timm.create_model, the reference's own NTXentHCL on a stub pytorch_metric_learning base — all == oracle/contrastive_ref.py."""
+    from oracle import contrastive_ref as C
+
+    base = f"{REF}/viscy-models/src/viscy_models"
+    stems = sys.modules.get("viscy_models.components.stems") or _load("viscy_models.components.stems", f"{base}/components/stems.py")
+    torch.manual_seed(2)
+    for cin, depth, ks, st_ in [(2, 15, (5, 4, 4), (5, 4, 4)), (1, 9, (3, 2, 2), (3, 2, 2)), (1, 12, (4, 4, 4), (2, 4, 4))]:
+        try:
+            r = stems.StemDepthtoChannels(cin, depth, 96, ks, st_)
+        except ValueError as e:
+            try:
+                C.StemDepthtoChannels(cin, depth, 96, ks, st_)
+                raise AssertionError("oracle accepted a shape the reference rejects")
+            except ValueError as e2:
+                assert str(e) == str(e2)
+                continue
+        o = C.StemDepthtoChannels(cin, depth, 96, ks, st_)
+        o.load_state_dict(r.state_dict())
+        x = torch.randn(2, cin, depth, 32, 48)
+        assert maxrel(o(x), r(x)) == 0.0
+    print("G10 StemDepthtoChannels: reference class == oracle (exact)")
+
+    # ---- encoder wiring
+    timm = sys.modules["timm"]
+    made = {}
+
+    def create_model(backbone, pretrained=False, features_only=False, drop_path_rate=0.0, num_classes=0):
+        assert not features_only and not pretrained and drop_path_rate == 0.0
+        m = C.ConvNeXt(backbone, num_classes=num_classes, **made.get("arch", {}))
+        return m
+
+    timm.create_model = create_model
+    ref = _load("viscy_models.contrastive.encoder", f"{base}/contrastive/encoder.py")
+    golden = {}
+    for tag, kw, arch, hw in [
+        ("v1_tiny_z15", dict(backbone="convnext_tiny", in_channels=2, in_stack_depth=15, embedding_dim=768, projection_dim=128), {}, 64),
+        ("v2_small_z9", dict(backbone="convnextv2_tiny", in_channels=1, in_stack_depth=9, stem_kernel_size=(3, 2, 2), stem_stride=(3, 2, 2),
+                             embedding_dim=64, projection_dim=32), dict(depths=(1, 1, 2, 1), dims=(24, 48, 96, 192)), 64),
+        ("v1_small_z5", dict(backbone="convnext_tiny", in_channels=1, in_stack_depth=5, embedding_dim=96, projection_dim=32),
+         dict(depths=(1, 2, 2, 1), dims=(32, 64, 96, 128)), 64),
+    ]:
+        made["arch"] = arch
+        r = ref.ContrastiveEncoder(**kw)
+        o = C.ContrastiveEncoder(**kw, **arch)
+        assert list(r.state_dict().keys()) == list(o.state_dict().keys()), tag
+        C.randomize_encoder_(o, seed=21)
+        r.load_state_dict(o.state_dict(), strict=True)
+        g = torch.Generator().manual_seed(45)
+        x = torch.randn((4, kw["in_channels"], kw["in_stack_depth"], hw, hw + 32), generator=g)
+        out = {}
+        for mode in ("eval", "train"):
+            getattr(r, mode)(); getattr(o, mode)()
+            er, pr = r(x)
+            eo, po = o(x)
+            assert maxrel(eo, er) == 0.0 and maxrel(po, pr) == 0.0, (tag, mode)
+            out[mode] = (eo.detach(), po.detach())
+        assert all(torch.equal(a, b) for a, b in zip(r.state_dict().values(), o.state_dict().values()))  # BN running stats moved alike
+        golden[tag] = {"kwargs": kw, "arch": arch, "seed": 21, "x_seed": 45, "x_shape": tuple(x.shape), "keys": list(o.state_dict().keys()),
+                       "eval": out["eval"], "train": out["train"],
+                       "running_after": {k: v.clone() for k, v in o.state_dict().items() if "running" in k or "num_batches" in k}}
+        print(f"G10 encoder {tag}: reference encoder.py on stub timm == oracle (exact, eval + train); keys={len(golden[tag]['keys'])}")
+
+    # ---- losses: the reference's NTXentHCL on a stub pml base
+    _stub("pytorch_metric_learning")
+    _stub("pytorch_metric_learning.losses", NTXentLoss=C.PairLossBase)
+    _stub("pytorch_metric_learning.utils")
+    cf = _stub("pytorch_metric_learning.utils.common_functions", to_dtype=lambda x, dtype=None, **k: x.to(dtype),
+               neg_inf=lambda dt: torch.finfo(dt).min, small_val=lambda dt: torch.finfo(dt).tiny)
+    sys.modules["pytorch_metric_learning.utils"].common_functions = cf
+    rl = _load("viscy_models.contrastive.loss", f"{base}/contrastive/loss.py")
+    lg = {}
+    for i, (n, dim, T, beta) in enumerate([(8, 64, 0.1, 0.0), (8, 64, 0.2, 0.5), (16, 32, 0.07, 1.0), (5, 16, 0.5, 0.25)]):
+        g = torch.Generator().manual_seed(100 + i)
+        e = torch.randn(2 * n, dim, generator=g, requires_grad=True)
+        labels = torch.cat((torch.arange(n), torch.arange(n)))
+        lr_ = rl.NTXentHCL(temperature=T, beta=beta)(e, labels)
+        (gr,) = torch.autograd.grad(lr_, e)
+        lo = C.NTXentHCL(temperature=T, beta=beta)(e, labels)
+        (go,) = torch.autograd.grad(lo, e)
+        assert lr_.item() == lo.item() and maxrel(go, gr) == 0.0, (n, beta)
+        lg[f"case{i}"] = {"n": n, "dim": dim, "temperature": T, "beta": beta, "seed": 100 + i, "loss": lo.item(), "grad": go}
+    sch = rl.NTXentLoss(temperature=0.07, temperature_schedule="cosine", temperature_start=0.2, temperature_warmup_epochs=10)
+    sco = C.NTXentLoss(temperature=0.07, temperature_schedule="cosine", temperature_start=0.2, temperature_warmup_epochs=10)
+    for ep in (0, 3, 10, 12):
+        sch.step(ep); sco.step(ep)
+        assert sch.temperature == sco.temperature
+    golden["loss"] = lg
+    print("G10 NTXentHCL: reference loss.py on a stub pytorch-metric-learning base == oracle (exact, values + gradients, 4 cases)")
+    torch.save(golden, os.path.join(GOLD, "contrastive.pt"))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     g6_hf_convnext()  # first: `transformers` must be imported before any third-party stub exists
+    g6b_hf_convnext_v1()
     g1_stem()
     g2_loss()
     g3_normalize()
     g8_wiring()
     g9_fcmae()
+    g10_contrastive()
     print("oracle pinned; fixtures written to tests/golden/")

@@ -367,6 +367,38 @@ def scale_weight_samples(W, s, dtype):
     return (W.detach().float().reshape(W.shape[0], -1)[None, :, :] * s.float()[:, None, :]).to(dtype)
 
 
+def avgpool_rows_fwd(x, B, hw, C):
+    return x.float().view(B, hw, C).mean(1)
+
+
+def avgpool_rows_bwd(dout, B, hw, C, dtype):
+    return (dout / hw).unsqueeze(1).expand(B, hw, C).reshape(B * hw, C).to(dtype)
+
+
+def bn1d_fwd(x, w, b, rmean, rvar, training, relu, eps=1e-5, momentum=0.1):
+    import torch.nn.functional as F
+
+    if training:
+        mean, var = x.mean(0), x.var(0, unbiased=False)
+    else:
+        mean, var = rmean.clone(), rvar.clone()
+    y = F.batch_norm(x, rmean, rvar, w, b, training, momentum, eps)
+    if relu:
+        y = y.relu()
+    return y, mean, (var + eps).rsqrt()
+
+
+def bn1d_bwd(dy, x, y, w, sm, sr, dw, db, training, relu):
+    d = dy * (y > 0) if relu else dy
+    xh = (x - sm) * sr
+    sb, sg = d.sum(0), (d * xh).sum(0)
+    dw += sg
+    db += sb
+    g = w * sr
+    B = x.shape[0]
+    return g * (d - sb / B - xh * sg / B) if training else g * d
+
+
 def rows_select(src, row_map, n_out, C, add=None):
     m = row_map.long()
     out = src[m.clamp_min(0)].clone()

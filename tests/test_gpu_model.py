@@ -516,3 +516,82 @@ def test_fcmae_unet_pretraining_steps_reduce_the_masked_loss():
     with torch.no_grad():
         vs.validation_step({"source": base}, 0)
     assert len(vs.validation_losses[0]) == 1
+
+
+# ------------------------------------------------------------------------------------------------ DynaCLR path (§8 f3)
+def _contrastive_pair(dtype):
+    from oracle import contrastive_ref as C
+    from viscy_amd.contrastive import ContrastiveEncoder
+
+    g = load_golden("contrastive.pt")["v2_small_z9"]
+    ref = C.randomize_encoder_(C.ContrastiveEncoder(**g["kwargs"], **g["arch"]), seed=g["seed"])
+    mine = ContrastiveEncoder(**g["kwargs"], **g["arch"])
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.cuda()
+    mine.compute_dtype = dtype
+    x = torch.randn(g["x_shape"], generator=torch.Generator().manual_seed(g["x_seed"]))
+    return g, ref, mine, x
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_contrastive_encoder_matches_reference_golden_fp32(mode):
+    """(embedding, projection) vs the REFERENCE's encoder.py run (G10), BatchNorm running statistics after a train-mode call,
+    every parameter gradient vs oracle autograd"""
+    g, ref, mine, x = _contrastive_pair(torch.float32)
+    getattr(ref, mode)()
+    getattr(mine, mode)()
+    emb, proj = mine(x.cuda())
+    assert relerr(emb, g[mode][0]) <= 1e-3 and relerr(proj, g[mode][1]) <= 1e-3
+    if mode == "train":
+        sd = mine.state_dict()
+        for k, v in g["running_after"].items():
+            torch.testing.assert_close(sd[k].cpu().float(), v.float(), rtol=1e-3, atol=1e-4)
+    er, pr = ref(x)
+    gen = torch.Generator().manual_seed(3)
+    de, dp = torch.randn(er.shape, generator=gen), torch.randn(pr.shape, generator=gen)
+    ((er * de).sum() + (pr * dp).sum()).backward()
+    ((emb * de.cuda()).sum() + (proj * dp.cuda()).sum()).backward()
+    worst = 0.0
+    for (name, p_ref), (n2, p) in zip(ref.named_parameters(), mine.named_parameters()):
+        assert name == n2
+        if mode == "train" and name in ("projection.0.bias", "projection.3.bias"):
+            continue  # exactly-zero gradient in front of a train-mode BatchNorm
+        e = relerr(p.grad, p_ref.grad)
+        worst = max(worst, e)
+        assert e <= 2e-3, (name, e)
+    print(mode, "contrastive worst relative gradient error", worst)
+
+
+def test_contrastive_module_trains_convnextv2_tiny_bf16():
+    """the DynaCLR recipe shape: convnextv2_tiny trunk, 2 channels x 15 slices, NT-Xent on (anchor, positive) pairs, fused
+    AdamW, bf16 — the loss falls and the embeddings of a pair become the nearest neighbours of each other"""
+    from viscy_amd.contrastive import ContrastiveEncoder, ContrastiveModule, NTXentLoss
+
+    torch.manual_seed(0)
+    enc = ContrastiveEncoder("convnextv2_tiny", in_channels=2, in_stack_depth=15, embedding_dim=768, projection_dim=128)
+    mod = ContrastiveModule(enc, loss_function=NTXentLoss(temperature=0.2), lr=2e-4).cuda()
+    enc.compute_dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(1)
+    base = torch.nn.functional.avg_pool3d(torch.randn(8, 2, 15, 96, 96, generator=g), (1, 5, 5), 1, (0, 2, 2)).cuda() * 3
+    batch = {"anchor": base, "positive": base + 0.5 * torch.randn(base.shape, generator=g).cuda()}
+    with torch.no_grad():
+        emb, proj = mod(base)
+    assert emb.shape == (8, 768) and proj.shape == (8, 128) and emb.dtype == torch.float32
+    opt = mod.configure_optimizers(t_total=20)
+    mod.train()
+    mod.on_train_epoch_start()
+    losses = []
+    for i in range(20):
+        opt.zero_grad()
+        loss = mod.training_step(batch, i)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(l == l for l in losses) and sum(losses[-3:]) / 3 < 0.9 * losses[0], losses
+    mod.eval()
+    with torch.no_grad():
+        pa = torch.nn.functional.normalize(mod.predict_step({"anchor": batch["anchor"]}, 0)["projections"], dim=1)
+        pp = torch.nn.functional.normalize(mod.predict_step({"anchor": batch["positive"]}, 0)["projections"], dim=1)
+    assert (pa @ pp.t()).argmax(1).tolist() == list(range(8))
+    with pytest.raises(NotImplementedError, match="convnextv2_tiny"):
+        ContrastiveEncoder("convnext_tiny", in_channels=2, in_stack_depth=15)

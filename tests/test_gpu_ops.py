@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from tests import ref_ops as R
+from tests.conftest import load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -635,3 +636,82 @@ def test_masked_mse_loss_vs_oracle(shape):
     torch.testing.assert_close(pc.grad.cpu(), 3.0 * p.grad, rtol=1e-5, atol=1e-9)
     with pytest.raises(ValueError, match="mask must be"):
         MaskedMSELoss()(pc, o.to(DEV), m[:, :, :-1].to(DEV))
+
+
+# ---------------------------------------------------------------- DynaCLR tail + loss (csrc/contrastive.hip)
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_avgpool_rows(dt):
+    H = _hip()
+    B, hw, C = 5, 36, 200
+    x, dout = rnd(B * hw, C, dt=dt, seed=1), rnd(B, C, seed=2)
+    close(H.avgpool_rows_fwd(x.to(DEV), B, hw, C), R.avgpool_rows_fwd(x, B, hw, C), torch.float32, "avgpool fwd")
+    close(H.avgpool_rows_bwd(dout.to(DEV), B, hw, C, dt), R.avgpool_rows_bwd(dout, B, hw, C, dt), dt, "avgpool bwd")
+
+
+@pytest.mark.parametrize("training", [True, False], ids=["train", "eval"])
+@pytest.mark.parametrize("relu", [True, False], ids=["relu", "plain"])
+def test_bn1d_fwd_bwd_vs_torch(training, relu):
+    """nn.BatchNorm1d semantics incl. the running-statistics update (momentum 0.1, unbiased variance)"""
+    H = _hip()
+    B, F = 12, 300
+    x, w, b = rnd(B, F, seed=1, scale=2.0) + 0.5, 1 + 0.2 * rnd(F, seed=2), 0.3 * rnd(F, seed=3)
+    rm, rv = 0.1 * rnd(F, seed=4), 0.5 + torch.rand(F, generator=torch.Generator().manual_seed(5))
+    dy = rnd(B, F, seed=6)
+    bn = torch.nn.BatchNorm1d(F)
+    with torch.no_grad():
+        bn.weight.copy_(w); bn.bias.copy_(b); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.train(training)
+    xr = x.clone().requires_grad_(True)
+    yr = bn(xr)
+    if relu:
+        yr = yr.relu()
+    yr.backward(dy)
+    rm_g, rv_g = rm.clone().to(DEV), rv.clone().to(DEV)
+    y, sm, sr = H.bn1d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), rm_g, rv_g, training, relu)
+    torch.testing.assert_close(y.cpu(), yr.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rm_g.cpu(), bn.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv_g.cpu(), bn.running_var, rtol=1e-5, atol=1e-6)
+    dw, db = torch.ones(F, device=DEV), torch.ones(F, device=DEV)  # the backward ADDS into the gradient buffers
+    dx = H.bn1d_bwd(dy.to(DEV), x.to(DEV), y, w.to(DEV), sm, sr, dw, db, training, relu)
+    torch.testing.assert_close(dx.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dw.cpu() - 1, bn.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu() - 1, bn.bias.grad, rtol=1e-4, atol=1e-4)
+    if training:
+        with pytest.raises(RuntimeError, match="more than 1 value per channel"):
+            H.bn1d_fwd(x[:1].to(DEV), w.to(DEV), b.to(DEV), rm_g, rv_g, True, relu)
+
+
+def test_ntxent_matches_reference_golden():
+    """values and gradients stored from the REFERENCE's NTXentHCL (G10), beta = 0 and beta > 0"""
+    from viscy_amd.contrastive import NTXentHCL, NTXentLoss
+
+    for c in load_golden("contrastive.pt")["loss"].values():
+        e = torch.randn(2 * c["n"], c["dim"], generator=torch.Generator().manual_seed(c["seed"]))
+        labels = torch.cat((torch.arange(c["n"]), torch.arange(c["n"])))
+        eg = e.to(DEV).requires_grad_(True)
+        loss = NTXentHCL(temperature=c["temperature"], beta=c["beta"])(eg, labels.to(DEV))
+        assert abs(loss.item() - c["loss"]) <= 2e-5 * abs(c["loss"]), c
+        (2.0 * loss).backward()
+        torch.testing.assert_close(eg.grad.cpu(), 2.0 * c["grad"], rtol=2e-4, atol=1e-6 + 2e-4 * c["grad"].abs().max().item())
+        if c["beta"] == 0.0:
+            l0 = NTXentLoss(temperature=c["temperature"])(e.to(DEV), labels.to(DEV))
+            assert abs(l0.item() - c["loss"]) <= 2e-5 * abs(c["loss"])
+
+
+@pytest.mark.parametrize("beta", [0.0, 0.7])
+def test_ntxent_general_labels_vs_oracle(beta):
+    """several positives per anchor, unequal class sizes, a large batch (N = 600 > one 256-thread sweep)"""
+    from oracle.contrastive_ref import NTXentHCL as RefLoss
+    from viscy_amd.contrastive import NTXentHCL
+
+    g = torch.Generator().manual_seed(9)
+    for N, D, ncls in [(37, 24, 9), (600, 128, 300)]:
+        e = torch.randn(N, D, generator=g, requires_grad=True)
+        labels = torch.randint(0, ncls, (N,), generator=g)
+        lr = RefLoss(temperature=0.2, beta=beta)(e, labels)
+        lr.backward()
+        eg = e.detach().to(DEV).requires_grad_(True)
+        lg = NTXentHCL(temperature=0.2, beta=beta)(eg, labels.to(DEV))
+        lg.backward()
+        assert abs(lg.item() - lr.item()) <= 5e-5 * abs(lr.item()), (N, lg.item(), lr.item())
+        torch.testing.assert_close(eg.grad.cpu(), e.grad, rtol=5e-4, atol=1e-7 + 5e-4 * e.grad.abs().max().item())

@@ -150,3 +150,54 @@ def test_fcmae_masked_oracle_matches_reference_golden(tag):
     torch.manual_seed(0)
     low = fcmae_ref.generate_mask((3, 1, 5, 128, 160), 32, 0.6)
     assert low.shape == (3, 1, 4, 5) and low.flatten(1).sum(1).tolist() == [12, 12, 12]
+
+
+# ------------------------------------------------------------------------------------------------ DynaCLR path (§8 f3)
+@pytest.mark.parametrize("tag", ["v1_tiny_z15", "v2_small_z9", "v1_small_z5"])
+def test_contrastive_encoder_golden(tag):
+    """oracle ContrastiveEncoder == what the REFERENCE's encoder.py produced on a stub timm (G10): eval + train outputs,
+    BatchNorm running statistics after the train-mode call, state-dict keys"""
+    from oracle import contrastive_ref as C
+
+    g = load_golden("contrastive.pt")[tag]
+    m = C.randomize_encoder_(C.ContrastiveEncoder(**g["kwargs"], **g["arch"]), seed=g["seed"])
+    assert list(m.state_dict().keys()) == g["keys"]
+    x = torch.randn(g["x_shape"], generator=torch.Generator().manual_seed(g["x_seed"]))
+    m.eval()
+    with torch.no_grad():
+        e, p = m(x)
+    torch.testing.assert_close(e, g["eval"][0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(p, g["eval"][1], rtol=1e-5, atol=1e-6)
+    m.train()
+    with torch.no_grad():
+        e, p = m(x)
+    torch.testing.assert_close(p, g["train"][1], rtol=1e-5, atol=1e-5)
+    for k, v in g["running_after"].items():
+        torch.testing.assert_close(m.state_dict()[k], v, rtol=1e-5, atol=1e-6)
+    if tag == "v1_tiny_z15":  # reference test_encoder.py:8-22 shapes
+        assert e.shape == (4, 768) and p.shape == (4, 128)
+
+
+def test_ntxent_golden_and_simclr_cross_entropy():
+    """NTXentHCL values / gradients stored from the REFERENCE's loss.py (G10); beta = 0 equals the textbook SimCLR
+    cross-entropy over each row's similarities without the self term (the pml semantics the reference relies on)"""
+    from oracle import contrastive_ref as C
+
+    cases = load_golden("contrastive.pt")["loss"]
+    for c in cases.values():
+        e = torch.randn(2 * c["n"], c["dim"], generator=torch.Generator().manual_seed(c["seed"]), requires_grad=True)
+        labels = torch.cat((torch.arange(c["n"]), torch.arange(c["n"])))
+        loss = C.NTXentHCL(temperature=c["temperature"], beta=c["beta"])(e, labels)
+        assert abs(loss.item() - c["loss"]) <= 1e-6 * abs(c["loss"])
+        (gr,) = torch.autograd.grad(loss, e)
+        torch.testing.assert_close(gr, c["grad"], rtol=1e-5, atol=1e-8)
+        if c["beta"] == 0.0:
+            en = torch.nn.functional.normalize(e.detach(), dim=1)
+            s = en @ en.t() / c["temperature"]
+            s.fill_diagonal_(float("-inf"))
+            n = c["n"]
+            tgt = torch.cat((torch.arange(n) + n, torch.arange(n)))
+            assert abs(torch.nn.functional.cross_entropy(s, tgt).item() - c["loss"]) <= 1e-5 * abs(c["loss"])
+    # reference test_loss.py: a stem that cannot fold the depth is rejected with the reference's message
+    with pytest.raises(ValueError, match="more channels"):
+        C.StemDepthtoChannels(1, 12, 96, (4, 4, 4), (2, 4, 4))

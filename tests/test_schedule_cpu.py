@@ -165,3 +165,49 @@ def test_inference_schedule_skips_preactivation_store():
         a, sv = eng.forward(x, torch.float32, need_bwd=False)
         b, _ = eng.forward(x, torch.float32, need_bwd=True)
     assert sv is None and torch.equal(a, b)
+
+
+# ---------------------------------------------------------------- DynaCLR ContrastiveEncoder schedule
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_contrastive_schedule_matches_reference_golden(mode):
+    """embedding / projection + every parameter gradient + BatchNorm running statistics: engine schedule (kernels = plain
+    torch) vs the reference-generated golden (tests/golden/contrastive.pt, G10) and vs autograd of the oracle"""
+    from oracle import contrastive_ref as C
+    from tests.conftest import load_golden
+    from viscy_amd.contrastive import ContrastiveEncoder
+
+    gold = load_golden("contrastive.pt")["v2_small_z9"]
+    ref = C.randomize_encoder_(C.ContrastiveEncoder(**gold["kwargs"], **gold["arch"]), seed=gold["seed"])
+    mine = ContrastiveEncoder(**gold["kwargs"], **gold["arch"])
+    assert list(mine.state_dict().keys()) == gold["keys"]
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    getattr(ref, mode)()
+    getattr(mine, mode)()
+    x = torch.randn(gold["x_shape"], generator=torch.Generator().manual_seed(gold["x_seed"]))
+    eng = Engine(mine._core, ops=ref_ops)
+    with torch.no_grad():
+        (emb, proj), sv = eng.forward(x, torch.float32, need_bwd=True)
+    sc = lambda t: 1e-4 * t.abs().max().item()  # noqa: E731
+    torch.testing.assert_close(emb, gold[mode][0], rtol=2e-4, atol=sc(gold[mode][0]))
+    torch.testing.assert_close(proj, gold[mode][1], rtol=2e-4, atol=sc(gold[mode][1]))
+    if mode == "train":
+        for k, v in gold["running_after"].items():
+            torch.testing.assert_close(mine.state_dict()[k].float(), v.float(), rtol=1e-4, atol=1e-5)
+    er, pr = ref(x)
+    g = torch.Generator().manual_seed(3)
+    de, dp = torch.randn(er.shape, generator=g), torch.randn(pr.shape, generator=g)
+    ((er * de).sum() + (pr * dp).sum()).backward()
+    with torch.no_grad():
+        eng.backward(sv, (de, dp))
+    named = dict(mine.named_parameters())
+    worst = 0.0
+    for name, p_ref in ref.named_parameters():
+        gr = eng.g(named[name])
+        if mode == "train" and name in ("projection.0.bias", "projection.3.bias"):
+            # a bias in front of a train-mode BatchNorm has an exactly-zero gradient; both sides are round-off
+            assert gr.abs().max() < 1e-4 and p_ref.grad.abs().max() < 1e-4
+            continue
+        err = ((gr - p_ref.grad).abs().max() / p_ref.grad.abs().max().clamp_min(1e-6)).item()
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err)
+    print(mode, "contrastive max rel grad err", worst)

@@ -84,6 +84,12 @@ _SIGS = {
     "vsx_scale_weight_samples": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_voxel_shuffle_fwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),
     "vsx_voxel_shuffle_bwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),
+    "vsx_avgpool_rows_fwd": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "vsx_avgpool_rows_bwd": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "vsx_bn1d_fwd": (_I32, [_P] * 8 + [_I32, _I32, _F32, _F32, _I32, _I32, _P]),
+    "vsx_bn1d_bwd": (_I32, [_P] * 9 + [_I32] * 4 + [_P]),
+    "vsx_ntxent_fwd": (_I32, [_P] * 8 + [_I32, _I32, _F32, _F32, _P]),
+    "vsx_ntxent_bwd": (_I32, [_P] * 6 + [_I32, _I32, _P]),
     "vsx_rows_select": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
     "vsx_masked_mse_fwd": (_I32, [_P] * 5 + [_I32] * 3 + [_I64, _P]),
     "vsx_masked_mse_bwd": (_I32, [_P] * 6 + [_I32] * 3 + [_I64, _P]),

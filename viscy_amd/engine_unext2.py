@@ -121,9 +121,14 @@ class Engine:
             ps = [m.head.conv[1].weight, m.head.conv[1].bias, m.head.conv[0].adn.A.weight, m.head.conv[0].conv.weight,
                   m.head.conv[0].conv.bias]
         self._bucket_marks = [0]
-        for st in reversed(list(m.decoder.decoder_stages)):
-            ps += self._stage_params_rev(st.conv)
-        self._bucket_marks.append(len(ps))  # bucket 0 = head + decoder
+        if self.cfg.get("head") == "embed":  # ContrastiveEncoder: pooled-embedding tail instead of decoder + head
+            t = m.tail
+            ps = [t.bn4.weight, t.bn4.bias, t.fc3.weight, t.fc3.bias, t.bn1.weight, t.bn1.bias, t.fc0.weight, t.fc0.bias,
+                  t.norm.weight, t.norm.bias]
+        else:
+            for st in reversed(list(m.decoder.decoder_stages)):
+                ps += self._stage_params_rev(st.conv)
+        self._bucket_marks.append(len(ps))  # bucket 0 = head + decoder (or the embedding tail)
         for i in (3, 2):
             ps += self._stage_params_rev(getattr(m.encoder_stages, f"stages_{i}"))
         self._bucket_marks.append(len(ps))  # bucket 1 = encoder stages 3, 2
@@ -198,10 +203,17 @@ class Engine:
             enc.append((proj, [self._prep_block(b, dt, need_bwd) for b in st.blocks]))
         W["enc"] = enc
         dec = []
-        for us in m.decoder.decoder_stages:
-            st = us.conv
-            proj = self._prep_proj(st.downsample[0], st.downsample[1], dt, need_bwd)
-            dec.append((proj, [self._prep_block(b, dt, need_bwd) for b in st.blocks]))
+        if cfg.get("head") == "embed":
+            t = m.tail
+            E, Cf = t.fc0.weight.shape
+            P = t.fc3.weight.shape[0]
+            W["fc0"], W["fc0T"] = o.prep_weight(t.fc0.weight, E, Cf, 1, torch.float32, want=True, want_t=need_bwd)
+            W["fc3"], W["fc3T"] = o.prep_weight(t.fc3.weight, P, E, 1, torch.float32, want=True, want_t=need_bwd)
+        else:
+            for us in m.decoder.decoder_stages:
+                st = us.conv
+                proj = self._prep_proj(st.downsample[0], st.downsample[1], dt, need_bwd)
+                dec.append((proj, [self._prep_block(b, dt, need_bwd) for b in st.blocks]))
         W["dec"] = dec
         if cfg.get("head", "conv") == "conv":
             hc = m.head.conv[0].conv
@@ -318,9 +330,9 @@ class Engine:
         self._za = za = _ZeroArena(x.device, self._za_need.get(za_key, 0))
         if Cin != cfg["in_channels"] or Z != cfg["in_stack_depth"]:
             raise ValueError(f"expected input (B,{cfg['in_channels']},{cfg['in_stack_depth']},Y,X), got {tuple(x.shape)}")
-        if H % 32 or Wd % 32:
-            raise ValueError(f"Y and X must be divisible by 32 (got {H}x{Wd}); VSUNet pads to a multiple of 64")
         kz, ky, kx = cfg["stem_kernel"]
+        if H % (8 * ky) or Wd % (8 * kx):
+            raise ValueError(f"Y and X must be divisible by {8 * ky} (got {H}x{Wd}); VSUNet pads to a multiple of 64")
         h, w = H // ky, Wd // kx
         dims = cfg["dims"]
         C0 = dims[0]
@@ -359,6 +371,13 @@ class Engine:
                 cur = self._block_fwd(cur, bw, B, ch, cw, dt, st_sv["blocks"] if need_bwd else None, rows)
             feats.append((cur, ch, cw, cc))
             enc_sv.append(st_sv)
+        if cfg.get("head") == "embed":
+            out = self._embed_tail_fwd(feats[3], B, sv)
+            if need_bwd:
+                sv["enc"] = enc_sv
+                sv["feat_dims"] = [(a, b_, c) for (_, a, b_, c) in feats]
+            self._za_need[za_key] = za.used
+            return out, sv
         # ---- decoder
         dec_sv = []
         feat, fh, fw, fc = feats[3]
@@ -416,6 +435,53 @@ class Engine:
         self._za_need[za_key] = za.used
         return out, sv
 
+    # ------------------------------------------------------------------ ContrastiveEncoder tail (contrastive/encoder.py:93-154)
+    def _embed_tail_fwd(self, feat3, B, sv):
+        """global average pool -> LayerNorm (timm head.norm) = embedding; Linear -> BN -> ReLU -> Linear -> BN = projection.
+        fp32 throughout ([B, 768]-sized tensors); BatchNorm statistics are those of THIS call's batch (the reference runs
+        anchor and positive through separate forwards, dynaclr/engine.py:265-266)."""
+        o, m, W = self.ops, self.model, self.W
+        feat, fh, fw, fc = feat3
+        t = m.tail
+        training = bool(m.training)
+        pooled = o.avgpool_rows_fwd(feat, B, fh * fw, fc)
+        emb, mean, rstd = o.ln_fwd(pooled, t.norm.weight, t.norm.bias, B, fc)
+        E, P = t.fc0.weight.shape[0], t.fc3.weight.shape[0]
+        z0 = torch.empty((B, E), dtype=torch.float32, device=feat.device)
+        o.gemm("nt", emb, W["fc0"], z0, B, E, fc, fc, fc, E, dtype=torch.float32, epi=L.EPI_BIAS, bias=t.fc0.bias)
+        y1, sm1, sr1 = o.bn1d_fwd(z0, t.bn1.weight, t.bn1.bias, t.bn1.running_mean, t.bn1.running_var, training, True)
+        z3 = torch.empty((B, P), dtype=torch.float32, device=feat.device)
+        o.gemm("nt", y1, W["fc3"], z3, B, P, E, E, E, P, dtype=torch.float32, epi=L.EPI_BIAS, bias=t.fc3.bias)
+        y4, sm4, sr4 = o.bn1d_fwd(z3, t.bn4.weight, t.bn4.bias, t.bn4.running_mean, t.bn4.running_var, training, False)
+        if training:
+            t.bn1.num_batches_tracked += 1
+            t.bn4.num_batches_tracked += 1
+        if sv is not None:
+            sv["tail"] = (pooled, mean, rstd, emb, z0, y1, sm1, sr1, z3, y4, sm4, sr4, training, fh, fw, fc)
+        return emb, y4
+
+    def _embed_tail_bwd(self, sv, demb, dproj, dt, B):
+        o, m, W, g = self.ops, self.model, self.W, self.g
+        pooled, mean, rstd, emb, z0, y1, sm1, sr1, z3, y4, sm4, sr4, training, fh, fw, fc = sv["tail"]
+        t = m.tail
+        E, P = t.fc0.weight.shape[0], t.fc3.weight.shape[0]
+        dev = emb.device
+        d_emb = demb.contiguous().float() if demb is not None else None
+        if dproj is not None:
+            dz3 = o.bn1d_bwd(dproj.contiguous().float(), z3, y4, t.bn4.weight, sm4, sr4, g(t.bn4.weight), g(t.bn4.bias), training, False)
+            o.gemm("tn", y1, dz3, g(t.fc3.weight), B, P, E, E, P, E, dtype=torch.float32, colsum=g(t.fc3.bias))
+            dy1 = torch.empty((B, E), dtype=torch.float32, device=dev)
+            o.gemm("nt", dz3, W["fc3T"], dy1, B, E, P, P, P, E, dtype=torch.float32)
+            dz0 = o.bn1d_bwd(dy1, z0, y1, t.bn1.weight, sm1, sr1, g(t.bn1.weight), g(t.bn1.bias), training, True)
+            o.gemm("tn", emb, dz0, g(t.fc0.weight), B, E, fc, fc, E, fc, dtype=torch.float32, colsum=g(t.fc0.bias))
+            de = torch.empty((B, fc), dtype=torch.float32, device=dev)
+            o.gemm("nt", dz0, W["fc0T"], de, B, fc, E, E, E, fc, dtype=torch.float32)
+            d_emb = de if d_emb is None else d_emb + de
+        if d_emb is None:
+            d_emb = torch.zeros((B, fc), dtype=torch.float32, device=dev)
+        dpooled = o.ln_bwd(d_emb, pooled, mean, rstd, t.norm.weight, None, g(t.norm.weight), g(t.norm.bias), B, fc)
+        return o.avgpool_rows_bwd(dpooled, B, fh * fw, fc, dt)
+
     def _head_conv_bwd(self, sv, dout, dt, B, dev):
         """PixelToVoxelHead backward; returns the gradient of the decoder feature map."""
         o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, self.W
@@ -467,10 +533,12 @@ class Engine:
         o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, self.W
         dt = sv["dt"]
         B, H, Wd = sv["shape"]
-        dev = dout.device
+        dev = self.device
         za_key = ("bwd", B, H, Wd, sv["masked"])
         self._za = za = _ZeroArena(dev, self._za_need.get(za_key, 0))
-        if cfg.get("head", "conv") == "shuffle":
+        if cfg.get("head") == "embed":
+            d = self._embed_tail_bwd(sv, dout[0], dout[1], dt, B)
+        elif cfg.get("head", "conv") == "shuffle":
             fh, fw = sv["head"]
             d = o.voxel_shuffle_bwd(dout.contiguous().float(), B, fh, fw, cfg["out_channels"], cfg["out_stack_depth"],
                                     cfg["stem_kernel"][-1], True, dt)
@@ -478,7 +546,7 @@ class Engine:
             d = self._head_conv_bwd(sv, dout, dt, B, dev)
         # ---- decoder (reverse)
         dskips = {}
-        for k in (2, 1, 0):
+        for k in (2, 1, 0) if cfg.get("head") != "embed" else ():
             proj, blocks = W["dec"][k]
             st_sv = sv["dec"][k]
             cat, xn, mean, rstd, c_up, sc = st_sv["proj"]
@@ -514,7 +582,7 @@ class Engine:
                 dxn = torch.empty((B * 4 * ch * cw, cin), dtype=dt, device=dev)
                 o.gemm("nt", d, proj.WT, dxn, Mo, 4 * cin, proj.cout, proj.cout, proj.cout, cin, dtype=dt,
                        c_mode=L.A_PATCH2, c_cs=cin, gh=ch, gw=cw)
-                d = o.ln_bwd(dxn, prev, mean, rstd, proj.ln.weight, dskips[i - 1], g(proj.ln.weight), g(proj.ln.bias),
+                d = o.ln_bwd(dxn, prev, mean, rstd, proj.ln.weight, dskips.get(i - 1), g(proj.ln.weight), g(proj.ln.bias),
                              B * 4 * ch * cw, cin)
                 del dxn
             if i == 2 and self.on_bucket_ready:
@@ -551,7 +619,8 @@ class _UNeXt2Fn(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
+        dout = douts[0] if len(douts) == 1 else douts  # the embedding tail returns (embedding, projection)
         model, sv = ctx.model, ctx.sv
         if sv is None:
             raise RuntimeError("viscy_amd.UNeXt2: backward called but the forward ran without gradient bookkeeping")

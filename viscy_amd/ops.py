@@ -315,6 +315,57 @@ def scale_weight_samples(W: Tensor, s: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+def avgpool_rows_fwd(x: Tensor, B: int, hw: int, C: int) -> Tensor:
+    out = torch.empty((B, C), dtype=torch.float32, device=x.device)
+    check(lib().vsx_avgpool_rows_fwd(ptr(x), ptr(out), B, hw, C, dtype_code(x.dtype), stream()), "avgpool_rows_fwd")
+    return out
+
+
+def avgpool_rows_bwd(dout: Tensor, B: int, hw: int, C: int, dtype: torch.dtype) -> Tensor:
+    dx = torch.empty((B * hw, C), dtype=dtype, device=dout.device)
+    check(lib().vsx_avgpool_rows_bwd(ptr(dout), ptr(dx), B, hw, C, dtype_code(dtype), stream()), "avgpool_rows_bwd")
+    return dx
+
+
+def bn1d_fwd(x: Tensor, w: Tensor, b: Tensor, rmean: Tensor, rvar: Tensor, training: bool, relu: bool, eps: float = 1e-5,
+             momentum: float = 0.1):
+    B, F = x.shape
+    y = torch.empty_like(x)
+    sm = torch.empty(F, dtype=torch.float32, device=x.device)
+    sr = torch.empty(F, dtype=torch.float32, device=x.device)
+    check(lib().vsx_bn1d_fwd(ptr(x), ptr(w), ptr(b), ptr(rmean), ptr(rvar), ptr(y), ptr(sm), ptr(sr), B, F, eps, momentum,
+                             int(training), int(relu), stream()), "bn1d_fwd")
+    return y, sm, sr
+
+
+def bn1d_bwd(dy: Tensor, x: Tensor, y: Tensor, w: Tensor, sm: Tensor, sr: Tensor, dw: Tensor, db: Tensor, training: bool,
+             relu: bool) -> Tensor:
+    B, F = x.shape
+    dx = torch.empty_like(x)
+    check(lib().vsx_bn1d_bwd(ptr(dy), ptr(x), ptr(y), ptr(w), ptr(sm), ptr(sr), ptr(dx), ptr(dw), ptr(db), B, F, int(training),
+                             int(relu), stream()), "bn1d_bwd")
+    return dx
+
+
+def ntxent_fwd(E: Tensor, labels: Tensor, temperature: float, beta: float):
+    N, D = E.shape
+    dev = E.device
+    En, inv = torch.empty_like(E), torch.empty(N, dtype=torch.float32, device=dev)
+    S, dS = torch.empty((N, N), dtype=torch.float32, device=dev), torch.empty((N, N), dtype=torch.float32, device=dev)
+    rows, acc = torch.empty(2 * N, dtype=torch.float32, device=dev), torch.empty(2, dtype=torch.float32, device=dev)
+    check(lib().vsx_ntxent_fwd(ptr(E), ptr(labels), ptr(En), ptr(inv), ptr(S), ptr(dS), ptr(rows), ptr(acc), N, D,
+                               float(temperature), float(beta), stream()), "ntxent_fwd")
+    return acc, (dS, En, inv)
+
+
+def ntxent_bwd(saved, acc: Tensor, gout: Tensor) -> Tensor:
+    dS, En, inv = saved
+    N, D = En.shape
+    dE = torch.empty_like(En)
+    check(lib().vsx_ntxent_bwd(ptr(dS), ptr(En), ptr(inv), ptr(acc), ptr(gout), ptr(dE), N, D, stream()), "ntxent_bwd")
+    return dE
+
+
 def rows_select(src: Tensor, row_map: Tensor, n_out: int, C: int, add: Tensor | None = None) -> Tensor:
     """dst[r] = map[r] >= 0 ? src[map[r]] (+ add[r]) : 0 — masked_patchify / masked_unpatchify / mask multiply of fcmae.py:95-141."""
     assert row_map.dtype == torch.int32 and row_map.numel() == n_out
