@@ -157,6 +157,15 @@ int32_t vsx_masked_mse_fwd(const float* pred, const float* orig, const uint8_t* 
 int32_t vsx_masked_mse_bwd(const float* pred, const float* orig, const uint8_t* mask, const float* acc, const float* gout,
     float* dpred, int32_t B, int32_t C, int32_t Z, int64_t HW, vsx_stream_t stream);
 
+/* ConvNeXt-V1 layer scale (timm ConvNeXtBlock.gamma, ls_init_value 1e-6; the `convnext_tiny` trunk of
+ * viscy_models.contrastive.ContrastiveEncoder, encoder.py:93-99) folded into the block's second pointwise layer:
+ * Ws = diag(gamma) W [R,K], bs = gamma * b; unfold ADDS dW += diag(gamma) dWs, db += gamma dbs,
+ * dgamma += rowsum(dWs * W) + dbs * b.  fp32. */
+int32_t vsx_layer_scale_fold(const float* W, const float* b, const float* gamma, float* Ws, float* bs, int32_t R, int32_t K,
+    vsx_stream_t stream);
+int32_t vsx_layer_scale_unfold(const float* dWs, const float* dbs, const float* W, const float* b, const float* gamma,
+    float* dW, float* db, float* dgamma, int32_t R, int32_t K, vsx_stream_t stream);
+
 /* DynaCLR contrastive path: tail of viscy_models.contrastive.ContrastiveEncoder
  * (packages/viscy-models/src/viscy_models/contrastive/encoder.py:93-154) behind the ConvNeXt trunk.
  * Global average pool of a channels-last feature map x [B*hw, C] (dtype) -> out [B, C] fp32 (timm head.global_pool) and

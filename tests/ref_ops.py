@@ -367,6 +367,18 @@ def scale_weight_samples(W, s, dtype):
     return (W.detach().float().reshape(W.shape[0], -1)[None, :, :] * s.float()[:, None, :]).to(dtype)
 
 
+def layer_scale_fold(W, b, gamma):
+    R = W.shape[0]
+    return (gamma.view(R, 1) * W.reshape(R, -1)).contiguous(), gamma * b
+
+
+def layer_scale_unfold(dWs, dbs, W, b, gamma, dW, db, dgamma):
+    R = W.shape[0]
+    dW += (gamma.view(R, 1) * dWs.reshape(R, -1)).view_as(dW)
+    db += gamma * dbs
+    dgamma += (dWs.reshape(R, -1) * W.reshape(R, -1)).sum(1) + dbs * b
+
+
 def avgpool_rows_fwd(x, B, hw, C):
     return x.float().view(B, hw, C).mean(1)
 

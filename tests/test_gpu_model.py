@@ -519,11 +519,11 @@ def test_fcmae_unet_pretraining_steps_reduce_the_masked_loss():
 
 
 # ------------------------------------------------------------------------------------------------ DynaCLR path (§8 f3)
-def _contrastive_pair(dtype):
+def _contrastive_pair(dtype, tag="v2_small_z9"):
     from oracle import contrastive_ref as C
     from viscy_amd.contrastive import ContrastiveEncoder
 
-    g = load_golden("contrastive.pt")["v2_small_z9"]
+    g = load_golden("contrastive.pt")[tag]
     ref = C.randomize_encoder_(C.ContrastiveEncoder(**g["kwargs"], **g["arch"]), seed=g["seed"])
     mine = ContrastiveEncoder(**g["kwargs"], **g["arch"])
     mine.load_state_dict(ref.state_dict(), strict=True)
@@ -533,11 +533,13 @@ def _contrastive_pair(dtype):
     return g, ref, mine, x
 
 
+@pytest.mark.parametrize("tag", ["v2_small_z9", "v1_small_z5", "v1_tiny_z15"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_contrastive_encoder_matches_reference_golden_fp32(mode):
-    """(embedding, projection) vs the REFERENCE's encoder.py run (G10), BatchNorm running statistics after a train-mode call,
-    every parameter gradient vs oracle autograd"""
-    g, ref, mine, x = _contrastive_pair(torch.float32)
+def test_contrastive_encoder_matches_reference_golden_fp32(mode, tag):
+    """(embedding, projection) vs the REFERENCE's encoder.py run (G10; V2 = GRN blocks, V1 = layer-scale blocks, the full
+    convnext_tiny trunk at the DynaCLR shape 2 ch x 15 slices), BatchNorm running statistics after a train-mode call, every
+    parameter gradient vs oracle autograd"""
+    g, ref, mine, x = _contrastive_pair(torch.float32, tag)
     getattr(ref, mode)()
     getattr(mine, mode)()
     emb, proj = mine(x.cuda())
@@ -559,7 +561,7 @@ def test_contrastive_encoder_matches_reference_golden_fp32(mode):
         e = relerr(p.grad, p_ref.grad)
         worst = max(worst, e)
         assert e <= 2e-3, (name, e)
-    print(mode, "contrastive worst relative gradient error", worst)
+    print(tag, mode, "contrastive worst relative gradient error", worst)
 
 
 def test_contrastive_module_trains_convnextv2_tiny_bf16():
@@ -593,5 +595,5 @@ def test_contrastive_module_trains_convnextv2_tiny_bf16():
         pa = torch.nn.functional.normalize(mod.predict_step({"anchor": batch["anchor"]}, 0)["projections"], dim=1)
         pp = torch.nn.functional.normalize(mod.predict_step({"anchor": batch["positive"]}, 0)["projections"], dim=1)
     assert (pa @ pp.t()).argmax(1).tolist() == list(range(8))
-    with pytest.raises(NotImplementedError, match="convnextv2_tiny"):
-        ContrastiveEncoder("convnext_tiny", in_channels=2, in_stack_depth=15)
+    with pytest.raises(NotImplementedError, match="resnet50"):
+        ContrastiveEncoder("resnet50", in_channels=2, in_stack_depth=15)

@@ -715,3 +715,20 @@ def test_ntxent_general_labels_vs_oracle(beta):
         lg.backward()
         assert abs(lg.item() - lr.item()) <= 5e-5 * abs(lr.item()), (N, lg.item(), lr.item())
         torch.testing.assert_close(eg.grad.cpu(), e.grad, rtol=5e-4, atol=1e-7 + 5e-4 * e.grad.abs().max().item())
+
+
+def test_layer_scale_fold_unfold():
+    H = _hip()
+    Rr, K = 37, 148
+    W, b, gam = rnd(Rr, K, seed=1), rnd(Rr, seed=2), 0.5 + 0.2 * rnd(Rr, seed=3)
+    dWs, dbs = rnd(Rr, K, seed=4), rnd(Rr, seed=5)
+    Ws, bs = H.layer_scale_fold(*cuda(W, b, gam))
+    Wr, br = R.layer_scale_fold(W, b, gam)
+    assert torch.equal(Ws.cpu(), Wr) and torch.equal(bs.cpu(), br)
+    outs = []
+    for ops, dev in ((R, "cpu"), (H, DEV)):
+        dW, db, dg = torch.ones(Rr, K, device=dev), torch.ones(Rr, device=dev), torch.ones(Rr, device=dev)
+        ops.layer_scale_unfold(dWs.to(dev), dbs.to(dev), W.to(dev), b.to(dev), gam.to(dev), dW, db, dg)
+        outs.append((dW.cpu(), db.cpu(), dg.cpu()))
+    for a, c in zip(outs[1], outs[0]):
+        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-5)

@@ -168,15 +168,16 @@ def test_inference_schedule_skips_preactivation_store():
 
 
 # ---------------------------------------------------------------- DynaCLR ContrastiveEncoder schedule
+@pytest.mark.parametrize("tag", ["v2_small_z9", "v1_small_z5"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_contrastive_schedule_matches_reference_golden(mode):
+def test_contrastive_schedule_matches_reference_golden(mode, tag):
     """embedding / projection + every parameter gradient + BatchNorm running statistics: engine schedule (kernels = plain
     torch) vs the reference-generated golden (tests/golden/contrastive.pt, G10) and vs autograd of the oracle"""
     from oracle import contrastive_ref as C
     from tests.conftest import load_golden
     from viscy_amd.contrastive import ContrastiveEncoder
 
-    gold = load_golden("contrastive.pt")["v2_small_z9"]
+    gold = load_golden("contrastive.pt")[tag]
     ref = C.randomize_encoder_(C.ContrastiveEncoder(**gold["kwargs"], **gold["arch"]), seed=gold["seed"])
     mine = ContrastiveEncoder(**gold["kwargs"], **gold["arch"])
     assert list(mine.state_dict().keys()) == gold["keys"]
@@ -210,4 +211,4 @@ def test_contrastive_schedule_matches_reference_golden(mode):
         err = ((gr - p_ref.grad).abs().max() / p_ref.grad.abs().max().clamp_min(1e-6)).item()
         worst = max(worst, err)
         assert err < 2e-3, (name, err)
-    print(mode, "contrastive max rel grad err", worst)
+    print(tag, mode, "contrastive max rel grad err", worst)

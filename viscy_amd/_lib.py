@@ -84,6 +84,8 @@ _SIGS = {
     "vsx_scale_weight_samples": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_voxel_shuffle_fwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),
     "vsx_voxel_shuffle_bwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),
+    "vsx_layer_scale_fold": (_I32, [_P] * 5 + [_I32, _I32, _P]),
+    "vsx_layer_scale_unfold": (_I32, [_P] * 8 + [_I32, _I32, _P]),
     "vsx_avgpool_rows_fwd": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_avgpool_rows_bwd": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_bn1d_fwd": (_I32, [_P] * 8 + [_I32, _I32, _F32, _F32, _I32, _I32, _P]),

@@ -8,12 +8,12 @@ The trunk is the same ConvNeXt kernel schedule as the UNeXt2 encoder (``viscy_am
 7x7, LayerNorm, fc1 / GELU / GRN / fc2 GEMMs, 2x2 downsampling GEMMs); behind it ``vsx_avgpool_rows_*``, the LayerNorm kernel,
 two small fp32 GEMMs and ``vsx_bn1d_*`` produce ``(embedding, projection)``; ``vsx_ntxent_*`` is the loss.  Same constructor
 keywords and ``state_dict()`` keys as the reference (timm names: ``stem.conv``, ``encoder.stem.1``,
-``encoder.stages.i.{downsample.{0,1},blocks.j.{conv_dw,norm,mlp.fc1,mlp.grn,mlp.fc2}}``, ``encoder.head.norm``,
+``encoder.stages.i.{downsample.{0,1},blocks.j.{[gamma,]conv_dw,norm,mlp.fc1,[mlp.grn,]mlp.fc2}}``, ``encoder.head.norm``,
 ``projection.{0,1,3,4}`` incl. the BatchNorm buffers), parameters shared with the flat-buffer engine so the fused AdamW and
 the RCCL gradient all-reduce work unchanged.
 
-Built: ``backbone="convnextv2_tiny"`` (GRN blocks).  ``convnext_tiny`` (V1: layer scale, no GRN) and ``resnet50`` raise
-``NotImplementedError``; ``drop_path_rate`` must be 0 and ``pretrained`` False (no network here).  BatchNorm is per process
+Built: ``backbone="convnext_tiny"`` (V1 blocks: layer scale ``gamma`` folded into fc2 by ``vsx_layer_scale_fold`` /
+``_unfold``, identity GRN) and ``"convnextv2_tiny"`` (GRN blocks); ``resnet50`` raises ``NotImplementedError``; ``drop_path_rate`` must be 0 and ``pretrained`` False (no network here).  BatchNorm is per process
 under data parallelism, as in the reference's default (no SyncBatchNorm in its recipes' trainer sections).
 """
 
@@ -48,7 +48,7 @@ class _Tail(_Holder):
 
 
 class _EmbedCore(_Core):
-    def __init__(self, in_channels, in_stack_depth, stem_kernel_size, depths, dims, embedding_dim, projection_dim):
+    def __init__(self, in_channels, in_stack_depth, stem_kernel_size, depths, dims, embedding_dim, projection_dim, v1):
         super().__init__()
         kz = stem_kernel_size[0]
         ratio = (in_stack_depth - kz) // kz + 1
@@ -60,7 +60,7 @@ class _EmbedCore(_Core):
         self.cfg = dict(in_channels=in_channels, out_channels=0, in_stack_depth=in_stack_depth, out_stack_depth=0,
                         depths=tuple(depths), dims=tuple(dims), conv_mlp=False, stem_kernel=tuple(stem_kernel_size), ratio=ratio,
                         head="embed")
-        self.encoder_stages = _Encoder(depths, dims, False)
+        self.encoder_stages = _Encoder(depths, dims, False, v1=v1)
         self.stem = _Stem(in_channels, dims[0] // ratio, tuple(stem_kernel_size))
         self.tail = _Tail(dims[-1], embedding_dim, projection_dim)
         self.compute_dtype = None
@@ -86,8 +86,8 @@ class ContrastiveEncoder(nn.Module):
                  depths: Sequence[int] = (3, 3, 9, 3), dims: Sequence[int] = (96, 192, 384, 768)) -> None:
         """``depths`` / ``dims`` are an extension for tests (the reference takes them from the timm model name)."""
         super().__init__()
-        if backbone != "convnextv2_tiny":
-            raise NotImplementedError(f"backbone {backbone!r}: viscy_amd builds the convnextv2_tiny trunk (GRN blocks)")
+        if backbone not in ("convnext_tiny", "convnextv2_tiny"):
+            raise NotImplementedError(f"backbone {backbone!r}: viscy_amd builds the convnext_tiny / convnextv2_tiny trunks")
         if drop_path_rate or pretrained:
             raise NotImplementedError("drop_path_rate > 0 / pretrained weights are not built")
         if tuple(stem_kernel_size) != tuple(stem_stride):
@@ -95,7 +95,8 @@ class ContrastiveEncoder(nn.Module):
         if embedding_dim % 4 or projection_dim % 4:
             raise NotImplementedError("embedding_dim and projection_dim must be multiples of 4")
         self.backbone = backbone
-        core = _EmbedCore(in_channels, in_stack_depth, tuple(stem_kernel_size), tuple(depths), tuple(dims), embedding_dim, projection_dim)
+        core = _EmbedCore(in_channels, in_stack_depth, tuple(stem_kernel_size), tuple(depths), tuple(dims), embedding_dim, projection_dim,
+                          v1=backbone == "convnext_tiny")
         object.__setattr__(self, "_core", core)  # NOT a registered submodule: its parameters appear below, under reference names
         self.stem = core.stem
         enc = _Holder()

@@ -290,3 +290,53 @@ extern "C" int32_t vsx_scale_weight_samples(const float* W, const float* s, void
   VSX_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------ ConvNeXt-V1 layer scale folded into fc2 (DynaCLR trunk)
+// timm ConvNeXtBlock: y = x + gamma * (fc2(h) ) = x + h (diag(gamma) W2)^T + gamma * b2: the block kernels run with
+//   Ws[r, :] = gamma[r] * W[r, :],  bs[r] = gamma[r] * b[r]
+// and the gradients of (Ws, bs) are unfolded:  dW += gamma[r] * dWs[r, :],  db += gamma * dbs,
+//   dgamma[r] += sum_k dWs[r, k] W[r, k] + dbs[r] b[r].            One wave per row (K = 4C elements), all fp32.
+__global__ __launch_bounds__(256) void layer_scale_fold_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                               const float* __restrict__ gamma, float* __restrict__ Ws,
+                                                               float* __restrict__ bs, int R, int K) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float g = gamma[r];
+  for (int k = lane; k < K; k += 64) Ws[(size_t)r * K + k] = g * W[(size_t)r * K + k];
+  if (lane == 0) bs[r] = g * b[r];
+}
+__global__ __launch_bounds__(256) void layer_scale_unfold_kernel(const float* __restrict__ dWs, const float* __restrict__ dbs,
+                                                                 const float* __restrict__ W, const float* __restrict__ b,
+                                                                 const float* __restrict__ gamma, float* __restrict__ dW,
+                                                                 float* __restrict__ db, float* __restrict__ dgamma, int R,
+                                                                 int K) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float g = gamma[r];
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float d = dWs[(size_t)r * K + k];
+    dW[(size_t)r * K + k] += g * d;
+    acc = fmaf(d, W[(size_t)r * K + k], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    db[r] += g * dbs[r];
+    dgamma[r] += acc + dbs[r] * b[r];
+  }
+}
+extern "C" int32_t vsx_layer_scale_fold(const float* W, const float* b, const float* gamma, float* Ws, float* bs, int32_t R,
+                                        int32_t K, vsx_stream_t stream) {
+  VSX_CHECK(W && b && gamma && Ws && bs && R > 0 && K > 0, "vsx_layer_scale_fold: bad arguments");
+  hipLaunchKernelGGL(layer_scale_fold_kernel, dim3(vsx_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, W, b, gamma, Ws, bs, R, K);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int32_t vsx_layer_scale_unfold(const float* dWs, const float* dbs, const float* W, const float* b, const float* gamma,
+                                          float* dW, float* db, float* dgamma, int32_t R, int32_t K, vsx_stream_t stream) {
+  VSX_CHECK(dWs && dbs && W && b && gamma && dW && db && dgamma && R > 0 && K > 0, "vsx_layer_scale_unfold: bad arguments");
+  hipLaunchKernelGGL(layer_scale_unfold_kernel, dim3(vsx_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, dWs, dbs, W, b, gamma, dW,
+                     db, dgamma, R, K);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

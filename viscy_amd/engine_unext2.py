@@ -23,7 +23,7 @@ from . import _lib as L
 class _BlockW:
     """prepared operands + parameter handles of one ConvNeXt-V2 block"""
 
-    __slots__ = ("C", "p", "dw_w", "W1f", "W1fT", "b1f", "W2", "W2T")
+    __slots__ = ("C", "p", "dw_w", "W1f", "W1fT", "b1f", "W2", "W2T", "v1", "fc2_w", "fc2_b", "grn_w", "grn_b")
 
 
 class _ProjW:
@@ -75,6 +75,7 @@ class Engine:
         self.ops = ops
         self.model = model
         self.cfg = model.cfg
+        self._zeros4c = {}       # C -> zeros(4C): the identity GRN of ConvNeXt-V1 blocks
         self._za = None          # zero arena of the pass in flight
         self._za_need = {}       # (pass, B, H, W) -> fp32 elements the pass took last time
         params = list(model.parameters())
@@ -107,6 +108,10 @@ class Engine:
     def _stage_params_rev(self, stage):
         ps = []
         for blk in reversed(list(stage.blocks)):
+            if hasattr(blk, "gamma"):  # ConvNeXt-V1 block: layer scale, no GRN
+                ps += [blk.gamma, blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.norm.weight,
+                       blk.norm.bias, blk.conv_dw.weight, blk.conv_dw.bias]
+                continue
             ps += [blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.mlp.grn.weight, blk.mlp.grn.bias, blk.mlp.fc1.weight,
                    blk.mlp.fc1.bias, blk.norm.weight, blk.norm.bias, blk.conv_dw.weight, blk.conv_dw.bias]
         if not isinstance(stage.downsample, torch.nn.Identity):
@@ -165,7 +170,19 @@ class Engine:
         w.W1f, w.W1fT = o.prep_weight(blk.mlp.fc1.weight, 4 * C, C, 1, dt, want=True, want_t=need_bwd,
                                       gamma=blk.norm.weight)
         w.b1f = o.matvec(blk.mlp.fc1.weight, blk.norm.bias, blk.mlp.fc1.bias, 4 * C, C)
-        w.W2, w.W2T = o.prep_weight(blk.mlp.fc2.weight, C, 4 * C, 1, dt, want=True, want_t=need_bwd)
+        w.v1 = hasattr(blk, "gamma")
+        if w.v1:
+            # ConvNeXt-V1: y = x + gamma * fc2(gelu(fc1(.))) — the layer scale is folded into fc2 (vsx_layer_scale_fold) and
+            # the block runs the V2 schedule with a zero (identity) GRN; the fc2 gradients are unfolded in _block_bwd
+            w.fc2_w, w.fc2_b = o.layer_scale_fold(blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.gamma)
+            z = self._zeros4c.get(C)
+            if z is None:
+                z = self._zeros4c[C] = torch.zeros(4 * C, dtype=torch.float32, device=self.device)
+            w.grn_w = w.grn_b = z
+        else:
+            w.fc2_w, w.fc2_b = blk.mlp.fc2.weight, blk.mlp.fc2.bias
+            w.grn_w, w.grn_b = blk.mlp.grn.weight, blk.mlp.grn.bias
+        w.W2, w.W2T = o.prep_weight(w.fc2_w, C, 4 * C, 1, dt, want=True, want_t=need_bwd)
         return w
 
     def _prep_proj(self, ln, conv, dt, need_bwd):
@@ -254,20 +271,20 @@ class Engine:
         gact = torch.empty((M, 4 * C), dtype=dt, device=x.device)
         o.gemm("nt", xh, w.W1f, h, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=w.b1f, red0=colsq,
                hw=hw, C2=gact)
-        s = o.grn_scale(colsq, blk.mlp.grn.weight)
+        s = o.grn_scale(colsq, w.grn_w)
         out = torch.empty((M, C), dtype=dt, device=x.device)
         if dt == torch.bfloat16 and C > 64 and hw % 128 == 0 and hw // 128 >= 8:
             # large feature maps: fold the GRN affine into per-sample fc2 weights,
             #   (g·s_b + β)·W2ᵀ = g·(W2·diag(s_b))ᵀ + W2·β,
             # so fc2 is a plain GEMM (the operand prologue costs +60 % on these launches); B·C·4C extra weight bytes
             # are small next to the M·4C activation bytes when a sample spans >= 8 row tiles
-            Ws = o.scale_weight_samples(blk.mlp.fc2.weight, s, dt)
-            b2 = o.matvec(blk.mlp.fc2.weight, blk.mlp.grn.bias, blk.mlp.fc2.bias, C, 4 * C)
+            Ws = o.scale_weight_samples(w.fc2_w, s, dt)
+            b2 = o.matvec(w.fc2_w, w.grn_b, w.fc2_b, C, 4 * C)
             o.gemm("nt", gact, Ws, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, hw=hw, b_bstride=C * 4 * C,
                    epi=L.EPI_BIAS_RES, bias=b2, res=xres, ldr=C)
         else:
             o.gemm("nt", gact, w.W2, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
-                   grn_b=blk.mlp.grn.bias, hw=hw, epi=L.EPI_BIAS_RES, bias=blk.mlp.fc2.bias, res=xres, ldr=C)
+                   grn_b=w.grn_b, hw=hw, epi=L.EPI_BIAS_RES, bias=w.fc2_b, res=xres, ldr=C)
         if rows is not None:
             out = o.rows_select(out, rows[1], B * H * Wd, C)  # masked_unpatchify: zero rows where masked (shortcut is 0 there)
         if save is not None:
@@ -286,15 +303,24 @@ class Engine:
             idx, inv, keep, Lr = rows
             M, hw = B * Lr, Lr
             dout = o.rows_select(dfull, idx, M, C)
+        if w.v1:  # gradients of the folded (Ws, bs) and of the (constant, zero) GRN land in scratch
+            dW2, db2 = self._za.take(C, 4 * C), self._za.take(C)
+            dgw, dgb = self._za.take(4 * C), self._za.take(4 * C)
+        else:
+            dW2, db2 = g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias)
+            dgw, dgb = g(blk.mlp.grn.weight), g(blk.mlp.grn.bias)
         # fc2: weight gradient (Z recomputed in the operand prologue) + bias gradient
-        o.gemm("tn", gact, dout, g(blk.mlp.fc2.weight), M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
-               grn_b=blk.mlp.grn.bias, hw=hw, colsum=g(blk.mlp.fc2.bias))
+        o.gemm("tn", gact, dout, dW2, M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
+               grn_b=w.grn_b, hw=hw, colsum=db2)
+        if w.v1:
+            o.layer_scale_unfold(dW2, db2, blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.gamma, g(blk.mlp.fc2.weight),
+                                 g(blk.mlp.fc2.bias), g(blk.gamma))
         # fc2 data gradient dZ, with Σ dZ·gelu(h) (GRN statistics path) and Σ dZ (GRN beta gradient)
         PS = self._za.take(2, B, 4 * C)
         dz = torch.empty((M, 4 * C), dtype=dt, device=dev)
         o.gemm("nt", dout, w.W2T, dz, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_DZ, aux=gact, ldx=4 * C, red0=PS[0],
                red1=PS[1], hw=hw)
-        t = o.grn_bwd_stats(colsq, PS[0], blk.mlp.grn.weight, g(blk.mlp.grn.weight), Sb=PS[1], dbeta=g(blk.mlp.grn.bias))
+        t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw, Sb=PS[1], dbeta=dgb)
         db1f = self._za.take(4 * C)
         o.grn_gelu_bwd(dz, h, s, t, db1f, M, 4 * C, hw)  # dz now holds dH
         dxh = torch.empty((M, C), dtype=dt, device=dev)

@@ -315,6 +315,21 @@ def scale_weight_samples(W: Tensor, s: Tensor, dtype: torch.dtype) -> Tensor:
     return out
 
 
+def layer_scale_fold(W: Tensor, b: Tensor, gamma: Tensor):
+    R = W.shape[0]
+    K = W.numel() // R
+    Ws, bs = torch.empty((R, K), dtype=torch.float32, device=W.device), torch.empty(R, dtype=torch.float32, device=W.device)
+    check(lib().vsx_layer_scale_fold(ptr(W), ptr(b), ptr(gamma), ptr(Ws), ptr(bs), R, K, stream()), "layer_scale_fold")
+    return Ws, bs
+
+
+def layer_scale_unfold(dWs: Tensor, dbs: Tensor, W: Tensor, b: Tensor, gamma: Tensor, dW: Tensor, db: Tensor, dgamma: Tensor) -> None:
+    R = W.shape[0]
+    K = W.numel() // R
+    check(lib().vsx_layer_scale_unfold(ptr(dWs), ptr(dbs), ptr(W), ptr(b), ptr(gamma), ptr(dW), ptr(db), ptr(dgamma), R, K, stream()),
+          "layer_scale_unfold")
+
+
 def avgpool_rows_fwd(x: Tensor, B: int, hw: int, C: int) -> Tensor:
     out = torch.empty((B, C), dtype=torch.float32, device=x.device)
     check(lib().vsx_avgpool_rows_fwd(ptr(x), ptr(out), B, hw, C, dtype_code(x.dtype), stream()), "avgpool_rows_fwd")

@@ -86,25 +86,43 @@ class _Block(_Holder):
         self.mlp = _Mlp(c, conv_mlp)
 
 
+class _MlpV1(_Holder):
+    def __init__(self, c: int):
+        super().__init__()
+        self.fc1 = _Conv((4 * c, c))
+        self.fc2 = _Conv((c, 4 * c))
+
+
+class _BlockV1(_Holder):
+    """timm ConvNeXtBlock of the V1 family: layer scale ``gamma`` (ls_init_value 1e-6), plain MLP, no GRN"""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.gamma = nn.Parameter(1e-6 * torch.ones(c))
+        self.conv_dw = _Conv((c, 1, 7, 7))
+        self.norm = _LN(c)
+        self.mlp = _MlpV1(c)
+
+
 class _Stage(_Holder):
-    def __init__(self, cin: int, cout: int, stride: int, depth: int, conv_mlp: bool):
+    def __init__(self, cin: int, cout: int, stride: int, depth: int, conv_mlp: bool, v1: bool = False):
         super().__init__()
         if cin != cout or stride > 1:
             ks = 2 if stride > 1 else 1
             self.downsample = nn.Sequential(_LN(cin), _Conv((cout, cin, ks, ks)))
         else:
             self.downsample = nn.Identity()
-        self.blocks = nn.Sequential(*[_Block(cout, conv_mlp) for _ in range(depth)])
+        self.blocks = nn.Sequential(*[(_BlockV1(cout) if v1 else _Block(cout, conv_mlp)) for _ in range(depth)])
 
 
 class _Encoder(_Holder):
-    def __init__(self, depths, dims, conv_mlp):
+    def __init__(self, depths, dims, conv_mlp, v1: bool = False):
         super().__init__()
         self.stem_0 = nn.Identity()
         self.stem_1 = _LN(dims[0])
         prev = dims[0]
         for i, (d, c) in enumerate(zip(depths, dims)):
-            setattr(self, f"stages_{i}", _Stage(prev, c, 2 if i > 0 else 1, d, conv_mlp))
+            setattr(self, f"stages_{i}", _Stage(prev, c, 2 if i > 0 else 1, d, conv_mlp, v1))
             prev = c
 
 
