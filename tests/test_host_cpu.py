@@ -258,3 +258,46 @@ def test_prediction_writer_2d_target_and_write_input(tiny_hcs_zarr, tmp_path):
         for zi in range(3):
             np.testing.assert_allclose(got[zi + 1], float(zi))
         np.testing.assert_array_equal(img.oindex[slice(0, 1), [0], slice(1, 4)][0, 0], pos[n][0, 0][1:4])
+
+
+# ------------------------------------------------------------------------------------------------ DynaCLR global negatives (§8 f3)
+def _gather_worker(rank, world, init_file, out):
+    from oracle.contrastive_ref import NTXentLoss as RefLoss
+    from viscy_amd.parallel import all_gather_with_local_grad, scale_for_mean_reduction
+
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(world, 2, 3, 10, generator=g)          # [rank, anchor/positive, B, features]
+    P = torch.randn(10, 6, generator=g).requires_grad_(True)  # the shared "model"
+    a, p = X[rank, 0] @ P, X[rank, 1] @ P
+    ga, gp = all_gather_with_local_grad(a), all_gather_with_local_grad(p)
+    idx = torch.arange(ga.shape[0])
+    loss = RefLoss(temperature=0.3)(torch.cat((ga, gp)), torch.cat((idx, idx)))
+    scale_for_mean_reduction(loss).backward()
+    grad = P.grad.clone()
+    dist.all_reduce(grad)                                   # what FlatDataParallel does, then 1 / world in the optimiser
+    out[rank] = (float(loss), grad / world, ga.detach().clone())
+    dist.destroy_process_group()
+
+
+def test_all_gather_with_local_grad_reproduces_the_global_batch_gradient():
+    """world-2 gloo: gathered NT-Xent (every rank evaluates the global batch, differentiates its own rows) + mean-reduced
+    data-parallel gradients == one process holding the whole batch"""
+    from oracle.contrastive_ref import NTXentLoss as RefLoss
+
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gather_worker, args=(world, tempfile.mktemp(), out), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(world, 2, 3, 10, generator=g)
+    P = torch.randn(10, 6, generator=g).requires_grad_(True)
+    a, p = X[:, 0].reshape(-1, 10) @ P, X[:, 1].reshape(-1, 10) @ P   # rank-major, as the gather concatenates
+    idx = torch.arange(a.shape[0])
+    loss = RefLoss(temperature=0.3)(torch.cat((a, p)), torch.cat((idx, idx)))
+    loss.backward()
+    for r in range(world):
+        l_r, g_r, ga_r = out[r]
+        assert abs(l_r - loss.item()) < 1e-6
+        torch.testing.assert_close(ga_r, a.detach(), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(g_r, P.grad, rtol=1e-5, atol=1e-6)

@@ -8,6 +8,7 @@ rows:
                     ("32-true", the reference's predict precision) and bf16, eager and hipGraph-captured windows
   fwd_2048_b8       UNeXt2 forward at the roofline target shape (B=8, Z=5, 2048x2048), bf16
   fcmae_pretrain    FCMAE masked pre-training step (mask_ratio 0.5, MaskedMSELoss, fused AdamW), B=256, vs the dense step
+  dynaclr_train     ContrastiveModule step (convnext_tiny / convnextv2_tiny trunk, 2 ch x 15 slices, 256^2, NT-Xent, fused AdamW)
   augment_chain     normalise + affine + crop + contrast + scale + noise + smooth on (B,2,15,384,384)-class batches
 """
 
@@ -99,6 +100,34 @@ def row_fcmae():
     return out
 
 
+def row_dynaclr():
+    """DynaCLR training step (SURVEY §8 f3 / BASELINE config 5 shape): convnext_tiny trunk, 2 ch x 15 slices, 256x256 patches,
+    NT-Xent(T = 0.07 ... here 0.2) on (anchor, positive) batches, fused AdamW, bf16, eager launches"""
+    from viscy_amd.contrastive import ContrastiveEncoder, ContrastiveModule, NTXentLoss
+
+    out = {"row": "dynaclr_train"}
+    for backbone in ("convnext_tiny", "convnextv2_tiny"):
+        for B in (64, 256):
+            torch.cuda.empty_cache()
+            enc = ContrastiveEncoder(backbone, in_channels=2, in_stack_depth=15, embedding_dim=768, projection_dim=128)
+            mod = ContrastiveModule(enc, loss_function=NTXentLoss(temperature=0.2), lr=2e-4).cuda()
+            enc.compute_dtype = torch.bfloat16
+            a = torch.randn(B, 2, 15, 256, 256, device="cuda")
+            batch = {"anchor": a, "positive": a + 0.1 * torch.randn_like(a)}
+            opt = mod.configure_optimizers(t_total=100)
+            mod.train()
+
+            def step():
+                opt.zero_grad()
+                mod.training_step(batch, 0).backward()
+                opt.step()
+
+            s = timed(step, iters=5, warmup=2)
+            out[f"{backbone}_B{B}"] = {"ms_per_step": round(s * 1e3, 1), "pairs_per_s": round(B / s, 1), "images_per_s": round(2 * B / s, 1)}
+            del enc, mod, opt, batch, a
+    return out
+
+
 def row_augment():
     from viscy_amd import transforms as T
 
@@ -137,8 +166,8 @@ def row_augment():
 
 
 if __name__ == "__main__":
-    want = sys.argv[1:] or ["augment", "fcmae", "fwd2048", "predict"]
-    rows = {"augment": row_augment, "fcmae": row_fcmae, "fwd2048": row_fwd2048, "predict": row_predict}
+    want = sys.argv[1:] or ["augment", "fcmae", "dynaclr", "fwd2048", "predict"]
+    rows = {"augment": row_augment, "fcmae": row_fcmae, "dynaclr": row_dynaclr, "fwd2048": row_fwd2048, "predict": row_predict}
     for w in want:
         torch.cuda.reset_peak_memory_stats()
         try:

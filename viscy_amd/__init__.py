@@ -5,7 +5,7 @@
 See DESIGN.md (what is built and why) and INTEGRATION.md (how it binds to the reference).
 """
 
-__all__ = ["UNeXt2", "MixedLoss", "VSUNet", "HCSDataModule", "HCSPredictionWriter", "FcmaeUNet", "FullyConvolutionalMAE", "MaskedMSELoss", "FlatAdamW", "FlatDataParallel", "TrainStep"]
+__all__ = ["UNeXt2", "MixedLoss", "VSUNet", "HCSDataModule", "HCSPredictionWriter", "FcmaeUNet", "FullyConvolutionalMAE", "MaskedMSELoss", "ContrastiveEncoder", "ContrastiveModule", "NTXentLoss", "NTXentHCL", "FlatAdamW", "FlatDataParallel", "TrainStep"]
 
 
 def __getattr__(name):
@@ -19,6 +19,10 @@ def __getattr__(name):
         from .fcmae import FullyConvolutionalMAE as v
     elif name == "MaskedMSELoss":
         from .losses import MaskedMSELoss as v
+    elif name in ("ContrastiveEncoder", "ContrastiveModule", "NTXentLoss", "NTXentHCL"):
+        from . import contrastive as _c
+
+        v = getattr(_c, name)
     elif name == "VSUNet":
         from .vsunet import VSUNet as v
     elif name == "HCSDataModule":

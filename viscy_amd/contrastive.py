@@ -218,7 +218,7 @@ class ContrastiveModule(nn.Module):
     def __init__(self, encoder: ContrastiveEncoder, loss_function: nn.Module | None = None, lr: float = 1e-3,
                  schedule: Literal["WarmupCosine", "Constant"] = "Constant", log_batches_per_epoch: int = 8,
                  log_samples_per_batch: int = 1, example_input_array_shape: Sequence[int] = (1, 2, 15, 256, 256),
-                 ckpt_path: str | None = None, freeze_backbone: bool = False, **unused) -> None:
+                 ckpt_path: str | None = None, freeze_backbone: bool = False, gather_embeddings: bool = False, **unused) -> None:
         super().__init__()
         if freeze_backbone:
             raise NotImplementedError("freeze_backbone is not built (the fused flat-buffer optimiser updates every parameter)")
@@ -229,6 +229,9 @@ class ContrastiveModule(nn.Module):
         self.lr, self.schedule = lr, schedule
         self.log_batches_per_epoch, self.log_samples_per_batch = log_batches_per_epoch, log_samples_per_batch
         self.example_input_array = torch.rand(*example_input_array_shape)
+        # extension beyond the reference (BASELINE config 5): under torch.distributed the projections of all ranks are
+        # all-gathered so that every anchor sees world * 2B - 2 negatives instead of 2B - 2; False = the reference's behaviour
+        self.gather_embeddings = gather_embeddings
         self.current_epoch = 0
         self.logged: dict[str, list] = {}
         if ckpt_path is not None:
@@ -248,9 +251,16 @@ class ContrastiveModule(nn.Module):
     def _step(self, batch: dict, stage: str) -> Tensor:
         _, anchor_projection = self(batch["anchor"])      # two forwards: BatchNorm statistics per call, as in the reference
         _, positive_projection = self(batch["positive"])
+        if self.gather_embeddings:
+            from .parallel import all_gather_with_local_grad, scale_for_mean_reduction
+
+            anchor_projection = all_gather_with_local_grad(anchor_projection)
+            positive_projection = all_gather_with_local_grad(positive_projection)
         indices = torch.arange(0, anchor_projection.size(0), device=anchor_projection.device)
         loss = self.loss_function(torch.cat((anchor_projection, positive_projection)), torch.cat((indices, indices)))
         self._log(f"loss/{stage}", loss)
+        if self.gather_embeddings:
+            loss = scale_for_mean_reduction(loss)
         return loss
 
     def training_step(self, batch: dict, batch_idx: int) -> Tensor:

@@ -65,3 +65,25 @@ def shard_indices(n: int, rank: int, world: int, seed: int, epoch: int, shuffle:
         total = (n + world - 1) // world * world
         idx += idx[: total - len(idx)]
     return idx[rank:total:world]
+
+
+def all_gather_with_local_grad(t: torch.Tensor) -> torch.Tensor:
+    """[n, D] per rank -> [world * n, D], rank-major, where this rank's own rows keep their autograd history and the other
+    ranks' rows are constants (one RCCL all-gather over xGMI, no gradient exchange).  Used for global negatives in the
+    DynaCLR NT-Xent loss (BASELINE config 5): every rank evaluates the loss of the GLOBAL batch; its backward yields
+    d loss_global / d (local rows), and the data-parallel gradient SUM over ranks is the gradient of the global loss —
+    ``scale_for_mean_reduction`` compensates the 1 / world of a mean reduction."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t.detach().contiguous())
+    parts[dist.get_rank()] = t
+    return torch.cat(parts)
+
+
+def scale_for_mean_reduction(loss: torch.Tensor) -> torch.Tensor:
+    """same value, gradient multiplied by the world size (see ``all_gather_with_local_grad``)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return loss
+    w = dist.get_world_size()
+    return loss * w - loss.detach() * (w - 1)
