@@ -301,3 +301,69 @@ def test_all_gather_with_local_grad_reproduces_the_global_batch_gradient():
         assert abs(l_r - loss.item()) < 1e-6
         torch.testing.assert_close(ga_r, a.detach(), rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(g_r, P.grad, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ mmap preload (§8 f4)
+def test_mmap_preload_serves_the_same_batches(tiny_hcs_zarr, tmp_path):
+    """hcs.py:241-349 protocol: prepare_data stages the fit FOVs once (`.done` marker, partial caches rebuilt, fingerprint
+    per channel / filter set); the fit batches read from the buffer are identical to those read from the zarr store."""
+    path, _ = tiny_hcs_zarr
+    kw = dict(z_window_size=3, batch_size=2, num_workers=0, normalizations=[NormalizeSampled(["Phase3D"], "fov_statistics")],
+              normalize_on_device=False)
+    plain = HCSDataModule(path, "Phase3D", "Nuclei", **kw)
+    plain.setup("fit")
+    mm = HCSDataModule(path, "Phase3D", "Nuclei", mmap_preload=True, scratch_dir=tmp_path, **kw)
+    with pytest.raises(RuntimeError, match="prepare_data"):
+        mm.setup("fit")
+    cache = mm._mmap_cache_dir
+    assert str(cache).startswith(str(tmp_path)) and cache != HCSDataModule(path, "Nuclei", "Phase3D", mmap_preload=True,
+                                                                           scratch_dir=tmp_path, **kw)._mmap_cache_dir
+    cache.mkdir(parents=True)
+    (cache / "data.mmap").write_bytes(b"partial")       # a killed preload left debris without the marker
+    mm.prepare_data()
+    assert (cache / ".done").exists()
+    stamp = (cache / "data.mmap").stat().st_mtime_ns
+    mm.prepare_data()                                    # second call: cache found, nothing rewritten
+    assert (cache / "data.mmap").stat().st_mtime_ns == stamp
+    mm.setup("fit")
+    assert len(mm.train_dataset) == len(plain.train_dataset) and len(mm.val_dataset) == len(plain.val_dataset)
+    for ds_a, ds_b in ((plain.train_dataset, mm.train_dataset), (plain.val_dataset, mm.val_dataset)):
+        for i in range(len(ds_a)):
+            a, b = ds_a[i], ds_b[i]
+            assert a["index"] == b["index"]
+            assert torch.equal(a["source"], b["source"]) and torch.equal(a["target"], b["target"])
+    ba, bb = next(iter(plain.val_dataloader())), next(iter(mm.val_dataloader()))
+    assert torch.equal(ba["source"], bb["source"]) and ba["index"][0] == bb["index"][0]
+    mm.setup("predict")                                  # predict reads the store directly
+    assert not isinstance(mm.predict_dataset.positions[0], type(mm.train_dataset.positions[0]))
+
+
+def test_rand_weighted_cropd_multi_sample_host_crop(tiny_hcs_zarr):
+    """CPU-worker RandWeightedCropd (MONAI semantics): N crops per stack, inside the volume, centres follow the weight map,
+    reproducible from the random state, uniform when the map is empty; HCSDataModule flattens them into the batch"""
+    from viscy_amd.transforms import RandWeightedCropd
+
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 5, 96, 128, generator=g)
+    w = torch.zeros(1, 5, 96, 128)
+    w[:, :, 60:70, 90:100] = 1.0                       # all the mass in one blob
+    t = RandWeightedCropd(["source", "target", "weight"], w_key="weight", spatial_size=(-1, 32, 48), num_samples=6).set_random_state(7)
+    outs = t({"source": img, "target": img * 2, "weight": w, "norm_meta": None})
+    assert isinstance(outs, list) and len(outs) == 6
+    for o in outs:
+        assert o["source"].shape == (1, 5, 32, 48) and torch.equal(o["target"], o["source"] * 2)
+        assert o["weight"].sum() > 0                    # every window contains part of the blob: centres sit on it
+    again = RandWeightedCropd(["source", "target", "weight"], "weight", (-1, 32, 48), 6).set_random_state(7)(
+        {"source": img, "target": img * 2, "weight": w})
+    assert all(torch.equal(a["source"], b["source"]) for a, b in zip(outs, again))
+    flat = RandWeightedCropd(["source"], "weight", (5, 32, 48), 200).set_random_state(1)({"source": img, "weight": torch.zeros_like(w)})
+    ys = {int((img[0, 0] == o["source"][0, 0, 0, 0]).nonzero()[0, 0]) for o in flat}
+    assert len(ys) > 20                                 # empty map -> uniform over the valid centres
+    # through the data module: 2 stacks x 3 samples = batch of 6 patches of the crop size
+    path, _ = tiny_hcs_zarr
+    dm = HCSDataModule(path, "Phase3D", "Nuclei", z_window_size=3, batch_size=6, num_workers=0, yx_patch_size=(32, 32),
+                       augmentations=[RandWeightedCropd(["Phase3D", "Nuclei"], w_key="Nuclei", spatial_size=(-1, 32, 32), num_samples=3)])
+    dm.setup("fit")
+    assert dm.train_patches_per_stack == 3
+    b = next(iter(dm.train_dataloader()))
+    assert b["source"].shape == (6, 1, 3, 32, 32) and b["target"].shape == (6, 1, 3, 32, 32)

@@ -337,9 +337,15 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 1) void gemm_nt_kernel(const V
           // second output: the activation g = gelu(h) (storage-rounded); the GRN statistics use the stored value
           float gv[VN];
 #pragma unroll
-          for (int j = 0; j < VN; ++j) {
-            gv[j] = round_to<T>(gelu_f(round_to<T>(v[j])));
+          for (int j = 0; j < VN; j += 2) {  // packed fp32 pairs (gelu_parts2)
+            const vsx_v2f x = {round_to<T>(v[j]), round_to<T>(v[j + 1])};
+            vsx_v2f cdf, pdf;
+            gelu_parts2(x, cdf, pdf);
+            const vsx_v2f gg = x * cdf;
+            gv[j] = round_to<T>(gg.x);
+            gv[j + 1] = round_to<T>(gg.y);
             r0[j] += gv[j] * gv[j];
+            r0[j + 1] += gv[j + 1] * gv[j + 1];
           }
           stvec<T>(reinterpret_cast<T*>(p.C2) + (size_t)m * p.ldc + c_coff + n, pack<T>(gv));
         } else if (epi == VSX_EPI_DZ) {
@@ -662,9 +668,15 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
           } else if constexpr (EPI == VSX_EPI_BIAS_GELU_SQ) {
             float gv[VN];
 #pragma unroll
-            for (int j = 0; j < VN; ++j) {
-              gv[j] = round_to<T>(gelu_f(round_to<T>(v[j])));
+            for (int j = 0; j < VN; j += 2) {  // packed fp32 pairs (gelu_parts2)
+              const vsx_v2f x = {round_to<T>(v[j]), round_to<T>(v[j + 1])};
+              vsx_v2f cdf, pdf;
+              gelu_parts2(x, cdf, pdf);
+              const vsx_v2f gg = x * cdf;
+              gv[j] = round_to<T>(gg.x);
+              gv[j + 1] = round_to<T>(gg.y);
               r0[j] += gv[j] * gv[j];
+              r0[j + 1] += gv[j + 1] * gv[j + 1];
             }
             stvec<T>(reinterpret_cast<T*>(p.C2) + (size_t)m * p.ldc + ccol, pack<T>(gv));
           } else if constexpr (EPI == VSX_EPI_DZ) {

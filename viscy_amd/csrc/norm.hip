@@ -403,11 +403,17 @@ __global__ __launch_bounds__(256) void grn_gelu_bwd_kernel(T* __restrict__ dz, c
         unpack<T>(u ? d1 : d0, dv);
         unpack<T>(u ? h1 : h0, hv);
 #pragma unroll
-        for (int j = 0; j < VN; ++j) {
-          float gv, dgv;
-          gelu_both(hv[j], gv, dgv);
-          o[j] = round_to<T>((dv[j] * sv[j] + gv * tv[j]) * dgv);
+        for (int j = 0; j < VN; j += 2) {  // packed fp32 pairs (gelu_parts2)
+          const vsx_v2f x = {hv[j], hv[j + 1]}, d2 = {dv[j], dv[j + 1]};
+          const vsx_v2f s2 = {sv[j], sv[j + 1]}, t2 = {tv[j], tv[j + 1]};
+          vsx_v2f cdf, pdf;
+          gelu_parts2(x, cdf, pdf);
+          const vsx_v2f gv = x * cdf, dgv = cdf + x * pdf;
+          const vsx_v2f r = (d2 * s2 + gv * t2) * dgv;
+          o[j] = round_to<T>(r.x);
+          o[j + 1] = round_to<T>(r.y);
           cs[j] += o[j];
+          cs[j + 1] += o[j + 1];
         }
         stvec<T>(dz + (size_t)m * N + n, pack<T>(o));
       }

@@ -8,7 +8,8 @@ that ``VSUNet`` + the HIP path drop in behind the same batch contract:
 Covered: fit / predict / test set-up, seeded FOV train/val split, Z-sliding windows over T, CPU
 normalisations + augmentations composed per sample in the workers, collation of multi-sample crops,
 ``on_after_batch_transfer`` GPU augmentations + spatial-shape validation + ``target_2d`` slicing,
-``DistributedSampler`` sharding under DP.  Not built: mmap preload, foreground masks, non-zero
+``DistributedSampler`` sharding under DP, mmap preload (``prepare_data`` stages the fit FOVs into one memory-mapped buffer
+under ``scratch_dir``).  Not built: foreground masks, non-zero
 rejection sampling (marked NotImplemented when requested).  I/O is plain host code.
 """
 
@@ -62,6 +63,35 @@ class Compose:
             else:
                 sample = t(sample)
         return sample
+
+
+class _MmapArray:
+    """the slice of the staged buffer that holds one FOV, with the ImageArray surface SlidingWindowDataset uses"""
+
+    def __init__(self, slab: np.ndarray, path: str):
+        self._slab, self.path = slab, path
+        self.frames, self.channels, self.slices, self.height, self.width = slab.shape
+        self.shape, self.dtype = slab.shape, slab.dtype
+        self.oindex = self
+
+    def __getitem__(self, idx):
+        t, c, z = idx
+        return np.ascontiguousarray(self._slab[t, :, z][:, list(c)])
+
+
+class _MmapPosition:
+    def __init__(self, pos, slab: np.ndarray, channel_names: list[str], array_key: str):
+        self._pos, self._names, self._array_key = pos, list(channel_names), array_key
+        self._arr = _MmapArray(slab, pos[array_key].path)
+        self.name, self.zattrs, self.channel_names = pos.name, pos.zattrs, list(channel_names)
+
+    def __getitem__(self, key):
+        if key != self._array_key:
+            return self._pos[key]
+        return self._arr
+
+    def get_channel_index(self, name: str) -> int:
+        return self._names.index(name)
 
 
 class SlidingWindowDataset(Dataset):
@@ -161,8 +191,10 @@ class HCSDataModule(_DMBase):
                  normalize_on_device: bool = True):
         if _DMBase is not object:  # pragma: no cover
             super().__init__()
-        if mmap_preload or fg_mask_key is not None or ground_truth_masks is not None or min_nonzero_fraction > 0:
-            raise NotImplementedError("mmap_preload / fg_mask_key / ground_truth_masks / min_nonzero_fraction are not built")
+        if fg_mask_key is not None or ground_truth_masks is not None or min_nonzero_fraction > 0:
+            raise NotImplementedError("fg_mask_key / ground_truth_masks / min_nonzero_fraction are not built")
+        self.mmap_preload = bool(mmap_preload)
+        self.scratch_dir = Path(scratch_dir) if scratch_dir is not None else None
         self.data_path = Path(data_path)
         self.source_channel, self.target_channel = _ensure_channel_list(source_channel), _ensure_channel_list(target_channel)
         self.batch_size, self.num_workers, self.target_2d = batch_size, num_workers, target_2d
@@ -195,8 +227,86 @@ class HCSDataModule(_DMBase):
                                      f"and number of samples {n} for transform type {type(aug)}.")
                 self.train_patches_per_stack = n
 
+    # ---- mmap preload (viscy_data/hcs.py:218-349): stage the fit FOVs once, uncompressed, into one memory-mapped buffer
+    @property
+    def _mmap_cache_dir(self) -> Path:
+        """hcs.py:218-234 — same fingerprint (dataset path, channels, array key, FOV filters), same directory layout"""
+        import hashlib
+        import os
+        import tempfile
+
+        scratch = self.scratch_dir or Path(tempfile.gettempdir())
+        ch_key = "|".join(self.source_channel) + "||" + "|".join(self.target_channel) + f"||{self.array_key}"
+        include_key = "|".join(sorted(self.include_fov_names)) if self.include_fov_names else ""
+        exclude_key = "|".join(sorted(self.exclude_fov_names)) if self.exclude_fov_names else ""
+        path_key = str(self.data_path.resolve()) + "||" + ch_key + f"||incl={include_key}||excl={exclude_key}"
+        fingerprint = hashlib.md5(path_key.encode()).hexdigest()[:12]
+        return scratch / os.getenv("SLURM_JOB_ID", "viscy_cache") / f"{self.data_path.name}_{fingerprint}"
+
+    @staticmethod
+    def _fov_t_offsets(positions, array_key: str) -> list[int]:
+        """hcs.py:351-378: cumulative T offsets, one slab of the buffer per FOV (T may differ between FOVs)"""
+        offsets = [0]
+        for pos in positions:
+            offsets.append(offsets[-1] + pos[array_key].frames)
+        return offsets
+
+    def _mmap_layout(self, positions):
+        all_ch = list(self.source_channel) + [c for c in self.target_channel if c not in self.source_channel]
+        arr0 = positions[0][self.array_key]
+        offsets = self._fov_t_offsets(positions, self.array_key)
+        shape = (offsets[-1], len(all_ch), arr0.slices, arr0.height, arr0.width)
+        return all_ch, offsets, shape, np.dtype(arr0.dtype)
+
     def prepare_data(self):
-        pass
+        """hcs.py:241-349.  The buffer is a raw ``numpy.memmap`` file ``data.mmap`` (the reference uses tensordict's
+        ``MemoryMappedTensor``, absent here: same bytes, same ``.done`` marker protocol, partial caches are rebuilt)."""
+        if not self.mmap_preload:
+            return
+        import shutil
+        from concurrent.futures import ThreadPoolExecutor
+
+        cache_dir = self._mmap_cache_dir
+        if (cache_dir / ".done").exists():
+            return
+        if cache_dir.exists():
+            shutil.rmtree(cache_dir)  # partial files of a killed preload
+        cache_dir.mkdir(parents=True, exist_ok=True)
+        try:
+            plate = open_ome_zarr(self.data_path, mode="r")
+            positions = self._filtered_positions(plate)
+            all_ch, offsets, shape, dtype = self._mmap_layout(positions)
+            buf = np.lib.format.open_memmap(cache_dir / "data.mmap", mode="w+", dtype=dtype, shape=shape)
+
+            def write_fov(i_pos):
+                i, pos = i_pos
+                img = pos[self.array_key]
+                if (img.slices, img.height, img.width) != shape[2:]:
+                    raise ValueError(f"{pos.name}: array shape {(img.slices, img.height, img.width)} differs from {shape[2:]}")
+                ch_idx = [pos.get_channel_index(c) for c in all_ch]
+                buf[offsets[i]:offsets[i + 1]] = img.oindex[slice(None), ch_idx, slice(None)]
+
+            with ThreadPoolExecutor(max_workers=min(len(positions), 16)) as pool:
+                list(pool.map(write_fov, enumerate(positions)))
+            buf.flush()
+            del buf
+            (cache_dir / ".done").touch()
+        except BaseException:
+            if cache_dir.exists():
+                shutil.rmtree(cache_dir)
+            raise
+
+    def _mmap_positions(self, positions):
+        """the FOVs of ``positions`` served from the staged buffer (read-only map shared by forked workers)"""
+        cache_dir = self._mmap_cache_dir
+        if not (cache_dir / ".done").exists():
+            raise RuntimeError(f"mmap_preload=True but no staged buffer at {cache_dir}: call prepare_data() before setup('fit')")
+        all_ch, offsets, shape, dtype = self._mmap_layout(positions)
+        buf = np.load(cache_dir / "data.mmap", mmap_mode="r")
+        if tuple(buf.shape) != tuple(shape) or buf.dtype != dtype:
+            raise RuntimeError(f"stale mmap cache at {cache_dir}: buffer {buf.shape} {buf.dtype}, dataset needs {shape} {dtype}; "
+                               "delete the directory to rebuild it")
+        return [_MmapPosition(pos, buf[offsets[i]:offsets[i + 1]], all_ch, self.array_key) for i, pos in enumerate(positions)]
 
     def _filtered_positions(self, plate):
         pos = [p for name, p in plate.positions()
@@ -211,6 +321,8 @@ class HCSDataModule(_DMBase):
         plate = open_ome_zarr(self.data_path, mode="r")
         positions = self._filtered_positions(plate)
         if stage in ("fit", "validate"):
+            if self.mmap_preload:  # predict / test read the zarr store directly (hcs.py:243-247)
+                positions = self._mmap_positions(positions)
             settings["channels"]["target"] = self.target_channel
             g = torch.Generator().manual_seed(self.seed)
             idx = torch.randperm(len(positions), generator=g).tolist()  # hcs.py:490-494,566-569

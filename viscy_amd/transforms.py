@@ -435,6 +435,74 @@ def fuse_affine_crop(transforms: Sequence) -> list:
 
 
 # ------------------------------------------------------------------------------------------------
+# RandWeightedCropd — the CPU-worker multi-sample crop of the fit recipes (viscy_transforms/_monai_wrappers.py:142-183, a
+# jsonargparse-friendly subclass of MONAI's RandWeightedCropd; MONAI 1.5.2 is not under /root/reference: the sampling below
+# restates its published ``weighted_patch_samples`` / ``SpatialCrop`` — "parity unpinned" for the third-party internals).
+# Host code by design: it runs inside DataLoader workers on per-FOV stacks before batching (hcs.py:783); the batched device
+# version is BatchedRandWeightedCropd below.
+# ------------------------------------------------------------------------------------------------
+class RandWeightedCropd:
+    """``num_samples`` crops of ``spatial_size`` per sample, centres drawn with probability proportional to the weight map
+    ``sample[w_key]`` (1, Z, Y, X) restricted to the centres whose window fits; ``-1`` / non-positive entries of
+    ``spatial_size`` keep the whole axis.  Returns a list of ``num_samples`` dicts (MONAI's multi-sample convention, which
+    ``HCSDataModule`` flattens: train batch = ``batch_size // num_samples`` stacks)."""
+
+    is_spatial = True
+
+    def __init__(self, keys, w_key: str, spatial_size: Sequence[int], num_samples: int = 1, allow_missing_keys: bool = False,
+                 lazy: bool = False):
+        self.keys, self.w_key = _keys(keys), w_key
+        self.spatial_size, self.num_samples = tuple(int(s) for s in spatial_size), int(num_samples)
+        self.allow_missing_keys = allow_missing_keys
+        import numpy as _np
+
+        self.R = _np.random.RandomState()
+
+    def set_random_state(self, seed: int | None = None, state=None):
+        import numpy as _np
+
+        self.R = state if state is not None else _np.random.RandomState(seed)
+        return self
+
+    def _centers(self, w: Tensor) -> list[tuple[int, ...]]:
+        import numpy as _np
+
+        img_size = tuple(w.shape)
+        win = tuple(m if s <= 0 else min(s, m) for s, m in zip(self.spatial_size, img_size))  # fall_back_tuple
+        sl = tuple(slice(k // 2, m - k + k // 2) if m > k else slice(m // 2, m // 2 + 1) for k, m in zip(win, img_size))
+        v = _np.asarray(w[sl], dtype=_np.float64)
+        v_size = v.shape
+        v = v.ravel().copy()
+        v[~_np.isfinite(v)] = 0.0
+        if (v < 0).any():
+            v -= v.min()  # shift to non-negative
+        c = _np.cumsum(v)
+        if not c[-1] or not _np.isfinite(c[-1]) or c[-1] < 0:  # uniform sampling
+            idx = self.R.randint(0, len(c), size=self.num_samples)
+        else:
+            r = self.R.random(self.num_samples)
+            idx = _np.minimum(_np.searchsorted(c, r * c[-1], side="right"), len(c) - 1)
+        diff = [min(k, m) // 2 for k, m in zip(win, img_size)]
+        return [tuple(int(u) + d for u, d in zip(_np.unravel_index(int(i), v_size), diff)) for i in idx], win
+
+    def __call__(self, sample: dict) -> list[dict]:
+        w = sample[self.w_key]
+        centers, win = self._centers(w[0])
+        out = []
+        for ctr in centers:
+            sl = tuple(slice(max(c - k // 2, 0), max(c - k // 2, 0) + k) for c, k in zip(ctr, win))  # SpatialCrop(roi_center, roi_size)
+            d = dict(sample)
+            for k in self.keys:
+                if k not in sample:
+                    if self.allow_missing_keys:
+                        continue
+                    raise KeyError(k)
+                d[k] = sample[k][(slice(None),) + sl]
+            out.append(d)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
 # K23 BatchedRandWeightedCropd (_crop.py:263-386)
 # ------------------------------------------------------------------------------------------------
 def crop3d(x: Tensor, starts: Tensor, size: Sequence[int]) -> Tensor:
