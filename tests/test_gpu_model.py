@@ -597,3 +597,41 @@ def test_contrastive_module_trains_convnextv2_tiny_bf16():
     assert (pa @ pp.t()).argmax(1).tolist() == list(range(8))
     with pytest.raises(NotImplementedError, match="resnet50"):
         ContrastiveEncoder("resnet50", in_channels=2, in_stack_depth=15)
+
+
+def test_graph_captured_contrastive_and_pretraining_steps_match_eager():
+    """TrainStep(loss_fn=...): the DynaCLR step and the FCMAE masked pre-training step replayed as one hipGraph give the same
+    trajectory as eager launches (same seeds; the mask draw is device-side randomness inside the capture)"""
+    from viscy_amd.contrastive import ContrastiveEncoder, ContrastiveModule, NTXentLoss
+    from viscy_amd.losses import MaskedMSELoss
+    from viscy_amd.vsunet import FcmaeUNet
+
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(4, 1, 5, 64, 64, generator=g).cuda()
+    p = a + 0.3 * torch.randn(a.shape, generator=g).cuda()
+    traj = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        enc = ContrastiveEncoder("convnext_tiny", in_channels=1, in_stack_depth=5, embedding_dim=64, projection_dim=32,
+                                 depths=(1, 1, 2, 1), dims=(32, 64, 96, 128))
+        mod = ContrastiveModule(enc, loss_function=NTXentLoss(temperature=0.3), lr=1e-3).cuda()
+        enc.compute_dtype = torch.float32
+        opt = mod.configure_optimizers(t_total=8)
+        mod.train()
+        step = mod.make_train_step(opt, use_graph=use_graph)
+        traj.append([step(a, p).item() for _ in range(8 if not use_graph else 6)])
+        assert int(enc.projection[1].num_batches_tracked) >= 12
+    # the capture runs two real warm-up steps first (TrainStep._capture): replay i continues from eager step i + 2
+    assert all(abs(x - y) <= 2e-3 * abs(x) + 1e-5 for x, y in zip(traj[0][2:], traj[1])), traj
+    assert traj[0][-1] < traj[0][0]
+    # FCMAE masked pre-training under capture: finite, decreasing, and a fresh mask every replay
+    kw = dict(in_channels=1, out_channels=1, encoder_blocks=[1, 1, 1, 1], dims=[16, 32, 64, 128], decoder_conv_blocks=1,
+              in_stack_depth=5, pretraining=True)
+    vs = FcmaeUNet(fit_mask_ratio=0.5, model_config=kw, loss_function=MaskedMSELoss(), lr=1e-3).cuda()
+    vs.model.compute_dtype = torch.bfloat16
+    opt = vs.configure_optimizers(t_total=30)
+    x = torch.nn.functional.avg_pool3d(torch.randn(4, 1, 5, 128, 128, generator=g), (1, 9, 9), 1, (0, 4, 4)).cuda() * 4
+    step = vs.make_pretrain_step(opt)
+    losses = [step(x, x).item() for _ in range(30)]
+    assert all(l == l for l in losses) and len(set(losses)) > 20
+    assert sum(losses[-5:]) < 0.8 * sum(losses[:5]), losses

@@ -96,6 +96,11 @@ def row_fcmae():
 
         s = timed(step, iters=5, warmup=2)
         out["masked_0.5" if ratio else "dense"] = {"ms_per_step": round(s * 1e3, 1), "patches_per_s": round(B / s, 1)}
+        if ratio:
+            gs = vs.make_pretrain_step(opt)
+            sg = timed(lambda: gs(x, x), iters=5, warmup=2)
+            out["masked_0.5"].update(graph_ms_per_step=round(sg * 1e3, 1), graph_patches_per_s=round(B / sg, 1))
+            del gs
         del vs, opt
     return out
 
@@ -123,8 +128,11 @@ def row_dynaclr():
                 opt.step()
 
             s = timed(step, iters=5, warmup=2)
-            out[f"{backbone}_B{B}"] = {"ms_per_step": round(s * 1e3, 1), "pairs_per_s": round(B / s, 1), "images_per_s": round(2 * B / s, 1)}
-            del enc, mod, opt, batch, a
+            gs = mod.make_train_step(opt)
+            sg = timed(lambda: gs(batch["anchor"], batch["positive"]), iters=5, warmup=2)
+            out[f"{backbone}_B{B}"] = {"ms_per_step": round(s * 1e3, 1), "pairs_per_s": round(B / s, 1), "images_per_s": round(2 * B / s, 1),
+                                        "graph_ms_per_step": round(sg * 1e3, 1), "graph_images_per_s": round(2 * B / sg, 1)}
+            del enc, mod, opt, batch, a, gs
     return out
 
 

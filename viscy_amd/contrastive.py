@@ -233,12 +233,28 @@ class ContrastiveModule(nn.Module):
         # all-gathered so that every anchor sees world * 2B - 2 negatives instead of 2B - 2; False = the reference's behaviour
         self.gather_embeddings = gather_embeddings
         self.current_epoch = 0
+        self._logging = True
         self.logged: dict[str, list] = {}
         if ckpt_path is not None:
             self.load_state_dict(torch.load(ckpt_path, weights_only=True, map_location="cpu")["state_dict"], strict=False)
 
     def _log(self, key: str, value) -> None:
-        self.logged.setdefault(key, []).append(value.detach() if torch.is_tensor(value) else value)
+        if self._logging:
+            self.logged.setdefault(key, []).append(value.detach() if torch.is_tensor(value) else value)
+
+    def make_train_step(self, optimizer, ddp=None, use_graph: bool = True):
+        """the whole contrastive step (zero-grad, two forwards, NT-Xent, backward, fused AdamW) as ONE hipGraph replay per batch
+        (``viscy_amd.step.TrainStep``); call ``step(anchor, positive) -> loss`` with fixed shapes"""
+        from .step import TrainStep
+
+        def loss_fn(anchor, positive):
+            was, self._logging = self._logging, False  # the captured tensors must not pile up in the log
+            try:
+                return self._step({"anchor": anchor, "positive": positive}, "train")
+            finally:
+                self._logging = was
+
+        return TrainStep(self.model, None, optimizer, ddp=ddp, use_graph=use_graph, loss_fn=loss_fn)
 
     def on_train_epoch_start(self) -> None:
         if hasattr(self.loss_function, "step"):

@@ -19,8 +19,12 @@ import torch
 
 
 class TrainStep:
-    def __init__(self, model, criterion, optimizer, ddp=None, use_graph: bool = True):
+    def __init__(self, model, criterion, optimizer, ddp=None, use_graph: bool = True, loss_fn=None):
+        """``loss_fn(x, t) -> scalar loss`` replaces ``criterion(model(x), t)`` for steps of another shape (DynaCLR: two
+        forwards + NT-Xent on (anchor, positive); FCMAE pre-training: masked forward + MaskedMSELoss with ``t`` unused).
+        Everything it launches must be capturable: device-side randomness only, no host synchronisation."""
         self.model, self.crit, self.opt, self.ddp = model, criterion, optimizer, ddp
+        self.loss_fn = loss_fn
         self.use_graph = use_graph
         self.graph = None
         self.x = self.t = self.loss = None
@@ -30,7 +34,7 @@ class TrainStep:
     # ---- the captured body
     def _fwd_bwd(self):
         self.opt.zero_grad()
-        loss = self.crit(self.model(self.x), self.t)
+        loss = self.loss_fn(self.x, self.t) if self.loss_fn is not None else self.crit(self.model(self.x), self.t)
         loss.backward()
         return loss.detach()
 

@@ -312,6 +312,17 @@ class FcmaeUNet(VSUNet):
         target = x * mask.unsqueeze(2) if return_target else None
         return pred, target, loss
 
+    def make_pretrain_step(self, optimizer, ddp=None, use_graph: bool = True):
+        """masked pre-training step (device-side mask draw, masked forward, MaskedMSELoss, backward, fused AdamW) as one
+        hipGraph replay (``viscy_amd.step.TrainStep``); call ``step(source, source) -> loss`` with fixed shapes"""
+        from .step import TrainStep
+
+        def loss_fn(x, _unused):
+            pred, mask = self.forward(x, mask_ratio=self.fit_mask_ratio)
+            return self.loss_function(pred, x, mask)
+
+        return TrainStep(self.model, None, optimizer, ddp=ddp, use_graph=use_graph, loss_fn=loss_fn)
+
     def forward_fit_supervised(self, batch: dict):
         """engine.py:921-939"""
         x, target = batch["source"], batch["target"]
