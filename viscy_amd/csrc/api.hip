@@ -10,6 +10,7 @@ int g_vsx_tn_tr = 1;
 int g_vsx_nt_wide = 1;
 int g_vsx_nt_fast = 1;
 int g_vsx_tn_wide = 1;
+int g_vsx_ggb_blocks = 2048;  // grn_gelu_bwd: target workgroup count (tuning knob, see norm.hip)
 int g_vsx_nt_tall = 0;  // 256x128 NT tiles: -5..-9 % on isolated wide-output launches, nothing on the whole step (measured) -> off
 
 void vsx_set_error(const char* fmt, ...) {
@@ -27,6 +28,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "nt_fast")) { g_vsx_nt_fast = value; return 0; }
   if (name && !strcmp(name, "tn_wide")) { g_vsx_tn_wide = value; return 0; }
   if (name && !strcmp(name, "nt_tall")) { g_vsx_nt_tall = value; return 0; }
+  if (name && !strcmp(name, "ggb_blocks")) { g_vsx_ggb_blocks = value; return 0; }
   vsx_set_error("vsx_set_flag: unknown flag '%s'", name ? name : "(null)");
   return 1;
 }
@@ -36,5 +38,6 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "nt_fast")) return g_vsx_nt_fast;
   if (name && !strcmp(name, "tn_wide")) return g_vsx_tn_wide;
   if (name && !strcmp(name, "nt_tall")) return g_vsx_nt_tall;
+  if (name && !strcmp(name, "ggb_blocks")) return g_vsx_ggb_blocks;
   return -1;
 }

@@ -355,6 +355,7 @@ extern "C" int32_t vsx_grn_bwd_stats(const float* colsq, const float* P, const f
   return 0;
 }
 
+extern int g_vsx_ggb_blocks;
 // ------------------------------------------------------------------ GRN + GELU backward (pass 2)
 // dh = (dz * s[b,n] + gelu(h) * t[b,n]) * gelu'(h), written over dz; colsum[n] += Σ_m dh
 // Block = [256/tpr row slots][tpr column chunks]; every thread streams its column chunk down the
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void grn_gelu_bwd_kernel(T* __restrict__ dz, c
   __shared__ float red[256 * VN];
   const int cl = threadIdx.x % tpr;
   const int cc = blockIdx.x * tpr + cl;
-  const int slot = threadIdx.x / tpr, nslot = 256 / tpr;
+  const int slot = threadIdx.x / tpr, nslot = blockDim.x / tpr;
   const bool active = cc * VN < N;
   const int n = cc * VN;
   float cs[VN];
@@ -461,22 +462,30 @@ extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, con
   VSX_CHECK(dz && h && s && t && colsum && ws && ws_rows > 0 && M > 0 && N > 0 && hw > 0 && N % vn == 0,
             "vsx_grn_gelu_bwd: bad arguments");
   int ncc = N / vn;
-  int tpr = 1;
-  while (tpr < ncc && tpr < 256) tpr <<= 1;
-  int gx = vsx_cdiv(ncc, tpr);
+  // column chunks per block = an exact divisor-like split of the row (no power-of-two padding: with tpr rounded up to 64 /
+  // 128 / 256 a quarter of the lanes of every wave idled on the 4C = 384 / 768 / 1536 / 3072 rows)
+  int gx = vsx_cdiv(ncc, 256);
+  int tpr = vsx_cdiv(ncc, gx);
+  int p2 = 1;
+  while (p2 < ncc && p2 < 256) p2 <<= 1;
+  if (ncc * 5 >= p2 * 4 && ncc <= 256) {  // >= 80 % of a power of two (4C = 896): full waves win (measured, tools/perf_ggb.py)
+    gx = 1;
+    tpr = p2;
+  }
   int nslot = 256 / tpr;
+  const int nthreads = tpr * nslot;
   int ngroups = vsx_cdiv(M, nslot);
-  int gy = vsx_cdiv(2048, gx);
+  int gy = vsx_cdiv(g_vsx_ggb_blocks, gx);
   if (gy > vsx_cdiv(ngroups, 4)) gy = vsx_cdiv(ngroups, 4);  // >= 4 rows per thread
   if (gy > ws_rows) gy = ws_rows;
   if (gy < 1) gy = 1;
   dim3 grid(gx, gy);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VSX_BF16)
-    hipLaunchKernelGGL(grn_gelu_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)dz, (const bf16_t*)h, s, t, ws, M, N,
+    hipLaunchKernelGGL(grn_gelu_bwd_kernel<bf16_t>, grid, dim3(nthreads), 0, st, (bf16_t*)dz, (const bf16_t*)h, s, t, ws, M, N,
                        hw, tpr);
   else
-    hipLaunchKernelGGL(grn_gelu_bwd_kernel<float>, grid, dim3(256), 0, st, (float*)dz, (const float*)h, s, t, ws, M, N, hw,
+    hipLaunchKernelGGL(grn_gelu_bwd_kernel<float>, grid, dim3(nthreads), 0, st, (float*)dz, (const float*)h, s, t, ws, M, N, hw,
                        tpr);
   VSX_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv(N, 64), vsx_cdiv(gy, 64)), dim3(256), 0, st, ws, colsum, gy, N);

@@ -141,7 +141,7 @@ def grn_bwd_stats(colsq: Tensor, P: Tensor, gamma: Tensor, dgamma: Tensor, eps: 
 
 
 def grn_gelu_bwd(dz: Tensor, h: Tensor, s: Tensor, t: Tensor, colsum: Tensor, M: int, N: int, hw: int) -> None:
-    rows = 1024
+    rows = 2048
     ws = _workspace(dz.device, rows * N)
     check(lib().vsx_grn_gelu_bwd(ptr(dz), ptr(h), ptr(s), ptr(t), ptr(colsum), ptr(ws), rows, M, N, hw,
                                  dtype_code(dz.dtype), stream()), "grn_gelu_bwd")
