@@ -635,3 +635,32 @@ def test_graph_captured_contrastive_and_pretraining_steps_match_eager():
     losses = [step(x, x).item() for _ in range(30)]
     assert all(l == l for l in losses) and len(set(losses)) > 20
     assert sum(losses[-5:]) < 0.8 * sum(losses[:5]), losses
+
+
+def test_contrastive_paired_forward_matches_two_forwards():
+    """ContrastiveModule: one trunk pass over [anchor; positive] (per-group BatchNorm) == the reference's two forwards — loss,
+    gradients and BatchNorm running statistics"""
+    from viscy_amd.contrastive import ContrastiveEncoder, ContrastiveModule, NTXentHCL
+
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(6, 2, 15, 64, 64, generator=g).cuda()
+    batch = {"anchor": a, "positive": a + 0.3 * torch.randn(a.shape, generator=g).cuda()}
+    res = []
+    for paired in (True, False):
+        torch.manual_seed(0)
+        enc = ContrastiveEncoder("convnextv2_tiny", in_channels=2, in_stack_depth=15, embedding_dim=64, projection_dim=32,
+                                 depths=(1, 1, 2, 1), dims=(24, 48, 96, 192))
+        mod = ContrastiveModule(enc, loss_function=NTXentHCL(temperature=0.2, beta=0.3)).cuda().train()
+        mod.paired_forward = paired
+        enc.compute_dtype = torch.float32
+        loss = mod.training_step(batch, 0)
+        loss.backward()
+        res.append((loss.item(), {n: p.grad.clone() for n, p in enc.named_parameters()},
+                    {k: v.clone() for k, v in enc.state_dict().items() if "running" in k or "num_batches" in k}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
+    for n in res[0][1]:
+        if res[1][1][n].abs().max() < 1e-6:
+            continue
+        assert relerr(res[0][1][n], res[1][1][n]) <= 1e-3, n
+    for k in res[0][2]:
+        torch.testing.assert_close(res[0][2][k].float(), res[1][2][k].float(), rtol=1e-5, atol=1e-6)

@@ -212,3 +212,44 @@ def test_contrastive_schedule_matches_reference_golden(mode, tag):
         worst = max(worst, err)
         assert err < 2e-3, (name, err)
     print(tag, mode, "contrastive max rel grad err", worst)
+
+
+def test_contrastive_paired_forward_equals_two_calls():
+    """one trunk pass over [anchor; positive] with per-group BatchNorm == two separate forwards of the oracle (what the
+    reference's training_step does): projections, running statistics after both calls, every parameter gradient"""
+    from oracle import contrastive_ref as C
+    from tests.conftest import load_golden
+    from viscy_amd.contrastive import ContrastiveEncoder
+
+    gold = load_golden("contrastive.pt")["v1_small_z5"]
+    ref = C.randomize_encoder_(C.ContrastiveEncoder(**gold["kwargs"], **gold["arch"]), seed=gold["seed"]).train()
+    mine = ContrastiveEncoder(**gold["kwargs"], **gold["arch"])
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine.train()
+    g = torch.Generator().manual_seed(8)
+    a = torch.randn(3, 1, 5, 64, 64, generator=g)
+    p = a + 0.3 * torch.randn(a.shape, generator=g)
+    eng = Engine(mine._core, ops=ref_ops)
+    with torch.no_grad():
+        (emb, proj), sv = eng.forward(torch.cat((a, p)), torch.float32, need_bwd=True, bn_groups=2)
+    ea, pa = ref(a)
+    ep, pp = ref(p)
+    torch.testing.assert_close(proj, torch.cat((pa, pp)).detach(), rtol=2e-4, atol=1e-4 * pa.abs().max().item())
+    torch.testing.assert_close(emb, torch.cat((ea, ep)).detach(), rtol=2e-4, atol=1e-4 * ea.abs().max().item())
+    for k, v in ref.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            torch.testing.assert_close(mine.state_dict()[k].float(), v.float(), rtol=1e-4, atol=1e-5)
+    loss = C.NTXentLoss(temperature=0.3)(torch.cat((pa, pp)), torch.cat((torch.arange(3), torch.arange(3))))
+    dpa, dpp = torch.autograd.grad(loss, (pa, pp), retain_graph=True)
+    loss.backward()
+    with torch.no_grad():
+        eng.backward(sv, (None, torch.cat((dpa, dpp))))
+    named = dict(mine.named_parameters())
+    for name, p_ref in ref.named_parameters():
+        gr = eng.g(named[name])
+        if name in ("projection.0.bias", "projection.3.bias", "encoder.head.norm.bias"):
+            # a per-batch constant shift in front of a train-mode BatchNorm: exactly-zero gradient, both sides are round-off
+            assert gr.abs().max() < 1e-4 and p_ref.grad.abs().max() < 1e-4
+            continue
+        err = ((gr - p_ref.grad).abs().max() / p_ref.grad.abs().max().clamp_min(1e-6)).item()
+        assert err < 2e-3, (name, err)

@@ -145,6 +145,12 @@ class ContrastiveEncoder(nn.Module):
         """(embedding [B, num_features], projection [B, projection_dim]) — encoder.py:138-154"""
         return self._core(x)
 
+    def forward_groups(self, x: Tensor, groups: int) -> tuple[Tensor, Tensor]:
+        """``groups`` batches concatenated along dim 0, equal to ``groups`` separate ``forward`` calls (BatchNorm batch
+        statistics and running-statistics updates per group, in order) with ONE pass of the trunk: half the launches and
+        twice the rows per GEMM for the (anchor, positive) step"""
+        return self._core(x, None, groups)
+
 
 # ------------------------------------------------------------------------------------------------ losses
 class _NTXentFn(torch.autograd.Function):
@@ -232,6 +238,7 @@ class ContrastiveModule(nn.Module):
         # extension beyond the reference (BASELINE config 5): under torch.distributed the projections of all ranks are
         # all-gathered so that every anchor sees world * 2B - 2 negatives instead of 2B - 2; False = the reference's behaviour
         self.gather_embeddings = gather_embeddings
+        self.paired_forward = True  # False: two separate forwards, literally as the reference does
         self.current_epoch = 0
         self._logging = True
         self.logged: dict[str, list] = {}
@@ -265,8 +272,14 @@ class ContrastiveModule(nn.Module):
         return self.model(x)
 
     def _step(self, batch: dict, stage: str) -> Tensor:
-        _, anchor_projection = self(batch["anchor"])      # two forwards: BatchNorm statistics per call, as in the reference
-        _, positive_projection = self(batch["positive"])
+        a, p_ = batch["anchor"], batch["positive"]
+        if self.paired_forward and a.shape == p_.shape:
+            # one trunk pass over [anchor; positive]; BatchNorm statistics stay per call (dynaclr/engine.py:265-266)
+            _, proj = self.model.forward_groups(torch.cat((a, p_)), 2)
+            anchor_projection, positive_projection = proj[: a.shape[0]], proj[a.shape[0]:]
+        else:
+            _, anchor_projection = self(a)
+            _, positive_projection = self(p_)
         if self.gather_embeddings:
             from .parallel import all_gather_with_local_grad, scale_for_mean_reduction
 

@@ -346,7 +346,7 @@ class Engine:
         return dx
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: Tensor, dt: torch.dtype, need_bwd: bool, masks=None):
+    def forward(self, x: Tensor, dt: torch.dtype, need_bwd: bool, masks=None, bn_groups: int = 1):
         """``masks``: None (dense) or, per encoder stage, ``(idx, inv, keep, L)`` int32 row maps of the FCMAE mask at that
         stage's resolution (see ``viscy_amd.fcmae.stage_row_maps``)."""
         o, cfg, m = self.ops, self.cfg, self.model
@@ -398,7 +398,7 @@ class Engine:
             feats.append((cur, ch, cw, cc))
             enc_sv.append(st_sv)
         if cfg.get("head") == "embed":
-            out = self._embed_tail_fwd(feats[3], B, sv)
+            out = self._embed_tail_fwd(feats[3], B, sv, bn_groups)
             if need_bwd:
                 sv["enc"] = enc_sv
                 sv["feat_dims"] = [(a, b_, c) for (_, a, b_, c) in feats]
@@ -462,10 +462,30 @@ class Engine:
         return out, sv
 
     # ------------------------------------------------------------------ ContrastiveEncoder tail (contrastive/encoder.py:93-154)
-    def _embed_tail_fwd(self, feat3, B, sv):
+    def _bn_groups_fwd(self, z, bn, training, relu, groups):
+        """BatchNorm1d over ``groups`` consecutive row blocks, each with its own batch statistics and its own running-stat
+        update, in order (== that many separate forward calls of the module)"""
+        o = self.ops
+        n = z.shape[0] // groups
+        ys, sms, srs = [], [], []
+        for gi in range(groups):
+            y, sm, sr = o.bn1d_fwd(z[gi * n:(gi + 1) * n], bn.weight, bn.bias, bn.running_mean, bn.running_var, training, relu)
+            ys.append(y); sms.append(sm); srs.append(sr)
+        return (ys[0] if groups == 1 else torch.cat(ys)), sms, srs
+
+    def _bn_groups_bwd(self, dy, z, y, bn, sms, srs, training, relu):
+        o, g = self.ops, self.g
+        groups = len(sms)
+        n = z.shape[0] // groups
+        dx = [o.bn1d_bwd(dy[gi * n:(gi + 1) * n], z[gi * n:(gi + 1) * n], y[gi * n:(gi + 1) * n], bn.weight, sms[gi], srs[gi],
+                         g(bn.weight), g(bn.bias), training, relu) for gi in range(groups)]
+        return dx[0] if groups == 1 else torch.cat(dx)
+
+    def _embed_tail_fwd(self, feat3, B, sv, bn_groups: int = 1):
         """global average pool -> LayerNorm (timm head.norm) = embedding; Linear -> BN -> ReLU -> Linear -> BN = projection.
         fp32 throughout ([B, 768]-sized tensors); BatchNorm statistics are those of THIS call's batch (the reference runs
-        anchor and positive through separate forwards, dynaclr/engine.py:265-266)."""
+        anchor and positive through separate forwards, dynaclr/engine.py:265-266); ``bn_groups = 2`` gives a concatenated
+        [anchor; positive] batch exactly those per-call statistics while the trunk runs once."""
         o, m, W = self.ops, self.model, self.W
         feat, fh, fw, fc = feat3
         t = m.tail
@@ -475,13 +495,15 @@ class Engine:
         E, P = t.fc0.weight.shape[0], t.fc3.weight.shape[0]
         z0 = torch.empty((B, E), dtype=torch.float32, device=feat.device)
         o.gemm("nt", emb, W["fc0"], z0, B, E, fc, fc, fc, E, dtype=torch.float32, epi=L.EPI_BIAS, bias=t.fc0.bias)
-        y1, sm1, sr1 = o.bn1d_fwd(z0, t.bn1.weight, t.bn1.bias, t.bn1.running_mean, t.bn1.running_var, training, True)
+        if B % bn_groups:
+            raise ValueError(f"batch {B} is not divisible into {bn_groups} BatchNorm groups")
+        y1, sm1, sr1 = self._bn_groups_fwd(z0, t.bn1, training, True, bn_groups)
         z3 = torch.empty((B, P), dtype=torch.float32, device=feat.device)
         o.gemm("nt", y1, W["fc3"], z3, B, P, E, E, E, P, dtype=torch.float32, epi=L.EPI_BIAS, bias=t.fc3.bias)
-        y4, sm4, sr4 = o.bn1d_fwd(z3, t.bn4.weight, t.bn4.bias, t.bn4.running_mean, t.bn4.running_var, training, False)
+        y4, sm4, sr4 = self._bn_groups_fwd(z3, t.bn4, training, False, bn_groups)
         if training:
-            t.bn1.num_batches_tracked += 1
-            t.bn4.num_batches_tracked += 1
+            t.bn1.num_batches_tracked += bn_groups
+            t.bn4.num_batches_tracked += bn_groups
         if sv is not None:
             sv["tail"] = (pooled, mean, rstd, emb, z0, y1, sm1, sr1, z3, y4, sm4, sr4, training, fh, fw, fc)
         return emb, y4
@@ -494,11 +516,11 @@ class Engine:
         dev = emb.device
         d_emb = demb.contiguous().float() if demb is not None else None
         if dproj is not None:
-            dz3 = o.bn1d_bwd(dproj.contiguous().float(), z3, y4, t.bn4.weight, sm4, sr4, g(t.bn4.weight), g(t.bn4.bias), training, False)
+            dz3 = self._bn_groups_bwd(dproj.contiguous().float(), z3, y4, t.bn4, sm4, sr4, training, False)
             o.gemm("tn", y1, dz3, g(t.fc3.weight), B, P, E, E, P, E, dtype=torch.float32, colsum=g(t.fc3.bias))
             dy1 = torch.empty((B, E), dtype=torch.float32, device=dev)
             o.gemm("nt", dz3, W["fc3T"], dy1, B, E, P, P, P, E, dtype=torch.float32)
-            dz0 = o.bn1d_bwd(dy1, z0, y1, t.bn1.weight, sm1, sr1, g(t.bn1.weight), g(t.bn1.bias), training, True)
+            dz0 = self._bn_groups_bwd(dy1, z0, y1, t.bn1, sm1, sr1, training, True)
             o.gemm("tn", emb, dz0, g(t.fc0.weight), B, E, fc, fc, E, fc, dtype=torch.float32, colsum=g(t.fc0.bias))
             de = torch.empty((B, fc), dtype=torch.float32, device=dev)
             o.gemm("nt", dz0, W["fc0T"], de, B, fc, E, E, E, fc, dtype=torch.float32)
@@ -638,9 +660,9 @@ class Engine:
 # ------------------------------------------------------------------------------------------------
 class _UNeXt2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, model, dt, need_bwd, masks, *params):
+    def forward(ctx, x, model, dt, need_bwd, masks, bn_groups, *params):
         eng = model.engine()
-        out, sv = eng.forward(x, dt, need_bwd, masks)
+        out, sv = eng.forward(x, dt, need_bwd, masks, bn_groups)
         ctx.model, ctx.sv = model, sv
         return out
 
@@ -654,7 +676,7 @@ class _UNeXt2Fn(torch.autograd.Function):
         ctx.sv = None
         if model.grad_mode == "flat":
             eng.backward(sv, dout)
-            return (None, None, None, None, None) + tuple(None for _ in eng.order)
+            return (None, None, None, None, None, None) + tuple(None for _ in eng.order)
         # autograd mode: compute into a zeroed flat buffer and hand views back to autograd
         saved = eng.flat_grad
         eng.flat_grad = torch.zeros_like(saved)
@@ -667,14 +689,14 @@ class _UNeXt2Fn(torch.autograd.Function):
             grads = tuple(eng.grad_of[id(p)] for p in eng.order)
         finally:
             eng.flat_grad, eng.grad_of = saved, old
-        return (None, None, None, None, None) + grads
+        return (None, None, None, None, None, None) + grads
 
 
-def unext2_apply(model, x: Tensor, masks=None) -> Tensor:
+def unext2_apply(model, x: Tensor, masks=None, bn_groups: int = 1) -> Tensor:
     eng = model.engine()
     dt = model._resolve_dtype()
     if model.grad_mode == "flat":
         eng.attach_grads()
     need_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in eng.order)
     with torch.autocast("cuda", enabled=False):
-        return _UNeXt2Fn.apply(x.float(), model, dt, need_bwd, masks, *eng.order)
+        return _UNeXt2Fn.apply(x.float(), model, dt, need_bwd, masks, bn_groups, *eng.order)

@@ -273,7 +273,7 @@ class _Core(nn.Module):
         self._engine = None  # parameter storage moves: flat views must be rebuilt
         return super()._apply(fn, *a, **k)
 
-    def forward(self, x: Tensor, masks=None) -> Tensor:
+    def forward(self, x: Tensor, masks=None, bn_groups: int = 1) -> Tensor:
         if not x.is_cuda:
             raise RuntimeError(
                 f"viscy_amd.{type(self).__name__} runs on MI355X HIP kernels only (no CPU / eager fallback): move the model "
@@ -282,7 +282,7 @@ class _Core(nn.Module):
         L.lib()  # raises loudly when libvsx.so is missing
         from .engine_unext2 import unext2_apply
 
-        return unext2_apply(self, x, masks)
+        return unext2_apply(self, x, masks, bn_groups)
 
 
 class UNeXt2(_Core):
