@@ -664,3 +664,42 @@ def test_contrastive_paired_forward_matches_two_forwards():
         assert relerr(res[0][1][n], res[1][1][n]) <= 1e-3, n
     for k in res[0][2]:
         torch.testing.assert_close(res[0][2][k].float(), res[1][2][k].float(), rtol=1e-5, atol=1e-6)
+
+
+def test_fcmae_finetune_with_frozen_encoder():
+    """FcmaeUNet(freeze_encoder=True) (cytoland engine.py:204-206 + the FCMAE fine-tuning recipe): the backward stops after
+    the decoder, the fused AdamW leaves encoder + stem untouched, decoder gradients equal those of the unfrozen run"""
+    from viscy_amd.losses import MixedLoss
+    from viscy_amd.vsunet import FcmaeUNet
+
+    kw = dict(in_channels=1, out_channels=2, encoder_blocks=[1, 1, 2, 1], dims=[16, 32, 64, 128], decoder_conv_blocks=1,
+              in_stack_depth=5, pretraining=False)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 1, 5, 64, 64, generator=g).cuda()
+    t = torch.rand(2, 2, 5, 64, 64, generator=g).cuda()
+    grads = []
+    for frozen in (True, False):
+        torch.manual_seed(0)
+        vs = FcmaeUNet(model_config=kw, loss_function=MixedLoss(0.5, 0.5, 0.0), lr=1e-3, freeze_encoder=frozen).cuda()
+        vs.model.compute_dtype = torch.float32
+        opt = vs.configure_optimizers(t_total=4)
+        before = {n: p.detach().clone() for n, p in vs.model.named_parameters()}
+        opt.zero_grad()
+        loss = vs.training_step({"source": x, "target": t}, 0)
+        loss.backward()
+        grads.append({n: vs.model.engine().g(p).clone() for n, p in vs.model.named_parameters() if not n.startswith("encoder.stem.conv2d")})
+        opt.step()
+        torch.cuda.synchronize()
+        moved = {n: not torch.equal(before[n], p.detach()) for n, p in vs.model.named_parameters() if not n.startswith("encoder.stem.conv2d")}
+        if frozen:
+            assert opt.n_active < vs.model.engine().flat.numel()
+            assert not any(v for n, v in moved.items() if n.startswith("encoder.")), [n for n, v in moved.items() if v and n.startswith("encoder.")]
+            assert all(v for n, v in moved.items() if n.startswith("decoder."))
+            assert all(not p.requires_grad for n, p in vs.model.named_parameters() if n.startswith("encoder."))
+        else:
+            assert all(moved.values())
+    for n in grads[0]:
+        if n.startswith("decoder."):
+            assert relerr(grads[0][n], grads[1][n]) <= 1e-5, n
+        else:
+            assert grads[0][n].abs().max() == 0

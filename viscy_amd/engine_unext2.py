@@ -155,6 +155,21 @@ class Engine:
     def g(self, p) -> Tensor:
         return self.grad_of[id(p)]
 
+    def encoder_frozen(self) -> bool:
+        """``model.encoder.requires_grad_(False)`` (cytoland engine.py:204-206, the FCMAE fine-tuning recipe): every
+        parameter from the encoder bucket on (encoder stages + stem: the tail of the flat buffer) is frozen — the backward
+        stops after the decoder and the optimiser skips the tail.  Any other pattern of frozen parameters is not built."""
+        lo = self._bucket_marks[1]
+        frozen = [not p.requires_grad for p in self.order]
+        if not any(frozen):
+            return False
+        if all(frozen[lo:]) and not any(frozen[:lo]):
+            return True
+        raise NotImplementedError("only a fully frozen encoder (+ stem) with a fully trainable decoder / head is built")
+
+    def trainable_numel(self) -> int:
+        return self.offsets[self._bucket_marks[1]] if self.encoder_frozen() else self.flat.numel()
+
     def attach_grads(self) -> None:
         for p in self.order:
             p.grad = self.grad_of[id(p)]
@@ -612,6 +627,12 @@ class Engine:
             del dcat
         if self.on_bucket_ready:
             self.on_bucket_ready(0)
+        if self.encoder_frozen():  # nothing below the decoder needs a gradient: skip ~40 % of the backward
+            self._za_need[za_key] = za.used
+            if self.on_bucket_ready:
+                self.on_bucket_ready(1)
+                self.on_bucket_ready(2)
+            return
         # ---- encoder (reverse); d = gradient w.r.t. feats[3]
         for i in (3, 2, 1, 0):
             proj, blocks = W["enc"][i]
@@ -686,7 +707,7 @@ class _UNeXt2Fn(torch.autograd.Function):
             eng.grad_of[id(p)] = eng.flat_grad[off : off + p.numel()].view(p.shape)
         try:
             eng.backward(sv, dout)
-            grads = tuple(eng.grad_of[id(p)] for p in eng.order)
+            grads = tuple(eng.grad_of[id(p)] if p.requires_grad else None for p in eng.order)
         finally:
             eng.flat_grad, eng.grad_of = saved, old
         return (None, None, None, None, None, None) + grads

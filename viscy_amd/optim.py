@@ -37,8 +37,11 @@ class FlatAdamW:
         self.base_lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.schedule, self.warmup_steps, self.t_total, self.warmup_multiplier = schedule, warmup_steps, t_total, warmup_multiplier
         dev = engine.flat.device
-        self.m = torch.zeros_like(engine.flat)
-        self.v = torch.zeros_like(engine.flat)
+        # a frozen encoder (VSUNet / FcmaeUNet freeze_encoder=True: engine.py:204-206) sits at the tail of the flat buffer
+        # (the order is head, decoder, encoder, stem): the fused launch then covers the trainable prefix only
+        self.n_active = engine.trainable_numel() if hasattr(engine, "trainable_numel") else engine.flat.numel()
+        self.m = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
         self.t = 0
         self.grad_scale = 1.0
         self._hyper_host = torch.zeros(8, dtype=torch.float32, pin_memory=dev.type == "cuda")
@@ -64,7 +67,8 @@ class FlatAdamW:
     def device_step(self) -> None:
         """device half (hipGraph-capturable): pinned → device copy of the 8 scalars + ONE fused AdamW launch"""
         self.hyper.copy_(self._hyper_host, non_blocking=True)
-        self.ops.adamw(self.engine.flat, self.engine.flat_grad, self.m, self.v, self.hyper)
+        n = self.n_active
+        self.ops.adamw(self.engine.flat[:n], self.engine.flat_grad[:n], self.m, self.v, self.hyper)
 
     def step(self) -> None:
         self.host_prepare()

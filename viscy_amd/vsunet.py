@@ -106,9 +106,9 @@ class VSUNet(_Base):
         if not net_class:
             raise ValueError(f"Architecture {architecture} not in {_UNET_ARCHITECTURE.keys()} (this build accelerates the "
                              "UNeXt2 path only)")
-        if freeze_encoder:
-            raise ValueError("freeze_encoder=True is not built (the fused flat-buffer optimiser updates every parameter)")
         self.model = net_class(**model_config)
+        if freeze_encoder:  # engine.py:204-206; only the FCMAE network has `.encoder` (as in the reference)
+            self.model.encoder.requires_grad_(False)
         if loss_function is None:
             from .losses import MixedLoss
 
@@ -271,8 +271,8 @@ class FcmaeUNet(VSUNet):
     and supervised fine-tuning (``pretraining = False``; ``encoder_only=True`` loads just the ``model.encoder.*`` weights of
     a pre-trained checkpoint) on the MI355X FCMAE network (``viscy_amd.fcmae``).
 
-    Same constructor keywords, hooks and logged keys (``loss/train``, ``loss/val``).  Differences: ``freeze_encoder`` is not
-    built (see ``VSUNet``), and ``on_fit_start`` checks the loss type only — the reference additionally insists on its
+    Same constructor keywords, hooks and logged keys (``loss/train``, ``loss/val``).  ``freeze_encoder=True`` stops the
+    backward after the decoder and restricts the fused AdamW launch to the decoder / head.  Difference: ``on_fit_start`` checks the loss type only — the reference additionally insists on its
     ``CombinedDataModule`` / ``GPUTransformDataModule`` containers (engine.py:870-878), which are outside this build; any data
     module that yields ``Sample`` dicts (or a list of them, merged like ``CombinedLoader`` batches) works."""
 
