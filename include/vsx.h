@@ -90,6 +90,8 @@ typedef struct VsxGemm {
   int64_t b_bstride;    /* NT: element stride between PER-SAMPLE weight matrices B[b] (b = m / hw); 0 = one shared B.
                          * Needs hw % 128 == 0, plain row operands, N > 64, K % 32 == 0 (the lean instantiation). Used to
                          * fold the GRN scale into fc2: a·W2^T with a = g·s[b] + beta  ==  g·(W2·diag(s[b]))^T + W2·beta */
+  const float* rscale;  /* NT, EPI_BIAS_RES: per-sample scale of the branch, c = (acc + bias) * rscale[m / hw] + res — stochastic
+                         * depth (timm DropPath: 0 or 1 / keep_prob per sample), NULL = 1.  Needs hw > 0. */
 } VsxGemm;
 
 /* K5/K8/K9/K11/K13 (pointwise / patch / 3x3 convolutions as MFMA GEMMs) — replaces
@@ -141,6 +143,11 @@ int32_t vsx_voxel_shuffle_fwd(const void* feat, float* out, int32_t B, int32_t h
     int32_t s, int32_t pool, int32_t dtype, vsx_stream_t stream);
 int32_t vsx_voxel_shuffle_bwd(const float* dout, void* dfeat, int32_t B, int32_t h, int32_t w, int32_t Cout, int32_t D,
     int32_t s, int32_t pool, int32_t dtype, vsx_stream_t stream);
+
+/* out[m, :] = x[m, :] * scale[m / hw]  (rows of C elements, dtype): the gradient of a stochastic-depth branch
+ * (timm DropPath in the ConvNeXt blocks, `drop_path_rate` / `encoder_drop_path_rate` of the reference models). */
+int32_t vsx_scale_rows_samples(const void* x, const float* scale, void* out, int64_t M, int32_t C, int32_t hw, int32_t dtype,
+    vsx_stream_t stream);
 
 /* FCMAE masked pre-training.  masked_patchify / masked_unpatchify / `x *= unmasked`
  * (viscy_models/unet/fcmae.py:95-141,216-226) on channels-last row matrices, as one row permutation:

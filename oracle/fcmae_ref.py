@@ -38,7 +38,7 @@ from typing import Sequence
 import torch
 from torch import Tensor, nn
 
-from .unext2_ref import GlobalResponseNormMlp, LayerNorm2d, PixelShuffleUp, PixelToVoxelHead, UNeXt2Decoder
+from .unext2_ref import DropPath, GlobalResponseNormMlp, LayerNorm2d, PixelShuffleUp, PixelToVoxelHead, UNeXt2Decoder
 
 
 def _init_weights(module: nn.Module) -> None:
@@ -100,12 +100,12 @@ class MaskedMSELoss(nn.Module):
 
 
 class MaskedConvNeXtV2Block(nn.Module):
-    def __init__(self, channels: int, kernel_size: int = 7, mlp_ratio: int = 4):
+    def __init__(self, channels: int, kernel_size: int = 7, mlp_ratio: int = 4, drop_path: float = 0.0):
         super().__init__()
         self.dwconv = nn.Conv2d(channels, channels, kernel_size, padding=kernel_size // 2, groups=channels)
         self.layernorm = nn.LayerNorm(channels)
         self.mlp = GlobalResponseNormMlp(channels, mlp_ratio * channels, channels, use_conv=False)
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.shortcut = nn.Identity()
 
     def forward(self, x: Tensor, unmasked: Tensor | None = None) -> Tensor:
@@ -116,18 +116,18 @@ class MaskedConvNeXtV2Block(nn.Module):
         t = _tokens(x, unmasked)                    # (B, L, C); L = HW without a mask
         t = self.layernorm(t)
         t = self.mlp(t.unsqueeze(1)).squeeze(1)     # GRN statistics over the (1, L) "spatial" axes = over the kept tokens
-        return _untokens(t, x.shape, unmasked) + shortcut
+        return self.drop_path(_untokens(t, x.shape, unmasked)) + shortcut
 
 
 class MaskedConvNeXtV2Stage(nn.Module):
-    def __init__(self, in_channels: int, out_channels: int, stride: int, num_blocks: int):
+    def __init__(self, in_channels: int, out_channels: int, stride: int, num_blocks: int, drop_path: float = 0.0):
         super().__init__()
         if in_channels != out_channels or stride > 1:
             k = stride if stride > 1 else 1
             self.downsample = nn.Sequential(LayerNorm2d(in_channels), nn.Conv2d(in_channels, out_channels, k, stride=stride))
         else:
             self.downsample = nn.Identity()
-        self.blocks = nn.ModuleList([MaskedConvNeXtV2Block(out_channels) for _ in range(num_blocks)])
+        self.blocks = nn.ModuleList([MaskedConvNeXtV2Block(out_channels, drop_path=drop_path) for _ in range(num_blocks)])
 
     def forward(self, x: Tensor, unmasked: Tensor | None = None) -> Tensor:
         x = self.downsample(x)
@@ -160,13 +160,14 @@ class MaskedAdaptiveProjection(nn.Module):
 
 
 class MaskedMultiscaleEncoder(nn.Module):
-    def __init__(self, in_channels: int, stage_blocks, dims, stem_kernel_size, in_stack_depth: int):
+    def __init__(self, in_channels: int, stage_blocks, dims, stem_kernel_size, in_stack_depth: int, drop_path_rate: float = 0.0):
         super().__init__()
         self.stem = MaskedAdaptiveProjection(in_channels, dims[0], stem_kernel_size[1:], stem_kernel_size[0], in_stack_depth)
         self.stages = nn.ModuleList()
         chs = [dims[0], *dims]
         for i, n in enumerate(stage_blocks):
-            self.stages.append(MaskedConvNeXtV2Stage(chs[i], chs[i + 1], 1 if i == 0 else 2, n))
+            # fcmae.py:404-414: drop_path_rates=[drop_path_rate] * num_blocks — the same rate for every block
+            self.stages.append(MaskedConvNeXtV2Stage(chs[i], chs[i + 1], 1 if i == 0 else 2, n, drop_path_rate))
         self.total_stride = stem_kernel_size[1] * 2 ** (len(self.stages) - 1)
         self.apply(_init_weights)
 
@@ -209,8 +210,8 @@ class FullyConvolutionalMAE(nn.Module):
                  pretraining: bool = True, head_conv: bool = False, head_conv_expansion_ratio: int = 4,
                  head_conv_pool: bool = True):
         super().__init__()
-        assert encoder_drop_path_rate == 0.0
-        self.encoder = MaskedMultiscaleEncoder(in_channels, encoder_blocks, dims, stem_kernel_size, in_stack_depth)
+        self.encoder = MaskedMultiscaleEncoder(in_channels, encoder_blocks, dims, stem_kernel_size, in_stack_depth,
+                                               encoder_drop_path_rate)
         dec = list(reversed(dims))
         if head_conv:
             dec[-1] = (in_stack_depth + 2) * in_channels * 4 * head_conv_expansion_ratio

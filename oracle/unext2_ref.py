@@ -92,11 +92,38 @@ class GlobalResponseNormMlp(nn.Module):
         return self.fc2(self.grn(self.act(self.fc1(x))))
 
 
-class ConvNeXtBlock(nn.Module):
-    """timm ConvNeXtBlock with use_grn=True, ls_init_value=None, drop_path=0."""
+class DropPath(nn.Module):
+    """timm.layers.DropPath (stochastic depth, scale_by_keep=True): in training mode the whole branch of a sample is
+    dropped with probability ``drop_prob`` and the survivors are divided by the keep probability.  ``inject`` ([B] scales)
+    replaces the Bernoulli draw (parity tests); the scales actually applied are kept in ``last``."""
 
-    def __init__(self, dim: int, conv_mlp: bool, kernel_size: int = 7, mlp_ratio: int = 4):
+    def __init__(self, drop_prob: float = 0.0):
         super().__init__()
+        self.drop_prob = drop_prob
+        self.inject = None
+        self.last = None
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+        if self.inject is not None:
+            m = self.inject.to(x.dtype).reshape(shape)
+        else:
+            m = x.new_empty(shape).bernoulli_(keep)
+            if keep > 0.0:
+                m.div_(keep)
+        self.last = m.reshape(-1).clone()
+        return x * m
+
+
+class ConvNeXtBlock(nn.Module):
+    """timm ConvNeXtBlock with use_grn=True, ls_init_value=None."""
+
+    def __init__(self, dim: int, conv_mlp: bool, kernel_size: int = 7, mlp_ratio: int = 4, drop_path: float = 0.0):
+        super().__init__()
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.use_conv_mlp = conv_mlp
         self.conv_dw = nn.Conv2d(dim, dim, kernel_size, padding=kernel_size // 2, groups=dim)
         self.norm = LayerNorm2d(dim) if conv_mlp else nn.LayerNorm(dim, eps=1e-6)
@@ -111,20 +138,21 @@ class ConvNeXtBlock(nn.Module):
             x = x.permute(0, 2, 3, 1)
             x = self.mlp(self.norm(x))
             x = x.permute(0, 3, 1, 2)
-        return x + shortcut
+        return self.drop_path(x) + shortcut
 
 
 class ConvNeXtStage(nn.Module):
     """timm ConvNeXtStage: optional (LayerNorm2d → conv k=stride) downsample, then blocks."""
 
-    def __init__(self, in_chs: int, out_chs: int, stride: int, depth: int, conv_mlp: bool):
+    def __init__(self, in_chs: int, out_chs: int, stride: int, depth: int, conv_mlp: bool, drop_path_rates=None):
         super().__init__()
+        drop_path_rates = drop_path_rates or [0.0] * depth
         if in_chs != out_chs or stride > 1:
             ks = 2 if stride > 1 else 1
             self.downsample = nn.Sequential(LayerNorm2d(in_chs), nn.Conv2d(in_chs, out_chs, ks, stride=stride))
         else:
             self.downsample = nn.Identity()
-        self.blocks = nn.Sequential(*[ConvNeXtBlock(out_chs, conv_mlp) for _ in range(depth)])
+        self.blocks = nn.Sequential(*[ConvNeXtBlock(out_chs, conv_mlp, drop_path=drop_path_rates[i]) for i in range(depth)])
 
     def forward(self, x: Tensor) -> Tensor:
         return self.blocks(self.downsample(x))
@@ -142,15 +170,17 @@ class ConvNeXtFeatures(nn.Module):
     """What ``timm.create_model(name, features_only=True)`` yields (FeatureListNet):
     flattened children ``stem_0, stem_1, stages_0..3``; returns the 4 stage outputs."""
 
-    def __init__(self, backbone: str, in_chans: int = 3):
+    def __init__(self, backbone: str, in_chans: int = 3, drop_path_rate: float = 0.0):
         super().__init__()
         depths, dims, conv_mlp = CONVNEXTV2_CFGS[backbone]
+        # timm ConvNeXt: dp_rates = [x.tolist() for x in torch.linspace(0, drop_path_rate, sum(depths)).split(depths)]
+        dp = [r.tolist() for r in torch.linspace(0, drop_path_rate, sum(depths)).split(list(depths))]
         self.feature_info = FeatureInfo(dims)
         self.stem_0 = nn.Conv2d(in_chans, dims[0], 4, stride=4)
         self.stem_1 = LayerNorm2d(dims[0])
         prev = dims[0]
         for i, (d, c) in enumerate(zip(depths, dims)):
-            setattr(self, f"stages_{i}", ConvNeXtStage(prev, c, 2 if i > 0 else 1, d, conv_mlp))
+            setattr(self, f"stages_{i}", ConvNeXtStage(prev, c, 2 if i > 0 else 1, d, conv_mlp, dp[i]))
             prev = c
         self.num_stages = len(depths)
 
@@ -324,11 +354,11 @@ class UNeXt2(nn.Module):
             raise ValueError(
                 f"Input stack depth {in_stack_depth} is not divisible by stem kernel depth {stem_kernel_size[0]}."
             )
-        if decoder_mode != "pixelshuffle" or decoder_upsample_pre_conv or pretrained or drop_path_rate:
-            raise NotImplementedError("oracle covers the pixelshuffle / no-pre-conv / drop_path=0 path only")
+        if decoder_mode != "pixelshuffle" or decoder_upsample_pre_conv or pretrained:
+            raise NotImplementedError("oracle covers the pixelshuffle / no-pre-conv path only")
         if out_stack_depth is None:
             out_stack_depth = in_stack_depth
-        enc = ConvNeXtFeatures(backbone)
+        enc = ConvNeXtFeatures(backbone, drop_path_rate=drop_path_rate)
         enc.apply(timm_init_weights)
         num_channels = enc.feature_info.channels()
         enc.stem_0 = nn.Identity()

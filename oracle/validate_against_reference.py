@@ -223,7 +223,7 @@ def g8_wiring():
     R = unext2_ref
 
     def create_model(backbone, pretrained=False, features_only=True, drop_path_rate=0.0):
-        m = R.ConvNeXtFeatures(backbone)
+        m = R.ConvNeXtFeatures(backbone, drop_path_rate=drop_path_rate)
         m.apply(R.timm_init_weights)
         return m
 
@@ -316,7 +316,7 @@ def g9_fcmae():
 
     conv_mod = sys.modules["timm.models.convnext"]
     conv_mod.Downsample = _Downsample
-    conv_mod.DropPath = lambda p: nn.Identity()
+    conv_mod.DropPath = R.DropPath
     conv_mod.GlobalResponseNormMlp = grn_mlp
     conv_mod.LayerNorm2d = R.LayerNorm2d
     conv_mod.create_conv2d = create_conv2d
@@ -395,6 +395,44 @@ def g9_fcmae():
         print(f"G9 fcmae masked {tag}: reference masked forward / MaskedMSELoss == oracle (exact), grads {worst:.1e}; "
               f"masked fraction {mask_r.float().mean():.3f}")
     torch.save(masked, os.path.join(GOLD, "fcmae_masked.pt"))
+
+    # ---- stochastic depth (encoder_drop_path_rate: 0.1 in every published VSCyto3D recipe): the reference wiring (same rate
+    # for every encoder block, fcmae.py:404-414; timm DropPath restated in unext2_ref.DropPath) in training mode
+    dp = {}
+    kw = dict(in_channels=1, out_channels=2, encoder_blocks=[2, 1, 2, 1], dims=[16, 32, 64, 128], in_stack_depth=5,
+              decoder_conv_blocks=1, pretraining=False, encoder_drop_path_rate=0.4)
+    r = ref.FullyConvolutionalMAE(**kw).train()
+    o = F.FullyConvolutionalMAE(**kw).train()
+    R.randomize_(o, seed=13)
+    r.load_state_dict(o.state_dict(), strict=True)
+    x = torch.randn((4, 1, 5, 64, 96), generator=torch.Generator().manual_seed(46))
+    torch.manual_seed(9)
+    yr = r(x)
+    torch.manual_seed(9)
+    yo = o(x)
+    assert maxrel(yo, yr) == 0.0
+    masks = [m.last.clone() for m in o.modules() if isinstance(m, R.DropPath)]
+    assert len(masks) == 6 and any((m == 0).any() for m in masks) and all(m.drop_prob == 0.4 for m in r.modules() if isinstance(m, R.DropPath))
+    dp["fcmae"] = {"kwargs": kw, "seed": 13, "x_seed": 46, "x_shape": tuple(x.shape), "masks": masks, "y": yo.detach()}
+    print(f"G9 fcmae stochastic depth: reference (train mode, rate 0.4 on all 6 encoder blocks) == oracle (exact); "
+          f"dropped {sum(int((m == 0).sum()) for m in masks)} of {6 * 4} branches")
+    uref = sys.modules["viscy_models.unet.unext2"]
+    kw = dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_atto", drop_path_rate=0.5)
+    r = uref.UNeXt2(**kw).train()
+    o = R.UNeXt2(**kw).train()
+    R.randomize_(o, seed=14)
+    r.load_state_dict(o.state_dict(), strict=True)
+    x = torch.randn((3, 1, 5, 64, 64), generator=torch.Generator().manual_seed(47))
+    torch.manual_seed(10)
+    yr = r(x)
+    torch.manual_seed(10)
+    yo = o(x)
+    assert maxrel(yo, yr) == 0.0
+    mods = [m for m in o.modules() if isinstance(m, R.DropPath)]
+    dp["unext2"] = {"kwargs": kw, "seed": 14, "x_seed": 47, "x_shape": tuple(x.shape), "rates": [m.drop_prob for m in mods],
+                    "masks": [m.last.clone() for m in mods], "y": yo.detach()}
+    print(f"G8 unext2 stochastic depth: reference wiring (drop_path_rate -> timm linspace over {len(mods) + 1} encoder blocks) == oracle (exact)")
+    torch.save(dp, os.path.join(GOLD, "droppath.pt"))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -45,7 +45,7 @@ def _gather(A: Tensor, M, K, lda, a_mode, gh, gw, cs, coff, pro, grn_s, grn_b, h
 
 def gemm(kind, A, B, Cout, M, N, K, lda, ldb, ldc, *, dtype, a_mode=A_ROWS, gh=0, gw=0, cs=0, nz=1, a_coff=None,
          b_off=None, c_coff=None, c_mode=A_ROWS, c_cs=0, pro=PRO_NONE, grn_s=None, grn_b=None, hw=0, epi=EPI_NONE,
-         bias=None, res=None, ldr=0, aux=None, ldx=0, red0=None, red1=None, colsum=None, C2=None, b_bstride=0):
+         bias=None, res=None, ldr=0, aux=None, ldx=0, red0=None, red1=None, colsum=None, C2=None, b_bstride=0, rscale=None):
     a_coff = list(a_coff) if a_coff else [0] * nz
     b_off = list(b_off) if b_off else [0] * nz
     c_coff = list(c_coff) if c_coff else [0] * nz
@@ -72,6 +72,8 @@ def gemm(kind, A, B, Cout, M, N, K, lda, ldb, ldc, *, dtype, a_mode=A_ROWS, gh=0
         if epi in (EPI_BIAS, EPI_BIAS_GELU_SQ, EPI_BIAS_RES, EPI_BIAS_STATS) and bias is not None:
             acc = acc + bias[None, :]
         if epi == EPI_BIAS_RES:
+            if rscale is not None:
+                acc = acc * rscale[bidx][:, None]
             acc = acc + res.reshape(-1, ldr).float()[:M, :N]
         out = rd(acc)
         if epi == EPI_BIAS_GELU_SQ:
@@ -409,6 +411,11 @@ def bn1d_bwd(dy, x, y, w, sm, sr, dw, db, training, relu):
     g = w * sr
     B = x.shape[0]
     return g * (d - sb / B - xh * sg / B) if training else g * d
+
+
+def scale_rows_samples(x, scale, M, C, hw):
+    idx = torch.arange(M, device=x.device) // hw
+    return (x.float() * scale[idx][:, None]).to(x.dtype)
 
 
 def rows_select(src, row_map, n_out, C, add=None):

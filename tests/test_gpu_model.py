@@ -703,3 +703,70 @@ def test_fcmae_finetune_with_frozen_encoder():
             assert relerr(grads[0][n], grads[1][n]) <= 1e-5, n
         else:
             assert grads[0][n].abs().max() == 0
+
+
+# ------------------------------------------------------------------------------------------------ stochastic depth
+@pytest.mark.parametrize("which", ["fcmae", "unext2"])
+def test_stochastic_depth_matches_reference_golden_fp32(which):
+    """`encoder_drop_path_rate` (0.1 in every published VSCyto3D recipe) / `drop_path_rate`: training-mode forward with the
+    reference run's per-sample branch scales injected == the reference's output; gradients vs oracle autograd; eval mode
+    has no stochastic depth; without injection the drop statistics follow the rate"""
+    from oracle import fcmae_ref
+    from viscy_amd.fcmae import FullyConvolutionalMAE
+    from viscy_amd.unext2 import UNeXt2
+
+    gold = load_golden("droppath.pt")[which]
+    kw = gold["kwargs"]
+    if which == "fcmae":
+        ref = unext2_ref.randomize_(fcmae_ref.FullyConvolutionalMAE(**kw), seed=gold["seed"]).train()
+        mine = FullyConvolutionalMAE(**kw)
+    else:
+        ref = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=gold["seed"]).train()
+        with torch.no_grad():
+            ref.head.conv[0].adn.A.weight.fill_(1.0)  # no PReLU kink in the gradient comparison
+        mine = UNeXt2(**kw)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.cuda().train()
+    mine.compute_dtype = torch.float32
+    x = torch.randn(gold["x_shape"], generator=torch.Generator().manual_seed(gold["x_seed"]))
+    for m, sc in zip([m for m in ref.modules() if isinstance(m, unext2_ref.DropPath)], gold["masks"]):
+        m.inject = sc
+    eng = mine.engine()
+    eng._dp_inject = [s.cuda() for s in gold["masks"]]
+    out = mine(x.cuda())
+    y = ref(x)
+    if which == "fcmae":
+        assert relerr(out, gold["y"]) <= 1e-3
+    assert relerr(out, y) <= 1e-3
+    dout = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
+    y.backward(dout)
+    out.backward(dout.cuda())
+    for (name, pr), (n2, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        if pr.grad is None or name == "head.conv.0.conv.bias":
+            continue
+        assert relerr(pm.grad, pr.grad) <= 2e-3, name
+    # device-side draws: branches are dropped at about the configured rate, survivors scaled by 1 / keep
+    eng._dp_inject = None
+    seen = []
+    orig = eng.ops.gemm
+
+    def spy(*a, **k):
+        if k.get("rscale") is not None:
+            seen.append(k["rscale"].clone())
+        return orig(*a, **k)
+
+    eng.ops = type("O", (), {**{n: getattr(eng.ops, n) for n in dir(eng.ops) if not n.startswith("__")}, "gemm": staticmethod(spy)})
+    with torch.no_grad():
+        for _ in range(20):
+            mine(x.cuda())
+    eng.ops = __import__("viscy_amd.ops", fromlist=["ops"])
+    vals = torch.cat(seen).cpu()
+    rate = kw.get("encoder_drop_path_rate", None)
+    if rate is not None:
+        u = vals.unique().tolist()
+        assert len(u) == 2 and u[0] == 0.0 and abs(u[1] - 1 / (1 - rate)) < 1e-5, u
+        assert abs((vals == 0).float().mean().item() - rate) < 0.08
+    mine.eval()
+    ref.eval()
+    with torch.no_grad():
+        assert relerr(mine(x.cuda()), ref(x)) <= 1e-3

@@ -253,3 +253,53 @@ def test_contrastive_paired_forward_equals_two_calls():
             continue
         err = ((gr - p_ref.grad).abs().max() / p_ref.grad.abs().max().clamp_min(1e-6)).item()
         assert err < 2e-3, (name, err)
+
+
+# ---------------------------------------------------------------- stochastic depth (drop_path_rate / encoder_drop_path_rate)
+@pytest.mark.parametrize("which", ["fcmae", "unext2"])
+def test_stochastic_depth_schedule_matches_reference_golden(which):
+    """training-mode forward with the reference run's per-sample branch scales injected == the reference's output
+    (tests/golden/droppath.pt), and the backward == oracle autograd with the same scales"""
+    from oracle import fcmae_ref
+    from tests.conftest import load_golden
+    from viscy_amd.fcmae import FullyConvolutionalMAE
+
+    gold = load_golden("droppath.pt")[which]
+    kw = gold["kwargs"]
+    if which == "fcmae":
+        ref = unext2_ref.randomize_(fcmae_ref.FullyConvolutionalMAE(**kw), seed=gold["seed"]).train()
+        mine = FullyConvolutionalMAE(**kw)
+        core = mine._core
+    else:
+        ref = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=gold["seed"]).train()
+        mine = core = UNeXt2(**kw)
+        assert [round(r, 6) for r in core.cfg["drop_path"][1:]] == [round(r, 6) for r in gold["rates"]]
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine.train()
+    x = torch.randn(gold["x_shape"], generator=torch.Generator().manual_seed(gold["x_seed"]))
+    for m, sc in zip([m for m in ref.modules() if isinstance(m, unext2_ref.DropPath)], gold["masks"]):
+        m.inject = sc
+    eng = Engine(core, ops=ref_ops)
+    eng._dp_inject = [s.clone() for s in gold["masks"]]
+    with torch.no_grad():
+        out, sv = eng.forward(x, torch.float32, need_bwd=True)
+    assert eng._dp_inject == []
+    torch.testing.assert_close(out, gold["y"], rtol=2e-4, atol=1e-4 * gold["y"].abs().max().item())
+    y = ref(x)
+    dout = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
+    y.backward(dout)
+    with torch.no_grad():
+        eng.backward(sv, dout)
+    named = dict(mine.named_parameters())
+    for name, p_ref in ref.named_parameters():
+        if p_ref.grad is None or name == "head.conv.0.conv.bias":
+            continue
+        gr = eng.g(named[name])
+        err = ((gr - p_ref.grad).abs().max() / p_ref.grad.abs().max().clamp_min(1e-6)).item()
+        assert err < 2e-3, (name, err)
+    # evaluation mode: no stochastic depth
+    mine.eval()
+    ref.eval()
+    with torch.no_grad():
+        out_e, _ = eng.forward(x, torch.float32, need_bwd=False)
+        torch.testing.assert_close(out_e, ref(x), rtol=2e-4, atol=1e-4 * gold["y"].abs().max().item())

@@ -39,6 +39,7 @@ class VsxGemm(C.Structure):
         ("aux", _P), ("ldx", _I32),
         ("red0", _P), ("red1", _P), ("colsum", _P), ("C2", _P),
         ("b_bstride", _I64),
+        ("rscale", _P),
     ]
 
 
@@ -92,6 +93,7 @@ _SIGS = {
     "vsx_bn1d_bwd": (_I32, [_P] * 9 + [_I32] * 4 + [_P]),
     "vsx_ntxent_fwd": (_I32, [_P] * 8 + [_I32, _I32, _F32, _F32, _P]),
     "vsx_ntxent_bwd": (_I32, [_P] * 6 + [_I32, _I32, _P]),
+    "vsx_scale_rows_samples": (_I32, [_P, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "vsx_rows_select": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _P]),
     "vsx_masked_mse_fwd": (_I32, [_P] * 5 + [_I32] * 3 + [_I64, _P]),
     "vsx_masked_mse_bwd": (_I32, [_P] * 6 + [_I32] * 3 + [_I64, _P]),

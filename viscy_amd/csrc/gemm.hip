@@ -331,8 +331,9 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 1) void gemm_nt_kernel(const V
         if (epi == VSX_EPI_BIAS_RES) {
           float rf[VN];
           unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n), rf);
+          const float rs = p.rscale ? p.rscale[b] : 1.f;  // stochastic depth: the branch of sample b is dropped / rescaled
 #pragma unroll
-          for (int j = 0; j < VN; ++j) v[j] += rf[j];
+          for (int j = 0; j < VN; ++j) v[j] = fmaf(v[j], rs, rf[j]);
         } else if (epi == VSX_EPI_BIAS_GELU_SQ) {
           // second output: the activation g = gelu(h) (storage-rounded); the GRN statistics use the stored value
           float gv[VN];
@@ -663,8 +664,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
           if constexpr (EPI == VSX_EPI_BIAS_RES) {
             float rf[VN];
             unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ldr + n), rf);
+            const float rs = p.rscale ? p.rscale[p.hw > 0 ? m / p.hw : 0] : 1.f;  // stochastic depth (see VsxGemm.rscale)
 #pragma unroll
-            for (int j = 0; j < VN; ++j) v[j] += rf[j];
+            for (int j = 0; j < VN; ++j) v[j] = fmaf(v[j], rs, rf[j]);
           } else if constexpr (EPI == VSX_EPI_BIAS_GELU_SQ) {
             float gv[VN];
 #pragma unroll
@@ -850,6 +852,7 @@ extern "C" int32_t vsx_gemm_nt(const VsxGemm* p, int32_t dtype, vsx_stream_t str
   if (p->epi == VSX_EPI_BIAS_GELU_SQ) VSX_CHECK(p->C2 != nullptr, "vsx_gemm_nt: EPI_BIAS_GELU_SQ needs the second output C2");
   if (p->epi == VSX_EPI_BIAS_STATS) VSX_CHECK(p->red1 != nullptr, "vsx_gemm_nt: EPI_BIAS_STATS needs red1");
   if (p->epi == VSX_EPI_BIAS_RES) VSX_CHECK(p->res != nullptr, "vsx_gemm_nt: EPI_BIAS_RES needs res");
+  if (p->rscale) VSX_CHECK(p->epi == VSX_EPI_BIAS_RES && p->hw > 0, "vsx_gemm_nt: rscale needs EPI_BIAS_RES and hw");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   return dtype == VSX_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
 }

@@ -193,3 +193,37 @@ extern "C" int32_t vsx_masked_mse_bwd(const float* pred, const float* orig, cons
   VSX_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------ per-sample row scaling (stochastic-depth backward)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_rows_samples_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                                 T* __restrict__ out, long M, int cv, int hw) {
+  constexpr int VN = VT<T>::N;
+  const long total = M * cv;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+    const long m = g / cv;
+    const float s = scale[m / hw];
+    float f[VN];
+    unpack<T>(ldvec<T>(x + g * VN), f);
+#pragma unroll
+    for (int j = 0; j < VN; ++j) f[j] *= s;
+    stvec<T>(out + g * VN, pack<T>(f));
+  }
+}
+
+extern "C" int32_t vsx_scale_rows_samples(const void* x, const float* scale, void* out, int64_t M, int32_t C, int32_t hw,
+                                          int32_t dtype, vsx_stream_t stream) {
+  const int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(x && scale && out && M > 0 && C > 0 && hw > 0 && C % vn == 0, "vsx_scale_rows_samples: bad arguments (C=%d)", C);
+  const long total = (long)M * (C / vn);
+  long nb = (total + 255) / 256;
+  if (nb > 256L * 64) nb = 256L * 64;
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(scale_rows_samples_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale,
+                       (bf16_t*)out, (long)M, C / vn, hw);
+  else
+    hipLaunchKernelGGL(scale_rows_samples_kernel<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale,
+                       (float*)out, (long)M, C / vn, hw);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

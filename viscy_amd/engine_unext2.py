@@ -23,7 +23,7 @@ from . import _lib as L
 class _BlockW:
     """prepared operands + parameter handles of one ConvNeXt-V2 block"""
 
-    __slots__ = ("C", "p", "dw_w", "W1f", "W1fT", "b1f", "W2", "W2T", "v1", "fc2_w", "fc2_b", "grn_w", "grn_b")
+    __slots__ = ("C", "p", "dw_w", "W1f", "W1fT", "b1f", "W2", "W2T", "v1", "fc2_w", "fc2_b", "grn_w", "grn_b", "dp")
 
 
 class _ProjW:
@@ -76,6 +76,7 @@ class Engine:
         self.model = model
         self.cfg = model.cfg
         self._zeros4c = {}       # C -> zeros(4C): the identity GRN of ConvNeXt-V1 blocks
+        self._dp_inject = None   # tests: list of per-sample branch scales [B], consumed in forward block order
         self._za = None          # zero arena of the pass in flight
         self._za_need = {}       # (pass, B, H, W) -> fp32 elements the pass took last time
         params = list(model.parameters())
@@ -185,6 +186,7 @@ class Engine:
         w.W1f, w.W1fT = o.prep_weight(blk.mlp.fc1.weight, 4 * C, C, 1, dt, want=True, want_t=need_bwd,
                                       gamma=blk.norm.weight)
         w.b1f = o.matvec(blk.mlp.fc1.weight, blk.norm.bias, blk.mlp.fc1.bias, 4 * C, C)
+        w.dp = 0.0  # stochastic-depth rate of this block (set by prepare() from cfg["drop_path"])
         w.v1 = hasattr(blk, "gamma")
         if w.v1:
             # ConvNeXt-V1: y = x + gamma * fc2(gelu(fc1(.))) — the layer scale is folded into fc2 (vsx_layer_scale_fold) and
@@ -233,6 +235,12 @@ class Engine:
             if not isinstance(st.downsample, torch.nn.Identity):
                 proj = self._prep_proj(st.downsample[0], st.downsample[1], dt, need_bwd)
             enc.append((proj, [self._prep_block(b, dt, need_bwd) for b in st.blocks]))
+        rates = cfg.get("drop_path")  # per encoder block, forward order (timm: linspace over all blocks; FCMAE: constant)
+        if rates:
+            flat_blocks = [bw for _, blocks in enc for bw in blocks]
+            assert len(rates) == len(flat_blocks)
+            for bw, r in zip(flat_blocks, rates):
+                bw.dp = float(r)
         W["enc"] = enc
         dec = []
         if cfg.get("head") == "embed":
@@ -288,6 +296,12 @@ class Engine:
                hw=hw, C2=gact)
         s = o.grn_scale(colsq, w.grn_w)
         out = torch.empty((M, C), dtype=dt, device=x.device)
+        # stochastic depth (timm DropPath, scale_by_keep): the whole branch of a sample is dropped with probability dp and
+        # the survivors are scaled by 1 / (1 - dp); training mode only.  One device-side draw per block (graph-capturable).
+        dpm = None
+        if w.dp > 0.0 and self.model.training:
+            inj = self._dp_inject
+            dpm = inj.pop(0) if inj else (torch.rand(B, device=x.device) < (1.0 - w.dp)).float() / (1.0 - w.dp)
         if dt == torch.bfloat16 and C > 64 and hw % 128 == 0 and hw // 128 >= 8:
             # large feature maps: fold the GRN affine into per-sample fc2 weights,
             #   (g·s_b + β)·W2ᵀ = g·(W2·diag(s_b))ᵀ + W2·β,
@@ -296,21 +310,21 @@ class Engine:
             Ws = o.scale_weight_samples(w.fc2_w, s, dt)
             b2 = o.matvec(w.fc2_w, w.grn_b, w.fc2_b, C, 4 * C)
             o.gemm("nt", gact, Ws, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, hw=hw, b_bstride=C * 4 * C,
-                   epi=L.EPI_BIAS_RES, bias=b2, res=xres, ldr=C)
+                   epi=L.EPI_BIAS_RES, bias=b2, res=xres, ldr=C, rscale=dpm)
         else:
             o.gemm("nt", gact, w.W2, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
-                   grn_b=w.grn_b, hw=hw, epi=L.EPI_BIAS_RES, bias=w.fc2_b, res=xres, ldr=C)
+                   grn_b=w.grn_b, hw=hw, epi=L.EPI_BIAS_RES, bias=w.fc2_b, res=xres, ldr=C, rscale=dpm)
         if rows is not None:
             out = o.rows_select(out, rows[1], B * H * Wd, C)  # masked_unpatchify: zero rows where masked (shortcut is 0 there)
         if save is not None:
-            save.append((x, xh, rstd, h, gact, colsq, s, rows))
+            save.append((x, xh, rstd, h, gact, colsq, s, rows, dpm))
         return out
 
     def _block_bwd(self, dout, w, saved, B, H, Wd, dt):
         o, g = self.ops, self.g
         C, M = w.C, B * H * Wd
         blk = w.p
-        x, xh, rstd, h, gact, colsq, s, rows = saved
+        x, xh, rstd, h, gact, colsq, s, rows, dpm = saved
         dev = dout.device
         hw = H * Wd
         dfull = dout
@@ -318,6 +332,8 @@ class Engine:
             idx, inv, keep, Lr = rows
             M, hw = B * Lr, Lr
             dout = o.rows_select(dfull, idx, M, C)
+        if dpm is not None:  # the branch saw dout * (0 | 1/keep) of its sample; the shortcut keeps the full gradient (dfull)
+            dout = o.scale_rows_samples(dout, dpm, M, C, hw)
         if w.v1:  # gradients of the folded (Ws, bs) and of the (constant, zero) GRN land in scratch
             dW2, db2 = self._za.take(C, 4 * C), self._za.take(C)
             dgw, dgb = self._za.take(4 * C), self._za.take(4 * C)

@@ -118,8 +118,8 @@ class FullyConvolutionalMAE(nn.Module):
                  pretraining: bool = True, head_conv: bool = False, head_conv_expansion_ratio: int = 4,
                  head_conv_pool: bool = True) -> None:
         super().__init__()
-        if encoder_drop_path_rate:
-            raise NotImplementedError("encoder_drop_path_rate > 0 is not built")
+        if not 0.0 <= float(encoder_drop_path_rate) < 1.0:
+            raise ValueError(f"encoder_drop_path_rate must be in [0, 1), got {encoder_drop_path_rate}")
         if len(dims) != 4 or len(encoder_blocks) != 4:
             raise NotImplementedError("four encoder stages (as in every published configuration) are built")
         stem_kernel_size = tuple(stem_kernel_size)
@@ -127,6 +127,8 @@ class FullyConvolutionalMAE(nn.Module):
             raise ValueError(f"Input stack depth {in_stack_depth} is not divisible by stem kernel depth {stem_kernel_size[0]}.")
         core = _FcmaeCore(in_channels, out_channels, encoder_blocks, dims, stem_kernel_size, in_stack_depth, decoder_conv_blocks,
                           head_conv, head_conv_expansion_ratio, head_conv_pool)
+        if encoder_drop_path_rate:  # fcmae.py:404-414: the SAME rate for every encoder block (published recipes: 0.1)
+            core.cfg["drop_path"] = [float(encoder_drop_path_rate)] * sum(encoder_blocks)
         object.__setattr__(self, "_core", core)  # NOT a registered submodule: its parameters appear below, under reference names
         enc, stem = _Holder(), _Holder()
         stem.conv3d = _share(core.stem.conv)
@@ -171,6 +173,10 @@ class FullyConvolutionalMAE(nn.Module):
     def _apply(self, fn, *a, **k):
         self._core._engine = None  # parameter storage moves: flat views must be rebuilt
         return super()._apply(fn, *a, **k)
+
+    def train(self, mode: bool = True):
+        self._core.train(mode)  # stochastic depth is active in training mode only; the engine reads the core's flag
+        return super().train(mode)
 
     @property
     def total_stride(self) -> int:

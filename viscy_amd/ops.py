@@ -72,6 +72,7 @@ def gemm(
     colsum: Tensor | None = None,
     C2: Tensor | None = None,
     b_bstride: int = 0,
+    rscale: Tensor | None = None,
 ) -> None:
     """kind='nt': C[M,N] = pro(A)[M,K]·B[N,K]^T (+epilogue);  kind='tn': C[N,K](fp32) += B[M,N]^T·pro(A)[M,K]."""
     for t in (bias, grn_s, grn_b, red0, red1, colsum):
@@ -96,6 +97,7 @@ def gemm(
     p.red0, p.red1, p.colsum = ptr(red0), ptr(red1), ptr(colsum)
     p.C2 = ptr(C2)
     p.b_bstride = b_bstride
+    p.rscale = ptr(rscale)
     fn = lib().vsx_gemm_nt if kind == "nt" else lib().vsx_gemm_tn
     check(fn(C.byref(p), dtype_code(dtype), stream()), f"gemm_{kind}")
 
@@ -379,6 +381,12 @@ def ntxent_bwd(saved, acc: Tensor, gout: Tensor) -> Tensor:
     dE = torch.empty_like(En)
     check(lib().vsx_ntxent_bwd(ptr(dS), ptr(En), ptr(inv), ptr(acc), ptr(gout), ptr(dE), N, D, stream()), "ntxent_bwd")
     return dE
+
+
+def scale_rows_samples(x: Tensor, scale: Tensor, M: int, C: int, hw: int) -> Tensor:
+    out = torch.empty_like(x)
+    check(lib().vsx_scale_rows_samples(ptr(x), ptr(scale), ptr(out), M, C, hw, dtype_code(x.dtype), stream()), "scale_rows_samples")
+    return out
 
 
 def rows_select(src: Tensor, row_map: Tensor, n_out: int, C: int, add: Tensor | None = None) -> Tensor:

@@ -320,8 +320,8 @@ class UNeXt2(_Core):
             raise NotImplementedError("decoder_upsample_pre_conv=True is not built")
         if pretrained:
             raise NotImplementedError("pretrained timm weights cannot be downloaded here; load a state_dict instead")
-        if drop_path_rate:
-            raise NotImplementedError("drop_path_rate > 0 is not built")
+        if not 0.0 <= float(drop_path_rate) < 1.0:
+            raise ValueError(f"drop_path_rate must be in [0, 1), got {drop_path_rate}")
         if out_stack_depth is None:
             out_stack_depth = in_stack_depth
         depths, dims, conv_mlp = CONVNEXTV2_CFGS[backbone]
@@ -329,6 +329,10 @@ class UNeXt2(_Core):
                     out_stack_depth=out_stack_depth, depths=depths, dims=dims, conv_mlp=conv_mlp,
                     stem_kernel_size=stem_kernel_size, decoder_conv_blocks=decoder_conv_blocks, head="conv",
                     head_channels_from=out_channels, head_pool=head_pool, head_expansion_ratio=head_expansion_ratio)
+        if drop_path_rate:
+            # timm ConvNeXt: stochastic-depth rates rise linearly over all encoder blocks (torch.linspace(0, rate, sum(depths)));
+            # the decoder stages are built without drop path (blocks.py:54-74)
+            self.cfg["drop_path"] = torch.linspace(0, float(drop_path_rate), sum(depths)).tolist()
 
     @property
     def num_blocks(self) -> int:
