@@ -770,3 +770,22 @@ def test_stochastic_depth_matches_reference_golden_fp32(which):
     ref.eval()
     with torch.no_grad():
         assert relerr(mine(x.cuda()), ref(x)) <= 1e-3
+
+
+def test_contrastive_encoder_stochastic_depth_modes():
+    """drop_path_rate (0.1 in the DynaCLR configs): identity in eval mode, random per-sample drops in training mode"""
+    from viscy_amd.contrastive import ContrastiveEncoder
+
+    torch.manual_seed(0)
+    kw = dict(in_channels=1, in_stack_depth=5, embedding_dim=64, projection_dim=32, depths=(1, 1, 2, 1), dims=(24, 48, 96, 192))
+    a = ContrastiveEncoder("convnextv2_tiny", drop_path_rate=0.5, **kw).cuda()
+    b = ContrastiveEncoder("convnextv2_tiny", **kw).cuda()
+    b.load_state_dict(a.state_dict())
+    assert [round(r, 4) for r in a.cfg["drop_path"]] == [0.0, 0.125, 0.25, 0.375, 0.5]
+    x = torch.randn(6, 1, 5, 64, 64).cuda()
+    a.eval(); b.eval()
+    with torch.no_grad():
+        assert torch.equal(a(x)[0], b(x)[0])
+        a.train(); b.train()
+        e1, e2, eb = a(x)[0], a(x)[0], b(x)[0]
+    assert not torch.equal(e1, e2) and not torch.equal(e1, eb)

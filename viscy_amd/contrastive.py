@@ -13,7 +13,8 @@ keywords and ``state_dict()`` keys as the reference (timm names: ``stem.conv``, 
 the RCCL gradient all-reduce work unchanged.
 
 Built: ``backbone="convnext_tiny"`` (V1 blocks: layer scale ``gamma`` folded into fc2 by ``vsx_layer_scale_fold`` /
-``_unfold``, identity GRN) and ``"convnextv2_tiny"`` (GRN blocks); ``resnet50`` raises ``NotImplementedError``; ``drop_path_rate`` must be 0 and ``pretrained`` False (no network here).  BatchNorm is per process
+``_unfold``, identity GRN) and ``"convnextv2_tiny"`` (GRN blocks); ``resnet50`` raises ``NotImplementedError``;
+``pretrained`` must be False (no network here); ``drop_path_rate`` is timm's linear stochastic-depth schedule (training mode).  BatchNorm is per process
 under data parallelism, as in the reference's default (no SyncBatchNorm in its recipes' trainer sections).
 """
 
@@ -88,8 +89,10 @@ class ContrastiveEncoder(nn.Module):
         super().__init__()
         if backbone not in ("convnext_tiny", "convnextv2_tiny"):
             raise NotImplementedError(f"backbone {backbone!r}: viscy_amd builds the convnext_tiny / convnextv2_tiny trunks")
-        if drop_path_rate or pretrained:
-            raise NotImplementedError("drop_path_rate > 0 / pretrained weights are not built")
+        if pretrained:
+            raise NotImplementedError("pretrained timm weights cannot be downloaded here; load a state_dict instead")
+        if not 0.0 <= float(drop_path_rate) < 1.0:
+            raise ValueError(f"drop_path_rate must be in [0, 1), got {drop_path_rate}")
         if tuple(stem_kernel_size) != tuple(stem_stride):
             raise NotImplementedError("stem_stride must equal stem_kernel_size (patchifying stem)")
         if embedding_dim % 4 or projection_dim % 4:
@@ -97,6 +100,8 @@ class ContrastiveEncoder(nn.Module):
         self.backbone = backbone
         core = _EmbedCore(in_channels, in_stack_depth, tuple(stem_kernel_size), tuple(depths), tuple(dims), embedding_dim, projection_dim,
                           v1=backbone == "convnext_tiny")
+        if drop_path_rate:  # timm ConvNeXt: rates rise linearly over all blocks; active in training mode only
+            core.cfg["drop_path"] = torch.linspace(0, float(drop_path_rate), sum(depths)).tolist()
         object.__setattr__(self, "_core", core)  # NOT a registered submodule: its parameters appear below, under reference names
         self.stem = core.stem
         enc = _Holder()
