@@ -172,3 +172,38 @@ def crop3d(img: Tensor, z0, y0, x0, size) -> Tensor:
     """_crop.py:368-384"""
     cz, cy, cx = size
     return torch.stack([img[b, :, z0[b] : z0[b] + cz, y0[b] : y0[b] + cy, x0[b] : x0[b] + cx] for b in range(img.shape[0])])
+
+
+def kornia_affine_matrix3d(angles_xyz_deg: Tensor, scale_xyz: Tensor, shears_deg: Tensor, translations_xyz: Tensor, shape_dhw) -> Tensor:
+    """What kornia 0.8.3 ``RandomAffine3D`` applies (``get_affine_matrix3d``; kornia is neither under /root/reference nor
+    installed: restated from its published source, "parity unpinned"), as a product of elementary homogeneous matrices:
+    T(c) · R(-angles as rotation vector) · diag(scale) · T(-c), translation added, then the shear matrix about c.
+    Argument conventions as BatchedRandAffined builds them (_affine.py:165-276): kornia (x, y, z) order, degrees."""
+    D, H, W = shape_dhw
+    B = angles_xyz_deg.shape[0]
+    c = torch.tensor([(W - 1) / 2.0, (H - 1) / 2.0, (D - 1) / 2.0], dtype=torch.float64)
+    out = []
+    for b in range(B):
+        w = torch.deg2rad(-angles_xyz_deg[b].double())
+        K = torch.tensor([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]], dtype=torch.float64)
+        R = torch.linalg.matrix_exp(K)  # rotation vector -> matrix
+        A = torch.eye(4, dtype=torch.float64)
+        A[:3, :3] = R @ torch.diag(scale_xyz[b].double())
+        Tc, Tn = torch.eye(4, dtype=torch.float64), torch.eye(4, dtype=torch.float64)
+        Tc[:3, 3], Tn[:3, 3] = c, -c
+        M = Tc @ A @ Tn
+        M[:3, 3] += translations_xyz[b].double()
+        sxy, sxz, syx, syz, szx, szy = torch.tan(torch.deg2rad(shears_deg[b].double()))
+        m11 = sxy * syx + 1
+        m21 = sxz * syx + syz
+        S3 = torch.tensor([[1.0, -syx, -(syx * szy + szx)],
+                           [-sxy, m11, -(sxy * szx + szy * m11)],
+                           [-sxz, -m21, sxz * szx + szy * m21 + 1]], dtype=torch.float64)
+        S = torch.eye(4, dtype=torch.float64)
+        S[:3, :3] = S3
+        # translation column that kornia derives from the centre
+        S[0, 3] = syx * c[1] + (syx * szy + szx) * c[2]
+        S[1, 3] = sxy * c[0] + m11 * c[1] + (sxy * szx + szy * m11) * c[2] - c[1]
+        S[2, 3] = sxz * c[0] + m21 * c[1] + (sxz * szx + szy * m21 + 1) * c[2] - c[2]
+        out.append(M @ S)
+    return torch.stack(out)

@@ -367,3 +367,64 @@ def test_rand_weighted_cropd_multi_sample_host_crop(tiny_hcs_zarr):
     assert dm.train_patches_per_stack == 3
     b = next(iter(dm.train_dataloader()))
     assert b["source"].shape == (6, 1, 3, 32, 32) and b["target"].shape == (6, 1, 3, 32, 32)
+
+
+# ------------------------------------------------------------------------------------------------ BatchedRandAffined parameters
+def test_affine_arguments_follow_the_reference_conventions():
+    """host half of BatchedRandAffined — argument parsing and parameter sampling as viscy_transforms/_affine.py:165-357 and
+    its tests (test_affine.py): ZYX -> kornia XYZ order, radians -> degrees, scale ranges, isotropic scale, 3-value shear
+    shorthand, Z-shear scaling, the safe-crop scale floor; matrix composition vs the oracle restatement of kornia"""
+    import math
+
+    from oracle import transforms_ref as R
+    from viscy_amd.transforms import BatchedRandAffined, kornia_affine_matrix3d
+
+    # the published VSCyto3D fine-tuning recipe (finetune_a549_infected.yml)
+    t = BatchedRandAffined(keys=["source", "target"], prob=0.8, rotate_range=[3.14, 0, 0], shear_range=[0.0, 0.05, 0.05],
+                           scale_range=[[0.7, 1.3], [0.5, 1.5], [0.5, 1.5]])
+    t.generator = torch.Generator().manual_seed(0)
+    assert t.degrees[0] == (0.0, 0.0) and t.degrees[1] == (0.0, 0.0) and abs(t.degrees[2][1] - math.degrees(3.14)) < 1e-9
+    assert t.scale == [(0.5, 1.5), (0.5, 1.5), (0.7, 1.3)]                       # (x, y, z)
+    assert t.shears == [(0.0, 0.0)] * 3 + [(-0.05, 0.05), (-0.05, 0.05), (-0.0, 0.0)]
+    prm = t.sample_parameters((64, 1, 20, 600, 600))
+    assert prm["scale"][:, 2].min() >= 0.7 and prm["scale"][:, 2].max() <= 1.3   # test_affine_per_axis_scale
+    assert prm["scale"][:, :2].min() >= 0.5 and prm["scale"][:, :2].max() <= 1.5
+    assert (prm["angles"][:, :2] == 0).all() and prm["angles"][:, 2].abs().max() > 90
+    assert prm["shears"][:, 3:5].abs().max() <= 0.05 * 20 / 600 + 1e-12           # scale_z_shear: Z facets * depth / yx
+    assert 0.6 < prm["apply"].float().mean() < 0.95
+    m = t.randomize((64, 1, 20, 600, 600))
+    assert m.shape == (64, 3, 4) and m.dtype == torch.float32
+    # flat range: independent per axis inside the range (test_affine_scale_range_not_inverted / anisotropic default)
+    t2 = BatchedRandAffined(keys=["img"], prob=1.0, scale_range=[0.5, 1.5])
+    s2 = t2.sample_parameters((8, 1, 8, 32, 32))["scale"]
+    assert s2.min() >= 0.5 and s2.max() <= 1.5 and not all(torch.equal(s2[i, :1].expand(3), s2[i]) for i in range(8))
+    t3 = BatchedRandAffined(keys=["img"], prob=1.0, scale_range=[0.5, 1.5], isotropic_scale=True)
+    s3 = t3.sample_parameters((8, 1, 8, 32, 32))["scale"]
+    assert torch.equal(s3[:, 0], s3[:, 1]) and torch.equal(s3[:, 0], s3[:, 2])
+    with pytest.raises(ValueError, match="isotropic_scale=True cannot be combined"):
+        BatchedRandAffined(keys=["img"], scale_range=[[0.9, 1.1], [0.5, 1.5], [0.5, 1.5]], isotropic_scale=True)
+    with pytest.raises(ValueError, match="scale_range must be"):
+        BatchedRandAffined(keys=["img"], scale_range=[0.5, 1.0, 1.5, 2.0])
+    # test_compute_scale_floor_known_angles
+    ang = torch.tensor([[0, 0, 0.0], [0, 0, 45.0], [0, 0, 90.0], [0, 0, 180.0]])
+    fl = BatchedRandAffined._compute_scale_floor(ang, torch.Size([4, 1, 13, 624, 624]), (8, 512, 512))
+    Rr = 624 / 512
+    assert math.isclose(fl[0, 0].item(), 1 / Rr, rel_tol=1e-5) and math.isclose(fl[1, 0].item(), math.sqrt(2) / Rr, rel_tol=1e-5)
+    assert math.isclose(fl[2, 0].item(), 1 / Rr, rel_tol=1e-5) and all(math.isclose(fl[i, 2].item(), 8 / 13, rel_tol=1e-5) for i in range(4))
+    t4 = BatchedRandAffined(keys=["a"], prob=1.0, rotate_range=[3.14, 0, 0], scale_range=[[0.7, 1.3], [0.5, 1.5], [0.5, 1.5]],
+                            safe_crop_size=[8, 512, 512])
+    p4 = t4.sample_parameters((16, 1, 13, 624, 624))
+    assert (p4["scale"] >= BatchedRandAffined._compute_scale_floor(p4["angles"], (16, 1, 13, 624, 624), (8, 512, 512)) - 1e-9).all()
+    # matrix composition == the oracle's restatement of kornia's get_affine_matrix3d
+    g = torch.Generator().manual_seed(1)
+    ang = (torch.rand(6, 3, generator=g) - 0.5) * 120
+    sc = 0.5 + torch.rand(6, 3, generator=g)
+    sh = (torch.rand(6, 6, generator=g) - 0.5) * 20
+    tr = (torch.rand(6, 3, generator=g) - 0.5) * 8
+    torch.testing.assert_close(kornia_affine_matrix3d(ang, sc, sh, tr, (9, 40, 56)), R.kornia_affine_matrix3d(ang, sc, sh, tr, (9, 40, 56)),
+                               rtol=1e-10, atol=1e-9)
+    # a pure rotation about Z keeps the centre and rotates the YX plane
+    M = kornia_affine_matrix3d(torch.tensor([[0.0, 0.0, 90.0]]), torch.ones(1, 3), torch.zeros(1, 6), torch.zeros(1, 3), (5, 11, 11))[0]
+    c = torch.tensor([5.0, 5.0, 2.0, 1.0], dtype=torch.float64)
+    torch.testing.assert_close(M @ c, c)
+    assert abs(M[2, 2] - 1) < 1e-12 and abs(M[0, 0]) < 1e-12 and abs(abs(M[0, 1]) - 1) < 1e-12

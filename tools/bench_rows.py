@@ -144,7 +144,8 @@ def row_augment():
     tgt = torch.rand(B, 2, 20, 600, 600, device="cuda") * 100
     keys = ["source", "target"]
     chain = [
-        T.BatchedRandAffined(keys=keys, prob=0.8, rotate_range=[3.14, 0.0, 0.0], scale_range=[0.0, 0.2, 0.2], shear_range=0.05),
+        T.BatchedRandAffined(keys=keys, prob=0.8, rotate_range=[3.14, 0.0, 0.0], scale_range=[[0.7, 1.3], [0.5, 1.5], [0.5, 1.5]],
+                             shear_range=[0.0, 0.05, 0.05]),  # the published VSCyto3D fine-tuning recipe
         T.BatchedCenterSpatialCropd(keys=keys, roi_size=(15, 384, 384)),
         T.BatchedRandAdjustContrastd(keys=["source"], prob=0.5, gamma=(0.8, 1.2)),
         T.BatchedRandScaleIntensityd(keys=["source"], prob=0.5, factors=0.5),

@@ -18,6 +18,8 @@ torch's generator (RNG streams of kornia / MONAI cannot be reproduced); every tr
 
 from __future__ import annotations
 
+import math
+
 from typing import Iterable, Sequence
 
 import torch
@@ -342,54 +344,160 @@ def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear", window=None) 
     return y
 
 
+def _axis_angle_matrix(rot_rad: Tensor) -> Tensor:
+    """rotation vector (B, 3) [radians, axis * angle] -> (B, 3, 3), Rodrigues (kornia ``axis_angle_to_rotation_matrix``)"""
+    th = rot_rad.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    k = rot_rad / th
+    K = torch.zeros(rot_rad.shape[0], 3, 3, dtype=rot_rad.dtype)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -k[:, 2], k[:, 1], k[:, 2], -k[:, 0], -k[:, 1], k[:, 0]
+    th = th.view(-1, 1, 1)
+    return torch.eye(3, dtype=rot_rad.dtype) + th.sin() * K + (1 - th.cos()) * (K @ K)
+
+
+def kornia_affine_matrix3d(angles_xyz_deg: Tensor, scale_xyz: Tensor, shears_deg: Tensor, translations_xyz: Tensor,
+                           shape_dhw) -> Tensor:
+    """Forward (input -> output) voxel matrix (B, 4, 4) of kornia 0.8.3 ``get_affine_matrix3d`` as ``RandomAffine3D`` calls it
+    (restated from the published source — kornia is not under /root/reference: parity unpinned): rotation vector
+    ``-angles`` about the volume centre ((W-1)/2, (H-1)/2, (D-1)/2), per-axis scale, translation, then the six shear facets
+    (sxy, sxz, syx, syz, szx, szy; tangent of degrees) about the same centre.  All in kornia's (x, y, z) order, float64."""
+    D, H, W = shape_dhw
+    B = angles_xyz_deg.shape[0]
+    f = torch.float64
+    ctr = torch.tensor([(W - 1) / 2.0, (H - 1) / 2.0, (D - 1) / 2.0], dtype=f)
+    R = _axis_angle_matrix(torch.deg2rad(-angles_xyz_deg.to(f))) @ torch.diag_embed(scale_xyz.to(f))
+    P = torch.eye(4, dtype=f).repeat(B, 1, 1)
+    P[:, :3, :3] = R
+    frm, to = torch.eye(4, dtype=f).repeat(B, 1, 1), torch.eye(4, dtype=f).repeat(B, 1, 1)
+    frm[:, :3, 3], to[:, :3, 3] = ctr, -ctr
+    M = frm @ P @ to
+    M[:, :3, 3] += translations_xyz.to(f)
+    t = torch.tan(torch.deg2rad(shears_deg.to(f)))
+    sxy, sxz, syx, syz, szx, szy = t.unbind(1)
+    one = torch.ones_like(sxy)
+    m00, m10, m20 = one, sxy, sxz
+    m01, m11, m21 = syx, sxy * syx + one, sxz * syx + syz
+    m02 = syx * szy + szx
+    m12 = sxy * szx + szy * m11
+    m22 = sxz * szx + szy * m21 + one
+    x, y, z = ctr
+    m03 = m01 * y + m02 * z
+    m13 = m10 * x + m11 * y + m12 * z - y
+    m23 = m20 * x + m21 * y + m22 * z - z
+    S = torch.eye(4, dtype=f).repeat(B, 1, 1)
+    S[:, 0, :] = torch.stack([m00, -m01, -m02, m03], 1)
+    S[:, 1, :] = torch.stack([-m10, m11, -m12, m13], 1)
+    S[:, 2, :] = torch.stack([-m20, -m21, m22, m23], 1)
+    return M @ S
+
+
 class BatchedRandAffined(_BatchedRand):
-    """One random 3-D affine per sample (rotation about Z in degrees-space of the recipes: ``rotate_range`` in radians
-    as in the reference signature, per-axis / isotropic scale, XY shear), same matrix for every key, trilinear
-    resampling with zero padding.  The matrix composition is this package's own (kornia's parameter sampling cannot
-    be reproduced bit-for-bit — SURVEY §7); inject ``params=Minv`` (B,3,4) for exact control."""
+    """``viscy_transforms.BatchedRandAffined`` (_affine.py:107-393): one random 3-D affine per sample, the same matrix for
+    every key, trilinear resampling with zero padding (``vsx_warp_affine3d``).  Arguments as in the reference:
+
+    * ``rotate_range`` — radians per axis in (Z, Y, X) order, a value ``v`` meaning ``(-v, v)`` (or explicit ``(lo, hi)``);
+    * ``shear_range`` — degrees: ``(min, max)`` for all six facets, six ``(min, max)`` pairs, or MONAI's three-value
+      shorthand ``[s_zy, s_zx, s_yz]`` (-> facets szy, szx, syz = ±value); ``scale_z_shear`` multiplies the Z-related facets
+      by ``depth / max(Y, X)`` (_affine.py:281-300);
+    * ``scale_range`` — ``(min, max)`` sampled independently per axis, or three ``(min, max)`` pairs in (Z, Y, X) order;
+      ``isotropic_scale`` reuses the first axis' draw; ``safe_crop_size`` / ``safe_crop_coverage`` raise the scale to the floor
+      that keeps a following centre crop inside the source (_affine.py:310-357);
+    * ``translate_range`` — voxels per axis (Z, Y, X), a value ``v`` meaning ``(-v, v)``.
+
+    The random stream is this class' own (``generator``); the matrix composition restates kornia's
+    (``kornia_affine_matrix3d``).  ``params=Minv`` (B, 3, 4: output -> input voxel) injects the matrices."""
+
+    is_spatial = True
 
     def __init__(self, keys, prob: float = 0.1, rotate_range=None, shear_range=None, translate_range=None, scale_range=None,
-                 mode: str = "bilinear", padding_mode: str = "zeros", isotropic_scale: bool = False,
-                 safe_crop_size=None, safe_crop_coverage: float = 1.0, scale_z_shear: bool = False,
-                 allow_missing_keys: bool = False):
+                 isotropic_scale: bool = False, scale_z_shear: bool = True, mode: str = "bilinear", padding_mode: str = "zeros",
+                 safe_crop_size=None, safe_crop_coverage: float = 1.0, allow_missing_keys: bool = False):
         super().__init__(keys, prob)
         if padding_mode != "zeros":
             raise NotImplementedError("only zero padding is built")
-        if translate_range is not None:
-            raise NotImplementedError("translate_range is not built")
-        rr = rotate_range if rotate_range is not None else (0.0, 0.0, 0.0)
-        if isinstance(rr, (int, float)):
-            rr = (rr, 0.0, 0.0)
-        self.rot_z = float(rr[0])  # reference recipes: rotate_range: [3.14, 0.0, 0.0] → about Z (first entry)
-        if any(float(v) != 0.0 for v in list(rr)[1:]):
-            raise NotImplementedError("rotation about Y / X is not built (the UNeXt2 recipes rotate about Z only)")
-        sr = scale_range if scale_range is not None else 0.0
-        self.scale_rng = [float(sr)] * 3 if isinstance(sr, (int, float)) else [float(v) for v in sr]  # (Z, Y, X) deltas
-        sh = shear_range if shear_range is not None else 0.0
-        self.shear = float(sh if isinstance(sh, (int, float)) else sh[0])
-        self.mode, self.isotropic = mode, isotropic_scale
+        self.mode = mode
+
+        def pairs(v, n):  # per-axis (Z, Y, X) values -> kornia (X, Y, Z) list of (lo, hi)
+            if v is None:
+                return [(0.0, 0.0)] * n
+            if isinstance(v, (int, float)):
+                v = [v] * n
+            out = [(float(a[0]), float(a[1])) if isinstance(a, (tuple, list)) else (-float(a), float(a)) for a in v]
+            return list(reversed(out))
+
+        rr = pairs(rotate_range, 3)
+        self.degrees = [(math.degrees(lo), math.degrees(hi)) for lo, hi in rr]
+        self.translate = pairs(translate_range, 3)
+        # shears: kornia facet order (sxy, sxz, syx, syz, szx, szy), degrees
+        if shear_range is None:
+            self.shears = [(0.0, 0.0)] * 6
+        elif isinstance(shear_range, (int, float)):
+            self.shears = [(-float(shear_range), float(shear_range))] * 6
+        elif len(shear_range) == 2 and not isinstance(shear_range[0], (list, tuple)):
+            self.shears = [(float(shear_range[0]), float(shear_range[1]))] * 6
+        elif len(shear_range) == 6:
+            self.shears = [(float(p_[0]), float(p_[1])) if isinstance(p_, (list, tuple)) else (-float(p_), float(p_)) for p_ in shear_range]
+        elif len(shear_range) == 3 and not isinstance(shear_range[0], (list, tuple)):
+            s_zy, s_zx, s_yz = (float(v) for v in shear_range)
+            self.shears = [(0.0, 0.0)] * 3 + [(-s_yz, s_yz), (-s_zx, s_zx), (-s_zy, s_zy)]
+        else:
+            raise ValueError(f"shear_range must be (min, max), [s_zy, s_zx, s_yz] (3-value), or 6 (min, max) pairs. Got {shear_range!r}.")
+        per_axis = False
+        if scale_range is None:
+            self.scale = None
+        elif len(scale_range) == 3 and isinstance(scale_range[0], (list, tuple)):
+            z, y, x = scale_range
+            self.scale, per_axis = [tuple(map(float, x)), tuple(map(float, y)), tuple(map(float, z))], True
+        elif len(scale_range) == 2:
+            self.scale = [(float(scale_range[0]), float(scale_range[1]))] * 3
+        else:
+            raise ValueError(f"scale_range must be (min, max) or [(z_min, z_max), (y_min, y_max), (x_min, x_max)]. "
+                             f"Got {scale_range!r} with length {len(scale_range)}.")
+        if isotropic_scale and per_axis:
+            raise ValueError("isotropic_scale=True cannot be combined with per-axis scale_range. Use a flat (min, max) range instead.")
+        self.isotropic = bool(isotropic_scale and self.scale is not None)
+        self.scale_z_shear = scale_z_shear
+        self.safe_crop_size = tuple(safe_crop_size) if safe_crop_size is not None else None
+        self.safe_crop_coverage = safe_crop_coverage
+
+    def _uniform(self, B: int, ranges) -> Tensor:
+        lo = torch.tensor([r[0] for r in ranges], dtype=torch.float64)
+        hi = torch.tensor([r[1] for r in ranges], dtype=torch.float64)
+        return lo + (hi - lo) * torch.rand(B, len(ranges), generator=self.generator, dtype=torch.float64)
+
+    def sample_parameters(self, shape) -> dict:
+        """kornia-style parameter block: angles / scale / shears / translations in (x, y, z) order + the apply mask"""
+        B, _, D, H, W = shape
+        prm = {"apply": self._rand(B) < self.prob, "angles": self._uniform(B, self.degrees),
+               "translations": self._uniform(B, self.translate), "shears": self._uniform(B, self.shears),
+               "scale": self._uniform(B, self.scale) if self.scale is not None else torch.ones(B, 3, dtype=torch.float64)}
+        if self.isotropic:
+            prm["scale"] = prm["scale"][:, :1].expand(-1, 3).clone()
+        if self.safe_crop_size is not None:
+            floor = self._compute_scale_floor(prm["angles"], shape, self.safe_crop_size) * self.safe_crop_coverage
+            if self.isotropic:
+                floor = floor.max(dim=-1, keepdim=True).values.expand_as(floor)
+            prm["scale"] = torch.max(prm["scale"], floor)
+        if self.scale_z_shear and max(H, W) > 1 and D < max(H, W):  # _scale_z_shear_facets: sxz, syz, szx, szy
+            prm["shears"][:, [1, 3, 4, 5]] *= D / max(H, W)
+        return prm
+
+    @staticmethod
+    def _compute_scale_floor(angles: Tensor, input_shape, safe_crop_size) -> Tensor:
+        """_affine.py:310-357: per-axis minimum scale (kornia X, Y, Z order) such that a centre crop of ``safe_crop_size``
+        (Z, Y, X) behind a Z rotation by ``angles[:, 2]`` degrees samples inside the source"""
+        th = torch.deg2rad(angles[:, 2])
+        c, s_ = th.cos().abs(), th.sin().abs()
+        dz, dy, dx = (v / 2.0 for v in safe_crop_size)
+        hz, hy, hx = input_shape[2] / 2.0, input_shape[3] / 2.0, input_shape[4] / 2.0
+        return torch.stack([(c * dx + s_ * dy) / hx, (s_ * dx + c * dy) / hy, torch.full_like(c, dz / hz)], dim=-1)
 
     def randomize(self, shape) -> Tensor:
+        """output -> input voxel matrices (B, 3, 4); identity where the transform is not applied"""
         B, _, D, H, W = shape
-        do = self._rand(B) < self.prob
-        u = lambda: self._rand(B) * 2 - 1  # noqa: E731
-        ang = u() * self.rot_z
-        sc = torch.stack([1 + u() * self.scale_rng[2], 1 + u() * self.scale_rng[1], 1 + u() * self.scale_rng[0]], dim=1)  # x,y,z
-        if self.isotropic:
-            sc = sc[:, :1].expand(-1, 3).clone()
-        shr = u() * self.shear
-        ang, shr = torch.where(do, ang, torch.zeros(B)), torch.where(do, shr, torch.zeros(B))
-        sc = torch.where(do.view(-1, 1), sc, torch.ones(B, 3))
-        c, s = ang.cos(), ang.sin()
-        A = torch.zeros(B, 4, 4)
-        A[:, 0, 0], A[:, 0, 1], A[:, 1, 0], A[:, 1, 1], A[:, 2, 2], A[:, 3, 3] = c, -s, s, c, 1.0, 1.0
-        S = torch.diag_embed(torch.cat([sc, torch.ones(B, 1)], dim=1))
-        Sh = torch.eye(4).repeat(B, 1, 1)
-        Sh[:, 0, 1] = shr
-        ctr = torch.eye(4).repeat(B, 1, 1)
-        ctr[:, 0, 3], ctr[:, 1, 3], ctr[:, 2, 3] = (W - 1) / 2.0, (H - 1) / 2.0, (D - 1) / 2.0
-        fwd = ctr @ A @ Sh @ S @ torch.linalg.inv(ctr)
-        return torch.linalg.inv(fwd)[:, :3].contiguous()
+        prm = self.sample_parameters(shape)
+        M = kornia_affine_matrix3d(prm["angles"], prm["scale"], prm["shears"], prm["translations"], (D, H, W))
+        M = torch.where(prm["apply"].view(-1, 1, 1), M, torch.eye(4, dtype=torch.float64).expand(B, 4, 4))
+        return torch.linalg.inv(M)[:, :3].float().contiguous()
 
     def __call__(self, sample: dict, params: Tensor | None = None, crop_roi_size=None) -> dict:
         """``crop_roi_size``: produce only the centre window a following ``BatchedCenterSpatialCropd(roi_size)`` would
