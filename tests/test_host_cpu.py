@@ -428,3 +428,34 @@ def test_affine_arguments_follow_the_reference_conventions():
     c = torch.tensor([5.0, 5.0, 2.0, 1.0], dtype=torch.float64)
     torch.testing.assert_close(M @ c, c)
     assert abs(M[2, 2] - 1) < 1e-12 and abs(M[0, 0]) < 1e-12 and abs(abs(M[0, 1]) - 1) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ CombinedDataModule
+def test_combined_loader_modes_and_datamodule(tiny_hcs_zarr):
+    """viscy_data/combined.py:22-120 + the CombinedLoader semantics it relies on"""
+    from viscy_amd.data import CombinedDataModule, CombinedLoader, CombineMode
+
+    a, b = [1, 2, 3, 4, 5], ["x", "y"]
+    assert [o for o, _, _ in CombinedLoader([a, b], "min_size")] == [[1, "x"], [2, "y"]]
+    assert [o for o, _, _ in CombinedLoader([a, b], "max_size_cycle")] == [[1, "x"], [2, "y"], [3, "x"], [4, "y"], [5, "x"]]
+    assert [o for o, _, _ in CombinedLoader([a, b], "max_size")] == [[1, "x"], [2, "y"], [3, None], [4, None], [5, None]]
+    assert list(CombinedLoader([a, b], "sequential")) == [(1, 0, 0), (2, 1, 0), (3, 2, 0), (4, 3, 0), (5, 4, 0), ("x", 0, 1), ("y", 1, 1)]
+    assert [len(CombinedLoader([a, b], m)) for m in ("min_size", "max_size_cycle", "max_size", "sequential")] == [2, 5, 5, 7]
+    path, _ = tiny_hcs_zarr
+    kw = dict(z_window_size=3, num_workers=0, normalizations=[NormalizeSampled(["Phase3D"], "fov_statistics")], normalize_on_device=False,
+              yx_patch_size=(128, 128))
+    dm = CombinedDataModule([HCSDataModule(path, "Phase3D", "Nuclei", batch_size=2, **kw), HCSDataModule(path, "Phase3D", "Nuclei", batch_size=3, **kw)],
+                            train_mode="MAX_SIZE_CYCLE", val_mode=CombineMode.SEQUENTIAL)
+    assert dm.train_mode == "max_size_cycle" and dm.val_mode == "sequential"
+    dm.prepare_data()
+    dm.setup("fit")
+    tl = dm.train_dataloader()
+    batch, bi, di = next(iter(tl))
+    assert isinstance(batch, list) and len(batch) == 2 and batch[0]["source"].shape[0] == 2 and batch[1]["source"].shape[0] == 3
+    assert len(tl) == max(len(d.train_dataloader()) for d in dm.data_modules)
+    out = dm.on_after_batch_transfer(batch, 0)          # dispatched to the children, one sub-batch each
+    assert isinstance(out, list) and out[1]["source"].shape[0] == 3
+    idxs = [di for _, _, di in dm.val_dataloader()]
+    assert idxs == sorted(idxs) and set(idxs) == {0, 1}
+    dm.training = False
+    assert all(d.training is False for d in dm.data_modules)

@@ -41,6 +41,11 @@ class Trainer:
         module.to(self.device)
         module.trainer = self
         self.datamodule = datamodule
+        datamodule.trainer = self
+        if not dist.is_initialized() or dist.get_rank() == 0:
+            datamodule.prepare_data()  # e.g. mmap staging (prepare_data_per_node: once per node)
+        if dist.is_initialized():
+            dist.barrier()
         datamodule.setup("fit")
         if hasattr(module, "on_fit_start"):
             module.on_fit_start()
@@ -49,14 +54,25 @@ class Trainer:
         opt = module.configure_optimizers(t_total=steps_per_epoch * (1 if self.fast_dev_run else self.max_epochs))
         ddp = FlatDataParallel(module.model.engine(), opt) if dist.is_initialized() else None
         use_bf16 = self.precision.startswith("bf16")
+        from .data.combined import CombinedLoader
+
         for epoch in range(1 if self.fast_dev_run else self.max_epochs):
             module.train()
-            if hasattr(train_dl, "sampler") and hasattr(train_dl.sampler, "set_epoch"):
+            datamodule.training = True
+            if hasattr(module, "on_train_epoch_start"):
+                module.current_epoch = epoch
+                module.on_train_epoch_start()
+            if isinstance(train_dl, CombinedLoader):
+                train_dl.set_epoch(epoch)
+            elif hasattr(train_dl, "sampler") and hasattr(train_dl.sampler, "set_epoch"):
                 train_dl.sampler.set_epoch(epoch)
             for i, batch in enumerate(train_dl):
                 if i >= steps_per_epoch:
                     break
-                batch = datamodule.on_after_batch_transfer(self._to_device(batch), 0)
+                di = 0
+                if isinstance(train_dl, CombinedLoader):  # yields (batch, batch_idx, dataloader_idx) like Lightning's
+                    batch, _, di = batch
+                batch = datamodule.on_after_batch_transfer(self._to_device(batch), di)
                 opt.zero_grad()
                 with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
                     loss = module.training_step(batch, i)
@@ -67,13 +83,19 @@ class Trainer:
                 self.global_step += 1
             module.on_train_epoch_end()
             module.eval()
+            datamodule.training = False
             with torch.no_grad():
-                for j, batch in enumerate(datamodule.val_dataloader()):
-                    batch = datamodule.on_after_batch_transfer(self._to_device(batch), 0)
+                val_dl = datamodule.val_dataloader()
+                for j, batch in enumerate(val_dl):
+                    di = 0
+                    if isinstance(val_dl, CombinedLoader):
+                        batch, j, di = batch
+                    batch = datamodule.on_after_batch_transfer(self._to_device(batch), di)
                     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
-                        module.validation_step(batch, j, 0)
+                        module.validation_step(batch, j, di)
                     if self.fast_dev_run:
                         break
+            datamodule.training = True
             module.on_validation_epoch_end()
         torch.cuda.synchronize()
         self.finished = True
