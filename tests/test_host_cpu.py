@@ -459,3 +459,46 @@ def test_combined_loader_modes_and_datamodule(tiny_hcs_zarr):
     assert idxs == sorted(idxs) and set(idxs) == {0, 1}
     dm.training = False
     assert all(d.training is False for d in dm.data_modules)
+
+
+def _sharded_worker(rank, world, init_file, out):
+    from viscy_amd.data import ShardedDistributedSampler
+
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    s = ShardedDistributedSampler(list(range(11)), shuffle=True, seed=3, drop_last=True)
+    s.set_epoch(2)
+    out[rank] = list(s)
+    dist.destroy_process_group()
+
+
+def test_sharded_sampler_and_batched_concat_datamodule(tiny_hcs_zarr):
+    """viscy_data/distributed.py:16-58 (world-2 gloo): rank r permutes ITS contiguous shard; combined.py:186-378: the joint
+    loader hands over per-dataset micro-batches that on_after_batch_transfer merges into one batch; CPU CenterSpatialCropd"""
+    from viscy_amd.data import BatchedConcatDataModule, ConcatDataModule
+    from viscy_amd.transforms import CenterSpatialCropd, RandWeightedCropd
+
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sharded_worker, args=(2, tempfile.mktemp(), out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert sorted(r0) == [0, 1, 2, 3, 4] and sorted(r1) == [5, 6, 7, 8, 9]       # num_samples = 5: shards [0,5) and [5,10)
+    g = torch.Generator().manual_seed(3 + 2)                                        # seed + epoch, one permutation per shard
+    assert r0 == torch.randperm(5, generator=g).tolist() and r1 == (torch.randperm(5, generator=g) + 5).tolist()
+    path, _ = tiny_hcs_zarr
+    kw = dict(z_window_size=3, batch_size=3, num_workers=0, yx_patch_size=(32, 32), normalize_on_device=False,
+              normalizations=[NormalizeSampled(["Phase3D"], "fov_statistics")])
+    mk = lambda: HCSDataModule(path, "Phase3D", "Nuclei", augmentations=[  # noqa: E731
+        RandWeightedCropd(["Phase3D", "Nuclei"], w_key="Nuclei", spatial_size=(-1, 48, 48), num_samples=2),
+        CenterSpatialCropd(["Phase3D", "Nuclei"], roi_size=(-1, 32, 32))], **kw)
+    with pytest.raises(ValueError, match="divisible by `num_samples`"):
+        mk().setup("fit")                        # 3 % 2: standalone modules insist on the divisibility (hcs.py:787-800) ...
+    dm = BatchedConcatDataModule([mk(), mk()])  # ... children of the batched container do not
+    dm.setup("fit")
+    assert dm.train_patches_per_stack == 2 and len(dm.train_dataset) == 2 * len(dm.data_modules[0].train_dataset)
+    batch = next(iter(dm.train_dataloader()))
+    assert isinstance(batch, list) and all("_dataset_idx" in mb for mb in batch)
+    merged = dm.on_after_batch_transfer(batch, 0)
+    assert merged["source"].shape == (6, 1, 3, 32, 32) and merged["target"].shape == (6, 1, 3, 32, 32)   # 3 stacks x 2 crops
+    assert "norm_meta" not in merged and "_dataset_idx" not in merged
+    with pytest.raises(ValueError, match="Inconsistent batch size"):
+        ConcatDataModule([mk(), HCSDataModule(path, "Phase3D", "Nuclei", z_window_size=3, batch_size=4, num_workers=0)])

@@ -213,6 +213,7 @@ class HCSDataModule(_DMBase):
         self.seed = seed
         self.training = True  # set by the trainer loop (Lightning: trainer.training / trainer.validating)
         self.train_patches_per_stack = 1
+        self._patch_error, self._is_batched_concat_child = None, False
         # MI355X-first: when nothing intensity-dependent runs in the workers, ship raw patches + statistics and normalise
         # in HBM right after the transfer (one vsx_normalize launch per stacked key) instead of per sample on host cores.
         from ..transforms import NormalizeSampled
@@ -222,9 +223,9 @@ class HCSDataModule(_DMBase):
         for aug in self.augmentations:
             n = getattr(getattr(aug, "cropper", None), "num_samples", None) or getattr(aug, "num_samples", None)
             if n:
-                if batch_size % n:
-                    raise ValueError(f"Batch size must be divisible by `num_samples` per stack. Got batch size {batch_size} "
-                                     f"and number of samples {n} for transform type {type(aug)}.")
+                if batch_size % n:  # raised in setup("fit") (hcs.py:787-800), not for children of a BatchedConcatDataModule
+                    self._patch_error = (f"Batch size must be divisible by `num_samples` per stack. Got batch size {batch_size} "
+                                         f"and number of samples {n} for transform type {type(aug)}.")
                 self.train_patches_per_stack = n
 
     # ---- mmap preload (viscy_data/hcs.py:218-349): stage the fit FOVs once, uncompressed, into one memory-mapped buffer
@@ -321,6 +322,8 @@ class HCSDataModule(_DMBase):
         plate = open_ome_zarr(self.data_path, mode="r")
         positions = self._filtered_positions(plate)
         if stage in ("fit", "validate"):
+            if self._patch_error and not self._is_batched_concat_child:
+                raise ValueError(self._patch_error)
             if self.mmap_preload:  # predict / test read the zarr store directly (hcs.py:243-247)
                 positions = self._mmap_positions(positions)
             settings["channels"]["target"] = self.target_channel

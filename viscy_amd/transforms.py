@@ -680,3 +680,33 @@ class BatchedRandWeightedCropd(_BatchedRand):
                 raise KeyError(k)
             d[k] = crop3d(d[k], starts, self._spatial_size)
         return d
+
+
+class CenterSpatialCropd:
+    """``viscy_transforms.CenterSpatialCropd`` (_monai_wrappers.py:510-540, MONAI's transform): host-side centre crop of the
+    trailing spatial dims of (C, Z, Y, X) samples in the DataLoader workers; ``roi_size`` entries <= 0 keep the axis."""
+
+    is_spatial = True
+
+    def __init__(self, keys, roi_size, allow_missing_keys: bool = False, lazy: bool = False):
+        self.keys, self.allow_missing_keys = _keys(keys), allow_missing_keys
+        self.roi_size = roi_size
+
+    def __call__(self, sample: dict) -> dict:
+        d = dict(sample)
+        for k in self.keys:
+            if k not in d:
+                if self.allow_missing_keys:
+                    continue
+                raise KeyError(k)
+            x = d[k]
+            nsp = x.ndim - 1
+            roi = [self.roi_size] * nsp if isinstance(self.roi_size, int) else list(self.roi_size)
+            sl = [slice(None)]
+            for dim, size in zip(x.shape[1:], roi):
+                size = dim if size <= 0 else min(size, dim)
+                c = dim // 2                      # MONAI SpatialCrop(roi_center = dim // 2, roi_size)
+                start = max(c - size // 2, 0)
+                sl.append(slice(start, start + size))
+            d[k] = x[tuple(sl)]
+        return d
