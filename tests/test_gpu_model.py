@@ -789,3 +789,35 @@ def test_contrastive_encoder_stochastic_depth_modes():
         a.train(); b.train()
         e1, e2, eb = a(x)[0], a(x)[0], b(x)[0]
     assert not torch.equal(e1, e2) and not torch.equal(e1, eb)
+
+
+def test_unext2_single_output_channel_bf16_runs_the_head_in_fp32():
+    """1 -> 1 channel virtual staining in bf16: the head's 4-channel planes are not whole bf16 vectors, so the head runs in
+    fp32 behind the bf16 trunk; forward / gradients track the fp32 oracle within the bf16 bars"""
+    kw = dict(in_channels=1, out_channels=1, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True)
+    ref, mine = _pair(kw)
+    with torch.no_grad():
+        ref.head.conv[0].adn.A.weight.fill_(1.0)
+        mine.head.conv[0].adn.A.weight.fill_(1.0)
+    mine = mine.cuda()
+    mine.compute_dtype = torch.bfloat16
+    x = torch.randn(2, 1, 5, 64, 64, generator=torch.Generator().manual_seed(3))
+    y = ref(x)
+    out = mine(x.cuda())
+    assert out.shape == (2, 1, 5, 64, 64)
+    torch.testing.assert_close(out.cpu(), y.detach(), rtol=2e-2, atol=0.03 * y.abs().max().item())
+    dout = torch.randn(y.shape, generator=torch.Generator().manual_seed(4))
+    y.backward(dout)
+    out.backward(dout.cuda())
+    cos = torch.nn.functional.cosine_similarity(
+        torch.cat([p.grad.flatten().cpu() for p in mine.parameters()]), torch.cat([p.grad.flatten() for p in ref.parameters()]), dim=0)
+    assert cos > 0.99, cos
+
+
+def test_atto_backbone_under_bf16_autocast_falls_back_to_fp32_kernels():
+    kw = dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_atto")
+    ref, mine = _pair(kw)
+    x = torch.randn(1, 1, 5, 64, 64, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = mine(x.cuda())
+        assert relerr(out, ref(x)) <= 1e-3   # fp32 accuracy: the 60-channel decoder rows cannot be bf16 vectors

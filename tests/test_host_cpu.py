@@ -502,3 +502,100 @@ def test_sharded_sampler_and_batched_concat_datamodule(tiny_hcs_zarr):
     assert "norm_meta" not in merged and "_dataset_idx" not in merged
     with pytest.raises(ValueError, match="Inconsistent batch size"):
         ConcatDataModule([mk(), HCSDataModule(path, "Phase3D", "Nuclei", z_window_size=3, batch_size=4, num_workers=0)])
+
+
+# ------------------------------------------------------------------------------------------------ YAML seam
+def test_yaml_recipes_compose_and_instantiate(tmp_path, tiny_hcs_zarr):
+    """viscy_utils/compose.py:31-140 semantics (base: lists, deep merge, lists replace, private keys stripped, cycles) and the
+    class_path map: the published VSCyto3D fine-tuning recipe's tree (shrunk) builds the MI355X objects"""
+    from viscy_amd import config as C
+    from viscy_amd.data import CombinedDataModule
+    from viscy_amd.losses import MixedLoss
+    from viscy_amd.transforms import BatchedRandAffined, RandWeightedCropd
+    from viscy_amd.vsunet import VSUNet
+
+    path, _ = tiny_hcs_zarr
+    (tmp_path / "recipes").mkdir()
+    (tmp_path / "recipes" / "fit.yml").write_text(
+        "trainer:\n  max_epochs: 7\n  precision: bf16-mixed\n  callbacks:\n    - class_path: lightning.pytorch.callbacks.LearningRateMonitor\n"
+        "      init_args: {logging_interval: step}\n_anchors: &a {x: 1}\nmodel:\n  init_args:\n    lr: 0.5\n    model_config: {in_channels: 1, dims: [1, 2, 3, 4]}\n")
+    (tmp_path / "leaf.yml").write_text(f"""
+base:
+  - recipes/fit.yml
+model:
+  class_path: cytoland.engine.VSUNet
+  init_args:
+    architecture: fcmae
+    model_config:
+      out_channels: 2
+      encoder_blocks: [1, 1, 1, 1]
+      encoder_drop_path_rate: 0.1
+      dims: [16, 32, 64, 128]
+      decoder_conv_blocks: 1
+      in_stack_depth: 5
+      pretraining: false
+    loss_function:
+      class_path: viscy_utils.losses.MixedLoss
+      init_args: {{l1_alpha: 0.5, l2_alpha: 0.0, ms_dssim_alpha: 0.5}}
+    lr: 0.0002
+    schedule: WarmupCosine
+trainer:
+  strategy: ddp_find_unused_parameters_true
+  logger:
+    class_path: lightning.pytorch.loggers.TensorBoardLogger
+    init_args: {{save_dir: /tmp}}
+data:
+  class_path: viscy_data.combined.CombinedDataModule
+  init_args:
+    train_mode: MAX_SIZE_CYCLE
+    val_mode: SEQUENTIAL
+    data_modules:
+      - class_path: viscy_data.hcs.HCSDataModule
+        init_args:
+          data_path: {path}
+          source_channel: Phase3D
+          target_channel: [Nuclei]
+          z_window_size: 5
+          batch_size: 4
+          num_workers: 0
+          mmap_preload: true
+          scratch_dir: {tmp_path}/scratch
+          yx_patch_size: [64, 64]
+          augmentations:
+            - class_path: viscy_transforms.RandWeightedCropd
+              init_args: {{keys: [Phase3D, Nuclei], w_key: Nuclei, spatial_size: [5, 96, 96], num_samples: 2}}
+          normalizations:
+            - class_path: viscy_transforms.NormalizeSampled
+              init_args: {{keys: [Phase3D], level: fov_statistics, subtrahend: mean, divisor: std}}
+          gpu_augmentations:
+            - class_path: viscy_transforms.BatchedRandAffined
+              init_args:
+                keys: [source, target]
+                prob: 0.8
+                rotate_range: [3.14, 0, 0]
+                shear_range: [0.0, 0.05, 0.05]
+                scale_range: [[0.7, 1.3], [0.5, 1.5], [0.5, 1.5]]
+            - class_path: viscy_transforms.BatchedCenterSpatialCropd
+              init_args: {{keys: [source, target], roi_size: [5, 64, 64]}}
+""")
+    cfg = C.load_composed_config(tmp_path / "leaf.yml")
+    assert "base" not in cfg and "_anchors" not in cfg
+    assert cfg["trainer"]["max_epochs"] == 7 and cfg["trainer"]["strategy"] == "ddp_find_unused_parameters_true"
+    assert cfg["model"]["init_args"]["lr"] == 0.0002                                   # leaf overrides base
+    assert cfg["model"]["init_args"]["model_config"]["dims"] == [16, 32, 64, 128]      # lists replace
+    assert cfg["model"]["init_args"]["model_config"]["in_channels"] == 1               # dicts merge
+    (tmp_path / "a.yml").write_text("base: [b.yml]\n")
+    (tmp_path / "b.yml").write_text("base: a.yml\n")
+    with pytest.raises(ValueError, match="Circular"):
+        C.load_composed_config(tmp_path / "a.yml")
+    module, dm, trainer, skipped = C.build(cfg)
+    assert isinstance(module, VSUNet) and isinstance(module.loss_function, MixedLoss) and module.schedule == "WarmupCosine"
+    assert module.model.cfg["drop_path"] == [0.1] * 4
+    assert isinstance(dm, CombinedDataModule) and dm.train_mode == "max_size_cycle" and dm.data_modules[0].mmap_preload
+    assert isinstance(dm.data_modules[0].augmentations[0], RandWeightedCropd) and dm.data_modules[0].train_patches_per_stack == 2
+    assert isinstance(dm.data_modules[0]._gpu_augmentations.transforms[0].affine, BatchedRandAffined)  # fused with the crop
+    assert trainer.max_epochs == 7 and trainer.callbacks == []
+    assert set(skipped) == {"lightning.pytorch.callbacks.LearningRateMonitor", "lightning.pytorch.loggers.TensorBoardLogger",
+                            "trainer.strategy=ddp_find_unused_parameters_true"}
+    with pytest.raises(KeyError, match="no viscy_amd counterpart"):
+        C.instantiate({"class_path": "viscy_models.unet.Unet2d", "init_args": {}})

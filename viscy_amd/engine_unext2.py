@@ -258,14 +258,22 @@ class Engine:
         if cfg.get("head", "conv") == "conv":
             hc = m.head.conv[0].conv
             cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
-            W["head_Wc"], _ = o.prep_weight(hc.weight, cmid, c3, 27, dt, tapmode=1)
+            hdt = self._head_dtype(dt)
+            W["head_Wc"], _ = o.prep_weight(hc.weight, cmid, c3, 27, hdt, tapmode=1)
             if need_bwd:
-                if dt == torch.bfloat16 and c3 == 8 and cmid == 32 and cfg["out_stack_depth"] == 5:
+                if hdt == torch.bfloat16 and c3 == 8 and cmid == 32 and cfg["out_stack_depth"] == 5:
                     W["head_Wp"] = o.head_conv_dgrad_prep(W["head_Wc"])  # direct LDS-tiled dgrad (csrc/headconv.hip)
-                W["head_Wd"] = o.prep_head_dgrad(hc.weight, cmid, c3, cfg["out_stack_depth"], dt)
+                W["head_Wd"] = o.prep_head_dgrad(hc.weight, cmid, c3, cfg["out_stack_depth"], hdt)
         self.W = W
         self._prepared_for = key
         return W
+
+    def _head_dtype(self, dt: torch.dtype) -> torch.dtype:
+        """PixelToVoxelHead works on 4 * out_channels channels per depth plane: with out_channels odd (1 -> 1 virtual staining)
+        that is not a whole number of 16-byte bf16 vectors, and the (small) head then runs in fp32 behind a bf16 trunk"""
+        if dt == torch.bfloat16 and self.model.head.conv[0].conv.weight.shape[1] % 8:
+            return torch.float32
+        return dt
 
     # ------------------------------------------------------------------ block forward / backward
     def _block_fwd(self, x, w, B, H, Wd, dt, save, rows=None):
@@ -469,16 +477,17 @@ class Engine:
         hc = m.head.conv[0].conv
         cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
         cout = cfg["out_channels"]
-        hin = o.head_shuffle_fwd(feat, B, fh, fw, c3, D7, cfg["head_pool"])
+        hdt = self._head_dtype(dt)
+        hin = o.head_shuffle_fwd(feat if hdt == dt else feat.float(), B, fh, fw, c3, D7, cfg["head_pool"])
         H2, W2 = 2 * fh, 2 * fw
         Mh = B * H2 * W2
         stats = self._za.take(2, B, cmid)
-        direct = o.head_conv_supported(H2, W2, c3, cmid, Zo, dt)
+        direct = o.head_conv_supported(H2, W2, c3, cmid, Zo, hdt)
         if direct:
             U = o.head_conv_fwd(hin, W["head_Wc"], hc.bias, stats[0], stats[1], B, H2, W2, c3, cmid, Zo)
         else:
-            U = torch.empty((Mh, Zo * cmid), dtype=dt, device=x.device)
-            o.gemm_z("nt", hin, W["head_Wc"], U, Mh, cmid, 27 * c3, D7 * c3, 27 * c3, Zo * cmid, dtype=dt,
+            U = torch.empty((Mh, Zo * cmid), dtype=hdt, device=x.device)
+            o.gemm_z("nt", hin, W["head_Wc"], U, Mh, cmid, 27 * c3, D7 * c3, 27 * c3, Zo * cmid, dtype=hdt,
                      a_mode=L.A_CONV3, gh=H2, gw=W2, cs=3 * c3, nz=Zo, a_coff=[z * c3 for z in range(Zo)],
                      b_off=[0] * Zo, c_coff=[z * cmid for z in range(Zo)], epi=L.EPI_BIAS_STATS, bias=hc.bias,
                      red0=stats[0], red1=stats[1], hw=H2 * W2)
@@ -622,7 +631,10 @@ class Engine:
             d = o.voxel_shuffle_bwd(dout.contiguous().float(), B, fh, fw, cfg["out_channels"], cfg["out_stack_depth"],
                                     cfg["stem_kernel"][-1], True, dt)
         else:
-            d = self._head_conv_bwd(sv, dout, dt, B, dev)
+            hdt = self._head_dtype(dt)
+            d = self._head_conv_bwd(sv, dout, hdt, B, dev)
+            if hdt != dt:
+                d = d.to(dt)
         # ---- decoder (reverse)
         dskips = {}
         for k in (2, 1, 0) if cfg.get("head") != "embed" else ():

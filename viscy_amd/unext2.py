@@ -254,12 +254,24 @@ class _Core(nn.Module):
             nn.init.uniform_(self.head.conv[1].bias, -bound, bound)
 
     # ---- engine plumbing
+    def _bf16_ok(self) -> bool:
+        """every channels-last row must be a whole number of 16-byte bf16 vectors (8 channels): true for every published
+        configuration except the `convnextv2_atto` U-Net, whose first decoder concat is 80 / 4 + 40 = 60 channels wide"""
+        dims = list(self.cfg["dims"])
+        widths = list(dims)
+        dec = self.cfg.get("decoder_channels")
+        if dec:
+            skips = list(reversed(dims))[1:]
+            widths += [dec[i] // 4 + skips[i] for i in range(len(skips))] + list(dec)
+        return all(w % 8 == 0 for w in widths)
+
     def _resolve_dtype(self) -> torch.dtype:
-        if self.compute_dtype is not None:
-            return self.compute_dtype
-        if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
-            return torch.bfloat16
-        return torch.float32
+        want = self.compute_dtype
+        if want is None:
+            want = torch.bfloat16 if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 else torch.float32
+        if want == torch.bfloat16 and not self._bf16_ok():
+            return torch.float32  # e.g. convnextv2_atto: exact fp32 kernels instead of failing on a 60-channel row
+        return want
 
     def engine(self, ops=None):
         from .engine_unext2 import Engine
