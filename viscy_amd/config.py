@@ -121,7 +121,7 @@ def instantiate(node, skipped: list | None = None):
 
 
 _SKIP = object()
-_TRAINER_KEYS = ("max_epochs", "precision", "fast_dev_run", "limit_train_batches")
+_TRAINER_KEYS = ("max_epochs", "precision", "fast_dev_run", "limit_train_batches", "default_root_dir")
 
 
 def build(cfg: dict):
@@ -142,7 +142,17 @@ def build(cfg: dict):
     kw = {k: tcfg[k] for k in _TRAINER_KEYS if k in tcfg}
     if isinstance(kw.get("fast_dev_run"), int):
         kw["fast_dev_run"] = bool(kw["fast_dev_run"])
-    return module, datamodule, Trainer(callbacks=callbacks, **kw), skipped
+    if "seed_everything" in cfg and cfg["seed_everything"] is not None:
+        kw["seed"] = int(cfg["seed_everything"])
+    if "return_predictions" in cfg:
+        kw["return_predictions"] = bool(cfg["return_predictions"])
+    trainer = Trainer(callbacks=callbacks, **kw)
+    ckpt = cfg.get("ckpt_path")
+    if ckpt:  # LightningCLI's top-level ckpt_path (predict / resume): Lightning-layout checkpoint, weights only here
+        import torch
+
+        module.load_state_dict(torch.load(ckpt, weights_only=True, map_location="cpu")["state_dict"])
+    return module, datamodule, trainer, skipped
 
 
 def main(argv=None) -> int:

@@ -17,8 +17,10 @@ from .parallel import FlatDataParallel
 
 class Trainer:
     def __init__(self, max_epochs: int = 1, fast_dev_run: bool = False, precision: str = "bf16-mixed",
-                 accelerator: str = "gpu", seed: int | None = 42, limit_train_batches: int | None = None, callbacks=None):
+                 accelerator: str = "gpu", seed: int | None = 42, limit_train_batches: int | None = None, callbacks=None,
+                 default_root_dir=None, return_predictions: bool = True):
         self.max_epochs, self.fast_dev_run, self.precision = max_epochs, fast_dev_run, precision
+        self.default_root_dir, self.return_predictions = default_root_dir, return_predictions
         self.callbacks = list(callbacks or [])
         self.datamodule = None
         self.limit_train_batches = limit_train_batches
@@ -99,6 +101,19 @@ class Trainer:
             module.on_validation_epoch_end()
         torch.cuda.synchronize()
         self.finished = True
+        if self.default_root_dir is not None and (not dist.is_initialized() or dist.get_rank() == 0):
+            self.save_checkpoint(module)
+
+    def save_checkpoint(self, module, path=None):
+        """a Lightning-layout checkpoint (``{"state_dict": ..., "epoch", "global_step"}``) that the reference's
+        ``VSUNet(ckpt_path=...)`` / ``predict --ckpt_path`` — and this build's — load"""
+        from pathlib import Path
+
+        path = Path(path) if path is not None else Path(self.default_root_dir) / "checkpoints" / "last.ckpt"
+        path.parent.mkdir(parents=True, exist_ok=True)
+        sd = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+        torch.save({"state_dict": sd, "epoch": self.max_epochs, "global_step": self.global_step}, path)
+        return path
 
     def predict(self, module, datamodule) -> list[torch.Tensor]:
         """Lightning's predict loop as the reference uses it: ``on_predict_start`` hooks, ``predict_step`` per batch,
@@ -120,7 +135,8 @@ class Trainer:
                     batch = datamodule.on_after_batch_transfer(batch, 0)
                     datamodule.training = was
                 pred = module.predict_step(batch, j)
-                outs.append(pred)
+                if self.return_predictions:
+                    outs.append(pred)
                 for cb in self.callbacks:
                     if hasattr(cb, "write_on_batch_end") and getattr(cb, "interval", "batch") in ("batch", "batch_and_epoch"):
                         cb.write_on_batch_end(self, module, pred, None, batch, j, 0)
