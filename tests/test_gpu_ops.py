@@ -322,7 +322,8 @@ def test_head_conv_direct_bf16(B, gh, gw):
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("tr", [1, 0], ids=["tr_read", "scalar_read"])
 @pytest.mark.parametrize("M,N,K", [(512, 160, 40), (1000, 96, 384), (70, 8, 32), (9000, 384, 96), (4100, 768, 3072),
-                                   (4096, 384, 128), (8192, 224, 896), (2048, 96, 384)])  # lean (M % 64 == 0): 64-row steps
+                                   (4096, 384, 128), (8192, 224, 896), (2048, 96, 384),  # lean (M % 64 == 0): 64-row steps
+                                   (8192, 896, 224), (4096, 256, 520), (4096, 520, 232)])  # rectangular 256x128 / 128x256 tiles
 def test_gemm_tn(dt, tr, M, N, K):
     from viscy_amd import _lib
 
@@ -350,8 +351,8 @@ def test_gemm_tn(dt, tr, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("M,N,K,hw", [(300, 40, 160, 100), (4096, 224, 896, 1024), (1024, 96, 384, 256)],
-                         ids=["generic", "lean_wide", "lean"])
+@pytest.mark.parametrize("M,N,K,hw", [(300, 40, 160, 100), (4096, 224, 896, 1024), (1024, 96, 384, 256), (4096, 896, 224, 1024)],
+                         ids=["generic", "lean_wide_rect_n", "lean", "rect_k"])
 def test_gemm_tn_grn_and_patch2(dt, M, N, K, hw):
     H = _hip()
     X, Hh = rnd(M, N, dt=dt, seed=1), rnd(M, K, dt=dt, seed=2)

@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 extern int g_vsx_tn_tr;
+extern int g_vsx_tn_rect;
 extern int g_vsx_nt_wide;
 extern int g_vsx_nt_fast;
 extern int g_vsx_tn_wide;
@@ -1060,27 +1061,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
 // plus a per-lane offset computed once, column tails are clamped at load time (a clamped column only feeds
 // outputs that are never written), the GRN prologue is a template parameter.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BT, bool TR, bool PRO, int BMS = 32, int NBUF = 2>
-__global__ __launch_bounds__(256, (BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1) void gemm_tn_fast_kernel(const VsxGemm p) {
+// BTK_ != 0: rectangular output tile BT (N) x BTK_ (K).  A 256-wide side that spans the whole C-wide dimension of a weight
+// gradient (dW2: N = C, dW1: K = C, C <= 256) makes the 4C-wide activation operand stream through exactly ONE workgroup per
+// pixel split instead of two (PMC: the square-tile TN launches fetched 1.7x their algorithmic bytes) and halves the fragment
+// reads per MFMA (12 transposing reads per 32 MFMAs instead of 8 per 16).
+template <typename T, int BT, bool TR, bool PRO, int BMS = 32, int NBUF = 2, int BTK_ = 0>
+__global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1)) void gemm_tn_fast_kernel(const VsxGemm p) {
   constexpr int ES = sizeof(T);
   constexpr int VN = VT<T>::N;
-  constexpr int LD = BT + 16;
-  constexpr int LDB = LD * ES;
-  constexpr int CPR = BT / VN;
-  constexpr int NCH = (BMS * CPR + 255) / 256;
-  constexpr int TILE_BYTES = BMS * LDB;
-  constexpr int F = BT / 2 / 16;
+  constexpr int BTN = BT, BTK = BTK_ != 0 ? BTK_ : BT;
+  constexpr int LDBX = (BTN + 16) * ES, LDBY = (BTK + 16) * ES;
+  constexpr int CPRX = BTN / VN, CPRY = BTK / VN;
+  constexpr int NCHX = (BMS * CPRX + 255) / 256, NCHY = (BMS * CPRY + 255) / 256;
+  constexpr int TILE_X = BMS * LDBX, TILE_Y = BMS * LDBY;
+  constexpr int FN_ = BTN / 2 / 16, FK_ = BTK / 2 / 16;
   constexpr int MK = Frag<T>::MK;
   typedef typename VT<T>::vec vec;
   typedef typename Frag<T>::type frag_t;
-  __shared__ __attribute__((aligned(16))) char smem[2 * NBUF * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * (TILE_X + TILE_Y)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int p16 = lane & 15, kq = lane >> 4;
   const int z = blockIdx.z;
-  const int tiles_k = (p.K + BT - 1) / BT;
+  const int tiles_k = (p.K + BTK - 1) / BTK;
   int bx = blockIdx.x, by = blockIdx.y;
   if ((gridDim.y & 7) == 0) {  // XCD-aware (see gemm_tn_kernel)
     const int L = bx + gridDim.x * by;
@@ -1089,7 +1094,7 @@ __global__ __launch_bounds__(256, (BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1) v
     by = (j / gridDim.x) * 8 + (L & 7);
   }
   const int tile_k = bx % tiles_k, tile_n = bx / tiles_k;
-  const int n0 = tile_n * BT, k0 = tile_k * BT;
+  const int n0 = tile_n * BTN, k0 = tile_k * BTK;
   const int total_steps = p.M / BMS;
   const int nsplit = gridDim.y;
   if (by >= total_steps) return;
@@ -1097,35 +1102,41 @@ __global__ __launch_bounds__(256, (BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1) v
   const char* Xb = reinterpret_cast<const char*>(p.B) + (size_t)p.b_off[z] * ES;
   const char* Yb = reinterpret_cast<const char*>(p.A) + (size_t)p.a_coff[z] * ES;
   const size_t xstep = (size_t)BMS * p.ldb * ES, ystep = (size_t)BMS * p.lda * ES;
-  uint32_t xoff[NCH], yoff[NCH];
-  int lds_o[NCH], kcol[NCH];
-  bool live[NCH];
+  uint32_t xoff[NCHX], yoff[NCHY];
+  int ldsx[NCHX], ldsy[NCHY], kcol[NCHY];
+  bool livex[NCHX], livey[NCHY];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int cid = tid + i * 256, crow = cid / CPR, cch = cid % CPR;
-    live[i] = cid < BMS * CPR;
-    int nn = n0 + cch * VN, kk = k0 + cch * VN;
+  for (int i = 0; i < NCHX; ++i) {
+    const int cid = tid + i * 256, crow = cid / CPRX, cch = cid % CPRX;
+    livex[i] = cid < BMS * CPRX;
+    int nn = n0 + cch * VN;
     nn = nn < p.N ? nn : p.N - VN;
+    xoff[i] = (uint32_t)(crow * p.ldb + nn) * ES;
+    ldsx[i] = crow * LDBX + cch * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < NCHY; ++i) {
+    const int cid = tid + i * 256, crow = cid / CPRY, cch = cid % CPRY;
+    livey[i] = cid < BMS * CPRY;
+    int kk = k0 + cch * VN;
     kk = kk < p.K ? kk : p.K - VN;
     kcol[i] = kk;
-    xoff[i] = (uint32_t)(crow * p.ldb + nn) * ES;
     yoff[i] = (uint32_t)(crow * p.lda + kk) * ES;
-    lds_o[i] = crow * LDB + cch * 16;
+    ldsy[i] = crow * LDBY + cch * 16;
   }
 
-  vec xreg[NCH], yreg[NCH];
+  vec xreg[NCHX], yreg[NCHY];
   auto load_tiles = [&](int step, vec* xr, vec* yr) {
     const char* Xs = Xb + (size_t)step * xstep;
     const char* Ys = Yb + (size_t)step * ystep;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      if (live[i]) {
-        xr[i] = *reinterpret_cast<const vec*>(Xs + xoff[i]);
-        yr[i] = *reinterpret_cast<const vec*>(Ys + yoff[i]);
-      }
-    }
+    for (int i = 0; i < NCHX; ++i)
+      if (livex[i]) xr[i] = *reinterpret_cast<const vec*>(Xs + xoff[i]);
+#pragma unroll
+    for (int i = 0; i < NCHY; ++i)
+      if (livey[i]) yr[i] = *reinterpret_cast<const vec*>(Ys + yoff[i]);
   };
-  // GRN prologue operands: every chunk of this thread covers the SAME 8 (4) columns (256 % CPR == 0), and the sample
+  // GRN prologue operands: every chunk of this thread covers the SAME 8 (4) columns (256 % CPRY == 0), and the sample
   // index changes only every hw / BMS steps -> s[b, k..] and beta[k..] live in registers, reloaded on a sample change
   // (the first version re-read them from global memory for every chunk of every step)
   float gsr[VN], gbr[VN];
@@ -1135,8 +1146,8 @@ __global__ __launch_bounds__(256, (BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1) v
     for (int j = 0; j < VN; ++j) gbr[j] = p.grn_b[kcol[0] + j];
   }
   auto store_tiles = [&](int step, int buf, const vec* xr, const vec* yr) {
-    char* Xs = smem + buf * 2 * TILE_BYTES;
-    char* Ys = Xs + TILE_BYTES;
+    char* Xs = smem + buf * (TILE_X + TILE_Y);
+    char* Ys = Xs + TILE_X;
     if constexpr (PRO) {
       const int bnow = (step * BMS) / p.hw;  // (uniform)
       if (bnow != gcur) {
@@ -1147,9 +1158,15 @@ __global__ __launch_bounds__(256, (BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1) v
       }
     }
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      if (live[i]) {
+    for (int i = 0; i < NCHX; ++i) {
+      if (livex[i]) {
         const vec xv = xr[i];
+        *reinterpret_cast<vec*>(Xs + ldsx[i]) = xv;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCHY; ++i) {
+      if (livey[i]) {
         vec yv = yr[i];
         if constexpr (PRO) {
           float f[VN];
@@ -1158,40 +1175,39 @@ __global__ __launch_bounds__(256, (BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1) v
           for (int j = 0; j < VN; ++j) f[j] = fmaf(f[j], gsr[j], gbr[j]);
           yv = pack<T>(f);
         }
-        *reinterpret_cast<vec*>(Xs + lds_o[i]) = xv;
-        *reinterpret_cast<vec*>(Ys + lds_o[i]) = yv;
+        *reinterpret_cast<vec*>(Ys + ldsy[i]) = yv;
       }
     }
   };
 
-  f32x4 acc[F][F];
+  f32x4 acc[FN_][FK_];
 #pragma unroll
-  for (int i = 0; i < F; ++i)
+  for (int i = 0; i < FN_; ++i)
 #pragma unroll
-    for (int j = 0; j < F; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FK_; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;
-  const bool do_colsum = p.colsum != nullptr && tile_k == 0 && tid < BT;
+  const bool do_colsum = p.colsum != nullptr && tile_k == 0 && tid < BTN;
 
   const int nsteps = (total_steps - by + nsplit - 1) / nsplit;
   auto mma_step = [&](const char* Xs, const char* Ys) {
 #pragma unroll
     for (int kk = 0; kk < BMS / MK; ++kk) {
       // bf16: one MFMA contraction step = 32 tile rows (the transposing read addresses rows r, r + 16 of them)
-      const char* Xk = Xs + (sizeof(T) == 2 ? kk * 32 * LDB : 0);
-      const char* Yk = Ys + (sizeof(T) == 2 ? kk * 32 * LDB : 0);
-      frag_t xf[F], yf[F];
+      const char* Xk = Xs + (sizeof(T) == 2 ? kk * 32 * LDBX : 0);
+      const char* Yk = Ys + (sizeof(T) == 2 ? kk * 32 * LDBY : 0);
+      frag_t xf[FN_], yf[FK_];
 #pragma unroll
-      for (int i = 0; i < F; ++i) xf[i] = lds_frag_mn<T, TR>(Xk, LDB, (wn * F + i) * 16, p16, kq, kk);
+      for (int i = 0; i < FN_; ++i) xf[i] = lds_frag_mn<T, TR>(Xk, LDBX, (wn * FN_ + i) * 16, p16, kq, kk);
 #pragma unroll
-      for (int j = 0; j < F; ++j) yf[j] = lds_frag_mn<T, TR>(Yk, LDB, (wk * F + j) * 16, p16, kq, kk);
+      for (int j = 0; j < FK_; ++j) yf[j] = lds_frag_mn<T, TR>(Yk, LDBY, (wk * FK_ + j) * 16, p16, kq, kk);
 #pragma unroll
-      for (int i = 0; i < F; ++i)
+      for (int i = 0; i < FN_; ++i)
 #pragma unroll
-        for (int j = 0; j < F; ++j) acc[i][j] = mfma16(xf[i], yf[j], acc[i][j]);
+        for (int j = 0; j < FK_; ++j) acc[i][j] = mfma16(xf[i], yf[j], acc[i][j]);
     }
     if (do_colsum) {
 #pragma unroll 8
-      for (int r = 0; r < BMS; ++r) csum += to_f32<T>(*reinterpret_cast<const T*>(Xs + r * LDB + tid * ES));
+      for (int r = 0; r < BMS; ++r) csum += to_f32<T>(*reinterpret_cast<const T*>(Xs + r * LDBX + tid * ES));
     }
   };
   load_tiles(by, xreg, yreg);
@@ -1201,8 +1217,8 @@ __global__ __launch_bounds__(256, (BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1) v
     for (int st = 0; st < nsteps; ++st) {
       const int nxt = (st + 1) * nsplit + by;
       if (st + 1 < nsteps) load_tiles(nxt, xreg, yreg);
-      const char* Xs = smem + (st & 1) * 2 * TILE_BYTES;
-      mma_step(Xs, Xs + TILE_BYTES);
+      const char* Xs = smem + (st & 1) * (TILE_X + TILE_Y);
+      mma_step(Xs, Xs + TILE_X);
       if (st + 1 < nsteps) store_tiles(nxt, (st + 1) & 1, xreg, yreg);
       __syncthreads();
     }
@@ -1211,20 +1227,20 @@ __global__ __launch_bounds__(256, (BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1) v
       store_tiles(st * nsplit + by, 0, xreg, yreg);
       __syncthreads();
       if (st + 1 < nsteps) load_tiles((st + 1) * nsplit + by, xreg, yreg);
-      mma_step(smem, smem + TILE_BYTES);
+      mma_step(smem, smem + TILE_X);
       __syncthreads();
     }
   }
 
   float* W = reinterpret_cast<float*>(p.C) + p.c_coff[z];
 #pragma unroll
-  for (int i = 0; i < F; ++i)
+  for (int i = 0; i < FN_; ++i)
 #pragma unroll
-    for (int j = 0; j < F; ++j)
+    for (int j = 0; j < FK_; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + (wn * F + i) * 16 + kq * 4 + r;
-        const int k = k0 + (wk * F + j) * 16 + p16;
+        const int n = n0 + (wn * FN_ + i) * 16 + kq * 4 + r;
+        const int k = k0 + (wk * FK_ + j) * 16 + p16;
         if (n < p.N && k < p.K) atomicAdd(W + (size_t)n * p.ldc + k, acc[i][j][r]);
       }
   if (do_colsum && n0 + tid < p.N) atomicAdd(p.colsum + n0 + tid, csum);
@@ -1253,6 +1269,34 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
   if (fast) {
     if constexpr (sizeof(T) == 2 && BT == 128) {
       if (g_vsx_tn_wide && p->M % 64 == 0 && (p->pro == VSX_PRO_NONE || p->hw % 64 == 0) && p->M / 64 >= 2 * splits) {
+        if constexpr (TR) {
+          // rectangular tiles when one side of the weight gradient fits a single 256-wide tile (see the kernel's header)
+          // measured (tools/perf_nt.py, B = 512): C = 224 -9 % (dW1) / -14 % (dW2); C = 192 +4..8 % (a quarter of the
+          // 256-wide tile idles) -> only when the tile is >= 7/8 full
+          const bool n_full = g_vsx_tn_rect && p->N >= 224 && p->N <= 256 && p->K >= 256;
+          const bool k_full = g_vsx_tn_rect && !n_full && p->K >= 224 && p->K <= 256 && p->N >= 256;
+          if (n_full || k_full) {
+            const int t2 = n_full ? vsx_cdiv(p->K, 128) : vsx_cdiv(p->N, 128);
+            int want2 = vsx_cdiv(512, t2 * nz), sp2 = want2 < 1 ? 1 : (want2 > max_splits ? max_splits : want2);
+            if (sp2 > p->M / 128) sp2 = p->M / 128;
+            if (sp2 >= 8) sp2 &= ~7;
+            if (sp2 < 1) sp2 = 1;
+            dim3 g2(t2, sp2, nz);
+            if (n_full) {
+              if (p->pro == VSX_PRO_GRN)
+                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, true, 64, 1, 128>), g2, dim3(256), 0, s, *p);
+              else
+                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, false, 64, 1, 128>), g2, dim3(256), 0, s, *p);
+            } else {
+              if (p->pro == VSX_PRO_GRN)
+                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 128, TR, true, 64, 1, 256>), g2, dim3(256), 0, s, *p);
+              else
+                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 128, TR, false, 64, 1, 256>), g2, dim3(256), 0, s, *p);
+            }
+            VSX_LAUNCH_CHECK();
+            return 0;
+          }
+        }
         if (p->pro == VSX_PRO_GRN)
           hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, true, 64, 1>), grid, dim3(256), 0, s, *p);
         else
