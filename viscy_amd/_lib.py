@@ -132,6 +132,11 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        # VSX_FLAGS="nt_tall=1,tn_rect=0": tuning knobs of vsx_set_flag for A/B runs of unmodified programs (bench.py, tests)
+        for kv in filter(None, os.environ.get("VSX_FLAGS", "").split(",")):
+            name, _, val = kv.partition("=")
+            if l.vsx_set_flag(name.strip().encode(), int(val)) != 0:
+                raise RuntimeError(f"VSX_FLAGS: {l.vsx_last_error().decode(errors='replace')}")
     return _lib
 
 
