@@ -323,7 +323,7 @@ def main():
             },
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only (the other ranks would idle)
             res["cpu_baseline"] = cpu_baseline()
     if world > 1 or args.force_dp:
         torch.distributed.barrier()
