@@ -50,7 +50,8 @@ CLASS_MAP = {
 }
 for _t in ("NormalizeSampled", "MinMaxSampled", "RandWeightedCropd", "CenterSpatialCropd", "BatchedCenterSpatialCropd",
            "BatchedRandAffined", "BatchedRandAdjustContrastd", "BatchedRandScaleIntensityd", "BatchedRandGaussianNoised",
-           "BatchedRandGaussianSmoothd", "BatchedRandFlipd", "BatchedRandWeightedCropd"):
+           "BatchedRandGaussianSmoothd", "BatchedRandFlipd", "BatchedRandWeightedCropd", "BatchedRandInvertIntensityd",
+           "BatchedStackChannelsd"):
     CLASS_MAP[f"viscy_transforms.{_t}"] = f"viscy_amd.transforms.{_t}"
 
 

@@ -710,3 +710,38 @@ class CenterSpatialCropd:
                 sl.append(slice(start, start + size))
             d[k] = x[tuple(sl)]
         return d
+
+
+class BatchedRandInvertIntensityd(_BatchedRand):
+    """``viscy_transforms.BatchedRandInvertIntensityd`` (_invert_intensity.py:16-80): each sample of the batch is negated
+    with probability ``prob`` (one draw per sample, shared by the keys) — the scale kernel with factor -2 (x * (1 - 2))."""
+
+    is_spatial = False
+
+    def __init__(self, keys, prob: float = 0.1, allow_missing_keys: bool = False):
+        super().__init__(keys, prob)
+        self.allow_missing_keys = allow_missing_keys
+
+    def __call__(self, sample: dict, params: Tensor | None = None) -> dict:
+        first = next((k for k in self.keys if k in sample), None)
+        if first is None:
+            return sample
+        do = params if params is not None else self._rand(sample[first].shape[0]) < self.prob
+        f = torch.where(do.bool().cpu(), torch.tensor(-2.0), torch.tensor(0.0))
+        for k in self.keys:
+            if k in sample:
+                sample[k] = intensity_augment(sample[k], factor=f)
+        return sample
+
+
+class BatchedStackChannelsd:
+    """``viscy_transforms.BatchedStackChannelsd`` (_stack_channels.py:20-82): ``{"source": ["phase"], "target": ["nuclei",
+    "membrane"]}`` -> the named single-channel (B, 1, Z, Y, X) entries concatenated along the channel axis (data movement)."""
+
+    is_spatial = False
+
+    def __init__(self, channel_map: dict):
+        self.channel_map = {k: list(v) for k, v in channel_map.items()}
+
+    def __call__(self, sample: dict) -> dict:
+        return {key: torch.cat([sample[ch] for ch in chans], dim=1) for key, chans in self.channel_map.items()}
