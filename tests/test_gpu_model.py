@@ -821,3 +821,45 @@ def test_atto_backbone_under_bf16_autocast_falls_back_to_fp32_kernels():
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         out = mine(x.cuda())
         assert relerr(out, ref(x)) <= 1e-3   # fp32 accuracy: the 60-channel decoder rows cannot be bf16 vectors
+
+
+def test_large_batch_addressing_beyond_4gb_tensors():
+    """B = 640 patches: the 4C-wide activations of the last decoder stage pass 4 GB (2.6 M rows x 896 x 2 B), i.e. 32-bit byte
+    offsets would wrap.  Forward: the last samples of the big batch equal a small-batch run of the same samples.  Backward:
+    with an output gradient on the last samples only, the parameter gradients equal the small-batch gradients."""
+    from viscy_amd.unext2 import UNeXt2
+
+    torch.manual_seed(0)
+    m = UNeXt2(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True).cuda().eval()
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if "grn" in n_:
+                p.normal_(0, 0.1)
+    m.compute_dtype = torch.bfloat16
+    m.grad_mode = "flat"
+    B, k = 640, 3
+    g = torch.Generator().manual_seed(1)
+    tail = torch.randn(k, 1, 5, 256, 256, generator=g).cuda()
+    x = torch.zeros(B, 1, 5, 256, 256, device="cuda")
+    x[: B - k].normal_()
+    x[B - k:] = tail
+    with torch.no_grad():
+        y_big = m(x)[B - k:].clone()
+        y_small = m(tail)
+    torch.testing.assert_close(y_big, y_small, rtol=0, atol=0.02 * y_small.abs().max().item())  # bf16 run-to-run noise only
+    # backward
+    eng = m.engine()
+    dout_tail = torch.randn(y_small.shape, generator=g).cuda()
+    eng.flat_grad.zero_()
+    ys = m(tail)
+    ys.backward(dout_tail)
+    g_small = eng.flat_grad.clone()
+    eng.flat_grad.zero_()
+    yb = m(x)
+    dout = torch.zeros_like(yb)
+    dout[B - k:] = dout_tail
+    yb.backward(dout)
+    g_big = eng.flat_grad.clone()
+    cos = torch.nn.functional.cosine_similarity(g_big, g_small, dim=0).item()
+    assert cos > 0.999, cos
+    assert abs(g_big.norm().item() / g_small.norm().item() - 1) < 0.02

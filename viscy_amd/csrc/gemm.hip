@@ -504,7 +504,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int b_tile = p.hw > 0 ? m0 / p.hw : 0;  // the tile lies inside one sample (dispatch guarantees it)
-  const char* Abase = reinterpret_cast<const char*>(p.A) + (size_t)p.a_coff[z] * ES;
+  // the A panel is addressed from the tile's own first row (64-bit scalar base per workgroup), so the per-lane 32-bit
+  // offsets stay below BM * lda bytes whatever M is (M * lda * es passes 4 GB at B = 640 patches / B = 16 at 2048^2)
+  const char* Abase = reinterpret_cast<const char*>(p.A) + ((size_t)p.a_coff[z] + (size_t)m0 * (size_t)p.lda) * ES;
   const char* Bbase = reinterpret_cast<const char*>(p.B) + ((size_t)p.b_off[z] + (size_t)b_tile * (size_t)p.b_bstride) * ES;
   uint32_t offA[NA], offB[NB];
   int ldsA[NA], ldsB[NB];
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
     const int cid = tid + i * 256, row = cid / CPR, ch = cid % CPR;
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
-    offA[i] = (uint32_t)m * (uint32_t)(p.lda * ES) + ch * 16;
+    offA[i] = (uint32_t)(m - m0) * (uint32_t)(p.lda * ES) + ch * 16;
     ldsA[i] = row * RS + ch * 16;
   }
 #pragma unroll
@@ -770,7 +772,7 @@ static bool nt_fast_ok(const VsxGemm* p, int es) {
   if (p->epi == VSX_EPI_BIAS_STATS) return false;
   const bool reduce = p->epi == VSX_EPI_BIAS_GELU_SQ || p->epi == VSX_EPI_DZ;
   if ((reduce || p->pro == VSX_PRO_GRN || p->b_bstride != 0) && (p->hw <= 0 || p->hw % 128 != 0)) return false;
-  if ((unsigned long long)p->M * p->lda * es >= (1ull << 32) || (unsigned long long)p->N * p->ldb * es >= (1ull << 32)) return false;
+  if ((unsigned long long)256 * p->lda * es >= (1ull << 32) || (unsigned long long)p->N * p->ldb * es >= (1ull << 32)) return false;
   return true;
 }
 
