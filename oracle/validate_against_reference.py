@@ -160,6 +160,47 @@ def g3_normalize():
                os.path.join(GOLD, "normalize.pt"))
     print("G3 normalize: exact")
 
+    # ---- G4: the reference's BatchedRandScaleIntensity / BatchedRandGaussianNoise with their own draws (fixed seed); the
+    # oracle receives the drawn parameters (read back from the reference objects) and must reproduce the outputs exactly
+    class RandomizableTransform:
+        def __init__(self, prob=1.0, do_transform=True):
+            self.prob, self._do_transform = prob, do_transform
+
+    sys.modules["monai.transforms"].RandomizableTransform = RandomizableTransform
+    rs = _load("viscy_transforms._scale_intensity", f"{REF}/viscy-transforms/src/viscy_transforms/_scale_intensity.py")
+    x = torch.rand((6, 2, 5, 8, 8), generator=torch.Generator().manual_seed(3)) * 10
+    t = rs.BatchedRandScaleIntensity(factors=0.5, prob=0.5)
+    torch.manual_seed(11)
+    y = t(x.clone())
+    factors = t._broadcast_factors.reshape(6) - 1.0
+    assert torch.equal(y, transforms_ref.scale_intensity(x, factors)) and (factors == 0).any() and (factors != 0).any()
+    g4 = {"scale": {"x": x, "factors": factors, "y": y}}
+    try:
+        rn = _load("viscy_transforms._noise", f"{REF}/viscy-transforms/src/viscy_transforms/_noise.py")
+        tn = rn.BatchedRandGaussianNoise(prob=0.6, mean=0.0, std=0.3)
+        torch.manual_seed(12)
+        yn = tn(x.clone())
+        apply = tn._do_transform.clone()
+        # the reference draws ONE N(0,1) field for the whole batch and scales it per selected sample
+        std = torch.zeros(6)
+        field = torch.zeros(x.shape[1:])
+        if apply.any():
+            nb = tn.noise_batch  # expanded view of (mean + field * std_b)
+            first = int(torch.where(apply)[0][0])
+            diff = (yn - x)[apply]
+            # recover field * std_b per selected sample; std_b = ratio to the first selected sample's field scale
+            base = diff[0]
+            scale = (diff.reshape(diff.shape[0], -1) * base.reshape(1, -1)).sum(1) / (base * base).sum()
+            std[apply] = scale
+            field = base
+        yo = transforms_ref.gaussian_noise(x, field, std, apply, mean=0.0)
+        assert torch.allclose(yo, yn, rtol=1e-5, atol=1e-5)
+        g4["noise"] = {"x": x, "field": field, "std": std, "apply": apply, "y": yn}
+        print("G4 scale intensity: exact; gaussian noise: one shared field scaled per selected sample (1e-5)")
+    except Exception as e:  # the noise module pulls more of MONAI than the stub offers
+        print(f"G4 scale intensity: exact (noise module not importable here: {type(e).__name__})")
+    torch.save(g4, os.path.join(GOLD, "intensity.pt"))
+
 
 def g6_hf_convnext():
     from transformers import ConvNextV2Config

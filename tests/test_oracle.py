@@ -201,3 +201,9 @@ def test_ntxent_golden_and_simclr_cross_entropy():
     # reference test_loss.py: a stem that cannot fold the depth is rejected with the reference's message
     with pytest.raises(ValueError, match="more channels"):
         C.StemDepthtoChannels(1, 12, 96, (4, 4, 4), (2, 4, 4))
+
+
+def test_scale_intensity_golden():
+    """G4: the reference's BatchedRandScaleIntensity with its own draw (seed 11) == oracle with the drawn factors injected"""
+    g = load_golden("intensity.pt")["scale"]
+    assert torch.equal(transforms_ref.scale_intensity(g["x"], g["factors"]), g["y"])
