@@ -863,3 +863,49 @@ def test_large_batch_addressing_beyond_4gb_tensors():
     cos = torch.nn.functional.cosine_similarity(g_big, g_small, dim=0).item()
     assert cos > 0.999, cos
     assert abs(g_big.norm().item() / g_small.norm().item() - 1) < 0.02
+
+
+def test_edge_cases_of_the_widened_paths():
+    """degenerate inputs the reference semantics define: NT-Xent without negatives / with one pair, BatchNorm1d eval on a
+    single sample, FCMAE mask ratios that round to zero masked cells or leave a single kept cell"""
+    from oracle import fcmae_ref
+    from oracle.contrastive_ref import NTXentLoss as RefLoss
+    from viscy_amd.contrastive import ContrastiveEncoder, NTXentLoss
+    from viscy_amd.fcmae import FullyConvolutionalMAE
+
+    e = torch.randn(6, 16, generator=torch.Generator().manual_seed(0))
+    same = torch.zeros(6, dtype=torch.long)
+    eg = e.cuda().requires_grad_(True)
+    l0 = NTXentLoss(0.2)(eg, same.cuda())                      # no negatives anywhere: zero loss, zero gradient
+    l0.backward()
+    assert l0.item() == 0.0 and eg.grad.abs().max().item() == 0.0
+    pair = torch.tensor([0, 0, 1, 1])                           # two classes of two
+    lr = RefLoss(0.5)(e[:4], pair)
+    lg = NTXentLoss(0.5)(e[:4].cuda(), pair.cuda())
+    assert abs(lg.item() - lr.item()) <= 1e-5 * abs(lr.item())
+    enc = ContrastiveEncoder("convnextv2_tiny", in_channels=1, in_stack_depth=5, embedding_dim=32, projection_dim=16,
+                             depths=(1, 1, 1, 1), dims=(16, 32, 64, 128)).cuda()
+    enc.compute_dtype = torch.float32
+    enc.eval()
+    with torch.no_grad():
+        emb, proj = enc(torch.randn(1, 1, 5, 64, 64).cuda())   # eval-mode BatchNorm works on a single sample
+    assert emb.shape == (1, 128) and proj.shape == (1, 16) and torch.isfinite(proj).all()
+    enc.train()
+    with pytest.raises(RuntimeError, match="more than 1 value per channel"):
+        enc(torch.randn(1, 1, 5, 64, 64).cuda())                # ... training mode does not (as nn.BatchNorm1d)
+    kw = dict(in_channels=1, out_channels=1, encoder_blocks=[1, 1, 1, 1], dims=[16, 32, 64, 128], decoder_conv_blocks=1,
+              in_stack_depth=5, pretraining=True)
+    ref = unext2_ref.randomize_(fcmae_ref.FullyConvolutionalMAE(**kw), seed=2)
+    mine = FullyConvolutionalMAE(**kw)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.cuda()
+    mine.compute_dtype = torch.float32
+    x = torch.randn(2, 1, 5, 64, 96, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        y, mask = mine(x.cuda(), mask_ratio=0.1)                # int(6 * 0.1) = 0 masked cells: every token kept
+        assert not mask.any() and relerr(y, ref(x, mask=torch.zeros(2, 1, 2, 3, dtype=torch.bool))[0]) <= 1e-3
+        low = torch.ones(2, 1, 2, 3, dtype=torch.bool)
+        low[0, 0, 0, 1] = False
+        low[1, 0, 1, 2] = False                                  # a single kept cell per sample (L = 1 token at stage 3)
+        y1, _ = mine(x.cuda(), mask=low.cuda())
+        assert relerr(y1, ref(x, mask=low)[0]) <= 1e-3

@@ -599,3 +599,24 @@ data:
                             "trainer.strategy=ddp_find_unused_parameters_true"}
     with pytest.raises(KeyError, match="no viscy_amd counterpart"):
         C.instantiate({"class_path": "viscy_models.unet.Unet2d", "init_args": {}})
+
+
+def test_mmap_preload_with_unequal_time_axes(tmp_path):
+    """hcs.py:351-378: FOVs with different T occupy their own slabs of the staged buffer (cumulative offsets)"""
+    rng = np.random.default_rng(5)
+    pos = {"A/1/0": rng.random((3, 2, 4, 32, 32), dtype=np.float32), "A/2/0": rng.random((1, 2, 4, 32, 32), dtype=np.float32),
+           "B/1/0": rng.random((2, 2, 4, 32, 32), dtype=np.float32)}
+    path = str(tmp_path / "t.zarr")
+    write_hcs_plate(path, pos, ["Phase3D", "Nuclei"])
+    kw = dict(z_window_size=2, batch_size=1, num_workers=0, split_ratio=0.67, yx_patch_size=(32, 32))
+    plain = HCSDataModule(path, "Phase3D", "Nuclei", **kw)
+    plain.setup("fit")
+    mm = HCSDataModule(path, "Phase3D", "Nuclei", mmap_preload=True, scratch_dir=tmp_path / "s", **kw)
+    mm.prepare_data()
+    mm.setup("fit")
+    assert HCSDataModule._fov_t_offsets([p for _, p in open_ome_zarr(path).positions()], "0") == [0, 3, 4, 6]
+    n = len(plain.train_dataset)
+    assert n == len(mm.train_dataset) and n > 0
+    for i in range(n):
+        a, b = plain.train_dataset[i], mm.train_dataset[i]
+        assert a["index"] == b["index"] and torch.equal(a["source"], b["source"]) and torch.equal(a["target"], b["target"])
