@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FWD_GFLOP_PER_PATCH = 22.56  # SURVEY §8d / BASELINE.md §2 (256x256, Z=5, tiny)
+FWD_MB_PER_PATCH = 75.5  # forward "two-pass floor" 
 ALGO_MB_PER_PATCH = 226.5    # fwd+bwd two-pass-GRN floor, bf16 activations
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0
@@ -268,6 +269,21 @@ def main():
     with OpTimer(ops, only=dominant) as tm:
         for _ in range(3):
             eager(x, tgt)
+    # the metric's second half, "fwd HBM GB/s": forward-only passes (inference schedule, one hipGraph replay each) priced at
+    # SURVEY §8(d)'s algorithmic two-pass floor of 75.5 MB per patch
+    from viscy_amd.step import InferStep
+
+    model.eval()
+    infer = InferStep(model)
+    nf = max(3, min(args.steps, 10))
+    infer(x)
+    barrier()
+    tf0 = time.perf_counter()
+    for _ in range(nf):
+        infer(x)
+    barrier()
+    fwd_s = (time.perf_counter() - tf0) / nf
+    model.train()
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -329,6 +345,10 @@ def main():
                 "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 1e9, 1),
             },
             "roofline": roof,
+            "fwd": {"ms_per_pass": round(fwd_s * 1e3, 3), "patches_per_s_per_gpu": round(B / fwd_s, 1),
+                    "algorithmic_hbm_GBps": round(B / fwd_s * FWD_MB_PER_PATCH * scale / 1e3, 1),
+                    "frac_hbm_peak": round(B / fwd_s * FWD_MB_PER_PATCH * scale * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
+                    "tflops": round(B / fwd_s * FWD_GFLOP_PER_PATCH * scale / 1e3, 1)},
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only (the other ranks would idle)
             res["cpu_baseline"] = cpu_baseline()
