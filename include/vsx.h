@@ -250,9 +250,10 @@ int32_t vsx_ln_bwd(const void* dy, const void* x, const float* mean, const float
 int32_t vsx_grn_scale(const float* colsq, const float* gamma, float* s, int32_t nb, int32_t N, float eps,
     vsx_stream_t stream);
 
-/* backward of the GRN statistics path: P[b,n] = Σ_hw dz*g, Sb[b,n] = Σ_hw dz → t[b,n] (factor of g in dG), dgamma, dbeta. */
+/* backward of the GRN statistics path: P[b,n] = Σ_hw dz*g, Sb[b,n] = Σ_hw dz → t[b,n] (factor of g in dG), dgamma, dbeta
+ * (both ADDED to).  rowst: nb*N floats of scratch (per-sample dgamma contributions, column-reduced by a second launch). */
 int32_t vsx_grn_bwd_stats(const float* colsq, const float* P, const float* Sb, const float* gamma, float* t,
-    float* dgamma, float* dbeta, int32_t nb, int32_t N, float eps, vsx_stream_t stream);
+    float* dgamma, float* dbeta, float* rowst, int32_t nb, int32_t N, float eps, vsx_stream_t stream);
 
 /* K6/K7 backward, elementwise pass: dh = (dz*s + gelu(h)*t) * gelu'(h) written over dz; colsum[n] += Σ_m dh.  ws: ws_rows*N floats. */
 int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, const float* t, float* colsum, float* ws,

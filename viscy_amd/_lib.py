@@ -53,7 +53,7 @@ _SIGS = {
     "vsx_ln_fwd": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _F32, _I32, _P]),
     "vsx_ln_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "vsx_grn_scale": (_I32, [_P, _P, _P, _I32, _I32, _F32, _P]),
-    "vsx_grn_bwd_stats": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _F32, _P]),
+    "vsx_grn_bwd_stats": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _F32, _P]),
     "vsx_grn_gelu_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_dwconv7_fwd": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_dwconv7_bwd_data": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),

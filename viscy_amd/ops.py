@@ -137,7 +137,8 @@ def grn_bwd_stats(colsq: Tensor, P: Tensor, gamma: Tensor, dgamma: Tensor, eps: 
                   dbeta: Tensor | None = None) -> Tensor:
     """Sb [nb, N] = per-sample Σ_hw dz (EPI_DZ red1); dbeta[N] += Σ_b Sb."""
     t = torch.empty_like(colsq)
-    check(lib().vsx_grn_bwd_stats(ptr(colsq), ptr(P), ptr(Sb), ptr(gamma), ptr(t), ptr(dgamma), ptr(dbeta), colsq.shape[0],
+    rowst = torch.empty_like(colsq)
+    check(lib().vsx_grn_bwd_stats(ptr(colsq), ptr(P), ptr(Sb), ptr(gamma), ptr(t), ptr(dgamma), ptr(dbeta), ptr(rowst), colsq.shape[0],
                                   colsq.shape[1], eps, stream()), "grn_bwd_stats")
     return t
 
