@@ -13,6 +13,7 @@ int g_vsx_tn_wide = 1;
 int g_vsx_ggb_blocks = 2048;  // grn_gelu_bwd: target workgroup count (tuning knob, see norm.hip)
 int g_vsx_tn_rect = 1;  // TN: 256x128 / 128x256 output tiles when N or K of the weight gradient fits one 256-wide tile
 int g_vsx_dw_rows2 = 0;  // depthwise 7x7: two output rows per thread — measured +3..8 % (fwd) / +18 % (dgrad) SLOWER: off
+int g_vsx_dw_wg16 = 1;   // depthwise weight gradient: 8x16-pixel tiles (35 KB of LDS, 4 workgroups / CU) instead of 8x32 (63 KB, 2)
 int g_vsx_nt_tall = 0;  // 256x128 NT tiles: -5..-9 % on isolated wide-output launches, nothing on the whole step (measured) -> off
 
 void vsx_set_error(const char* fmt, ...) {
@@ -33,6 +34,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "ggb_blocks")) { g_vsx_ggb_blocks = value; return 0; }
   if (name && !strcmp(name, "tn_rect")) { g_vsx_tn_rect = value; return 0; }
   if (name && !strcmp(name, "dw_rows2")) { g_vsx_dw_rows2 = value; return 0; }
+  if (name && !strcmp(name, "dw_wg16")) { g_vsx_dw_wg16 = value; return 0; }
   vsx_set_error("vsx_set_flag: unknown flag '%s'", name ? name : "(null)");
   return 1;
 }
@@ -45,5 +47,6 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "ggb_blocks")) return g_vsx_ggb_blocks;
   if (name && !strcmp(name, "tn_rect")) return g_vsx_tn_rect;
   if (name && !strcmp(name, "dw_rows2")) return g_vsx_dw_rows2;
+  if (name && !strcmp(name, "dw_wg16")) return g_vsx_dw_wg16;
   return -1;
 }

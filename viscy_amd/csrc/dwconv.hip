@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
   constexpr int XT_BYTES = IH * IW * PITCH, DT_BYTES = TH * TW * PITCH;
   static_assert(NCV * 7 * TH <= 256, "thread mapping");
   typedef typename VT<T>::vec vec;
-  constexpr int PART_BYTES = TH * 50 * CB * 4;
+  constexpr int CR = 2;  // rows combined per round of the final reduction (a full TH-row staging buffer would be 51 KB)
+  constexpr int PART_BYTES = CR * 50 * CB * 4;
   constexpr int SMEM_BYTES = XT_BYTES + DT_BYTES > PART_BYTES ? XT_BYTES + DT_BYTES : PART_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   char* xt = smem;
@@ -335,32 +336,48 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const T* __restrict_
       }
     }
   }
-  // block reduction over the TH row-threads without atomics: every worker parks its 7 (+1) x VN partials
-  // in LDS as part[row][50][CB] (aliases the tiles), then 50*CB threads-strided sums over the rows
-  __syncthreads();
+  // block reduction over the TH row-threads without atomics: the workers of CR rows at a time park their 7 (+1) x VN
+  // partials in LDS as part[row % CR][50][CB] (aliases the tiles); 50*CB thread-strided sums accumulate over the rounds
   float* part = reinterpret_cast<float*>(smem);
-  if (worker) {
-    float* pr = part + (size_t)row * 50 * CB;
+  constexpr int NV = (50 * CB + 255) / 256;
+  float tot[NV];
 #pragma unroll
-    for (int kx = 0; kx < 7; ++kx)
+  for (int q = 0; q < NV; ++q) tot[q] = 0.f;
+  for (int r0 = 0; r0 < TH; r0 += CR) {
+    __syncthreads();
+    if (worker && row >= r0 && row < r0 + CR) {
+      float* pr = part + (size_t)(row - r0) * 50 * CB;
 #pragma unroll
-      for (int j = 0; j < VN; j += 4)
-        *reinterpret_cast<float4*>(pr + (ky * 7 + kx) * CB + cv * VN + j) =
-            make_float4(acc[kx][j], acc[kx][j + 1], acc[kx][j + 2], acc[kx][j + 3]);
-    if (ky == 3) {
+      for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
-      for (int j = 0; j < VN; j += 4)
-        *reinterpret_cast<float4*>(pr + 49 * CB + cv * VN + j) = make_float4(bsum[j], bsum[j + 1], bsum[j + 2], bsum[j + 3]);
+        for (int j = 0; j < VN; j += 4)
+          *reinterpret_cast<float4*>(pr + (ky * 7 + kx) * CB + cv * VN + j) =
+              make_float4(acc[kx][j], acc[kx][j + 1], acc[kx][j + 2], acc[kx][j + 3]);
+      if (ky == 3) {
+#pragma unroll
+        for (int j = 0; j < VN; j += 4)
+          *reinterpret_cast<float4*>(pr + 49 * CB + cv * VN + j) = make_float4(bsum[j], bsum[j + 1], bsum[j + 2], bsum[j + 3]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int i = threadIdx.x + q * 256;
+      if (i < 50 * CB) {
+#pragma unroll
+        for (int r = 0; r < CR; ++r)
+          if (r0 + r < TH) tot[q] += part[(size_t)r * 50 * CB + i];
+      }
     }
   }
-  __syncthreads();
   float* wrow = ws + (size_t)group * 50 * C;
-  for (int i = threadIdx.x; i < 50 * CB; i += 256) {
-    float a = 0.f;
 #pragma unroll
-    for (int r = 0; r < TH; ++r) a += part[(size_t)r * 50 * CB + i];
-    const int t = i / CB, c = c_base + (i - t * CB);
-    if (c < C) wrow[(size_t)t * C + c] = a;
+  for (int q = 0; q < NV; ++q) {
+    const int i = threadIdx.x + q * 256;
+    if (i < 50 * CB) {
+      const int t = i / CB, c = c_base + (i - t * CB);
+      if (c < C) wrow[(size_t)t * C + c] = tot[q];
+    }
   }
 }
 
@@ -409,6 +426,7 @@ template <typename T>
 static int dw_launch(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W,
                      int C, bool flip, hipStream_t s);
 extern int g_vsx_dw_rows2;
+extern int g_vsx_dw_wg16;
 template <>
 int dw_launch<bf16_t>(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W,
                       int C, bool flip, hipStream_t s) {
@@ -482,6 +500,7 @@ extern "C" int32_t vsx_dwconv7_bwd_weight(const void* dy, const void* x, float* 
             "vsx_dwconv7_bwd_weight: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VSX_BF16) {
+    if (W >= 24 && g_vsx_dw_wg16) return dw_wgrad_cfg<bf16_t, 4, 8, 16>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
     if (W >= 24) return dw_wgrad_cfg<bf16_t, 4, 8, 32>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
     return dw_wgrad_cfg<bf16_t, 4, 8, 8>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
   }
