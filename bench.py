@@ -184,6 +184,13 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel collective path even with one rank (RCCL smoke test on a single GPU)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: everything any library writes to file descriptor 1 during the run
+    # (RCCL prints a version banner through C stdio at communicator init and flushes it at exit, i.e. AFTER a Python print)
+    # is routed to stderr, and the result is written to the saved descriptor at the very end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -356,8 +363,8 @@ def main():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
-        sys.stdout.flush()
-        print(json.dumps(res), flush=True)  # the ONE JSON line, after every library banner (RCCL prints its own at init)
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
+    os.close(result_fd)
 
 
 if __name__ == "__main__":
