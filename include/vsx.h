@@ -211,6 +211,15 @@ int32_t vsx_head_out_bwd1(const void* U, const float* ssum, const float* ssq, co
     int32_t H2, int32_t W2, int32_t Z, int32_t Cmid, int32_t Cout, float eps, int32_t dtype,
     vsx_stream_t stream);
 
+/* backward pass 1 with the weight gradient of the 1x1x1 convolution folded in (bf16 only; replaces vsx_head_out_bwd1 +
+ * the vsx_gemm_tn over act/dv = autograd of nn.Conv3d(mid, 4*out, 1), heads.py:617-625): act is never materialised, the
+ * contraction over the voxels runs on MFMA inside the kernel.  dW2 [4*Cout, Cmid] and db2 [4*Cout] are ACCUMULATED into;
+ * scratch: B * (4*Cout*Cmid + 4*Cout) floats (zeroed here).  dv, S1, S2, dalpha as vsx_head_out_bwd1. */
+int32_t vsx_head_out_bwd1_wgrad(const void* U, const float* ssum, const float* ssq, const float* w2,
+    const float* alpha, const float* dout, void* dv, float* S1, float* S2, float* dalpha, float* dW2, float* db2,
+    float* scratch, int32_t B, int32_t H2, int32_t W2, int32_t Z, int32_t Cmid, int32_t Cout, float eps, int32_t dtype,
+    vsx_stream_t stream);
+
 /* backward pass 2: dU = rstd * (dn - S1/cnt - n̂ * S2/cnt)  (InstanceNorm3d backward). */
 int32_t vsx_head_out_bwd2(const void* U, const float* ssum, const float* ssq, const float* w2,
     const float* alpha, const void* dv, const float* S1, const float* S2, void* dU, int32_t B, int32_t H2,

@@ -279,6 +279,14 @@ def head_out_bwd1(U, ssum, ssq, w2, alpha, dout, S1, S2, dalpha, B, H2, W2, Z, C
     return a.detach().reshape(-1, Cmid).to(U.dtype), dvt.reshape(-1, 4 * Cout).to(U.dtype)
 
 
+def head_out_bwd1_wgrad(U, ssum, ssq, w2, alpha, dout, S1, S2, dalpha, dW2, db2, B, H2, W2, Z, Cmid, Cout, eps=1e-5):
+    """pass 1 + the 1x1x1 convolution's weight / bias gradient (storage-dtype operands, fp32 accumulation)"""
+    act, dv = head_out_bwd1(U, ssum, ssq, w2, alpha, dout, S1, S2, dalpha, B, H2, W2, Z, Cmid, Cout, eps)
+    dW2.view(4 * Cout, Cmid).add_(dv.float().t() @ act.float())
+    db2.add_(dv.float().sum(0))
+    return dv
+
+
 def head_out_bwd2(U, ssum, ssq, w2, alpha, dv, S1, S2, B, H2, W2, Z, Cmid, Cout, eps=1e-5):
     Uf = U.float()
     cnt = Z * H2 * W2

@@ -548,6 +548,47 @@ def test_head_tail_fwd_bwd(dt):
         close(g[4], al.grad, dt, "dalpha vs autograd")
 
 
+@pytest.mark.parametrize("cfg", [(2, 6, 10, 5, 32, 2), (3, 9, 7, 3, 32, 2), (1, 40, 52, 5, 64, 4), (2, 64, 80, 5, 32, 2)],
+                         ids=["mid32", "mid32-ragged", "mid64-multi-iter", "mid32-multi-iter"])
+def test_head_bwd1_with_folded_weight_gradient(cfg):
+    """bf16 pass 1 with the 1x1x1 weight gradient folded in (voxel contraction on MFMA inside the kernel) against
+    pass 1 + the explicit dv^T . act product; dW2 / db2 are accumulated into (non-zero start)."""
+    H = _hip()
+    dt = torch.bfloat16
+    B, H2, W2, Z, Cmid, Cout = cfg
+    Mh = B * H2 * W2
+    U = rnd(Mh, Z * Cmid, dt=dt, seed=11, scale=2.0) + 0.3
+    w2, alpha = rnd(4 * Cout, Cmid, seed=12, scale=0.2), torch.tensor([0.25])
+    dout = rnd(B, Cout, Z, 2 * H2, 2 * W2, seed=14)
+    u3 = U.float().view(B, H2 * W2 * Z, Cmid)
+    ssum, ssq = u3.sum(1), (u3 * u3).sum(1)
+    w0, b0 = rnd(4 * Cout, Cmid, seed=15), rnd(4 * Cout, seed=16)
+
+    def run(ops, dev):
+        mv = lambda t: t.to(dev)  # noqa: E731
+        S = torch.zeros(2, B, Cmid, device=dev)
+        dal = torch.zeros(1, device=dev)
+        dW, db = mv(w0).clone(), mv(b0).clone()
+        dv = ops.head_out_bwd1_wgrad(mv(U), mv(ssum), mv(ssq), mv(w2), mv(alpha), mv(dout), S[0], S[1], dal, dW, db, B, H2, W2,
+                                     Z, Cmid, Cout)
+        return dv, S, dal, dW - mv(w0), db - mv(b0)
+
+    g, r = run(H, DEV), run(R, "cpu")
+    assert torch.equal(g[0].cpu(), r[0]), "dv"
+    close(g[1], r[1], dt, "S")
+    close(g[2], r[2], dt, "dalpha")
+    # fp32 accumulation of identical bf16 products: only the summation order differs
+    for name, a, b in (("dW2", g[3], r[3]), ("db2", g[4], r[4])):
+        err = (a.cpu() - b).abs().max().item()
+        assert err <= 2e-5 * max(1.0, b.abs().max().item()) * (H2 * W2 * Z * B) ** 0.5, (name, err)
+    # and the unfused HIP pair gives the same gradient
+    S = torch.zeros(2, B, Cmid, device=DEV)
+    act, dv = H.head_out_bwd1(U.to(DEV), ssum.to(DEV), ssq.to(DEV), w2.to(DEV), alpha.to(DEV), dout.to(DEV), S[0], S[1],
+                              torch.zeros(1, device=DEV), B, H2, W2, Z, Cmid, Cout)
+    ref = dv.float().t() @ act.float()
+    assert (g[3] - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+
+
 # ------------------------------------------------------------------ parameter space
 def test_prep_unprep_adamw():
     H = _hip()

@@ -65,6 +65,7 @@ _SIGS = {
     "vsx_head_shuffle_bwd": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_head_out_fwd": (_I32, [_P] * 7 + [_I32] * 6 + [_F32, _I32, _P]),
     "vsx_head_out_bwd1": (_I32, [_P] * 11 + [_I32] * 6 + [_F32, _I32, _P]),
+    "vsx_head_out_bwd1_wgrad": (_I32, [_P] * 13 + [_I32] * 6 + [_F32, _I32, _P]),
     "vsx_head_out_bwd2": (_I32, [_P] * 9 + [_I32] * 6 + [_F32, _I32, _P]),
     "vsx_loss_pool": (_I32, [_P] * 7 + [_I32] * 3 + [_P]),
     "vsx_ssim_scale_fwd": (_I32, [_P] * 5 + [_I32] * 5 + [_P]),

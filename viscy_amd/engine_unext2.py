@@ -584,12 +584,17 @@ class Engine:
         w2 = m.head.conv[1].weight.view(4 * cout, cmid)
         # ---- head
         S = self._za.take(2, B, cmid)
-        act, dv = o.head_out_bwd1(U, stats[0], stats[1], w2, alpha, dout.contiguous().float(), S[0], S[1], g(alpha), B, H2,
-                                  W2, Zo, cmid, cout)
-        M5 = Mh * Zo
-        o.gemm("tn", act, dv, g(m.head.conv[1].weight), M5, 4 * cout, cmid, cmid, 4 * cout, cmid, dtype=dt,
-               colsum=g(m.head.conv[1].bias))
-        del act
+        if dt == torch.bfloat16 and (cmid, cout) in ((32, 2), (64, 4)):
+            # pass 1 with the 1x1x1 weight gradient folded in (voxel contraction on MFMA inside the kernel): the
+            # [M5, cmid] activation is never written and the skinny TN GEMM over it disappears
+            dv = o.head_out_bwd1_wgrad(U, stats[0], stats[1], w2, alpha, dout.contiguous().float(), S[0], S[1], g(alpha),
+                                       g(m.head.conv[1].weight), g(m.head.conv[1].bias), B, H2, W2, Zo, cmid, cout)
+        else:
+            act, dv = o.head_out_bwd1(U, stats[0], stats[1], w2, alpha, dout.contiguous().float(), S[0], S[1], g(alpha), B,
+                                      H2, W2, Zo, cmid, cout)
+            o.gemm("tn", act, dv, g(m.head.conv[1].weight), Mh * Zo, 4 * cout, cmid, cmid, 4 * cout, cmid, dtype=dt,
+                   colsum=g(m.head.conv[1].bias))
+            del act
         dU = o.head_out_bwd2(U, stats[0], stats[1], w2, alpha, dv, S[0], S[1], B, H2, W2, Zo, cmid, cout)
         del dv
         dWc = self._za.take(cmid, 27 * c3)

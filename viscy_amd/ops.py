@@ -229,6 +229,17 @@ def head_out_bwd1(U, ssum, ssq, w2, alpha, dout, S1, S2, dalpha, B, H2, W2, Z, C
     return act, dv
 
 
+def head_out_bwd1_wgrad(U, ssum, ssq, w2, alpha, dout, S1, S2, dalpha, dW2, db2, B, H2, W2, Z, Cmid, Cout, eps=1e-5) -> Tensor:
+    """bf16: pass 1 + the 1x1x1 weight / bias gradient (accumulated into dW2 / db2) in one launch; returns dv."""
+    M5 = B * H2 * W2 * Z
+    dv = torch.empty((M5, 4 * Cout), dtype=U.dtype, device=U.device)
+    scratch = torch.empty((B, 4 * Cout * (Cmid + 1)), dtype=torch.float32, device=U.device)
+    check(lib().vsx_head_out_bwd1_wgrad(ptr(U), ptr(ssum), ptr(ssq), ptr(w2), ptr(alpha), ptr(dout), ptr(dv), ptr(S1), ptr(S2),
+                                        ptr(dalpha), ptr(dW2), ptr(db2), ptr(scratch), B, H2, W2, Z, Cmid, Cout, eps,
+                                        dtype_code(U.dtype), stream()), "head_out_bwd1_wgrad")
+    return dv
+
+
 def head_out_bwd2(U, ssum, ssq, w2, alpha, dv, S1, S2, B, H2, W2, Z, Cmid, Cout, eps=1e-5) -> Tensor:
     dU = torch.empty_like(U)
     check(lib().vsx_head_out_bwd2(ptr(U), ptr(ssum), ptr(ssq), ptr(w2), ptr(alpha), ptr(dv), ptr(S1), ptr(S2), ptr(dU), B,
