@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
         float dnn = dn * nh[j];
         if (nh[j] <= 0.f) da += dA[j] * nh[j];
         if (!live) { dn = 0.f; dnn = 0.f; }
-        const float t1 = wave_sum(dn), t2 = wave_sum(dnn);
-        if ((threadIdx.x & 63) == 0) {
+        const float t1 = wave_sum_to_lane63(dn), t2 = wave_sum_to_lane63(dnn);
+        if ((threadIdx.x & 63) == 63) {
           part[wv][c0 + j] += t1;
           part[wv][CMID + c0 + j] += t2;
         }
@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256) void head_out_bwd1_kernel(const T* __restrict_
       _Pragma("unroll") for (int c = 0; c < CMID / VN; ++c) stvec<T>(act + row * CMID + c * VN, stage[c][threadIdx.x]);
     }
     if (!live) da = 0.f;
-    da = wave_sum(da);
-    if ((threadIdx.x & 63) == 0) part[wv][2 * CMID] += da;
+    da = wave_sum_to_lane63(da);
+    if ((threadIdx.x & 63) == 63) part[wv][2 * CMID] += da;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * CMID + 1; i += 256) {
@@ -267,16 +267,16 @@ __global__ __launch_bounds__(256) void head_out_bwd1_wgrad_kernel(const bf16_t* 
         float dnn = dn * nh[j];
         if (nh[j] <= 0.f) da += dA[j] * nh[j];
         if (!live) { dn = 0.f; dnn = 0.f; }
-        const float t1 = wave_sum(dn), t2 = wave_sum(dnn);
-        if (lane == 0) {
+        const float t1 = wave_sum_to_lane63(dn), t2 = wave_sum_to_lane63(dnn);
+        if (lane == 63) {
           part[wv][c0 + j] += t1;
           part[wv][CMID + c0 + j] += t2;
         }
       }
     }
     if (!live) da = 0.f;
-    da = wave_sum(da);
-    if (lane == 0) part[wv][2 * CMID] += da;
+    da = wave_sum_to_lane63(da);
+    if (lane == 63) part[wv][2 * CMID] += da;
     __syncthreads();  // the wave's transposed rows are complete (block-wide barrier: trip counts are uniform)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {

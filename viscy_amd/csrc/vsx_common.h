@@ -204,6 +204,15 @@ __device__ __forceinline__ float group_sum(float v) {  // sum over aligned group
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+// wave total delivered to lane 63 only, without LDS traffic: the two row-crossing steps are the gfx9 DPP row broadcasts
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) instead of two ds_bpermute + s_waitcnt.  For
+// reductions whose result one lane accumulates (head_out_bwd1: 64 of them per voxel).
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = group_sum<16>(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast:15
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));  // row_bcast:31
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
