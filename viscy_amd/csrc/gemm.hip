@@ -23,6 +23,7 @@ extern int g_vsx_nt_wide;
 extern int g_vsx_nt_fast;
 extern int g_vsx_tn_wide;
 extern int g_vsx_nt_tall;
+extern int g_vsx_nt_stream;
 
 // ------------------------------------------------------------------------------------------------
 // operand gather: returns the 16-byte chunk holding A(m, k .. k+VN-1) after the prologue
@@ -632,6 +633,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
 #pragma unroll
   for (int j = 0; j < VN; ++j) { r0[j] = 0.f; r1[j] = 0.f; }
   const size_t ccol = (size_t)p.c_coff[z] + n;
+  const bool ntst = (EPI == VSX_EPI_BIAS_GELU_SQ || EPI == VSX_EPI_DZ) && (p.pro & 256) != 0;  // set by launch_nt_fast
 #pragma unroll 1
   for (int half = 0; half < NPASS; ++half) {
     __syncthreads();
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
               r0[j] += gv[j] * gv[j];
               r0[j + 1] += gv[j + 1] * gv[j + 1];
             }
-            stvec<T>(reinterpret_cast<T*>(p.C2) + (size_t)m * p.ldc + ccol, pack<T>(gv));
+            stvec_stream(reinterpret_cast<T*>(p.C2) + (size_t)m * p.ldc + ccol, pack<T>(gv), ntst);
           } else if constexpr (EPI == VSX_EPI_DZ) {
             float gf[VN];
             unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldx + n), gf);
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
           }
           // inference passes C = nullptr with EPI_BIAS_GELU_SQ: only the activation (C2) is kept, not the pre-activation
           if (EPI != VSX_EPI_BIAS_GELU_SQ || p.C != nullptr)
-            stvec<T>(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + ccol, pack<T>(v));
+            stvec_stream(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + ccol, pack<T>(v), ntst);
         }
       }
     }
@@ -726,7 +728,10 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
 }
 
 template <typename T, int EPI, bool PRO>
-static int launch_nt_fast(const VsxGemm* p, hipStream_t s) {
+static int launch_nt_fast(const VsxGemm* pin, hipStream_t s) {
+  VsxGemm pq = *pin;
+  if (g_vsx_nt_stream) pq.pro |= 256;  // kernel-side flag bit (the prologue kind itself is a template parameter there)
+  const VsxGemm* p = &pq;
   int tiles = vsx_cdiv(p->M, 128) * vsx_cdiv(p->N, 128);
   dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
   if constexpr (sizeof(T) == 2) {

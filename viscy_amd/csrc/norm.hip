@@ -4,6 +4,7 @@
 // barriers); loads/stores are 16-byte vectors.
 #include "vsx_common.h"
 #include "../../include/vsx.h"
+extern int g_vsx_grn_stream;
 
 // ------------------------------------------------------------------ LayerNorm forward
 template <typename T, int G, int CPL>
@@ -370,7 +371,7 @@ extern int g_vsx_ggb_blocks;
 template <typename T>
 __global__ __launch_bounds__(256) void grn_gelu_bwd_kernel(T* __restrict__ dz, const T* __restrict__ h,
                                                            const float* __restrict__ s, const float* __restrict__ t,
-                                                           float* __restrict__ ws, int M, int N, int hw, int tpr) {
+                                                           float* __restrict__ ws, int M, int N, int hw, int tpr, int nt) {
   constexpr int VN = VT<T>::N;
   __shared__ float red[256 * VN];
   const int cl = threadIdx.x % tpr;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void grn_gelu_bwd_kernel(T* __restrict__ dz, c
           cs[j] += o[j];
           cs[j + 1] += o[j + 1];
         }
-        stvec<T>(dz + (size_t)m * N + n, pack<T>(o));
+        stvec_stream(dz + (size_t)m * N + n, pack<T>(o), nt != 0);
       }
     }
   }
@@ -487,10 +488,10 @@ extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, con
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VSX_BF16)
     hipLaunchKernelGGL(grn_gelu_bwd_kernel<bf16_t>, grid, dim3(nthreads), 0, st, (bf16_t*)dz, (const bf16_t*)h, s, t, ws, M, N,
-                       hw, tpr);
+                       hw, tpr, g_vsx_grn_stream);
   else
     hipLaunchKernelGGL(grn_gelu_bwd_kernel<float>, grid, dim3(nthreads), 0, st, (float*)dz, (const float*)h, s, t, ws, M, N, hw,
-                       tpr);
+                       tpr, g_vsx_grn_stream);
   VSX_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv(N, 64), vsx_cdiv(gy, 64)), dim3(256), 0, st, ws, colsum, gy, N);
   VSX_LAUNCH_CHECK();

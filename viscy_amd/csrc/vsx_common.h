@@ -127,6 +127,20 @@ __device__ __forceinline__ void stvec(T* p, const typename VT<T>::vec& v) {
   *reinterpret_cast<typename VT<T>::vec*>(p) = v;
 }
 
+// 16-byte store that streams past the caches when `nt` is set (outputs a later launch reads, never this one)
+typedef uint32_t vsx_u32x4 __attribute__((ext_vector_type(4)));
+typedef float vsx_f32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stvec_stream(bf16_t* p, const uint4& v, bool nt) {
+  const vsx_u32x4 w = {v.x, v.y, v.z, v.w};
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(w) : "memory");
+  else *reinterpret_cast<vsx_u32x4*>(p) = w;
+}
+__device__ __forceinline__ void stvec_stream(float* p, const float4& v, bool nt) {
+  const vsx_f32x4s w = {v.x, v.y, v.z, v.w};
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(w) : "memory");
+  else *reinterpret_cast<vsx_f32x4s*>(p) = w;
+}
+
 // ------------------------------------------------------------------ math
 // exact-erf GELU (nn.GELU default) and its derivative.  erf via Abramowitz-Stegun 7.1.26
 // (|abs err| <= 1.5e-7, below fp32 round-off of the surrounding arithmetic): one v_rcp, one v_exp
