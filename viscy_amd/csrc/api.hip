@@ -16,6 +16,7 @@ int g_vsx_dw_rows2 = 0;  // depthwise 7x7: two output rows per thread — measur
 int g_vsx_dw_wg16 = 1;   // depthwise weight gradient: 8x16-pixel tiles (35 KB of LDS, 4 workgroups / CU) instead of 8x32 (63 KB, 2)
 int g_vsx_nt_stream = 1;  // non-temporal stores for the wide outputs of the lean NT kernel (fc1 h / g, fc2 data gradient dz): +1.5 % on the step (same-box A/B)
 int g_vsx_grn_stream = 0;  // non-temporal store of dz in grn_gelu_bwd
+int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup instead of grid-strided rows
 int g_vsx_nt_tall = 0;  // 256x128 NT tiles: -5..-9 % on isolated wide-output launches, nothing on the whole step (measured) -> off
 
 void vsx_set_error(const char* fmt, ...) {
@@ -35,6 +36,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "nt_tall")) { g_vsx_nt_tall = value; return 0; }
   if (name && !strcmp(name, "nt_stream")) { g_vsx_nt_stream = value; return 0; }
   if (name && !strcmp(name, "grn_stream")) { g_vsx_grn_stream = value; return 0; }
+  if (name && !strcmp(name, "ggb_contig")) { g_vsx_ggb_contig = value; return 0; }
   if (name && !strcmp(name, "ggb_blocks")) { g_vsx_ggb_blocks = value; return 0; }
   if (name && !strcmp(name, "tn_rect")) { g_vsx_tn_rect = value; return 0; }
   if (name && !strcmp(name, "dw_rows2")) { g_vsx_dw_rows2 = value; return 0; }
@@ -50,6 +52,7 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "nt_tall")) return g_vsx_nt_tall;
   if (name && !strcmp(name, "nt_stream")) return g_vsx_nt_stream;
   if (name && !strcmp(name, "grn_stream")) return g_vsx_grn_stream;
+  if (name && !strcmp(name, "ggb_contig")) return g_vsx_ggb_contig;
   if (name && !strcmp(name, "ggb_blocks")) return g_vsx_ggb_blocks;
   if (name && !strcmp(name, "tn_rect")) return g_vsx_tn_rect;
   if (name && !strcmp(name, "dw_rows2")) return g_vsx_dw_rows2;

@@ -5,6 +5,7 @@
 #include "vsx_common.h"
 #include "../../include/vsx.h"
 extern int g_vsx_grn_stream;
+extern int g_vsx_ggb_contig;
 
 // ------------------------------------------------------------------ LayerNorm forward
 template <typename T, int G, int CPL>
@@ -371,7 +372,8 @@ extern int g_vsx_ggb_blocks;
 template <typename T>
 __global__ __launch_bounds__(256) void grn_gelu_bwd_kernel(T* __restrict__ dz, const T* __restrict__ h,
                                                            const float* __restrict__ s, const float* __restrict__ t,
-                                                           float* __restrict__ ws, int M, int N, int hw, int tpr, int nt) {
+                                                           float* __restrict__ ws, int M, int N, int hw, int tpr, int nt,
+                                                           int rpb) {
   constexpr int VN = VT<T>::N;
   __shared__ float red[256 * VN];
   const int cl = threadIdx.x % tpr;
@@ -385,10 +387,14 @@ __global__ __launch_bounds__(256) void grn_gelu_bwd_kernel(T* __restrict__ dz, c
   if (active) {
     int bcur = -1;
     float sv[VN], tv[VN];
-    const int mstep = gridDim.y * nslot;
-    for (int m0 = blockIdx.y * nslot + slot; m0 < M; m0 += 2 * mstep) {
+    // rpb > 0: the workgroup walks its own contiguous range of rpb rows (sequential pages, the sample index and with it
+    // s / t change once per hw rows); rpb = 0: rows strided by the grid (the first version)
+    const int mstep = rpb > 0 ? nslot : gridDim.y * nslot;
+    const int mbeg = rpb > 0 ? blockIdx.y * rpb : blockIdx.y * nslot;
+    const int mend = rpb > 0 ? (mbeg + rpb < M ? mbeg + rpb : M) : M;
+    for (int m0 = mbeg + slot; m0 < mend; m0 += 2 * mstep) {
       const int m1 = m0 + mstep;
-      const bool has1 = m1 < M;
+      const bool has1 = m1 < mend;
       typename VT<T>::vec d0 = ldvec<T>(dz + (size_t)m0 * N + n), h0 = ldvec<T>(h + (size_t)m0 * N + n);
       typename VT<T>::vec d1 = vzero<T>(), h1 = vzero<T>();
       if (has1) {
@@ -484,14 +490,19 @@ extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, con
   if (gy > vsx_cdiv(ngroups, 4)) gy = vsx_cdiv(ngroups, 4);  // >= 4 rows per thread
   if (gy > ws_rows) gy = ws_rows;
   if (gy < 1) gy = 1;
+  int rpb = 0;
+  if (g_vsx_ggb_contig) {
+    rpb = vsx_cdiv(vsx_cdiv(M, gy), 2 * nslot) * 2 * nslot;
+    gy = vsx_cdiv(M, rpb);
+  }
   dim3 grid(gx, gy);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VSX_BF16)
     hipLaunchKernelGGL(grn_gelu_bwd_kernel<bf16_t>, grid, dim3(nthreads), 0, st, (bf16_t*)dz, (const bf16_t*)h, s, t, ws, M, N,
-                       hw, tpr, g_vsx_grn_stream);
+                       hw, tpr, g_vsx_grn_stream, rpb);
   else
     hipLaunchKernelGGL(grn_gelu_bwd_kernel<float>, grid, dim3(nthreads), 0, st, (float*)dz, (const float*)h, s, t, ws, M, N, hw,
-                       tpr, g_vsx_grn_stream);
+                       tpr, g_vsx_grn_stream, rpb);
   VSX_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv(N, 64), vsx_cdiv(gy, 64)), dim3(256), 0, st, ws, colsum, gy, N);
   VSX_LAUNCH_CHECK();
