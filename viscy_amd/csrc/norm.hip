@@ -395,11 +395,11 @@ __global__ __launch_bounds__(256) void grn_gelu_bwd_kernel(T* __restrict__ dz, c
     for (int m0 = mbeg + slot; m0 < mend; m0 += 2 * mstep) {
       const int m1 = m0 + mstep;
       const bool has1 = m1 < mend;
-      typename VT<T>::vec d0 = ldvec<T>(dz + (size_t)m0 * N + n), h0 = ldvec<T>(h + (size_t)m0 * N + n);
+      typename VT<T>::vec d0 = ldvec<T>(dz + (size_t)m0 * N + n), h0 = ldvec_stream<T>(h + (size_t)m0 * N + n, (nt & 2) != 0);
       typename VT<T>::vec d1 = vzero<T>(), h1 = vzero<T>();
       if (has1) {
         d1 = ldvec<T>(dz + (size_t)m1 * N + n);
-        h1 = ldvec<T>(h + (size_t)m1 * N + n);
+        h1 = ldvec_stream<T>(h + (size_t)m1 * N + n, (nt & 2) != 0);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void grn_gelu_bwd_kernel(T* __restrict__ dz, c
           cs[j] += o[j];
           cs[j + 1] += o[j + 1];
         }
-        stvec_stream(dz + (size_t)m * N + n, pack<T>(o), nt != 0);
+        stvec_stream(dz + (size_t)m * N + n, pack<T>(o), (nt & 1) != 0);
       }
     }
   }

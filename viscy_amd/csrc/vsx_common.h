@@ -141,6 +141,16 @@ __device__ __forceinline__ void stvec_stream(float* p, const float4& v, bool nt)
   else *reinterpret_cast<vsx_f32x4s*>(p) = w;
 }
 
+// 16-byte load of a line this launch is the last reader of (`nt`: global_load_dwordx4 ... nt)
+template <typename T>
+__device__ __forceinline__ typename VT<T>::vec ldvec_stream(const T* p, bool nt) {
+  if (!nt) return ldvec<T>(p);
+  const vsx_u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const vsx_u32x4*>(p));
+  typename VT<T>::vec v;
+  __builtin_memcpy(&v, &w, 16);
+  return v;
+}
+
 // ------------------------------------------------------------------ math
 // exact-erf GELU (nn.GELU default) and its derivative.  erf via Abramowitz-Stegun 7.1.26
 // (|abs err| <= 1.5e-7, below fp32 round-off of the surrounding arithmetic): one v_rcp, one v_exp
