@@ -634,6 +634,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
   for (int j = 0; j < VN; ++j) { r0[j] = 0.f; r1[j] = 0.f; }
   const size_t ccol = (size_t)p.c_coff[z] + n;
   const bool ntst = (EPI == VSX_EPI_BIAS_GELU_SQ || EPI == VSX_EPI_DZ) && (p.pro & 256) != 0;  // set by launch_nt_fast
+  const bool ntld = EPI == VSX_EPI_DZ && (p.pro & 512) != 0;  // the dZ epilogue is the last reader of the stored activation
 #pragma unroll 1
   for (int half = 0; half < NPASS; ++half) {
     __syncthreads();
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
             stvec_stream(reinterpret_cast<T*>(p.C2) + (size_t)m * p.ldc + ccol, pack<T>(gv), ntst);
           } else if constexpr (EPI == VSX_EPI_DZ) {
             float gf[VN];
-            unpack<T>(ldvec<T>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldx + n), gf);
+            unpack<T>(ldvec_stream<T>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldx + n, ntld), gf);
 #pragma unroll
             for (int j = 0; j < VN; ++j) {
               const float dz = round_to<T>(v[j]);
@@ -730,7 +731,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
 template <typename T, int EPI, bool PRO>
 static int launch_nt_fast(const VsxGemm* pin, hipStream_t s) {
   VsxGemm pq = *pin;
-  if (g_vsx_nt_stream) pq.pro |= 256;  // kernel-side flag bit (the prologue kind itself is a template parameter there)
+  if (g_vsx_nt_stream & 1) pq.pro |= 256;
+  if (g_vsx_nt_stream & 2) pq.pro |= 512;  // kernel-side flag bit (the prologue kind itself is a template parameter there)
   const VsxGemm* p = &pq;
   int tiles = vsx_cdiv(p->M, 128) * vsx_cdiv(p->N, 128);
   dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
