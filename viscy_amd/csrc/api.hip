@@ -11,12 +11,13 @@ int g_vsx_nt_wide = 1;
 int g_vsx_nt_fast = 1;
 int g_vsx_tn_wide = 1;
 int g_vsx_ggb_blocks = 2048;  // grn_gelu_bwd: target workgroup count (tuning knob, see norm.hip)
-int g_vsx_tn_rect = 1;  // TN: 256x128 / 128x256 output tiles when N or K of the weight gradient fits one 256-wide tile
+int g_vsx_tn_rect = 3;  // rectangular TN tiles: bit 0 = when N or K is 224..256 wide, bit 1 = 256x128 when 256 divides N (no prologue), bit 2 = 128x256 when 256 divides K (slower: off)
 int g_vsx_dw_rows2 = 0;  // depthwise 7x7: two output rows per thread — measured +3..8 % (fwd) / +18 % (dgrad) SLOWER: off
 int g_vsx_dw_wg16 = 1;   // depthwise weight gradient: 8x16-pixel tiles (35 KB of LDS, 4 workgroups / CU) instead of 8x32 (63 KB, 2)
 int g_vsx_nt_stream = 3;  // lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B)
 int g_vsx_grn_stream = 2;  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
 int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup instead of grid-strided rows
+int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x splits)
 int g_vsx_nt_tall = 0;  // 256x128 NT tiles: -5..-9 % on isolated wide-output launches, nothing on the whole step (measured) -> off
 
 void vsx_set_error(const char* fmt, ...) {
@@ -37,6 +38,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "nt_stream")) { g_vsx_nt_stream = value; return 0; }
   if (name && !strcmp(name, "grn_stream")) { g_vsx_grn_stream = value; return 0; }
   if (name && !strcmp(name, "ggb_contig")) { g_vsx_ggb_contig = value; return 0; }
+  if (name && !strcmp(name, "tn_want")) { g_vsx_tn_want = value; return 0; }
   if (name && !strcmp(name, "ggb_blocks")) { g_vsx_ggb_blocks = value; return 0; }
   if (name && !strcmp(name, "tn_rect")) { g_vsx_tn_rect = value; return 0; }
   if (name && !strcmp(name, "dw_rows2")) { g_vsx_dw_rows2 = value; return 0; }
@@ -53,6 +55,7 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "nt_stream")) return g_vsx_nt_stream;
   if (name && !strcmp(name, "grn_stream")) return g_vsx_grn_stream;
   if (name && !strcmp(name, "ggb_contig")) return g_vsx_ggb_contig;
+  if (name && !strcmp(name, "tn_want")) return g_vsx_tn_want;
   if (name && !strcmp(name, "ggb_blocks")) return g_vsx_ggb_blocks;
   if (name && !strcmp(name, "tn_rect")) return g_vsx_tn_rect;
   if (name && !strcmp(name, "dw_rows2")) return g_vsx_dw_rows2;

@@ -24,6 +24,7 @@ extern int g_vsx_nt_fast;
 extern int g_vsx_tn_wide;
 extern int g_vsx_nt_tall;
 extern int g_vsx_nt_stream;
+extern int g_vsx_tn_want;
 
 // ------------------------------------------------------------------------------------------------
 // operand gather: returns the 16-byte chunk holding A(m, k .. k+VN-1) after the prologue
@@ -1261,7 +1262,7 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
   int nz = p->nz > 0 ? p->nz : 1;
   // split the pixel (contraction) axis so that the launch fills 256 CUs, but keep the number of
   // same-address atomics (= splits) small: they serialise at ~0.2 us each
-  int want = vsx_cdiv(768, tiles * nz);
+  int want = vsx_cdiv(g_vsx_tn_want, tiles * nz);
   int max_splits = vsx_cdiv(p->M, 256);
   int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
   // few tiles (skinny weight matrices, e.g. the head's 8x32): the atomics spread over few addresses anyway,
@@ -1282,10 +1283,15 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
           // rectangular tiles when one side of the weight gradient fits a single 256-wide tile (see the kernel's header)
           // measured (tools/perf_nt.py, B = 512): C = 224 -9 % (dW1) / -14 % (dW2); C = 192 +4..8 % (a quarter of the
           // 256-wide tile idles) -> only when the tile is >= 7/8 full
-          const bool n_full = g_vsx_tn_rect && p->N >= 224 && p->N <= 256 && p->K >= 256;
-          const bool k_full = g_vsx_tn_rect && !n_full && p->K >= 224 && p->K <= 256 && p->N >= 256;
+          // bit 1: 256x128 tiles also when 256 divides N exactly and there is no prologue (dW1 of the C = 192 / 384 / 768
+          // stages: -5..-11 % on those launches); bit 2 (off): the mirrored 128x256 tiles for the GRN-prologue operand —
+          // measured 1.7..2x SLOWER (twice the prologue work per workgroup at 2 workgroups per CU)
+          const bool n_div = (g_vsx_tn_rect & 2) && p->N % 256 == 0 && p->K >= 128 && p->pro == VSX_PRO_NONE;
+          const bool k_div = (g_vsx_tn_rect & 4) && !n_div && p->K % 256 == 0 && p->N >= 128;
+          const bool n_full = ((g_vsx_tn_rect & 1) && p->N >= 224 && p->N <= 256 && p->K >= 256) || n_div;
+          const bool k_full = ((g_vsx_tn_rect & 1) && !n_full && p->K >= 224 && p->K <= 256 && p->N >= 256) || (k_div && !n_full);
           if (n_full || k_full) {
-            const int t2 = n_full ? vsx_cdiv(p->K, 128) : vsx_cdiv(p->N, 128);
+            const int t2 = n_full ? vsx_cdiv(p->N, 256) * vsx_cdiv(p->K, 128) : vsx_cdiv(p->N, 128) * vsx_cdiv(p->K, 256);
             int want2 = vsx_cdiv(512, t2 * nz), sp2 = want2 < 1 ? 1 : (want2 > max_splits ? max_splits : want2);
             if (sp2 > p->M / 128) sp2 = p->M / 128;
             if (sp2 >= 8) sp2 &= ~7;
