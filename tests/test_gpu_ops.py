@@ -323,7 +323,8 @@ def test_head_conv_direct_bf16(B, gh, gw):
 @pytest.mark.parametrize("tr", [1, 0], ids=["tr_read", "scalar_read"])
 @pytest.mark.parametrize("M,N,K", [(512, 160, 40), (1000, 96, 384), (70, 8, 32), (9000, 384, 96), (4100, 768, 3072),
                                    (4096, 384, 128), (8192, 224, 896), (2048, 96, 384),  # lean (M % 64 == 0): 64-row steps
-                                   (8192, 896, 224), (4096, 256, 520), (4096, 520, 232)])  # rectangular 256x128 / 128x256 tiles
+                                   (8192, 896, 224), (4096, 256, 520), (4096, 520, 232),  # rectangular 256x128 / 128x256 tiles
+                                   (4096, 512, 384), (8192, 768, 192)])  # 256x128 tiles, several of them along N
 def test_gemm_tn(dt, tr, M, N, K):
     from viscy_amd import _lib
 
