@@ -6,13 +6,14 @@
 #include "../../include/vsx.h"
 extern int g_vsx_grn_stream;
 extern int g_vsx_ggb_contig;
+extern int g_vsx_ln_stream;
 
 // ------------------------------------------------------------------ LayerNorm forward
 template <typename T, int G, int CPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     int rows, int C, float eps, int iters) {
+                                                     int rows, int C, float eps, int iters, int nt) {
   // A lane group owns R rows per block and requests all of them before the first reduction: one row per group
   // (first version) meant one 16-byte load in flight per lane and 6 KB blocks -> 2.2 TB/s.
   constexpr int VN = VT<T>::N;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
     for (int i = 0; i < CPL; ++i) {
       const int c = gl + i * G;
       if (c < nch) {
-        unpack<T>(ldvec<T>(xr + c * VN), v[r][i]);
+        unpack<T>(ldvec_stream<T>(xr + c * VN, nt != 0), v[r][i]);
       } else {
 #pragma unroll
         for (int j = 0; j < VN; ++j) v[r][i][j] = 0.f;
@@ -105,8 +106,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* __restrict__ add,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows, int C, int iters) {
+                                                     float* __restrict__ dbeta, int rows, int C, int iters, int nt) {
   constexpr int VN = VT<T>::N;
+  const bool g_nt = nt != 0;  // dy and x have no later reader: stream them past the caches
   extern __shared__ float red[];  // [2][C] when dgamma != nullptr
   const int nch = C / VN;
   const int gl = threadIdx.x % G;
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       for (int i = 0; i < CPL; ++i) {
         const int c = gl + i * G;
         if (c < nch) {
-          xr[r][i] = ldvec<T>(x + ro + c * VN);
-          dr[r][i] = ldvec<T>(dy + ro + c * VN);
+          xr[r][i] = ldvec_stream<T>(x + ro + c * VN, g_nt);
+          dr[r][i] = ldvec_stream<T>(dy + ro + c * VN, g_nt);
           if (add) ar[r][i] = ldvec<T>(add + ro + c * VN);
         }
       }
@@ -228,7 +230,7 @@ static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float*
     int iters = vsx_cdiv(rows, RPI * R * 2048);           // <= 2048 workgroups, each sweeping `iters` windows
     if (iters < 1) iters = 1;
     hipLaunchKernelGGL((ln_fwd_kernel<T, G, CPL>), dim3(vsx_cdiv(rows, RPI * R * iters)), dim3(256), 0, s, (const T*)a0,
-                       (T*)out, mean, rstd, gamma, beta, rows, C, eps, iters);
+                       (T*)out, mean, rstd, gamma, beta, rows, C, eps, iters, g_vsx_ln_stream & 2);
   } else {
     int iters = vsx_cdiv(rows, RPI * 512);  // <= 512 blocks → <= 512 same-address atomics on dgamma / dbeta
     if (iters < 1) iters = 1;
@@ -236,7 +238,7 @@ static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float*
     size_t sh = dgamma ? 2 * (size_t)C * sizeof(float) : 0;
     hipLaunchKernelGGL((ln_bwd_kernel<T, G, CPL>), dim3(grid), dim3(256), sh, s, (const T*)a0, (const T*)a1,
                        (const float*)mean, (const float*)rstd, gamma, (const T*)add, (T*)out, dgamma, dbeta, rows, C,
-                       iters);
+                       iters, g_vsx_ln_stream & 1);
   }
   VSX_LAUNCH_CHECK();
   return 0;
