@@ -19,6 +19,7 @@ int g_vsx_grn_stream = 2;  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no
 int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup instead of grid-strided rows
 int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x splits)
 int g_vsx_ln_stream = 3;  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
+int g_vsx_tn_contig = 1;  // lean TN kernel: contiguous step range per split
 int g_vsx_nt_tall = 0;  // 256x128 NT tiles: -5..-9 % on isolated wide-output launches, nothing on the whole step (measured) -> off
 
 void vsx_set_error(const char* fmt, ...) {
@@ -40,6 +41,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "grn_stream")) { g_vsx_grn_stream = value; return 0; }
   if (name && !strcmp(name, "ggb_contig")) { g_vsx_ggb_contig = value; return 0; }
   if (name && !strcmp(name, "tn_want")) { g_vsx_tn_want = value; return 0; }
+  if (name && !strcmp(name, "tn_contig")) { g_vsx_tn_contig = value; return 0; }
   if (name && !strcmp(name, "ln_stream")) { g_vsx_ln_stream = value; return 0; }
   if (name && !strcmp(name, "ggb_blocks")) { g_vsx_ggb_blocks = value; return 0; }
   if (name && !strcmp(name, "tn_rect")) { g_vsx_tn_rect = value; return 0; }
@@ -58,6 +60,7 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "grn_stream")) return g_vsx_grn_stream;
   if (name && !strcmp(name, "ggb_contig")) return g_vsx_ggb_contig;
   if (name && !strcmp(name, "tn_want")) return g_vsx_tn_want;
+  if (name && !strcmp(name, "tn_contig")) return g_vsx_tn_contig;
   if (name && !strcmp(name, "ln_stream")) return g_vsx_ln_stream;
   if (name && !strcmp(name, "ggb_blocks")) return g_vsx_ggb_blocks;
   if (name && !strcmp(name, "tn_rect")) return g_vsx_tn_rect;

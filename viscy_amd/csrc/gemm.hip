@@ -25,6 +25,7 @@ extern int g_vsx_tn_wide;
 extern int g_vsx_nt_tall;
 extern int g_vsx_nt_stream;
 extern int g_vsx_tn_want;
+extern int g_vsx_tn_contig;
 
 // ------------------------------------------------------------------------------------------------
 // operand gather: returns the 16-byte chunk holding A(m, k .. k+VN-1) after the prologue
@@ -1198,7 +1199,14 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
   float csum = 0.f;
   const bool do_colsum = p.colsum != nullptr && tile_k == 0 && tid < BTN;
 
-  const int nsteps = (total_steps - by + nsplit - 1) / nsplit;
+  // steps of this split: interleaved with the other splits (by, by + nsplit, ...) or, with bit 10 of p.pro set by the
+  // launcher, one contiguous range — the GRN prologue then reloads s[b, k..] once per hw / BMS steps instead of on every
+  // step (a split stride of nsplit * BMS rows crosses a sample boundary each time on the small feature maps)
+  const bool contig = (p.pro & 1024) != 0;
+  const int sq = total_steps / nsplit, sr = total_steps % nsplit;
+  const int sbase = by * sq + (by < sr ? by : sr);
+  const int nsteps = contig ? sq + (by < sr ? 1 : 0) : (total_steps - by + nsplit - 1) / nsplit;
+  auto step_of = [&](int st) { return contig ? sbase + st : st * nsplit + by; };
   auto mma_step = [&](const char* Xs, const char* Ys) {
 #pragma unroll
     for (int kk = 0; kk < BMS / MK; ++kk) {
@@ -1220,12 +1228,12 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
       for (int r = 0; r < BMS; ++r) csum += to_f32<T>(*reinterpret_cast<const T*>(Xs + r * LDBX + tid * ES));
     }
   };
-  load_tiles(by, xreg, yreg);
+  load_tiles(step_of(0), xreg, yreg);
   if constexpr (NBUF == 2) {
-    store_tiles(by, 0, xreg, yreg);
+    store_tiles(step_of(0), 0, xreg, yreg);
     __syncthreads();
     for (int st = 0; st < nsteps; ++st) {
-      const int nxt = (st + 1) * nsplit + by;
+      const int nxt = step_of(st + 1);
       if (st + 1 < nsteps) load_tiles(nxt, xreg, yreg);
       const char* Xs = smem + (st & 1) * (TILE_X + TILE_Y);
       mma_step(Xs, Xs + TILE_X);
@@ -1234,9 +1242,9 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
     }
   } else {
     for (int st = 0; st < nsteps; ++st) {
-      store_tiles(st * nsplit + by, 0, xreg, yreg);
+      store_tiles(step_of(st), 0, xreg, yreg);
       __syncthreads();
-      if (st + 1 < nsteps) load_tiles((st + 1) * nsplit + by, xreg, yreg);
+      if (st + 1 < nsteps) load_tiles(step_of(st + 1), xreg, yreg);
       mma_step(smem, smem + TILE_X);
       __syncthreads();
     }
@@ -1277,6 +1285,8 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
                     (p->pro == VSX_PRO_NONE || (p->pro == VSX_PRO_GRN && p->hw > 0 && p->hw % 32 == 0)) &&
                     (unsigned long long)32 * (p->lda > p->ldb ? p->lda : p->ldb) * sizeof(T) < (1ull << 31);
   if (fast) {
+    VsxGemm pq = *p;
+    if (g_vsx_tn_contig) pq.pro |= 1024;  // kernel-side flag bit (the prologue kind is a template parameter there)
     if constexpr (sizeof(T) == 2 && BT == 128) {
       if (g_vsx_tn_wide && p->M % 64 == 0 && (p->pro == VSX_PRO_NONE || p->hw % 64 == 0) && p->M / 64 >= 2 * splits) {
         if constexpr (TR) {
@@ -1299,31 +1309,31 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
             dim3 g2(t2, sp2, nz);
             if (n_full) {
               if (p->pro == VSX_PRO_GRN)
-                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, true, 64, 1, 128>), g2, dim3(256), 0, s, *p);
+                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, true, 64, 1, 128>), g2, dim3(256), 0, s, pq);
               else
-                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, false, 64, 1, 128>), g2, dim3(256), 0, s, *p);
+                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, false, 64, 1, 128>), g2, dim3(256), 0, s, pq);
             } else {
               if (p->pro == VSX_PRO_GRN)
-                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 128, TR, true, 64, 1, 256>), g2, dim3(256), 0, s, *p);
+                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 128, TR, true, 64, 1, 256>), g2, dim3(256), 0, s, pq);
               else
-                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 128, TR, false, 64, 1, 256>), g2, dim3(256), 0, s, *p);
+                hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 128, TR, false, 64, 1, 256>), g2, dim3(256), 0, s, pq);
             }
             VSX_LAUNCH_CHECK();
             return 0;
           }
         }
         if (p->pro == VSX_PRO_GRN)
-          hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, true, 64, 1>), grid, dim3(256), 0, s, *p);
+          hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, true, 64, 1>), grid, dim3(256), 0, s, pq);
         else
-          hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, false, 64, 1>), grid, dim3(256), 0, s, *p);
+          hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, false, 64, 1>), grid, dim3(256), 0, s, pq);
         VSX_LAUNCH_CHECK();
         return 0;
       }
     }
     if (p->pro == VSX_PRO_GRN)
-      hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, true>), grid, dim3(256), 0, s, *p);
+      hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, true>), grid, dim3(256), 0, s, pq);
     else
-      hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, false>), grid, dim3(256), 0, s, *p);
+      hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, false>), grid, dim3(256), 0, s, pq);
     VSX_LAUNCH_CHECK();
     return 0;
   }
