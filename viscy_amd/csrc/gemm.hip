@@ -532,10 +532,6 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
   const float* grn_s = PRO ? p.grn_s + (size_t)b_tile * p.K : nullptr;
 
   vec ar[NA], br[NB];
-  // GRN prologue operands of the slab in flight: every chunk of this thread covers the same VN columns (256 % CPR == 0), so
-  // s[b, k..] / beta[k..] are fetched once per slab TOGETHER with the operand chunks (they used to be loaded inside lstore,
-  // i.e. with their full latency on the staging path between two barriers)
-  float4 gsr[VN / 4], gbr[VN / 4];
   auto gload = [&](int kt, vec* ar, vec* br) {
     const char* Ak = Abase + (size_t)kt * (BK * ES);
     const char* Bk = Bbase + (size_t)kt * (BK * ES);
@@ -543,14 +539,6 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
     for (int i = 0; i < NA; ++i) ar[i] = *reinterpret_cast<const vec*>(Ak + offA[i]);
 #pragma unroll
     for (int i = 0; i < NB; ++i) br[i] = *reinterpret_cast<const vec*>(Bk + offB[i]);
-    if constexpr (PRO) {
-      const int k = kt * BK + (tid % CPR) * VN;
-#pragma unroll
-      for (int j = 0; j < VN; j += 4) {
-        gsr[j / 4] = *reinterpret_cast<const float4*>(grn_s + k + j);
-        gbr[j / 4] = *reinterpret_cast<const float4*>(p.grn_b + k + j);
-      }
-    }
   };
   auto lstore = [&](int kt, int buf, const vec* ar, const vec* br) {
     char* S = smem + buf * STAGE;
@@ -558,12 +546,13 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
     for (int i = 0; i < NA; ++i) {
       vec v = ar[i];
       if constexpr (PRO) {  // a = g * s[b, k] + beta[k]
+        const int k = kt * BK + ((tid + i * 256) % CPR) * VN;
         float f[VN];
         unpack<T>(v, f);
 #pragma unroll
         for (int j = 0; j < VN; j += 4) {
-          const float4 sv = gsr[j / 4];
-          const float4 bv = gbr[j / 4];
+          const float4 sv = *reinterpret_cast<const float4*>(grn_s + k + j);
+          const float4 bv = *reinterpret_cast<const float4*>(p.grn_b + k + j);
           f[j] = fmaf(f[j], sv.x, bv.x); f[j + 1] = fmaf(f[j + 1], sv.y, bv.y);
           f[j + 2] = fmaf(f[j + 2], sv.z, bv.z); f[j + 3] = fmaf(f[j + 3], sv.w, bv.w);
         }

@@ -132,12 +132,12 @@ typedef uint32_t vsx_u32x4 __attribute__((ext_vector_type(4)));
 typedef float vsx_f32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void stvec_stream(bf16_t* p, const uint4& v, bool nt) {
   const vsx_u32x4 w = {v.x, v.y, v.z, v.w};
-  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(w) : "memory");
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");  // s_nop 1: the store reads its 4 data registers over two more cycles; hipcc does not pad after inline asm
   else *reinterpret_cast<vsx_u32x4*>(p) = w;
 }
 __device__ __forceinline__ void stvec_stream(float* p, const float4& v, bool nt) {
   const vsx_f32x4s w = {v.x, v.y, v.z, v.w};
-  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(w) : "memory");
+  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");  // s_nop 1: the store reads its 4 data registers over two more cycles; hipcc does not pad after inline asm
   else *reinterpret_cast<vsx_f32x4s*>(p) = w;
 }
 
