@@ -14,11 +14,11 @@ int g_vsx_ggb_blocks = 2048;  // grn_gelu_bwd: target workgroup count (tuning kn
 int g_vsx_tn_rect = 3;  // rectangular TN tiles: bit 0 = when N or K is 224..256 wide, bit 1 = 256x128 when 256 divides N (no prologue), bit 2 = 128x256 when 256 divides K (slower: off)
 int g_vsx_dw_rows2 = 0;  // depthwise 7x7: two output rows per thread — measured +3..8 % (fwd) / +18 % (dgrad) SLOWER: off
 int g_vsx_dw_wg16 = 1;   // depthwise weight gradient: 8x16-pixel tiles (35 KB of LDS, 4 workgroups / CU) instead of 8x32 (63 KB, 2)
-int g_vsx_nt_stream = 3;  // lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B)
-int g_vsx_grn_stream = 2;  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
+int g_vsx_nt_stream = 0;  // OFF (rare NaN in long runs not yet explained; measured gains below are with the value 3) —  // lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B)
+int g_vsx_grn_stream = 0;  // OFF (as nt_stream; measured with the value 2) —  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
 int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup instead of grid-strided rows
 int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x splits)
-int g_vsx_ln_stream = 3;  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
+int g_vsx_ln_stream = 0;  // OFF (as nt_stream; measured with the value 3) —  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
 int g_vsx_tn_contig = 1;  // lean TN kernel: contiguous step range per split
 int g_vsx_nt_tall = 0;  // 256x128 NT tiles: -5..-9 % on isolated wide-output launches, nothing on the whole step (measured) -> off
 

@@ -314,6 +314,11 @@ __global__ __launch_bounds__(256) void head_out_bwd1_wgrad_kernel(const bf16_t* 
   }
 }
 
+__global__ __launch_bounds__(256) void head_zero_kernel(float* __restrict__ p, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 // dW[i] += Σ_r dwp[r][i] (i < NWgt), db[i - NWgt] += ... for the remaining columns.  Block = 64 columns x 4 row slots over a
 // 64-row slab (same structure as norm.hip's reduce_rows; kept local to this TU)
 __global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* __restrict__ dwp, float* __restrict__ dW,
@@ -458,7 +463,9 @@ extern "C" int32_t vsx_head_out_bwd1_wgrad(const void* U, const float* ssum, con
   dim3 grid(vsx_cdiv(nvox, 256L * vpt), B);
   const int co4 = 4 * Cout, NW = co4 * Cmid + co4;
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(scratch, 0, (size_t)B * NW * sizeof(float), st);
+  // zero-fill by an ordinary kernel node (not hipMemsetAsync: keeps the captured training step free of memset nodes)
+  hipLaunchKernelGGL(head_zero_kernel, dim3(vsx_cdiv((long)B * NW, 256L)), dim3(256), 0, st, scratch, (long)B * NW);
+  VSX_LAUNCH_CHECK();
 #define HEAD_WG(CM, C4)                                                                                                   \
   hipLaunchKernelGGL((head_out_bwd1_wgrad_kernel<CM, C4>), grid, dim3(256), 0, st, (const bf16_t*)U, ssum, ssq, w2, alpha, \
                      dout, (bf16_t*)dv, S1, S2, dalpha, scratch, d, eps, (int)vpt)
