@@ -349,6 +349,7 @@ def main():
                 "hbm_frac_of_algorithmic_floor": round(value * ALGO_MB_PER_PATCH * scale * 1e6 / (world * HBM_PEAK_GBS * 1e9), 4),
                 "mfma_frac": round(value * 3 * FWD_GFLOP_PER_PATCH * scale * 1e9 / (world * MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
                 "final_loss": round(float(loss.item()), 5), "first_loss": round(float(l0.item()), 5),
+                "loss_finite": bool(torch.isfinite(loss).item()),  # a non-finite loss invalidates the line
                 "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 1e9, 1),
             },
             "roofline": roof,
@@ -357,6 +358,9 @@ def main():
                     "frac_hbm_peak": round(B / fwd_s * FWD_MB_PER_PATCH * scale * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
                     "tflops": round(B / fwd_s * FWD_GFLOP_PER_PATCH * scale / 1e3, 1)},
         }
+        if not res["whole_path"]["loss_finite"]:
+            print("bench.py: WARNING: the training loss is not finite after the timed steps — this measurement is INVALID",
+                  file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only (the other ranks would idle)
             res["cpu_baseline"] = cpu_baseline()
     if world > 1 or args.force_dp:
