@@ -273,6 +273,13 @@ int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, const float* t
 int32_t vsx_adamw(float* p, const float* g, float* m, float* v, const float* hyper, int64_t n,
     vsx_stream_t stream);
 
+/* Device-side half of the optimiser schedule (viscy_utils/optimizers.py:50-61: AdamW + MONAI WarmupCosineSchedule stepped per
+ * batch): reads cfg = {base_lr, beta1, beta2, eps, weight_decay, grad_scale, schedule (0 constant | 1 warm-up cosine),
+ * warmup_steps, t_total, warmup_multiplier, cycles} and the int32 step counter, writes the 8 scalars vsx_adamw reads for
+ * THIS step and increments the counter.  No host memory is touched: a captured step replays correctly however far the
+ * host runs ahead. */
+int32_t vsx_adamw_advance(const float* cfg, int32_t* step, float* hyper, vsx_stream_t stream);
+
 /* fp32 parameter viewed as [R, Cs, Tn] (out, in, taps) → GEMM operand dst [R, Tn*Cs] and/or dstT [Tn*Cs, R] in `dtype`, optionally scaled per
  * input channel by gamma (LayerNorm fold).  tapmode 1 = head Conv3d tap order (kz,ky,kx) → (ky,kx,kz). */
 int32_t vsx_prep_weight(const float* src, void* dst, void* dstT, const float* gamma, int32_t R, int32_t Cs,

@@ -367,6 +367,23 @@ def adamw(p, g, m, v, hyper):
     p.addcdiv_(m, v.sqrt() / (bc2**0.5) + eps, value=-lr / bc1)
 
 
+def adamw_advance(cfg, step, hyper):
+    import math
+
+    c = [float(t) for t in cfg.tolist()]
+    t0 = int(step.item())
+    lam = 1.0
+    if c[6] > 0.5:
+        warm, total, mult, cycles = c[7], c[8], c[9], c[10]
+        if t0 < warm:
+            lam = mult + (1 - mult) * (t0 / max(1.0, warm))
+        else:
+            lam = max(0.0, 0.5 * (1.0 + math.cos(math.pi * cycles * 2.0 * ((t0 - warm) / max(1.0, total - warm)))))
+    t = t0 + 1
+    hyper.copy_(torch.tensor([c[0] * lam, c[1], c[2], c[3], c[4], 1 - c[1] ** t, 1 - c[2] ** t, c[5]], dtype=torch.float32))
+    step.fill_(t)
+
+
 def head_conv_supported(H2, W2, c3, cmid, zo, dtype) -> bool:
     """the direct LDS-tiled head convolution exists only as a HIP kernel; the schedule falls back to the z-batched
     implicit GEMMs, which this backend states"""

@@ -72,6 +72,7 @@ _SIGS = {
     "vsx_ssim_scale_bwd": (_I32, [_P] * 7 + [_I32] * 5 + [_F32, _F32, _P, _I32, _P]),
     "vsx_loss_finalize": (_I32, [_P] * 5 + [_F32, _I32, _I32, _F32, _F32, _F32, _P, _P, _P, _P, _P]),
     "vsx_adamw": (_I32, [_P, _P, _P, _P, _P, _I64, _P]),
+    "vsx_adamw_advance": (_I32, [_P, _P, _P, _P]),
     "vsx_prep_weight": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_unprep_grad": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_matvec": (_I32, [_P, _P, _P, _P, _I32, _I32, _P]),

@@ -63,6 +63,47 @@ extern "C" int32_t vsx_adamw(float* p, const float* g, float* m, float* v, const
   return 0;
 }
 
+// ------------------------------------------------------------------ schedule + bias corrections on the device
+// One thread turns (constants, step counter) into the 8 per-step scalars the AdamW launch reads and advances the
+// counter.  The first version refreshed those scalars from a pinned host block with an asynchronous copy inside the
+// captured step: the copy reads the block when the GPU gets there, the host — many replays ahead of a 140 ms step — had
+// already overwritten it with a later step's lr / bias corrections (optim.py race).  Now nothing that changes
+// per step lives on the host: a hipGraph replay is a pure function of device state.
+// cfg: {base_lr, beta1, beta2, eps, weight_decay, grad_scale, schedule (0 constant | 1 MONAI WarmupCosine),
+//       warmup_steps, t_total, warmup_multiplier, cycles}
+__global__ void adamw_advance_kernel(const float* __restrict__ cfg, int* __restrict__ step, float* __restrict__ hyper) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int t0 = *step;  // optimiser steps taken so far = index of this step in the LambdaLR schedule
+  const double b1 = cfg[1], b2 = cfg[2];
+  double lam = 1.0;
+  if (cfg[6] > 0.5f) {
+    const double warm = cfg[7], total = cfg[8], mult = cfg[9], cycles = cfg[10];
+    if ((double)t0 < warm) {
+      lam = mult + (1.0 - mult) * ((double)t0 / fmax(1.0, warm));
+    } else {
+      const double progress = ((double)t0 - warm) / fmax(1.0, total - warm);
+      lam = fmax(0.0, 0.5 * (1.0 + cos(3.14159265358979323846 * cycles * 2.0 * progress)));
+    }
+  }
+  const int t = t0 + 1;
+  hyper[0] = (float)((double)cfg[0] * lam);
+  hyper[1] = cfg[1];
+  hyper[2] = cfg[2];
+  hyper[3] = cfg[3];
+  hyper[4] = cfg[4];
+  hyper[5] = (float)(1.0 - pow(b1, (double)t));
+  hyper[6] = (float)(1.0 - pow(b2, (double)t));
+  hyper[7] = cfg[5];
+  *step = t;
+}
+
+extern "C" int32_t vsx_adamw_advance(const float* cfg, int32_t* step, float* hyper, vsx_stream_t stream) {
+  VSX_CHECK(cfg && step && hyper, "vsx_adamw_advance: bad arguments");
+  hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cfg, step, hyper);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------ weight preparation
 // tap order of the GEMM K axis: k = t_dst * Cs + c.  tapmode 0: t_dst = t_src; tapmode 1 (head
 // Conv3d [.., kz, ky, kx] → (ky, kx, kz)): t_src = (kz*3 + ky)*3 + kx, t_dst = (ky*3 + kx)*3 + kz.

@@ -102,6 +102,7 @@ class Engine:
         self.order, self.offsets, self.numel = order, offs, total
         self.bucket_bounds = self._bucket_bounds()
         self.on_bucket_ready = None  # callable(bucket_index) set by viscy_amd.parallel
+        self._pending_bwd = 0        # forwards of the current step whose backward has not run yet
         self._prepared_for = None
         self.W = None
 
@@ -401,7 +402,11 @@ class Engine:
         h, w = H // ky, Wd // kx
         dims = cfg["dims"]
         C0 = dims[0]
-        sv = {"shape": (B, H, Wd), "dt": dt, "masked": masks is not None} if need_bwd else None
+        # the prepared operands travel with the forward that used them: a later (no_grad / other dtype) forward re-prepares
+        # self.W, and the backward of THIS forward must still see its own transposed weights
+        sv = {"shape": (B, H, Wd), "dt": dt, "masked": masks is not None, "W": W} if need_bwd else None
+        if need_bwd:
+            self._pending_bwd += 1
         # ---- stem: patch gather + projection GEMM, then encoder stem_1 LayerNorm2d
         P = o.stem_im2col(x.contiguous(), (kz, ky, kx), dt)
         M0, K0 = B * h * w, P.shape[1]
@@ -549,7 +554,7 @@ class Engine:
         return emb, y4
 
     def _embed_tail_bwd(self, sv, demb, dproj, dt, B):
-        o, m, W, g = self.ops, self.model, self.W, self.g
+        o, m, W, g = self.ops, self.model, sv["W"], self.g
         pooled, mean, rstd, emb, z0, y1, sm1, sr1, z3, y4, sm4, sr4, training, fh, fw, fc = sv["tail"]
         t = m.tail
         E, P = t.fc0.weight.shape[0], t.fc3.weight.shape[0]
@@ -572,7 +577,7 @@ class Engine:
 
     def _head_conv_bwd(self, sv, dout, dt, B, dev):
         """PixelToVoxelHead backward; returns the gradient of the decoder feature map."""
-        o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, self.W
+        o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, sv["W"]
         Zo, D7 = cfg["out_stack_depth"], cfg["out_stack_depth"] + 2
         hc = m.head.conv[0].conv
         cmid, c3 = hc.weight.shape[0], hc.weight.shape[1]
@@ -622,8 +627,21 @@ class Engine:
     # ------------------------------------------------------------------ backward
     def backward(self, sv, dout: Tensor) -> None:
         """Accumulates parameter gradients into the flat gradient buffer (no input gradient:
-        the image stack never requires grad on this path)."""
-        o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, self.W
+        the image stack never requires grad on this path).  ``on_bucket_ready(i)`` fires as bucket i completes — but only
+        during the LAST outstanding backward of the step: with several forwards per step (CombinedLoader batches, DynaCLR
+        with unpaired forwards) an earlier backward leaves buckets that later ones still accumulate into."""
+        last = self._pending_bwd <= 1
+        self._pending_bwd = max(self._pending_bwd - 1, 0)
+        for i in self.backward_stages(sv, dout):
+            if last and self.on_bucket_ready:
+                self.on_bucket_ready(i)
+
+    def backward_stages(self, sv, dout: Tensor):
+        """Generator form of the backward schedule: yields the bucket index (0 = head + decoder, 1 = encoder stages 3-2,
+        2 = stages 1-0 + stem) right after the last launch that writes into that bucket of the flat gradient buffer.
+        ``viscy_amd.step.TrainStep`` captures the stretch between two yields as one hipGraph segment and issues the
+        bucket's RCCL all-reduce between the segments."""
+        o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, sv["W"]
         dt = sv["dt"]
         B, H, Wd = sv["shape"]
         dev = self.device
@@ -658,13 +676,11 @@ class Engine:
             del dxn
             d, dskips[2 - k] = o.pixel_shuffle_cat_bwd(dcat, B, sh // 2, sw_ // 2, c_up, sc)
             del dcat
-        if self.on_bucket_ready:
-            self.on_bucket_ready(0)
+        yield 0
         if self.encoder_frozen():  # nothing below the decoder needs a gradient: skip ~40 % of the backward
             self._za_need[za_key] = za.used
-            if self.on_bucket_ready:
-                self.on_bucket_ready(1)
-                self.on_bucket_ready(2)
+            yield 1
+            yield 2
             return
         # ---- encoder (reverse); d = gradient w.r.t. feats[3]
         for i in (3, 2, 1, 0):
@@ -687,8 +703,8 @@ class Engine:
                 d = o.ln_bwd(dxn, prev, mean, rstd, proj.ln.weight, dskips.get(i - 1), g(proj.ln.weight), g(proj.ln.bias),
                              B * 4 * ch * cw, cin)
                 del dxn
-            if i == 2 and self.on_bucket_ready:
-                self.on_bucket_ready(1)
+            if i == 2:
+                yield 1
         # ---- stem_1 LayerNorm + stem projection
         P, f, mean, rstd = sv["stem"]
         ln1 = m.encoder_stages.stem_1
@@ -707,8 +723,7 @@ class Engine:
             g(m.stem.conv.weight).add_(torch.stack([dWe[:, dd, dd] for dd in range(Dp)], 0).sum(0).view_as(m.stem.conv.weight))
             g(m.stem.conv.bias).add_(dbe.view(co3, Dp).sum(1))
         self._za_need[za_key] = za.used
-        if self.on_bucket_ready:
-            self.on_bucket_ready(2)
+        yield 2
 
 
 # ------------------------------------------------------------------------------------------------

@@ -287,6 +287,13 @@ def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor) -> None:
     check(lib().vsx_adamw(ptr(p), ptr(g), ptr(m), ptr(v), ptr(hyper), p.numel(), stream()), "adamw")
 
 
+def adamw_advance(cfg: Tensor, step: Tensor, hyper: Tensor) -> None:
+    """schedule / bias corrections of the next optimiser step from device state (csrc/optim.hip): no host memory involved"""
+    if step.dtype != torch.int32:
+        raise TypeError("the optimiser step counter is int32")
+    check(lib().vsx_adamw_advance(ptr(cfg), ptr(step), ptr(hyper), stream()), "adamw_advance")
+
+
 # ------------------------------------------------------------------ direct head convolution (csrc/headconv.hip)
 def head_conv_supported(H2: int, W2: int, c3: int, cmid: int, zo: int, dtype: torch.dtype) -> bool:
     return bool(lib().vsx_head_conv_supported(H2, W2, c3, cmid, zo, dtype_code(dtype)))

@@ -6,6 +6,12 @@ Mirrors ``viscy_utils.optimizers.configure_adamw_scheduler``
 ``WarmupCosineSchedule(warmup_steps, t_total, warmup_multiplier)`` stepped per batch
 (λ(step) = m + (1-m)·step/max(1,warmup) during warm-up, then max(0, ½(1+cos(π·progress)))).
 The update itself is ONE fused HIP launch over the flat fp32 buffers (csrc/optim.hip).
+
+Everything that changes from step to step — the schedule position, the learning rate, Adam's bias corrections — is
+DEVICE state: an int32 step counter and an 8-float block that ``vsx_adamw_advance`` (one thread) recomputes right
+before the AdamW launch.  The host keeps a mirror of the counter for logging / checkpoints only.  (Round 1 refreshed
+the block from a pinned host buffer with an asynchronous copy; the host runs many hipGraph replays ahead of a 140 ms
+step, so a step could apply a later step's learning rate.  No per-step host → device traffic is left.)
 """
 
 from __future__ import annotations
@@ -42,10 +48,18 @@ class FlatAdamW:
         self.n_active = engine.trainable_numel() if hasattr(engine, "trainable_numel") else engine.flat.numel()
         self.m = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.n_active, dtype=torch.float32, device=dev)
-        self.t = 0
+        self.t = 0                 # host mirror of the device step counter (logging, checkpoints)
         self.grad_scale = 1.0
-        self._hyper_host = torch.zeros(8, dtype=torch.float32, pin_memory=dev.type == "cuda")
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cfg_dev = torch.zeros(16, dtype=torch.float32, device=dev)
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._cfg_sent = None
+
+    def _cfg(self):
+        b1, b2 = self.betas
+        return (float(self.base_lr), float(b1), float(b2), float(self.eps), float(self.wd), float(self.grad_scale),
+                1.0 if self.schedule == "WarmupCosine" else 0.0, float(self.warmup_steps), float(self.t_total),
+                float(self.warmup_multiplier), 0.5)
 
     def current_lr(self) -> float:
         if self.schedule == "WarmupCosine":
@@ -54,25 +68,33 @@ class FlatAdamW:
 
     def zero_grad(self) -> None:
         self.engine.flat_grad.zero_()
+        if hasattr(self.engine, "_pending_bwd"):
+            self.engine._pending_bwd = 0  # a new step: no forward of it is waiting for its backward yet
 
     def host_prepare(self) -> None:
-        """host half of a step: advance the schedule and refresh the pinned hyper-parameter block"""
-        lr = self.current_lr()
+        """host half of a step: advance the mirror counter; upload the schedule CONSTANTS if one of them was changed since
+        the last step (a blocking copy from pageable memory — rare, and never while a capture is open)"""
+        cfg = self._cfg()
+        if cfg != self._cfg_sent:
+            if torch.cuda.is_available() and self.cfg_dev.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FlatAdamW: optimiser constants changed inside a hipGraph capture")
+            self.cfg_dev[: len(cfg)].copy_(torch.tensor(cfg, dtype=torch.float32))
+            self._cfg_sent = cfg
         self.t += 1
-        b1, b2 = self.betas
-        h = self._hyper_host
-        h[0], h[1], h[2], h[3], h[4] = lr, b1, b2, self.eps, self.wd
-        h[5], h[6], h[7] = 1 - b1**self.t, 1 - b2**self.t, self.grad_scale
 
     def device_step(self) -> None:
-        """device half (hipGraph-capturable): pinned → device copy of the 8 scalars + ONE fused AdamW launch"""
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        """device half (hipGraph-capturable): schedule / bias corrections from the device counter + ONE fused AdamW launch"""
         n = self.n_active
+        self.ops.adamw_advance(self.cfg_dev, self.step_dev, self.hyper)
         self.ops.adamw(self.engine.flat[:n], self.engine.flat_grad[:n], self.m, self.v, self.hyper)
 
     def step(self) -> None:
         self.host_prepare()
         self.device_step()
+
+    def set_step(self, t: int) -> None:
+        self.t = int(t)
+        self.step_dev.fill_(int(t))
 
     def state_dict(self):
         return {"m": self.m, "v": self.v, "t": self.t}
@@ -80,4 +102,4 @@ class FlatAdamW:
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
-        self.t = int(sd["t"])
+        self.set_step(int(sd["t"]))

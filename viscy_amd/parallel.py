@@ -24,6 +24,7 @@ class FlatDataParallel:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.works = []
+        self._reduced = set()
         self.active = self.world > 1 or (force and dist.is_initialized())
         if self.active:
             if broadcast:  # DDP-style: rank 0's parameters win
@@ -33,14 +34,29 @@ class FlatDataParallel:
                 optimizer.grad_scale = 1.0 / self.world
 
     def _bucket_ready(self, i: int) -> None:
+        self.reduce_bucket(i)
+
+    def reduce_bucket(self, i: int) -> None:
+        """async all-reduce (SUM) of bucket i of the flat gradient buffer; RCCL runs it on its own stream behind everything
+        queued on the current stream so far, i.e. it overlaps whatever the caller launches next"""
+        if not self.active or i in self._reduced:
+            return
         lo, hi = self.engine.bucket_bounds[i]
+        self._reduced.add(i)
         self.works.append(dist.all_reduce(self.engine.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self) -> None:
-        """call after backward, before the optimizer step"""
+        """call after backward, before the optimizer step: reduces every bucket the backward hooks did not (a step with
+        several forwards fires the hooks only in its last backward; a step whose last backward never ran fires none),
+        then waits for all of them"""
+        if self.active:
+            for i in range(len(self.engine.bucket_bounds)):
+                self.reduce_bucket(i)
         for w in self.works:
             w.wait()
         self.works.clear()
+        self._reduced.clear()
+        self.engine._pending_bwd = 0
 
     def all_reduce_mean(self, t: torch.Tensor) -> torch.Tensor:
         """``self.log(..., sync_dist=True)`` equivalent for scalars (engine.py:294-303 of the reference)."""

@@ -6,11 +6,12 @@ the path is launched on the caller's stream with caller-owned buffers (include/v
 step — zero-grad, forward, MixedLoss, backward, AdamW — can be captured once into a hipGraph
 (``torch.cuda.CUDAGraph`` is the capture/replay plumbing) and replayed with ONE launch per step.
 Shapes must stay fixed between replays (the data loader's batch is copied into the static input
-buffers); hyper-parameters that change per step (lr schedule, Adam bias corrections) live in a
-pinned host buffer that is refreshed before every replay.
+buffers); what changes per step (lr schedule position, Adam bias corrections) is device state
+advanced by a kernel inside the step (viscy_amd/optim.py) — a replay reads no host memory.
 
-With world_size > 1 the graph holds forward + backward; the RCCL all-reduce of the flat gradient
-buffer and the fused AdamW launch run eagerly behind it (collectives stay outside the capture).
+With world_size > 1 the step is captured in segments that end where a gradient bucket completes; the
+bucket's RCCL all-reduce is issued between two replays and overlaps the next segment (collectives
+stay outside the captures).
 """
 
 from __future__ import annotations
@@ -19,70 +20,170 @@ import torch
 
 
 class TrainStep:
-    def __init__(self, model, criterion, optimizer, ddp=None, use_graph: bool = True, loss_fn=None):
-        """``loss_fn(x, t) -> scalar loss`` replaces ``criterion(model(x), t)`` for steps of another shape (DynaCLR: two
-        forwards + NT-Xent on (anchor, positive); FCMAE pre-training: masked forward + MaskedMSELoss with ``t`` unused).
-        Everything it launches must be capturable: device-side randomness only, no host synchronisation."""
+    """``step(x, t) -> loss`` = zero-grad, forward, loss, backward, gradient all-reduce (if data parallel), AdamW.
+
+    Two drivers:
+      * *direct* (``criterion`` given, the UNeXt2 / FCMAE supervised step): the engine's forward and its staged backward
+        (``Engine.backward_stages``) are called straight from here, the loss gradient comes from the criterion's own
+        backward.  The backward pauses after each gradient bucket, so with data parallelism the step is captured as
+        THREE hipGraph segments (… bucket 0 | bucket 1 | bucket 2) plus one for AdamW, and each bucket's RCCL all-reduce is
+        issued between two replays: it runs on RCCL's stream underneath the next segment, exactly like the eager hooks
+        (reference: DDP's bucketed overlap, ``recipes/topology/ddp_4gpu.yml``).  Collectives themselves stay outside the
+        captures.
+      * *autograd* (``loss_fn(x, t) -> loss``: DynaCLR's two forwards + NT-Xent, FCMAE masked pre-training): one
+        ``loss.backward()``, captured whole; with data parallelism the flat gradient buffer is reduced behind the graph.
+
+    Capturing runs two warm-up steps (allocator / workspace sizing); parameters, Adam moments, the step counter and the
+    module buffers are restored afterwards, so N calls are exactly N optimisation steps in every mode."""
+
+    def __init__(self, model, criterion, optimizer, ddp=None, use_graph: bool = True, loss_fn=None, segments: bool | None = None):
         self.model, self.crit, self.opt, self.ddp = model, criterion, optimizer, ddp
         self.loss_fn = loss_fn
         self.use_graph = use_graph
-        self.graph = None
+        self.graphs = None
+        self.gopt = None
         self.x = self.t = self.loss = None
         self.world = ddp.world if ddp is not None else 1
         self.dist = bool(ddp is not None and getattr(ddp, "active", self.world > 1))  # collectives outside the graph
+        from .unext2 import UNeXt2
 
-    # ---- the captured body
+        # the direct driver needs the plain `model(x) -> prediction` form with the engine right behind it
+        self.direct = loss_fn is None and isinstance(model, UNeXt2)
+        if loss_fn is None and not self.direct:
+            self.loss_fn = lambda x, t: criterion(model(x), t)
+        self.segments = (self.dist and self.direct) if segments is None else (bool(segments) and self.direct)
+
+    # ---- direct driver
+    def _loss_and_grad(self, pred):
+        from .losses import MixedLoss, _MixedLossFn
+
+        if isinstance(self.crit, MixedLoss):  # the criterion's kernels, without an autograd graph around them
+            class _Ctx:
+                pass
+
+            ctx = _Ctx()
+            loss = _MixedLossFn.forward(ctx, pred, self.t, float(self.crit.l1_alpha), float(self.crit.l2_alpha),
+                                        float(self.crit.ms_dssim_alpha))
+            one = torch.ones((), dtype=torch.float32, device=pred.device)
+            return loss, _MixedLossFn.backward(ctx, one)[0]
+        p = pred.detach().requires_grad_(True)
+        with torch.enable_grad():
+            loss = self.crit(p, self.t)
+        (dout,) = torch.autograd.grad(loss, p)
+        return loss.detach(), dout
+
+    def _direct_stages(self):
+        """generator: runs the step up to the end of gradient bucket i, yields i"""
+        eng = self.model.engine()
+        self.opt.zero_grad()
+        with torch.no_grad(), torch.autocast("cuda", enabled=False):
+            out, sv = eng.forward(self.x.float(), self.model._resolve_dtype(), True)
+            eng._pending_bwd = 0  # this driver runs the backward itself
+            loss, dout = self._loss_and_grad(out)
+            self.loss = loss.detach()
+            del out
+            for i in eng.backward_stages(sv, dout):
+                yield i
+
+    # ---- autograd driver
     def _fwd_bwd(self):
         self.opt.zero_grad()
-        loss = self.loss_fn(self.x, self.t) if self.loss_fn is not None else self.crit(self.model(self.x), self.t)
+        loss = self.loss_fn(self.x, self.t)
         loss.backward()
         return loss.detach()
 
+    def _eager(self, collectives: bool = True):
+        if self.direct:
+            for i in self._direct_stages():
+                if collectives and self.ddp is not None:
+                    self.ddp.reduce_bucket(i)
+        else:
+            self.loss = self._fwd_bwd()
+        if collectives and self.ddp is not None:
+            self.ddp.finish()
+
+    def _state(self):
+        eng = self.model.engine()
+        return [eng.flat, self.opt.m, self.opt.v, self.opt.step_dev] + [b for b in self.model.buffers()]
+
     def _capture(self):
         eng = self.model.engine()
+        eng.attach_grads()
         hook = eng.on_bucket_ready
-        eng.on_bucket_ready = None  # collectives are issued outside the capture
+        eng.on_bucket_ready = None  # collectives are issued outside the captures
+        state = self._state()
+        saved = [t.clone() for t in state]
+        t_host = self.opt.t
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):  # warm-up on a side stream (allocator / workspace sizing)
+        with torch.cuda.stream(s):  # warm-up on a side stream (allocator / workspace sizing); its updates are undone below
             for _ in range(2):
                 self.opt.host_prepare()
-                self._fwd_bwd()
-                if not self.dist:
-                    self.opt.device_step()
+                self._eager(collectives=False)
+                self.opt.device_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
         self.opt.host_prepare()
-        with torch.cuda.graph(g):
-            self.loss = self._fwd_bwd()
-            if not self.dist:
-                self.opt.device_step()
-        self.opt.t -= 1  # the capture pass records but does not execute: it is not an optimisation step
-        self.graph = g
+        graphs, pool = [], None
+
+        def capture(body):
+            nonlocal pool
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                body()
+            pool = g.pool()
+            graphs.append(g)
+
+        if self.direct and self.segments:
+            it = self._direct_stages()
+            for _ in range(len(eng.bucket_bounds)):
+                capture(lambda: next(it))
+            for _ in it:  # (exhausts the generator: nothing is launched after the last bucket)
+                raise RuntimeError("backward_stages launched work after the last gradient bucket")
+        elif self.direct:
+            capture(lambda: [None for _ in self._direct_stages()])
+        else:
+            def body():
+                self.loss = self._fwd_bwd()
+
+            capture(body)
+        gopt = torch.cuda.CUDAGraph()  # its own graph: with data parallelism it runs after the last bucket's all-reduce
+        with torch.cuda.graph(gopt, pool=pool):
+            self.opt.device_step()
+        self.gopt = gopt
+        # the warm-up steps (and nothing else: a capture records, it does not execute) changed the training state
+        with torch.no_grad():
+            for t, c in zip(state, saved):
+                t.copy_(c)
+        self.opt.t = t_host
+        self.graphs = graphs
         eng.on_bucket_ready = hook
 
     def __call__(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
         if not self.use_graph:
             self.x, self.t = x, t
-            loss = self._fwd_bwd()
-            if self.ddp is not None:
-                self.ddp.finish()
-            self.opt.step()
-            return loss
-        if self.graph is None:
+            self.opt.host_prepare()
+            self._eager()
+            self.opt.device_step()
+            return self.loss
+        if self.graphs is None:
             self.x, self.t = x.clone(), t.clone()
             self._capture()
         if x.data_ptr() != self.x.data_ptr():
             self.x.copy_(x, non_blocking=True)
             self.t.copy_(t, non_blocking=True)
         self.opt.host_prepare()
-        self.graph.replay()
-        if self.dist:
-            import torch.distributed as dist
-
-            dist.all_reduce(self.model.engine().flat_grad, op=dist.ReduceOp.SUM, group=self.ddp.pg)
-            self.opt.device_step()
+        if self.dist and self.segments:
+            for i, g in enumerate(self.graphs):
+                g.replay()
+                self.ddp.reduce_bucket(i)  # async on RCCL's stream: overlaps the next segment
+            self.ddp.finish()
+        else:
+            for g in self.graphs:
+                g.replay()
+            if self.dist:
+                self.ddp.finish()  # reduces all buckets behind the graph
+        self.gopt.replay()
         return self.loss
 
 

@@ -177,15 +177,16 @@ class _Head(_Holder):
 
 
 def _icnr_(weight: Tensor, scale: int) -> None:
-    """ICNR init (reference components/blocks.py:14-51) for a 2-D upsample of factor `scale`."""
+    """ICNR initialisation for a 2-D pixel shuffle of factor ``scale`` (what the reference's ``icnr_init`` produces,
+    components/blocks.py:14-51): draw ``out / scale²`` Kaiming-normal kernels and give each of them to the ``scale²``
+    consecutive output channels that one shuffled output channel is assembled from, so the up-sampling starts as
+    nearest-neighbour (no checkerboard).  (The reference reaches the same structure through a transpose / reshape / repeat
+    chain on an i.i.d. tensor; the distribution and the group structure are what matter — tests/test_dp_cpu.py.)"""
+    sf = scale * scale
     oc, ic, *dims = weight.shape
-    sf = scale**2
-    oc2 = oc // sf
-    k = nn.init.kaiming_normal_(torch.zeros([oc2, ic] + dims))
-    k = k.transpose(0, 1).reshape(oc2, ic, -1).repeat(1, 1, sf)
-    k = k.reshape([ic, oc] + dims).transpose(0, 1)
+    base = nn.init.kaiming_normal_(torch.empty([oc // sf, ic] + dims))
     with torch.no_grad():
-        weight.copy_(k)
+        weight.copy_(base.repeat_interleave(sf, dim=0))
 
 
 # ------------------------------------------------------------------------------------------------

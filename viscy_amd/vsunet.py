@@ -48,16 +48,18 @@ def _divisible_pad_amounts(shape_yx: Sequence[int], k: int) -> list[tuple[int, i
 
 
 def _center_crop_to_shape(tensor: Tensor, spatial_shape: Sequence[int]) -> Tensor:
-    """engine.py:61-71."""
-    slices = [slice(None)] * tensor.ndim
-    start_dim = tensor.ndim - len(spatial_shape)
-    for dim, size in enumerate(spatial_shape, start=start_dim):
-        current = tensor.shape[dim]
-        if current < size:
-            raise ValueError(f"Cannot crop dimension {dim} from {current} to {size}")
-        start = (current - size) // 2
-        slices[dim] = slice(start, start + size)
-    return tensor[tuple(slices)]
+    """Undo the symmetric DivisiblePad: keep the centred window of the trailing ``len(spatial_shape)`` axes (window start =
+    floor of half the surplus — the same convention as the reference's helper, engine.py:61-71)."""
+    out = tensor
+    first = tensor.ndim - len(spatial_shape)
+    for k, want in enumerate(spatial_shape):
+        axis = first + k
+        have = out.shape[axis]
+        if have < want:
+            raise ValueError(f"Cannot crop dimension {axis} from {have} to {want}")
+        if have != want:
+            out = out.narrow(axis, (have - want) // 2, want)
+    return out
 
 
 def blend_in(old_stack: Tensor, new_stack: Tensor, z_slice: slice) -> Tensor:
@@ -136,7 +138,13 @@ class VSUNet(_Base):
         if _HAVE_LIGHTNING:  # pragma: no cover
             self.log(key, value, **kw)
         else:
-            self.logged.setdefault(key, []).append(value.detach())
+            value = value.detach()
+            if kw.get("sync_dist") and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                    and torch.distributed.get_world_size() > 1:
+                value = value.clone()
+                torch.distributed.all_reduce(value, op=torch.distributed.ReduceOp.SUM)  # Lightning sync_dist: mean over ranks
+                value = value / torch.distributed.get_world_size()
+            self.logged.setdefault(key, []).append(value)
 
     def forward(self, x: Tensor) -> Tensor:
         return self.model(x)
@@ -169,6 +177,34 @@ class VSUNet(_Base):
             self.validation_losses.append([])
         self.validation_losses[dataloader_idx].append(loss.detach())
         self._log(f"loss/val/{dataloader_idx}", loss, sync_dist=True, batch_size=batch["source"].shape[0])
+
+    def test_step(self, batch, batch_idx: int):
+        """Test stage of the reference (engine.py:334-372): the centre Z slice of the first channel of prediction and target
+        is scored with MAE, MSE, cosine similarity (along X, averaged), Pearson r and R² over all pixels, logged per batch
+        as ``test_metrics/<name>`` together with ``position`` / ``time`` / ``slice`` of the first sample.  Not built: the
+        torchmetrics SSIM entry and the Cellpose segmentation metrics (third-party models, outside the hot path).  The
+        metric arithmetic is plain tensor code on the forward result (no kernel of the path)."""
+        target = batch["target"]
+        zc = target.shape[-3] // 2
+        t = target[:, 0, zc:zc + 1].float()
+        p = self.forward(batch["source"])[:, 0, zc:zc + 1].float()
+        pf, tf = p.flatten(), t.flatten()
+        pc, tc = pf - pf.mean(), tf - tf.mean()
+        mets = {
+            "test_metrics/MAE": (pf - tf).abs().mean(),
+            "test_metrics/MSE": ((pf - tf) ** 2).mean(),
+            "test_metrics/cosine": torch.nn.functional.cosine_similarity(p, t, dim=-1).mean(),
+            "test_metrics/pearson": (pc * tc).sum() / (pc.norm() * tc.norm()).clamp_min(1e-20),
+            "test_metrics/r2": 1 - ((pf - tf) ** 2).sum() / (tc ** 2).sum().clamp_min(1e-20),
+        }
+        for k, v in mets.items():
+            self._log(k, v, on_step=True, on_epoch=True)
+        if "index" in batch:
+            names, ts, zs = batch["index"]
+            where = {"position": float(names[0].split("/")[-2]), "time": float(ts[0]), "slice": float(zs[0])}
+            for k, v in where.items():
+                self._log(k, torch.tensor(v), on_step=True, on_epoch=False)
+        return mets
 
     def on_validation_epoch_end(self):
         loss_means = [torch.stack(l).mean() for l in self.validation_losses]
@@ -230,20 +266,19 @@ class VSUNet(_Base):
         """Z sliding-window inference with linear feathering (engine.py:760-805)."""
         if x.ndim != 5:
             raise ValueError(f"Expected input with 5 dimensions (B, C, Z, Y, X), got {x.shape}")
-        batch_size, _, depth, height, width = x.shape
-        in_stack_depth = getattr(self.model, "out_stack_depth", None)
-        if in_stack_depth is None:
+        window = getattr(self.model, "out_stack_depth", None)
+        if window is None:
             raise ValueError(f"Model {type(self.model).__name__} does not support sliding window prediction "
                              "(missing out_stack_depth attribute).")
-        if in_stack_depth > depth:
-            raise ValueError(f"in_stack_depth {in_stack_depth} > input depth {depth}")
-        out_tensor = x.new_zeros((batch_size, out_channel, depth, height, width))
-        for start in range(0, depth - in_stack_depth + 1, step):
-            end = start + in_stack_depth
-            pred = self.predict_step({"source": x[:, :, start:end].contiguous()}, 0)
-            z_slice = slice(start, end)
-            out_tensor[:, :, z_slice] = blend_in(out_tensor[:, :, z_slice], pred, z_slice)
-        return out_tensor
+        nz = x.shape[2]
+        if window > nz:
+            raise ValueError(f"in_stack_depth {window} > input depth {nz}")
+        result = x.new_zeros((x.shape[0], out_channel, nz, *x.shape[3:]))
+        for z0 in range(0, nz - window + 1, step):
+            zs = slice(z0, z0 + window)
+            pred = self.predict_step({"source": x[:, :, zs].contiguous()}, 0)
+            result[:, :, zs] = blend_in(result[:, :, zs], pred, zs)
+        return result
 
     # ---- optimiser (viscy_utils/optimizers.py:10-62)
     def configure_optimizers(self, t_total: int | None = None):
@@ -289,11 +324,11 @@ class FcmaeUNet(VSUNet):
             self._load_encoder_weights(ckpt_path)
 
     def _load_encoder_weights(self, ckpt_path: str) -> None:
-        """engine.py:855-868"""
-        state_dict = torch.load(ckpt_path, weights_only=True, map_location="cpu")["state_dict"]
-        prefix = "model.encoder."
-        encoder_weights = {k.removeprefix(prefix): v for k, v in state_dict.items() if k.startswith(prefix)}
-        self.model.encoder.load_state_dict(encoder_weights, strict=True)
+        """``encoder_only=True``: of a pre-trained Lightning checkpoint only the ``model.encoder.*`` entries are loaded, strictly
+        (reference behaviour: engine.py:855-868)"""
+        full = torch.load(ckpt_path, weights_only=True, map_location="cpu")["state_dict"]
+        tag = "model.encoder."
+        self.model.encoder.load_state_dict({name[len(tag):]: w for name, w in full.items() if name.startswith(tag)}, strict=True)
 
     def on_fit_start(self):
         from .losses import MaskedMSELoss
@@ -337,28 +372,26 @@ class FcmaeUNet(VSUNet):
 
     @staticmethod
     def _merge_batches(batch):
-        """engine.py:966-1004: concatenate the per-dataset batches a combined loader yields into one ``Sample``."""
+        """A combined loader hands over one ``Sample`` per dataset; they become ONE sample along the batch axis (reference
+        behaviour: engine.py:966-1004).  Tensors are concatenated; the ``index`` tuple is merged member by member (tensors
+        concatenated, FOV-name lists chained); anything else (e.g. ``norm_meta``) is taken from the first dataset."""
         if not isinstance(batch, list):
             return batch
-        combined = {}
-        for key in batch[0]:
-            vals = [b[key] for b in batch if key in b]
-            if isinstance(vals[0], Tensor):
-                combined[key] = torch.cat(vals, dim=0)
-            elif isinstance(vals[0], tuple):
-                merged = []
-                for i in range(len(vals[0])):
-                    elems = [v[i] for v in vals]
-                    if isinstance(elems[0], Tensor):
-                        merged.append(torch.cat(elems, dim=0))
-                    elif isinstance(elems[0], list):
-                        merged.append([x for sub in elems for x in sub])
-                    else:
-                        merged.append(elems[0])
-                combined[key] = tuple(merged)
-            else:
-                combined[key] = vals[0]
-        return combined
+
+        def join(items):
+            head = items[0]
+            if isinstance(head, Tensor):
+                return torch.cat(items, dim=0)
+            if isinstance(head, list):
+                return [e for it in items for e in it]
+            return head
+
+        out = {}
+        for key, head in batch[0].items():
+            items = [b[key] for b in batch if key in b]
+            out[key] = tuple(join(list(member)) for member in zip(*items)) if isinstance(head, tuple) else join(items) \
+                if isinstance(head, Tensor) else head
+        return out
 
     def training_step(self, batch, batch_idx: int):
         batch = self._merge_batches(batch)
