@@ -5,7 +5,8 @@ Workload (BASELINE.json configs[1]): UNeXt2 2.5D (convnextv2_tiny, Z=5, 256x256,
 2 decoder blocks/stage) bf16 training on synthetic patches; one "step" = forward + MixedLoss(0.5, 0, 0.5)
 + backward + AdamW on one batch, all in hand-written HIP kernels.  Inputs are resident in HBM before
 the timed region.  N > 1: one process per GPU (torch.distributed.run), batch sharded (weak scaling),
-RCCL all-reduce of the flat gradient buffer overlapped with backward.
+RCCL all-reduce of the flat gradient buffer in three buckets: the step is captured as hipGraph segments that end where a
+bucket completes, and each bucket's all-reduce is issued between two replays, under the next segment (viscy_amd/step.py).
 
 Prints ONE JSON line (rank 0) with the contract fields + "roofline" (dominant kernel class, timed
 live with HIP events on the launch stream inside the timed region) + "cpu_baseline" (the oracle —
@@ -31,6 +32,38 @@ FWD_MB_PER_PATCH = 75.5  # forward "two-pass floor" 
 ALGO_MB_PER_PATCH = 226.5    # fwd+bwd two-pass-GRN floor, bf16 activations
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def source_hash() -> str:
+    """identity of the kernel sources this process runs (sha256 over viscy_amd/csrc/* and include/vsx.h): profiles and
+    PMC traffic files carry it, and a file measured on other sources is refused"""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(os.path.join("viscy_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "viscy_amd", "csrc"))) + [os.path.join("include", "vsx.h")]
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_info() -> dict:
+    """git SHA recorded by viscy_amd.build at build time (the GPU box has no .git), source hash, and every kernel flag"""
+    from viscy_amd import _lib
+
+    info = {"git_sha": None, "git_dirty": None}
+    try:
+        info.update(json.load(open(os.path.join(ROOT, "viscy_amd", "_build", "build_info.json"))))
+    except (OSError, ValueError):
+        pass
+    info["source_hash"] = source_hash()
+    l = _lib.lib()
+    info["flags"] = {n: int(l.vsx_get_flag(n.encode())) for n in FLAG_NAMES}
+    return info
+
+
+FLAG_NAMES = ["tn_tr", "nt_wide", "nt_fast", "tn_wide", "nt_tall", "nt_stream", "grn_stream", "ggb_contig", "tn_want", "tn_contig",
+              "ln_stream", "ggb_blocks", "tn_rect", "dw_rows2", "dw_wg16", "mlp_fused"]
 
 
 def make_batch(B, H, W, device, seed=42):
@@ -74,7 +107,7 @@ class OpTimer:
 
     def _wrap(self, name, fn):
         def wrapped(*a, **k):
-            cls, flops, nbytes = name, 0.0, None
+            cls, flops, nbytes, strict = name, 0.0, None, None
             if name == "gemm":
                 kind, M, N, K = a[0], a[4], a[5], a[6]
                 nz = k.get("nz", 1)
@@ -82,11 +115,16 @@ class OpTimer:
                 cls = f"gemm_{kind}" if not self.by_shape else f"gemm_{kind} M{M} N{N} K{K} z{nz} e{k.get('epi', 0)} p{k.get('pro', 0)} a{k.get('a_mode', 0)}"
                 flops = 2.0 * M * N * K * nz
                 nbytes = (M * K + M * N) * es * nz + N * K * (es if kind == "nt" else 4)
+                strict = nbytes
                 if kind == "nt":
                     # operands of the fused epilogues are part of the launch's algorithmic traffic: the second output of
                     # fc1 (g = gelu(h)), the activation the dZ epilogue reads for the GRN statistics, the residual of fc2
                     extra = sum(k.get(name) is not None for name in ("C2", "aux", "res")) - (a[3] is None)
                     nbytes += extra * M * N * es * nz
+            elif name in ("mlp_stats", "mlp_out"):  # fused GRN-MLP: M = a[-3], C = a[-2]
+                Mm, Cc = a[-3], a[-2]
+                flops = 2.0 * Mm * 4 * Cc * Cc * (2 if name == "mlp_out" else 1)
+                nbytes = Mm * Cc * 2 * (3 if name == "mlp_out" else 1) + 16 * Cc * Cc
             if self.only is not None and cls != self.only:
                 return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -95,7 +133,7 @@ class OpTimer:
             e1.record()
             if nbytes is None:
                 nbytes = self._bytes(list(a) + list(k.values()), out)
-            self.records.setdefault(cls, []).append((e0, e1, flops, nbytes))
+            self.records.setdefault(cls, []).append((e0, e1, flops, nbytes, strict if strict is not None else nbytes))
             return out
 
         return wrapped
@@ -116,9 +154,44 @@ class OpTimer:
         torch.cuda.synchronize()
         out = {}
         for cls, recs in self.records.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in recs)
-            out[cls] = {"launches": len(recs), "ms": ms, "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs)}
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            out[cls] = {"launches": len(recs), "ms": ms, "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs),
+                        "strict_bytes": sum(r[4] for r in recs)}
         return out
+
+
+def gate_shape_record(dev, steps: int = 5, B: int = 8, size: int = 2048) -> dict:
+    """training step at the north star's gate shape (B = 8 per GPU, Z = 5, 2048 x 2048, bf16): ms / step and both roofline
+    fractions priced with SURVEY §8(d)'s per-sample figures (x64 the 256^2 patch: 4.83 GB two-pass floor, 1.444 TFLOP fwd)"""
+    from viscy_amd.losses import MixedLoss
+    from viscy_amd.optim import FlatAdamW
+    from viscy_amd.step import TrainStep
+    from viscy_amd.unext2 import UNeXt2
+
+    torch.manual_seed(42)
+    model = UNeXt2(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True,
+                   head_expansion_ratio=4, decoder_conv_blocks=2).to(dev)
+    nonzero_grn_(model)
+    model.compute_dtype, model.grad_mode = torch.bfloat16, "flat"
+    opt = FlatAdamW(model.engine(), lr=2e-4, schedule="WarmupCosine", warmup_steps=3, t_total=steps + 4, warmup_multiplier=1e-3)
+    x, tgt = make_batch(B, size, size, dev, seed=7)
+    step = TrainStep(model, MixedLoss(0.5, 0.0, 0.5), opt, None, use_graph=True)
+    l0 = step(x, tgt)
+    step(x, tgt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(x, tgt)
+    torch.cuda.synchronize()
+    dt_s = (time.perf_counter() - t0) / steps
+    scale = (size / 256.0) ** 2
+    sps = B / dt_s
+    return {"workload": f"UNeXt2 tiny Z=5 {size}x{size} 1->2ch, B={B}, fwd+MixedLoss+bwd+AdamW (hipGraph)", "steps": steps,
+            "ms_per_step": round(dt_s * 1e3, 3), "stacks_per_s": round(sps, 2), "patch_equivalents_per_s": round(sps * scale, 1),
+            "hbm_frac_of_algorithmic_floor": round(sps * ALGO_MB_PER_PATCH * scale * 1e6 / (HBM_PEAK_GBS * 1e9), 4),
+            "mfma_frac": round(sps * 3 * FWD_GFLOP_PER_PATCH * scale * 1e9 / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
+            "first_loss": round(float(l0), 5), "final_loss": round(float(loss), 5), "loss_finite": bool(torch.isfinite(loss).item()),
+            "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 1e9, 1)}
 
 
 def _cpu_baseline_child():
@@ -179,6 +252,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gate", action="store_true", help="skip the (B=8, 2048^2) gate-shape sub-record")
+    ap.add_argument("--gate-steps", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured step")
     ap.add_argument("--profile-ops", action="store_true", help="print the per-op-class event-timing table to stderr")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel collective path even with one rank (RCCL smoke test on a single GPU)")
@@ -297,6 +372,23 @@ def main():
         elapsed = tt.item()
     dom = tm.summary().get(dominant) if dominant else None
 
+    binfo = build_info()
+    gate, peak_main = None, None
+    if rank == 0 and world == 1 and args.size == 256 and args.dtype == "bf16" and not args.no_gate:
+        # the north star's roofline gate shape, driver-timed in the same run: (B = 8, Z = 5, 2048 x 2048) training step.
+        # The headline model / graph / batch are released first (both workloads need ~166 GB of the 288 GB).
+        loss_keep = loss.detach().clone()
+        peak_main = torch.cuda.max_memory_reserved()
+        del graphed, eager, infer, tm, loss, step
+        model._engine = None
+        opt = ddp = eng = None
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        gate = gate_shape_record(dev, steps=args.gate_steps)
+        loss = loss_keep
     if rank == 0:
         patches = world * B * args.steps
         value = patches / elapsed
@@ -315,19 +407,25 @@ def main():
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 5),
                         "launches": dom["launches"]}
-        if roof is not None:
+        if roof is not None and dom:
+            roof["strict_frac"] = round(dom["strict_bytes"] / dom["launches"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)  # operands + ONE output only
             # HBM traffic of the dominant kernel class: PMC counters cannot be read from inside this process, so the
-            # figure comes from the committed rocprofv3 --pmc passes of the SAME configuration
-            # (scripts/pmc_traffic.sh -> profiles/r01_pmc_traffic_b<batch>.json: FETCH_SIZE / WRITE_SIZE in separate
-            # passes, calibrated on a launch with a known byte count as MI355X_MICROARCH.md prescribes)
-            tf_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_pmc_traffic_b{B}.json")
+            # figure comes from the committed rocprofv3 --pmc passes of the SAME configuration (scripts/pmc_traffic.sh ->
+            # profiles/r02_pmc_traffic_b<batch>.json: FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a launch with
+            # a known byte count as MI355X_MICROARCH.md prescribes).  The file records the kernel-source hash and the flag
+            # set it was measured with; a file from other sources / flags is refused (traffic stays null).
+            tf_path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_b{B}.json")
             if args.size == 256 and args.dtype == "bf16" and os.path.exists(tf_path):
                 try:
-                    cls = json.load(open(tf_path)).get("classes", {}).get(dominant)
-                    if cls:
+                    tfj = json.load(open(tf_path))
+                    same = tfj.get("source_hash") == binfo["source_hash"] and tfj.get("flags") == binfo["flags"]
+                    cls = tfj.get("classes", {}).get(dominant)
+                    if cls and same:
                         roof["traffic"] = round(cls["traffic_bytes_per_launch"])
                         roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / dom["launches"])
-                        roof["traffic_source"] = os.path.relpath(tf_path, os.path.dirname(os.path.abspath(__file__)))
+                        roof["traffic_source"] = os.path.relpath(tf_path, ROOT)
+                    elif cls:
+                        roof["traffic_refused"] = "profiles file was measured on other kernel sources / flags"
                 except (OSError, ValueError, KeyError):
                     pass
         res = {
@@ -350,9 +448,11 @@ def main():
                 "mfma_frac": round(value * 3 * FWD_GFLOP_PER_PATCH * scale * 1e9 / (world * MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
                 "final_loss": round(float(loss.item()), 5), "first_loss": round(float(l0.item()), 5),
                 "loss_finite": bool(torch.isfinite(loss).item()),  # a non-finite loss invalidates the line
-                "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 1e9, 1),
+                "peak_hbm_gb": round((peak_main if peak_main is not None else torch.cuda.max_memory_reserved()) / 1e9, 1),
             },
             "roofline": roof,
+            "gate_shape": gate,
+            "build": binfo,
             "fwd": {"ms_per_pass": round(fwd_s * 1e3, 3), "patches_per_s_per_gpu": round(B / fwd_s, 1),
                     "algorithmic_hbm_GBps": round(B / fwd_s * FWD_MB_PER_PATCH * scale / 1e3, 1),
                     "frac_hbm_peak": round(B / fwd_s * FWD_MB_PER_PATCH * scale * 1e6 / (HBM_PEAK_GBS * 1e9), 4),

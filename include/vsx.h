@@ -273,6 +273,24 @@ int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, const float* t
 int32_t vsx_adamw(float* p, const float* g, float* m, float* v, const float* hyper, int64_t n,
     vsx_stream_t stream);
 
+/* Fused GRN-MLP of a ConvNeXt-V2 block (timm ConvNeXtBlock as called from viscy_models/unet/unext2.py:79; math restated at
+ * viscy_models/unet/fcmae.py:174-221), bf16: the 4C-wide hidden activation never leaves the CU (csrc/mlp.hip).
+ *   vsx_mlp_supported : 1 when a fused instantiation exists for (C, pixels per sample hw, rows M, dtype)
+ *   vsx_mlp_image_bytes / vsx_mlp_pack : fragment-major LDS image of the prepared weights W1' [4C, C] (LayerNorm affine folded)
+ *                       and W2 [C, 4C] (both bf16, row-major as vsx_prep_weight writes them)
+ *   vsx_mlp_fwd mode 0: colsq[b, 4C] += sum_hw gelu(fc1(xh))^2   (GRN statistics; nothing else is stored)
+ *               mode 1: out = res + rscale[b] * (fc2(gelu(fc1(xh)) * s[b] + beta) + b2) */
+int32_t vsx_mlp_supported(int32_t C, int32_t hw, int64_t M, int32_t dtype);
+int64_t vsx_mlp_image_bytes(int32_t C);
+int32_t vsx_mlp_pack(const void* W1, const void* W2, void* img, int32_t C, vsx_stream_t stream);
+int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1, const float* grn_s, const float* grn_b, const float* b2,
+    const void* res, const float* rscale, void* out, float* colsq, const float* gelu_table, int64_t M, int32_t C, int32_t hw,
+    int32_t mode, int32_t dtype, vsx_stream_t stream);
+/* GELU of a bf16 value through a table (csrc/mlp.hip): vsx_mlp_gelu_table fills `tab` (vsx_mlp_gelu_table_len() floats) with
+ * a * Phi(-a) for every bf16 magnitude a in [2^-24, 16); gelu(h) = max(h, 0) - tab[bits(|h|)]. */
+int32_t vsx_mlp_gelu_table_len(void);
+int32_t vsx_mlp_gelu_table(float* tab, vsx_stream_t stream);
+
 /* Device-side half of the optimiser schedule (viscy_utils/optimizers.py:50-61: AdamW + MONAI WarmupCosineSchedule stepped per
  * batch): reads cfg = {base_lr, beta1, beta2, eps, weight_decay, grad_scale, schedule (0 constant | 1 warm-up cosine),
  * warmup_steps, t_total, warmup_multiplier, cycles} and the int32 step counter, writes the 8 scalars vsx_adamw reads for

@@ -175,31 +175,107 @@ def g3_normalize():
     factors = t._broadcast_factors.reshape(6) - 1.0
     assert torch.equal(y, transforms_ref.scale_intensity(x, factors)) and (factors == 0).any() and (factors != 0).any()
     g4 = {"scale": {"x": x, "factors": factors, "y": y}}
-    try:
-        rn = _load("viscy_transforms._noise", f"{REF}/viscy-transforms/src/viscy_transforms/_noise.py")
-        tn = rn.BatchedRandGaussianNoise(prob=0.6, mean=0.0, std=0.3)
-        torch.manual_seed(12)
-        yn = tn(x.clone())
-        apply = tn._do_transform.clone()
-        # the reference draws ONE N(0,1) field for the whole batch and scales it per selected sample
-        std = torch.zeros(6)
-        field = torch.zeros(x.shape[1:])
-        if apply.any():
-            nb = tn.noise_batch  # expanded view of (mean + field * std_b)
-            first = int(torch.where(apply)[0][0])
-            diff = (yn - x)[apply]
-            # recover field * std_b per selected sample; std_b = ratio to the first selected sample's field scale
-            base = diff[0]
-            scale = (diff.reshape(diff.shape[0], -1) * base.reshape(1, -1)).sum(1) / (base * base).sum()
-            std[apply] = scale
-            field = base
-        yo = transforms_ref.gaussian_noise(x, field, std, apply, mean=0.0)
-        assert torch.allclose(yo, yn, rtol=1e-5, atol=1e-5)
-        g4["noise"] = {"x": x, "field": field, "std": std, "apply": apply, "y": yn}
-        print("G4 scale intensity: exact; gaussian noise: one shared field scaled per selected sample (1e-5)")
-    except Exception as e:  # the noise module pulls more of MONAI than the stub offers
-        print(f"G4 scale intensity: exact (noise module not importable here: {type(e).__name__})")
+    print("G4 scale intensity: exact (BatchedRandGaussianNoise / flip / weighted crop: see G4b)")
     torch.save(g4, os.path.join(GOLD, "intensity.pt"))
+
+
+def g4b_transform_pins():
+    """G4b: the pure-torch augmentations of the GPU chain — the reference's own ``_noise.py``, ``_flip.py`` and ``_crop.py``
+    executed unchanged on a stub of the few MONAI base classes they subclass (no MONAI arithmetic is involved in the
+    pinned paths: the noise draw, the flip loop and the weighted-crop sampling weights / gather are all written in the
+    reference files themselves).  The random draws are reproduced by replaying the reference's draw order with the same
+    seed, handed to the oracle as parameters, and the results must agree exactly."""
+    import numpy as np
+
+    class MapTransform:
+        def __init__(self, keys, allow_missing_keys=False):
+            self.keys = (keys,) if isinstance(keys, str) else tuple(keys)
+            self.allow_missing_keys = allow_missing_keys
+
+        def key_iterator(self, data):
+            for k in self.keys:
+                if k in data:
+                    yield k
+                elif not self.allow_missing_keys:
+                    raise KeyError(k)
+
+    class RandomizableTransform:
+        def __init__(self, prob=1.0, do_transform=True):
+            self.prob, self._do_transform = prob, do_transform
+
+    class RandGaussianNoise(RandomizableTransform):  # attribute surface of MONAI's class; its arithmetic is never called
+        def __init__(self, prob=0.1, mean=0.0, std=0.1, dtype=np.float32, sample_std=True):
+            RandomizableTransform.__init__(self, prob)
+            self.mean, self.std, self.dtype, self.sample_std = mean, std, dtype, sample_std
+
+    class _Named:
+        def __init__(self, *a, **k):
+            pass
+
+    _stub("monai")
+    _stub("monai.transforms", MapTransform=MapTransform, RandomizableTransform=RandomizableTransform,
+          RandGaussianNoise=RandGaussianNoise, RandGaussianNoised=type("RandGaussianNoised", (MapTransform, RandomizableTransform), {}),
+          CenterSpatialCrop=type("CenterSpatialCrop", (_Named,), {}), Cropd=type("Cropd", (_Named,), {}),
+          RandCropd=type("RandCropd", (_Named,), {}), RandSpatialCrop=type("RandSpatialCrop", (_Named,), {}))
+    _stub("viscy_transforms")
+    base = f"{REF}/viscy-transforms/src/viscy_transforms"
+    pins = {}
+    # ---- BatchedRandGaussianNoise (_noise.py:158-204)
+    rn = _load("viscy_transforms._noise", f"{base}/_noise.py")
+    x = torch.rand((6, 2, 5, 8, 8), generator=torch.Generator().manual_seed(3)) * 10
+    for tag, kw in {"sampled_std": dict(prob=0.6, mean=0.05, std=0.3), "fixed_std": dict(prob=0.5, mean=0.0, std=0.2, sample_std=False)}.items():
+        tn = rn.BatchedRandGaussianNoise(**kw)
+        torch.manual_seed(16)
+        yn = tn(x.clone())
+        torch.manual_seed(16)  # replay the reference's draw order: selection, per-sample std, ONE shared N(0,1) field
+        do = torch.rand(6) < kw["prob"]
+        n = int(do.sum())
+        std_sel = torch.rand(n) * kw["std"] if kw.get("sample_std", True) else torch.full((n,), kw["std"])
+        field = torch.normal(mean=0.0, std=1.0, size=x.shape[1:])
+        std = torch.zeros(6)
+        std[do] = std_sel
+        assert torch.equal(do, tn._do_transform) and 0 < n < 6
+        yo = transforms_ref.gaussian_noise(x, field, std, do, mean=kw["mean"])
+        assert torch.allclose(yo, yn, rtol=0, atol=2e-6), (yo - yn).abs().max()  # addcmul rounds once, mean + f * s twice
+        assert torch.equal(yn[~do], x[~do])
+        pins[f"noise_{tag}"] = {"x": x, "field": field, "std": std, "apply": do, "mean": kw["mean"], "y": yn}
+    # ---- BatchedRandFlip (_flip.py:12-50)
+    rf = _load("viscy_transforms._flip", f"{base}/_flip.py")
+    tf = rf.BatchedRandFlip(spatial_axes=[0, 1, 2], prob=0.5)
+    torch.manual_seed(5)
+    yf = tf(x.clone())
+    flips = tf._flip_spatial_dims.clone()
+    ours = x.clone()
+    for b in range(x.shape[0]):
+        dims = [a + 1 for a, f in zip((0, 1, 2), flips[b]) if bool(f)]
+        if dims:
+            ours[b] = torch.flip(x[b], dims)
+    assert torch.equal(ours, yf) and flips.any() and not flips.all()
+    pins["flip"] = {"x": x, "flips": flips, "y": yf}
+    # ---- BatchedRandWeightedCropd (_crop.py:263-386): pooled sampling weights, start indices, gather
+    rc = _load("viscy_transforms._crop", f"{base}/_crop.py")
+    g = torch.Generator().manual_seed(7)
+    wmap = torch.rand((4, 2, 6, 20, 24), generator=g) - 0.3   # negative values are clamped away
+    wmap[3] = -1.0                                             # an all-non-positive map falls back to uniform sampling
+    src = torch.rand((4, 1, 6, 20, 24), generator=g)
+    size = (4, 8, 10)
+    tc = rc.BatchedRandWeightedCropd(keys=["source", "target"], w_key="target", spatial_size=size)
+    torch.manual_seed(21)
+    z0, y0, x0 = tc._sample_crop_starts(wmap)
+    torch.manual_seed(21)
+    out = tc({"source": src, "target": wmap})
+    wts = transforms_ref.weighted_crop_window_weights(wmap, size[1:])
+    torch.manual_seed(21)  # the reference's draw: multinomial over its pooled weights, then randint for Z
+    idx = torch.multinomial(wts, 1).squeeze(1)
+    vx = 24 - 10 + 1
+    assert torch.equal(idx // vx, y0) and torch.equal(idx % vx, x0)
+    assert torch.equal(wts[3], torch.ones_like(wts[3]))
+    assert torch.equal(transforms_ref.crop3d(src, z0, y0, x0, size), out["source"])
+    assert torch.equal(transforms_ref.crop3d(wmap, z0, y0, x0, size), out["target"])
+    pins["weighted_crop"] = {"weight_map": wmap, "source": src, "size": size, "weights": wts, "z0": z0, "y0": y0, "x0": x0,
+                             "source_out": out["source"], "target_out": out["target"]}
+    torch.save(pins, os.path.join(GOLD, "transform_pins.pt"))
+    print("G4b transforms: BatchedRandGaussianNoise (2e-6), BatchedRandFlip (exact), BatchedRandWeightedCropd weights / starts / gather (exact)")
 
 
 def g6_hf_convnext():
@@ -630,6 +706,7 @@ if __name__ == "__main__":
     g1_stem()
     g2_loss()
     g3_normalize()
+    g4b_transform_pins()
     g8_wiring()
     g9_fcmae()
     g10_contrastive()

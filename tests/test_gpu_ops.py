@@ -775,3 +775,56 @@ def test_layer_scale_fold_unfold():
         outs.append((dW.cpu(), db.cpu(), dg.cpu()))
     for a, c in zip(outs[1], outs[0]):
         torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ fused GRN-MLP (csrc/mlp.hip)
+@pytest.mark.parametrize("C,hw,B", [(96, 256, 3), (96, 1024, 2), (192, 256, 2), (224, 512, 2), (384, 128, 3), (384, 256, 2)])
+@pytest.mark.parametrize("drop_path", [False, True], ids=["plain", "droppath"])
+def test_fused_grn_mlp_matches_unfused_kernels_and_reference(C, hw, B, drop_path):
+    """vsx_mlp_fwd (hidden activation on chip, fc1 recomputed in the output pass) against (a) the fp32 statement with the
+    same bf16 rounding points (h, g and the GRN output are bf16 values in both schedules) and (b) the unfused HIP kernels"""
+    if SELF_CHECK:
+        pytest.skip("HIP-only kernel")
+    from viscy_amd import _lib as L
+    from viscy_amd import ops
+
+    dt = torch.bfloat16
+    M, H4 = B * hw, 4 * C
+    assert ops.mlp_supported(C, hw, M, dt)
+    xh = rnd(M, C, dt=dt, seed=1).cuda()
+    res = rnd(M, C, dt=dt, seed=2).cuda()
+    W1 = rnd(H4, C, dt=dt, seed=3, scale=C ** -0.5).cuda()
+    W2 = rnd(C, H4, dt=dt, seed=4, scale=H4 ** -0.5).cuda()
+    b1, b2 = rnd(H4, seed=5, scale=0.1).cuda(), rnd(C, seed=6, scale=0.1).cuda()
+    gamma, beta = rnd(H4, seed=7, scale=0.3).cuda(), rnd(H4, seed=8, scale=0.1).cuda()
+    rs = (torch.tensor([0.0, 1.25, 1.25][:B] + [1.25] * max(0, B - 3))[:B]).cuda() if drop_path else None
+    img = ops.mlp_pack(W1, W2, C)
+    colsq = torch.zeros((B, H4), dtype=torch.float32, device="cuda")
+    ops.mlp_stats(xh, img, b1, colsq, M, C, hw)
+    s = ops.grn_scale(colsq, gamma)
+    out = ops.mlp_out(xh, img, b1, s, beta, b2, res, rs, M, C, hw)
+    # (a) fp32 statement with the kernels' rounding points
+    h = (xh.float() @ W1.float().T + b1).to(dt).float()
+    g = torch.nn.functional.gelu(h).to(dt).float()
+    colsq_ref = (g * g).view(B, hw, H4).sum(1)
+    close(colsq, colsq_ref, torch.float32, "colsq", scale=colsq_ref.abs().max().item() * 5)  # bf16 ulp flips of g at the GELU rounding
+    s_ref = 1 + gamma * colsq_ref.sqrt() / (colsq_ref.sqrt().mean(1, keepdim=True) + 1e-6)
+    z = (g.view(B, hw, H4) * s_ref[:, None] + beta).to(dt).float().view(M, H4)
+    branch = z @ W2.float().T + b2
+    if rs is not None:
+        branch = branch.view(B, hw, C) * rs.view(B, 1, 1)
+    ref = (res.float() + branch.reshape(M, C)).to(dt)
+    close(out, ref, dt, "fused mlp vs fp32 statement")
+    # (b) the unfused HIP schedule
+    hh, gg = torch.empty((M, H4), dtype=dt, device="cuda"), torch.empty((M, H4), dtype=dt, device="cuda")
+    csq2 = torch.zeros_like(colsq)
+    ops.gemm("nt", xh, W1, hh, M, H4, C, C, C, H4, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=b1, red0=csq2, hw=hw, C2=gg)
+    assert torch.equal(gg.float(), g.to(dt).float()) or (gg.float() - g).abs().max().item() <= 0.02 * g.abs().max().item()
+    close(colsq, csq2, torch.float32, "colsq vs unfused", scale=csq2.abs().max().item() * 5)
+    out2 = torch.empty((M, C), dtype=dt, device="cuda")
+    ops.gemm("nt", gg, W2, out2, M, C, H4, H4, H4, C, dtype=dt, pro=L.PRO_GRN, grn_s=ops.grn_scale(csq2, gamma), grn_b=beta,
+             hw=hw, epi=L.EPI_BIAS_RES, bias=b2, res=res, ldr=C, rscale=rs)
+    err = (out.float() - out2.float()).abs().max().item() / out2.float().abs().max().item()
+    assert err <= 1e-2, err  # one bf16 ulp of the output scale: the two schedules differ in accumulation order only
+    if drop_path:  # a dropped sample is exactly its shortcut
+        assert torch.equal(out[:hw], res[:hw])

@@ -290,3 +290,90 @@ def test_soak_graph_replayed_bf16_training(flags):
     finally:
         for k, v in saved.items():
             lib.vsx_set_flag(k.encode(), v)
+
+
+# ------------------------------------------------------------------ optimiser state lives on the device (pinned-hyper race)
+def test_unsynced_graph_replays_follow_the_warmup_cosine_schedule():
+    """N hipGraph replays enqueued WITHOUT any host synchronisation (the host runs far ahead of the device, as in bench.py)
+    must apply lr(0), lr(1), ... in order with Adam's bias corrections of steps 1, 2, ...: on a gradient that does not depend
+    on the parameters (the captured body only re-fills the gradient buffer) the trajectory equals torch.optim.AdamW +
+    LambdaLR(WarmupCosine) exactly.  A busy-kernel in front of the replays keeps the device behind the host."""
+    from viscy_amd.optim import FlatAdamW, warmup_cosine_lambda
+
+    class _Eng:
+        pass
+
+    n, steps = 1 << 20, 40
+    torch.manual_seed(0)
+    eng = _Eng()
+    eng.flat = torch.randn(n, device="cuda")
+    eng.flat_grad = torch.zeros(n, device="cuda")
+    gsrc = torch.randn(n, device="cuda")
+    p_ref = torch.nn.Parameter(eng.flat.detach().cpu().clone())
+    topt = torch.optim.AdamW([p_ref], lr=3e-3)
+    sch = torch.optim.lr_scheduler.LambdaLR(topt, lambda s: warmup_cosine_lambda(s, 3, steps, 1e-3))
+    opt = FlatAdamW(eng, lr=3e-3, schedule="WarmupCosine", warmup_steps=3, t_total=steps, warmup_multiplier=1e-3)
+    opt.host_prepare()
+    opt.t -= 1
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.flat_grad.copy_(gsrc)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.flat_grad.copy_(gsrc)
+        opt.device_step()
+    big = torch.randn(8192, 8192, device="cuda")
+    for _ in range(30):  # ~100+ ms of queued work: every replay below is enqueued before the first one runs
+        big = big @ big * 1e-4
+    for _ in range(steps):
+        opt.host_prepare()
+        g.replay()
+    torch.cuda.synchronize()
+    for _ in range(steps):
+        p_ref.grad = gsrc.cpu().clone()
+        topt.step()
+        sch.step()
+    torch.testing.assert_close(eng.flat.cpu(), p_ref.detach(), rtol=2e-5, atol=2e-6)
+    assert int(opt.step_dev) == steps == opt.t
+
+
+def test_segmented_capture_equals_single_graph_and_leaves_state_untouched():
+    """the step captured as three bucket segments + AdamW (the data-parallel layout, forced on one GPU) == the single
+    graph == eager: same loss and gradients at lr = 0; capturing (two warm-up steps inside) changes neither parameters nor
+    moments nor the step counter"""
+    import bench
+    from viscy_amd.losses import MixedLoss
+    from viscy_amd.optim import FlatAdamW
+    from viscy_amd.step import TrainStep
+
+    x, t = bench.make_batch(2, 192, 192, "cuda")
+    res = {}
+    for mode in ("eager", "graph", "segments"):
+        m = _bench_model(torch.float32, "convnextv2_femto", seed=0)
+        eng = m.engine()
+        opt = FlatAdamW(eng, lr=0.0, weight_decay=0.0)
+        before = eng.flat.clone()
+        step = TrainStep(m, MixedLoss(0.5, 0, 0.5), opt, use_graph=mode != "eager", segments=mode == "segments")
+        losses = [float(step(x, t)) for _ in range(3)]
+        if mode == "segments":
+            assert len(step.graphs) == 3
+        assert torch.equal(eng.flat, before) and int(opt.step_dev) == 3 and opt.t == 3
+        assert float(opt.m.abs().max()) > 0  # moments did move (gradients are not zero)
+        res[mode] = (losses, eng.flat_grad.clone())
+    for mode in ("graph", "segments"):
+        (le, ge), (lg, gg) = res["eager"], res[mode]
+        assert max(abs(a - b) for a, b in zip(le, lg)) < 1e-5 * max(1.0, abs(le[0]))
+        assert ((ge - gg).norm() / ge.norm()).item() < 1e-3
+    # a real learning rate: the first captured step starts from the untouched initial state in every mode
+    firsts = []
+    for mode in ("eager", "graph", "segments"):
+        m = _bench_model(torch.bfloat16, "convnextv2_tiny", seed=0)
+        opt = FlatAdamW(m.engine(), lr=5e-4, schedule="WarmupCosine", warmup_steps=3, t_total=10, warmup_multiplier=1e-3)
+        step = TrainStep(m, MixedLoss(0.5, 0, 0.5), opt, use_graph=mode != "eager", segments=mode == "segments")
+        ls = [float(step(x, t)) for _ in range(8)]
+        assert all(torch.isfinite(torch.tensor(ls))) and ls[-1] < ls[0]
+        firsts.append(ls[0])
+    assert max(firsts) - min(firsts) < 2e-3 * abs(firsts[0])

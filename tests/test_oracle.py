@@ -207,3 +207,22 @@ def test_scale_intensity_golden():
     """G4: the reference's BatchedRandScaleIntensity with its own draw (seed 11) == oracle with the drawn factors injected"""
     g = load_golden("intensity.pt")["scale"]
     assert torch.equal(transforms_ref.scale_intensity(g["x"], g["factors"]), g["y"])
+
+
+def test_oracle_transforms_match_the_reference_pins():
+    """G4b (oracle/validate_against_reference.py): outputs of the reference's own _noise.py / _flip.py / _crop.py (run on a
+    stub of their MONAI base classes) with the draws the reference made; the oracle reproduces them from those draws."""
+    from oracle import transforms_ref as R
+
+    pins = load_golden("transform_pins.pt")
+    for tag in ("noise_sampled_std", "noise_fixed_std"):
+        p = pins[tag]
+        y = R.gaussian_noise(p["x"], p["field"], p["std"], p["apply"], mean=p["mean"])
+        torch.testing.assert_close(y, p["y"], rtol=0, atol=2e-6)
+        assert torch.equal(y[~p["apply"]], p["x"][~p["apply"]]) and 0 < int(p["apply"].sum()) < p["x"].shape[0]
+    p = pins["weighted_crop"]
+    assert torch.equal(R.weighted_crop_window_weights(p["weight_map"], p["size"][1:]), p["weights"])
+    assert torch.equal(R.crop3d(p["source"], p["z0"], p["y0"], p["x0"], p["size"]), p["source_out"])
+    assert torch.equal(R.crop3d(p["weight_map"], p["z0"], p["y0"], p["x0"], p["size"]), p["target_out"])
+    p = pins["flip"]
+    assert p["flips"].any() and not p["flips"].all() and p["y"].shape == p["x"].shape

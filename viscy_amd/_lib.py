@@ -73,6 +73,12 @@ _SIGS = {
     "vsx_loss_finalize": (_I32, [_P] * 5 + [_F32, _I32, _I32, _F32, _F32, _F32, _P, _P, _P, _P, _P]),
     "vsx_adamw": (_I32, [_P, _P, _P, _P, _P, _I64, _P]),
     "vsx_adamw_advance": (_I32, [_P, _P, _P, _P]),
+    "vsx_mlp_supported": (_I32, [_I32, _I32, _I64, _I32]),
+    "vsx_mlp_image_bytes": (_I64, [_I32]),
+    "vsx_mlp_pack": (_I32, [_P, _P, _P, _I32, _P]),
+    "vsx_mlp_fwd": (_I32, [_P] * 11 + [_I64, _I32, _I32, _I32, _I32, _P]),
+    "vsx_mlp_gelu_table_len": (_I32, []),
+    "vsx_mlp_gelu_table": (_I32, [_P, _P]),
     "vsx_prep_weight": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_unprep_grad": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_matvec": (_I32, [_P, _P, _P, _P, _I32, _I32, _P]),

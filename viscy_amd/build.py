@@ -52,7 +52,26 @@ def build(verbose: bool = True) -> str:
         list(ex.map(run, jobs))
     if jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    _write_build_info()
     return LIB
+
+
+def _write_build_info() -> None:
+    """the GPU box receives a snapshot without .git: record HEAD (and whether the tree was dirty) next to the objects so that
+    bench.py can put it into its JSON line"""
+    import json
+
+    root = os.path.dirname(HERE)
+    if not os.path.isdir(os.path.join(root, ".git")):
+        return
+    try:
+        sha = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=20).stdout.strip()
+        dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], capture_output=True,
+                                    text=True, timeout=20).stdout.strip())
+        with open(os.path.join(BUILD, "build_info.json"), "w") as f:
+            json.dump({"git_sha": sha, "git_dirty": dirty}, f)
+    except (OSError, subprocess.SubprocessError):
+        pass
 
 
 if __name__ == "__main__":

@@ -20,6 +20,7 @@ int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup i
 int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x splits)
 int g_vsx_ln_stream = 0;  // OFF (as nt_stream; measured with the value 3) —  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
 int g_vsx_tn_contig = 1;  // lean TN kernel: contiguous step range per split
+int g_vsx_mlp_fused = 1;  // fused GRN-MLP (csrc/mlp.hip): bit 0 = inference forward (C = 96 / 192 / 224 blocks: measured 2..8 % faster than the unfused pair at a third of the traffic), bit 2 = also the C = 384 blocks (measured slower)
 int g_vsx_nt_tall = 0;  // 256x128 NT tiles: -5..-9 % on isolated wide-output launches, nothing on the whole step (measured) -> off
 
 void vsx_set_error(const char* fmt, ...) {
@@ -47,6 +48,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "tn_rect")) { g_vsx_tn_rect = value; return 0; }
   if (name && !strcmp(name, "dw_rows2")) { g_vsx_dw_rows2 = value; return 0; }
   if (name && !strcmp(name, "dw_wg16")) { g_vsx_dw_wg16 = value; return 0; }
+  if (name && !strcmp(name, "mlp_fused")) { g_vsx_mlp_fused = value; return 0; }
   vsx_set_error("vsx_set_flag: unknown flag '%s'", name ? name : "(null)");
   return 1;
 }
@@ -66,5 +68,6 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "tn_rect")) return g_vsx_tn_rect;
   if (name && !strcmp(name, "dw_rows2")) return g_vsx_dw_rows2;
   if (name && !strcmp(name, "dw_wg16")) return g_vsx_dw_wg16;
+  if (name && !strcmp(name, "mlp_fused")) return g_vsx_mlp_fused;
   return -1;
 }

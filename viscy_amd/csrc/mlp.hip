@@ -1,0 +1,495 @@
+// Fused GRN-MLP of a ConvNeXt-V2 block (timm ConvNeXtBlock / GlobalResponseNormMlp as called from
+// viscy_models/unet/unext2.py:79; block math restated at viscy_models/unet/fcmae.py:174-221):
+//
+//     out = shortcut + drop_path( fc2( GRN( gelu( fc1( LN(dwconv(x)) ) ) ) ) )
+//
+// in TWO passes over the C-wide LayerNorm output, with the 4C-wide hidden activation never leaving the CU:
+//   MODE 0 (statistics): fc1 -> +bias -> GELU -> per-sample column sums of g^2 (the GRN statistics), nothing stored;
+//   MODE 1 (output)    : fc1 recomputed -> +bias -> GELU -> g * s[b] + beta -> fc2 -> +bias -> * drop-path scale -> + shortcut.
+// (SURVEY §7 step 4 / VERDICT r1 "what's missing" 1.  The unfused schedule moved 8 of its 15 C-units per pixel as 4C-wide
+// h / g tensors through HBM in inference; this one moves 1 + 3.)
+//
+// gfx950 mapping
+//   * a workgroup owns BM = NW * 16 * MF pixel rows of ONE sample; each wave64 owns 16 * MF of them for the whole kernel:
+//     its LayerNorm rows live in registers as MFMA B fragments (loaded once, straight from HBM in fragment layout);
+//   * the hidden axis is walked in sub-chunks of 32 columns.  fc1 runs with SWAPPED roles (A = 16 weight rows, B = 16 pixel
+//     rows), so v_mfma_f32_16x16x32_bf16 leaves lane (p, q) holding hidden q*4..q*4+3 of pixel p — which IS an A fragment
+//     of the following fc2 MFMA (pixel rows x 32-deep contraction) once the contraction index is permuted
+//     (slot (q, j) <-> hidden j < 4 ? 4q + j : 16 + 4q + j - 4).  The activation therefore goes accumulator -> VALU
+//     (bias, GELU, GRN) -> bf16 pack -> MFMA operand without touching LDS or HBM; the permutation is baked into the fc2
+//     weight image;
+//   * weights are the only LDS traffic: both matrices are pre-packed (vsx_mlp_pack) into a FRAGMENT-MAJOR image — 1 KiB
+//     per (16 rows x 32 k) fragment, lane-linear — so a sub-chunk's stage is one contiguous block that
+//     global_load_lds_dwordx4 copies HBM/L2 -> LDS with no VGPR staging and no padding, and every fragment read is a
+//     conflict-free ds_read_b128 at (fragment base + lane * 16).  Double-buffered, one barrier per sub-chunk;
+//   * per-channel vectors (b1, beta, this sample's GRN scale, b2) sit in LDS for the whole kernel: no ordinary global load
+//     is live inside the loop (hipcc drains vmcnt(0) — and with it the weight prefetch — at the first use of one);
+//   * the shortcut is added with one identity-matrix MFMA per output fragment (exact: products with 1.0 / 0.0 in fp32), so
+//     the residual is read in the same 16-byte fragment layout as the input rows; the result leaves through a per-wave LDS
+//     transpose as one contiguous 16-byte-vector stream.
+#include "vsx_common.h"
+#include "../../include/vsx.h"
+
+typedef float mlp_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 mlp_bf16x8 __attribute__((ext_vector_type(8)));
+
+struct MlpArgs {
+  const bf16_t* xh;     // [M, C]  block LayerNorm output (affine folded into fc1)
+  const char* wimg;     // fragment-major image of (W1', W2), see vsx_mlp_pack
+  const float* b1;      // [4C]    folded fc1 bias
+  const float* grn_s;   // [B, 4C] GRN scale 1 + gamma * N       (MODE 1)
+  const float* grn_b;   // [4C]    GRN beta                      (MODE 1)
+  const float* b2;      // [C]     fc2 bias                      (MODE 1)
+  const bf16_t* res;    // [M, C]  shortcut                      (MODE 1)
+  const float* rscale;  // [B] stochastic-depth scale or NULL    (MODE 1)
+  bf16_t* out;          // [M, C]                                (MODE 1)
+  float* colsq;         // [B, 4C] += sum_hw gelu(h)^2           (MODE 0)
+  const float* gtab;    // [MLP_GT_N] r(a) = a * Phi(-a) for every bf16 a in [2^-24, 16)  (vsx_mlp_gelu_table)
+  int M, hw;
+};
+
+// GELU through a table: the pre-activation h is a bf16 value, so gelu(h) = max(h, 0) - r(|h|) with r(a) = a * Phi(-a) read
+// from a table indexed by the 15 magnitude bits of h (28 binades x 128 mantissas, fp32 entries computed in double on the
+// host: the result is the correctly rounded-to-fp32 erf GELU of h).  r underflows to 0 above the table and equals a / 2 to
+// 1e-8 below it, so clamping the index needs no fix-up.  The exp / rcp / polynomial evaluation it replaces cost ~120 VALU
+// cycles per element and made every pass of this kernel VALU-bound (measured: the statistics pass took the same time per
+// hidden element for C = 96 and C = 224); the table costs 6 VALU operations and one LDS read.
+#define MLP_GT_BASE (103 << 7)            /* bf16 magnitude bits of 2^-24 */
+#define MLP_GT_LIM (131 << 7)             /* ... of 16 */
+#define MLP_GT_N (MLP_GT_LIM - MLP_GT_BASE)
+
+__device__ __forceinline__ mlp_f32x4 mlp_mfma(const mlp_bf16x8& a, const mlp_bf16x8& b, const mlp_f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int C, int MF, int NW, int MODE>
+struct MlpGeom {
+  static constexpr int H4 = 4 * C, NHS = H4 / 32, KK = C / 32, NF = C / 16;
+  static constexpr int WM = 16 * MF, BM = NW * WM;
+  static constexpr int W1_PIECES = 2 * KK, IMG_PIECES = 2 * KK + NF;   // KiB per hidden sub-chunk in the image
+  static constexpr int NP = MODE == 0 ? W1_PIECES : IMG_PIECES;        // pieces staged per sub-chunk
+  static constexpr int STAGE_BYTES = NP * 1024;
+  static constexpr int OB_COLS = 64;                                   // output leaves in blocks of 64 columns
+  static constexpr int OB_RS = OB_COLS * 2 + 16;                       // staging row stride (bytes)
+  static constexpr int OUT_BYTES = MODE == 1 ? NW * WM * OB_RS : 16;
+  static constexpr int VEC_FLOATS = MODE == 0 ? H4 : 3 * H4 + C;
+  static constexpr int RED_FLOATS = MODE == 0 ? 2 * NW * 32 : 4;
+  static constexpr int LDS_BYTES = 2 * STAGE_BYTES + OUT_BYTES + (VEC_FLOATS + RED_FLOATS) * 4;
+};
+
+template <int C, int MF, int NW, int MODE>
+__global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
+  typedef MlpGeom<C, MF, NW, MODE> G;
+  constexpr int H4 = G::H4, NHS = G::NHS, KK = G::KK, NF = G::NF, WM = G::WM;
+  constexpr int VALU_OPS = MF * (MODE == 1 ? 80 : 64);  // VALU instructions of one sub-chunk's bias / GELU / GRN (from the ISA)
+  // SEPARATE LDS objects, on purpose: the two weight stages, the per-channel vectors and the output staging are distinct
+  // variables, so the compiler's alias scopes let fragment / vector reads proceed while the LDS-DMA prefetch of the OTHER
+  // stage is in flight (through one array every ds_read behind a global_load_lds costs an s_waitcnt vmcnt(0): no overlap)
+  __shared__ __attribute__((aligned(1024))) char buf0[G::STAGE_BYTES];
+  __shared__ __attribute__((aligned(1024))) char buf1[G::STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) float vec[G::VEC_FLOATS];
+  __shared__ __attribute__((aligned(16))) float red[G::RED_FLOATS];
+  __shared__ __attribute__((aligned(16))) char obuf[G::OUT_BYTES];
+  __shared__ __attribute__((aligned(16))) float gt[MLP_GT_N];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p16 = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * G::BM;   // the tile lies inside one sample (dispatch: hw % BM == 0)
+  const int b = m0 / a.hw;
+  const int row0 = m0 + wave * WM;
+
+  for (int i = tid; i < MLP_GT_N; i += NW * 64) gt[i] = a.gtab[i];
+  // ---- per-channel vectors -> LDS (once)
+  for (int i = tid; i < H4; i += NW * 64) {
+    vec[i] = a.b1[i];
+    if constexpr (MODE == 1) {
+      vec[H4 + i] = a.grn_s[(size_t)b * H4 + i];
+      vec[2 * H4 + i] = a.grn_b[i];
+    }
+  }
+  if constexpr (MODE == 1) {
+    for (int i = tid; i < C; i += NW * 64) vec[3 * H4 + i] = a.b2[i];
+  }
+  // ---- this wave's LayerNorm rows as fc1 B fragments: lane (p, q) holds row p, k = kk*32 + q*8 .. +7
+  mlp_bf16x8 xf[MF][KK];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+      xf[mf][kk] = *reinterpret_cast<const mlp_bf16x8*>(a.xh + (size_t)(row0 + mf * 16 + p16) * C + kk * 32 + kq * 8);
+
+  mlp_f32x4 oacc[MODE == 1 ? MF : 1][MODE == 1 ? NF : 1];
+  if constexpr (MODE == 1) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) oacc[mf][nf] = (mlp_f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // fc1 of one hidden sub-chunk (roles swapped): acc[hf][mf][r] = H[pixel mf*16 + p][hidden 32*hs + hf*16 + q*4 + r];
+  // `W` = the W1 fragments of that sub-chunk in a stage buffer (+ lane * 16)
+  auto gemm1 = [&](const char* W, mlp_f32x4 (&acc)[2][MF]) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) acc[hf][mf] = (mlp_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const mlp_bf16x8 wa = *reinterpret_cast<const mlp_bf16x8*>(W + (hf * KK + kk) * 1024);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) acc[hf][mf] = mlp_mfma(wa, xf[mf][kk], acc[hf][mf]);
+      }
+  };
+  // bias, GELU, GRN in registers (same rounding points as the unfused kernels: h and g are bf16 values); MODE 0 adds g^2
+  // into sq, MODE 1 packs z = g * s + beta as the fc2 A fragments
+  auto activate = [&](int hs, const mlp_f32x4 (&acc)[2][MF], mlp_bf16x8 (&zf)[MF], float (&sq)[2][4]) {
+    const float* vb = vec + hs * 32 + kq * 4;
+    float b1v[2][4], sv[2][4], bv[2][4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const float4 t1 = *reinterpret_cast<const float4*>(vb + hf * 16);
+      b1v[hf][0] = t1.x; b1v[hf][1] = t1.y; b1v[hf][2] = t1.z; b1v[hf][3] = t1.w;
+      if constexpr (MODE == 1) {
+        const float4 t2 = *reinterpret_cast<const float4*>(vb + H4 + hf * 16);
+        const float4 t3 = *reinterpret_cast<const float4*>(vb + 2 * H4 + hf * 16);
+        sv[hf][0] = t2.x; sv[hf][1] = t2.y; sv[hf][2] = t2.z; sv[hf][3] = t2.w;
+        bv[hf][0] = t3.x; bv[hf][1] = t3.y; bv[hf][2] = t3.z; bv[hf][3] = t3.w;
+      }
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sq[hf][r] = 0.f;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      // all 8 table reads of this pixel fragment are issued before the first is consumed (one LDS latency, not eight)
+      uint32_t P[4];
+      float rr[8];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          // h as a bf16 pair; its magnitude bits index the table
+          const uint32_t Pq = f32x2_to_bf16x2_bits(acc[hf][mf][r] + b1v[hf][r], acc[hf][mf][r + 1] + b1v[hf][r + 1]);
+          P[hf * 2 + r / 2] = Pq;
+          int a0 = (int)(Pq & 0x7FFFu), a1 = (int)((Pq >> 16) & 0x7FFFu);
+          a0 = a0 < MLP_GT_BASE ? MLP_GT_BASE : (a0 > MLP_GT_LIM - 1 ? MLP_GT_LIM - 1 : a0);
+          a1 = a1 < MLP_GT_BASE ? MLP_GT_BASE : (a1 > MLP_GT_LIM - 1 ? MLP_GT_LIM - 1 : a1);
+          rr[hf * 4 + r] = gt[a0 - MLP_GT_BASE];
+          rr[hf * 4 + r + 1] = gt[a1 - MLP_GT_BASE];
+        }
+      float z[8];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const uint32_t Pq = P[hf * 2 + r / 2];
+          const float h0 = __uint_as_float(Pq << 16), h1 = __uint_as_float(Pq & 0xFFFF0000u);
+          const float g0 = round_bf16(fmaxf(h0, 0.f) - rr[hf * 4 + r]);
+          const float g1 = round_bf16(fmaxf(h1, 0.f) - rr[hf * 4 + r + 1]);
+          if constexpr (MODE == 0) {
+            sq[hf][r] = fmaf(g0, g0, sq[hf][r]);
+            sq[hf][r + 1] = fmaf(g1, g1, sq[hf][r + 1]);
+          } else {
+            z[hf * 4 + r] = fmaf(g0, sv[hf][r], bv[hf][r]);
+            z[hf * 4 + r + 1] = fmaf(g1, sv[hf][r + 1], bv[hf][r + 1]);
+          }
+        }
+      if constexpr (MODE == 1) {
+        union { uint4 u; mlp_bf16x8 v; } pk;
+        pk.u = pack<bf16_t>(z);
+        zf[mf] = pk.v;
+      }
+    }
+  };
+
+  // ---- software pipeline over the hidden sub-chunks.  Stage s (buffer s & 1) = [W1 of sub-chunk s + 1 | W2 of sub-chunk s]:
+  // while the VALU works through bias / GELU / GRN of sub-chunk s, the SAME wave's MFMA pipe already runs fc1 of sub-chunk
+  // s + 1 (independent instructions in one basic block), then fc2 of sub-chunk s.  Without the shift every wave of the
+  // workgroup sits in the same phase between two barriers — all in MFMA, then all in VALU — and the two pipes never overlap
+  // (measured: 29 % MFMA utilisation on the C = 224 blocks).
+  auto stage_load2 = [&](int s, char* dst) {
+    // W1 pieces of sub-chunk s + 1 (absent for the last stage), W2 pieces of sub-chunk s
+    const char* src1 = a.wimg + (size_t)(s + 1) * (G::IMG_PIECES * 1024) + lane * 16;
+    const char* src2 = a.wimg + (size_t)s * (G::IMG_PIECES * 1024) + lane * 16;
+    for (int p = wave; p < G::NP; p += NW) {
+      if (p < G::W1_PIECES && s + 1 >= NHS) continue;
+      const char* src = p < G::W1_PIECES ? src1 : src2;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+    }
+  };
+  mlp_f32x4 hcur[2][MF], hnxt[2][MF];
+  // prologue: W1 of sub-chunk 0 goes where "stage -1" would sit (buffer 1)
+  {
+    const char* src = a.wimg + lane * 16;
+    for (int p = wave; p < G::W1_PIECES; p += NW)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
+                                       (__attribute__((address_space(3))) void*)(buf1 + p * 1024), 16, 0, 0);
+  }
+  stage_load2(0, buf0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  gemm1(buf1 + lane * 16, hcur);
+
+  auto step = [&](int hs, const char* Sb, char* other) {
+    // stage hs has landed for everyone (waited + barrier by the caller); every wave is done with stage hs - 1 in `other`
+    if (hs + 1 < NHS) stage_load2(hs + 1, other);
+    const char* S = Sb + lane * 16;
+    if constexpr (MODE == 0) {
+      if (hs > 0 && wave == (hs - 1) % NW && lane < 32) {  // column sums of the previous sub-chunk (parked before the barrier)
+        const float* r = red + ((hs - 1) & 1) * NW * 32 + lane;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += r[w * 32];
+        atomicAdd(a.colsq + (size_t)b * H4 + (hs - 1) * 32 + lane, t);
+      }
+    }
+    mlp_bf16x8 zf[MF];
+    float sq[2][4];
+    // three scheduling regions.  Inside the GEMM regions the fragment reads run three ahead of the MFMAs that consume them
+    // (left alone, hipcc sinks every ds_read_b128 to just before its two MFMAs: read - wait - MFMA - MFMA chains with every
+    // LDS latency exposed — 31 waits per sub-chunk at C = 224); the activation region in between is left to the compiler
+    // (it batches the eight table reads of a fragment by itself)
+    __builtin_amdgcn_sched_barrier(0);
+    gemm1(S, hnxt);  // fc1 of the NEXT sub-chunk (the last step multiplies stale fragments, result unused)
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+    for (int i = 0; i < 2 * KK; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    activate(hs, hcur, zf, sq);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MODE == 0) {
+      // sum over this wave's pixels: the 16 lanes of a DPP row share q, i.e. the same 8 hidden columns
+      float* rw = red + (hs & 1) * NW * 32 + wave * 32;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = group_sum<16>(sq[hf][r]);
+          if (p16 == 0) rw[hf * 16 + kq * 4 + r] = t;
+        }
+    } else {
+      // fc2: out[pixel][n] += Z[pixel][32 hidden] . W2[n][same 32 hidden, permuted alike in the image]
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const mlp_bf16x8 wb = *reinterpret_cast<const mlp_bf16x8*>(S + (G::W1_PIECES + nf) * 1024);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) oacc[mf][nf] = mlp_mfma(zf[mf], wb, oacc[mf][nf]);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) hcur[hf][mf] = hnxt[hf][mf];
+  };
+
+  static_assert(NHS % 2 == 0, "the hidden axis is walked two sub-chunks (one per stage buffer) per loop trip");
+#pragma unroll 1
+  for (int hs = 0; hs < NHS; hs += 2) {
+    if (hs > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    step(hs, buf0, buf1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    step(hs + 1, buf1, buf0);
+  }
+
+  if constexpr (MODE == 0) {
+    __syncthreads();
+    if (wave == (NHS - 1) % NW && lane < 32) {
+      const float* r = red + ((NHS - 1) & 1) * NW * 32 + lane;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += r[w * 32];
+      atomicAdd(a.colsq + (size_t)b * H4 + (NHS - 1) * 32 + lane, t);
+    }
+    return;
+  } else {
+    const float rs = a.rscale ? a.rscale[b] : 1.f;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const float bias = vec[3 * H4 + nf * 16 + p16];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[mf][nf][r] = (oacc[mf][nf][r] + bias) * rs;
+    }
+    // shortcut: OUT += RES . I  (B fragment of the identity: lane (n, q) holds 1.0 at slot j = h2*16 + n - q*8)
+    mlp_bf16x8 idB[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      union { unsigned short h[8]; mlp_bf16x8 v; } u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u.h[j] = (h2 * 16 + p16 == kq * 8 + j) ? (unsigned short)0x3F80 : (unsigned short)0;
+      idB[h2] = u.v;
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const mlp_bf16x8 rf = *reinterpret_cast<const mlp_bf16x8*>(a.res + (size_t)(row0 + mf * 16 + p16) * C + kk * 32 + kq * 8);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) oacc[mf][kk * 2 + h2] = mlp_mfma(rf, idB[h2], oacc[mf][kk * 2 + h2]);
+      }
+    // per-wave transpose through LDS, 64 columns at a time: accumulator layout (4 rows x 1 column per lane) -> 16-byte
+    // vectors, 8 lanes per 128-byte row segment
+    char* ost = obuf + wave * (WM * G::OB_RS);
+    bf16_t* orow = a.out + (size_t)row0 * C;
+#pragma unroll
+    for (int cb = 0; cb < NF; cb += 4) {
+      const int nfe = cb + 4 < NF ? cb + 4 : NF;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = cb; nf < cb + 4; ++nf) {
+          if (nf < NF) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *reinterpret_cast<unsigned short*>(ost + (mf * 16 + kq * 4 + r) * G::OB_RS + ((nf - cb) * 16 + p16) * 2) =
+                  (unsigned short)f32_to_bf16_bits(oacc[mf][nf][r]);
+          }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int chs = (nfe - cb) * 2;  // 16-byte chunks per row in this block (8 for a full block)
+      for (int idx = lane; idx < WM * chs; idx += 64) {
+        const int row = idx / chs, ch = idx - row * chs;
+        const uint4 v = *reinterpret_cast<const uint4*>(ost + row * G::OB_RS + ch * 16);
+        *reinterpret_cast<uint4*>(orow + (size_t)row * C + cb * 16 + ch * 8) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight image
+// piece (hs, hf, kk) lane (p, q): W1[hs*32 + hf*16 + p][kk*32 + q*8 .. +7]
+// piece (hs, nf)     lane (p, q): W2[nf*16 + p][hs*32 + q*4 .. +3], W2[nf*16 + p][hs*32 + 16 + q*4 .. +3]
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const bf16_t* __restrict__ W1, const bf16_t* __restrict__ W2,
+                                                       char* __restrict__ img, int C) {
+  const int H4 = 4 * C, KK = C / 32, NF = C / 16, PPS = 2 * KK + NF;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)(H4 / 32) * PPS * 64;
+  if (gid >= total) return;
+  const int lane = (int)(gid & 63);
+  const long piece = gid >> 6;
+  const int hs = (int)(piece / PPS), pp = (int)(piece % PPS);
+  const int p16 = lane & 15, kq = lane >> 4;
+  uint4 v;
+  if (pp < 2 * KK) {
+    const int hf = pp / KK, kk = pp % KK;
+    v = *reinterpret_cast<const uint4*>(W1 + (size_t)(hs * 32 + hf * 16 + p16) * C + kk * 32 + kq * 8);
+  } else {
+    const int nf = pp - 2 * KK;
+    const bf16_t* r = W2 + (size_t)(nf * 16 + p16) * H4 + hs * 32 + kq * 4;
+    const uint2 lo = *reinterpret_cast<const uint2*>(r), hi = *reinterpret_cast<const uint2*>(r + 16);
+    v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+  *reinterpret_cast<uint4*>(img + (size_t)gid * 16) = v;
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch
+struct MlpCfg { int C, MF, NW; };
+// rows per workgroup must divide the pixels of a sample; the large maps take 256-row workgroups (8 waves x 32 rows: weight
+// traffic L2 -> LDS per flop is 1 / rows).  C = 384 (16 x 16 maps: 128-row workgroups, one wave per SIMD at 256 + 212
+// registers) measured 875 us against 614 us for the unfused pair at B = 512 and is left to the unfused schedule unless
+// bit 2 of the mlp_fused flag asks for it (tools/perf_mlp.py)
+extern int g_vsx_mlp_fused;
+static const MlpCfg kMlpCfgs[] = {{96, 2, 8}, {192, 2, 8}, {224, 2, 8}, {384, 2, 4}};
+
+static const MlpCfg* mlp_cfg(int C, int hw, long M) {
+  for (const MlpCfg& c : kMlpCfgs) {
+    const int bm = c.NW * 16 * c.MF;
+    if (c.C == 384 && !(g_vsx_mlp_fused & 4)) continue;
+    if (c.C == C && hw % bm == 0 && M % bm == 0) return &c;
+  }
+  return nullptr;
+}
+
+extern "C" int32_t vsx_mlp_supported(int32_t C, int32_t hw, int64_t M, int32_t dtype) {
+  return dtype == VSX_BF16 && mlp_cfg(C, hw, M) != nullptr;
+}
+
+extern "C" int64_t vsx_mlp_image_bytes(int32_t C) { return (int64_t)(4 * C / 32) * (2 * (C / 32) + C / 16) * 1024; }
+
+extern "C" int32_t vsx_mlp_pack(const void* W1, const void* W2, void* img, int32_t C, vsx_stream_t stream) {
+  VSX_CHECK(W1 && W2 && img && C > 0 && C % 32 == 0, "vsx_mlp_pack: bad arguments (C = %d must be a multiple of 32)", C);
+  const long total = (long)(4 * C / 32) * (2 * (C / 32) + C / 16) * 64;
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(vsx_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W1,
+                     (const bf16_t*)W2, (char*)img, C);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int C, int MF, int NW, int MODE>
+static int mlp_launch(const MlpArgs& a, hipStream_t s) {
+  typedef MlpGeom<C, MF, NW, MODE> G;
+  hipLaunchKernelGGL((mlp_fused_kernel<C, MF, NW, MODE>), dim3(a.M / G::BM), dim3(NW * 64), 0, s, a);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int MODE>
+static int mlp_dispatch(const MlpCfg* c, const MlpArgs& a, hipStream_t s) {
+  if (c->C == 96) return mlp_launch<96, 2, 8, MODE>(a, s);
+  if (c->C == 192) return mlp_launch<192, 2, 8, MODE>(a, s);
+  if (c->C == 224) return mlp_launch<224, 2, 8, MODE>(a, s);
+  return mlp_launch<384, 2, 4, MODE>(a, s);
+}
+
+/* mode 0: colsq[b, 4C] += sum over the sample's pixels of gelu(fc1(xh))^2 (bf16-rounded g, as the unfused fc1 epilogue);
+ * mode 1: out = res + rscale[b] * (fc2(gelu(fc1(xh)) * s[b] + beta) + b2). */
+extern "C" int32_t vsx_mlp_gelu_table_len(void) { return MLP_GT_N; }
+
+// tab[i] = a * Phi(-a) for the bf16 value a whose magnitude bits are MLP_GT_BASE + i (double precision, once per process)
+__global__ void mlp_gelu_table_kernel(float* __restrict__ tab) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= MLP_GT_N) return;
+  const double a = (double)__uint_as_float((uint32_t)(MLP_GT_BASE + i) << 16);
+  tab[i] = (float)(a * 0.5 * erfc(a * 0.70710678118654752440));
+}
+
+extern "C" int32_t vsx_mlp_gelu_table(float* tab, vsx_stream_t stream) {
+  VSX_CHECK(tab != nullptr, "vsx_mlp_gelu_table: null pointer");
+  hipLaunchKernelGGL(mlp_gelu_table_kernel, dim3(vsx_cdiv(MLP_GT_N, 256)), dim3(256), 0, (hipStream_t)stream, tab);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1, const float* grn_s, const float* grn_b,
+                               const float* b2, const void* res, const float* rscale, void* out, float* colsq,
+                               const float* gtab, int64_t M, int32_t C, int32_t hw, int32_t mode, int32_t dtype,
+                               vsx_stream_t stream) {
+  VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_fwd: bf16 only (the fp32 parity mode runs the unfused schedule)");
+  VSX_CHECK(xh && wimg && b1 && gtab && M > 0 && hw > 0, "vsx_mlp_fwd: bad arguments");
+  const MlpCfg* c = mlp_cfg(C, hw, M);
+  VSX_CHECK(c != nullptr, "vsx_mlp_fwd: unsupported shape C=%d hw=%d M=%ld (query vsx_mlp_supported first)", C, hw, (long)M);
+  VSX_CHECK(M < (1ll << 31), "vsx_mlp_fwd: M too large");
+  MlpArgs a;
+  a.xh = (const bf16_t*)xh; a.wimg = (const char*)wimg; a.b1 = b1; a.grn_s = grn_s; a.grn_b = grn_b; a.b2 = b2;
+  a.res = (const bf16_t*)res; a.rscale = rscale; a.out = (bf16_t*)out; a.colsq = colsq; a.gtab = gtab; a.M = (int)M; a.hw = hw;
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) {
+    VSX_CHECK(colsq != nullptr, "vsx_mlp_fwd: mode 0 needs colsq");
+    return mlp_dispatch<0>(c, a, s);
+  }
+  VSX_CHECK(mode == 1 && grn_s && grn_b && b2 && res && out, "vsx_mlp_fwd: mode 1 needs s, beta, b2, res, out");
+  return mlp_dispatch<1>(c, a, s);
+}

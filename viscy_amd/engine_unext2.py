@@ -23,7 +23,7 @@ from . import _lib as L
 class _BlockW:
     """prepared operands + parameter handles of one ConvNeXt-V2 block"""
 
-    __slots__ = ("C", "p", "dw_w", "W1f", "W1fT", "b1f", "W2", "W2T", "v1", "fc2_w", "fc2_b", "grn_w", "grn_b", "dp")
+    __slots__ = ("C", "p", "dw_w", "W1f", "W1fT", "b1f", "W2", "W2T", "v1", "fc2_w", "fc2_b", "grn_w", "grn_b", "dp", "img")
 
 
 class _ProjW:
@@ -188,6 +188,7 @@ class Engine:
                                       gamma=blk.norm.weight)
         w.b1f = o.matvec(blk.mlp.fc1.weight, blk.norm.bias, blk.mlp.fc1.bias, 4 * C, C)
         w.dp = 0.0  # stochastic-depth rate of this block (set by prepare() from cfg["drop_path"])
+        w.img = None  # fragment-major LDS image of (W1f, W2) for the fused GRN-MLP kernel, packed on first use
         w.v1 = hasattr(blk, "gamma")
         if w.v1:
             # ConvNeXt-V1: y = x + gamma * fc2(gelu(fc1(.))) — the layer scale is folded into fc2 (vsx_layer_scale_fold) and
@@ -277,6 +278,16 @@ class Engine:
         return dt
 
     # ------------------------------------------------------------------ block forward / backward
+    def _mlp_mode(self, C, hw, M, dt, training: bool) -> bool:
+        """fused GRN-MLP kernel available for this block shape (bf16, C a supported width, whole workgroup tiles per sample)
+        and enabled (``mlp_fused`` flag, bit 0; the training forward keeps the unfused pair: it has to store h anyway and
+        the backward consumes the stored activation)"""
+        o = self.ops
+        if dt != torch.bfloat16 or not o.mlp_supported(C, hw, M, dt):
+            return False
+        flag = L.lib().vsx_get_flag(b"mlp_fused") if o.__name__.endswith("viscy_amd.ops") else 0
+        return bool(flag & 1) and not training
+
     def _block_fwd(self, x, w, B, H, Wd, dt, save, rows=None):
         """One ConvNeXt-V2 block on a dense channels-last map [B*H*W, C].  ``rows = (idx, inv, keep, L)`` selects the FCMAE
         masked path (fcmae.py:196-230): ``x`` arrives already multiplied by the mask, the depthwise convolution runs dense,
@@ -296,6 +307,24 @@ class Engine:
         xh, _, rstd = o.ln_fwd(y, None, None, M, C, 1e-6, need_mean=False)
         del y
         colsq = self._za.take(B, 4 * C)
+        # stochastic depth (timm DropPath, scale_by_keep): the whole branch of a sample is dropped with probability dp and
+        # the survivors are scaled by 1 / (1 - dp); training mode only.  One device-side draw per block (graph-capturable).
+        dpm = None
+        if w.dp > 0.0 and self.model.training:
+            inj = self._dp_inject
+            dpm = inj.pop(0) if inj else (torch.rand(B, device=x.device) < (1.0 - w.dp)).float() / (1.0 - w.dp)
+        fused = self._mlp_mode(C, hw, M, dt, save is not None)
+        if fused and save is None:
+            # inference: the 4C-wide hidden never leaves the CU (csrc/mlp.hip) — pass 1 = GRN statistics, pass 2 = fc1
+            # recomputed, GELU, GRN, fc2, bias, shortcut
+            if w.img is None:
+                w.img = o.mlp_pack(w.W1f, w.W2, C)
+            o.mlp_stats(xh, w.img, w.b1f, colsq, M, C, hw)
+            s = o.grn_scale(colsq, w.grn_w)
+            out = o.mlp_out(xh, w.img, w.b1f, s, w.grn_b, w.fc2_b, xres, dpm, M, C, hw)
+            if rows is not None:
+                out = o.rows_select(out, rows[1], B * H * Wd, C)
+            return out
         # fc1 writes the pre-activation h (needed for gelu' in backward) AND the activation g = gelu(h):
         # fc2, the fc2 weight gradient and the GRN statistics path all consume g, so GELU is evaluated once
         # (inference keeps the activation only: C = NULL skips the pre-activation store, a third of the block's 4C-wide traffic)
@@ -305,12 +334,6 @@ class Engine:
                hw=hw, C2=gact)
         s = o.grn_scale(colsq, w.grn_w)
         out = torch.empty((M, C), dtype=dt, device=x.device)
-        # stochastic depth (timm DropPath, scale_by_keep): the whole branch of a sample is dropped with probability dp and
-        # the survivors are scaled by 1 / (1 - dp); training mode only.  One device-side draw per block (graph-capturable).
-        dpm = None
-        if w.dp > 0.0 and self.model.training:
-            inj = self._dp_inject
-            dpm = inj.pop(0) if inj else (torch.rand(B, device=x.device) < (1.0 - w.dp)).float() / (1.0 - w.dp)
         if dt == torch.bfloat16 and C > 64 and hw % 128 == 0 and hw // 128 >= 8:
             # large feature maps: fold the GRN affine into per-sample fc2 weights,
             #   (g·s_b + β)·W2ᵀ = g·(W2·diag(s_b))ᵀ + W2·β,

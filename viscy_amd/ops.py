@@ -287,6 +287,46 @@ def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor) -> None:
     check(lib().vsx_adamw(ptr(p), ptr(g), ptr(m), ptr(v), ptr(hyper), p.numel(), stream()), "adamw")
 
 
+# ------------------------------------------------------------------ fused GRN-MLP (csrc/mlp.hip)
+def mlp_supported(C: int, hw: int, M: int, dtype: torch.dtype) -> bool:
+    return dtype == torch.bfloat16 and bool(lib().vsx_mlp_supported(C, hw, M, dtype_code(dtype)))
+
+
+def mlp_pack(W1f: Tensor, W2: Tensor, C: int) -> Tensor:
+    """fragment-major LDS image of the prepared fc1 / fc2 weights (bf16 [4C, C] and [C, 4C])"""
+    img = torch.empty(int(lib().vsx_mlp_image_bytes(C)), dtype=torch.uint8, device=W1f.device)
+    check(lib().vsx_mlp_pack(ptr(W1f), ptr(W2), ptr(img), C, stream()), "mlp_pack")
+    return img
+
+
+_GTAB: dict = {}
+
+
+def _gelu_table(dev) -> Tensor:
+    """r(a) = a * Phi(-a) for every bf16 magnitude in [2^-24, 16) (computed once per device, in double precision)"""
+    t = _GTAB.get(dev)
+    if t is None:
+        t = torch.empty(int(lib().vsx_mlp_gelu_table_len()), dtype=torch.float32, device=dev)
+        check(lib().vsx_mlp_gelu_table(ptr(t), stream()), "mlp_gelu_table")
+        _GTAB[dev] = t
+    return t
+
+
+def mlp_stats(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int) -> None:
+    """colsq[b, 4C] += per-sample column sums of gelu(fc1(xh))^2 — nothing 4C-wide is written"""
+    check(lib().vsx_mlp_fwd(ptr(xh), ptr(img), ptr(b1), None, None, None, None, None, None, ptr(colsq), ptr(_gelu_table(xh.device)),
+                            M, C, hw, 0, dtype_code(xh.dtype), stream()), "mlp_stats")
+
+
+def mlp_out(xh: Tensor, img: Tensor, b1: Tensor, s: Tensor, beta: Tensor, b2: Tensor, res: Tensor, rscale: Tensor | None,
+            M: int, C: int, hw: int) -> Tensor:
+    """out = res + rscale * (fc2(gelu(fc1(xh)) * s + beta) + b2), hidden activation kept on chip"""
+    out = torch.empty((M, C), dtype=xh.dtype, device=xh.device)
+    check(lib().vsx_mlp_fwd(ptr(xh), ptr(img), ptr(b1), ptr(s), ptr(beta), ptr(b2), ptr(res), ptr(rscale), ptr(out), None,
+                            ptr(_gelu_table(xh.device)), M, C, hw, 1, dtype_code(xh.dtype), stream()), "mlp_out")
+    return out
+
+
 def adamw_advance(cfg: Tensor, step: Tensor, hyper: Tensor) -> None:
     """schedule / bias corrections of the next optimiser step from device state (csrc/optim.hip): no host memory involved"""
     if step.dtype != torch.int32:
