@@ -176,7 +176,7 @@ def gate_shape_record(dev, steps: int = 5, B: int = 8, size: int = 2048) -> dict
     opt = FlatAdamW(model.engine(), lr=2e-4, schedule="WarmupCosine", warmup_steps=3, t_total=steps + 4, warmup_multiplier=1e-3)
     x, tgt = make_batch(B, size, size, dev, seed=7)
     step = TrainStep(model, MixedLoss(0.5, 0.0, 0.5), opt, None, use_graph=True)
-    l0 = step(x, tgt)
+    l0 = step(x, tgt).clone()  # (the step returns its static loss tensor: keep the first value)
     step(x, tgt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

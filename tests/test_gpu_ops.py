@@ -790,7 +790,15 @@ def test_fused_grn_mlp_matches_unfused_kernels_and_reference(C, hw, B, drop_path
 
     dt = torch.bfloat16
     M, H4 = B * hw, 4 * C
-    assert ops.mlp_supported(C, hw, M, dt)
+    L.lib().vsx_set_flag(b"mlp_fused", 7)  # bit 2: the C = 384 instantiation too (off by default: measured slower)
+    try:
+        assert ops.mlp_supported(C, hw, M, dt)
+        _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops)
+    finally:
+        L.lib().vsx_set_flag(b"mlp_fused", 1)
+
+
+def _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops):
     xh = rnd(M, C, dt=dt, seed=1).cuda()
     res = rnd(M, C, dt=dt, seed=2).cuda()
     W1 = rnd(H4, C, dt=dt, seed=3, scale=C ** -0.5).cuda()

@@ -32,6 +32,16 @@ def main(fetch_csv, write_csv, steps, batch, out):
     for k, v in w:
         agg[k]["write"] += v * cal["write"]["bytes_per_count"]
     res = {"steps": steps, "batch": batch, "calibration": cal, "kernels": {}}
+    try:  # identity of what was measured: bench.py refuses a traffic file from other kernel sources / flags
+        import os
+
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+
+        bi = bench.build_info()
+        res["source_hash"], res["flags"], res["git_sha"] = bi["source_hash"], bi["flags"], bi.get("git_sha")
+    except Exception as e:  # noqa: BLE001
+        res["identity_error"] = repr(e)
     for k, d in sorted(agg.items(), key=lambda kv: -(kv[1]["read"] + kv[1]["write"])):
         if k == "normalize_kernel":
             continue
@@ -44,6 +54,8 @@ def main(fetch_csv, write_csv, steps, batch, out):
         base = re.sub(r"^_Z\d+", "", k)
         base = re.sub(r"_kernel.*", "", base)
         base = {"gemm_nt_fast": "gemm_nt", "gemm_tn_fast": "gemm_tn"}.get(base, base)
+        if base.startswith("mlp_fused"):  # bench.py's OpTimer classes: mlp_stats (MODE 0) / mlp_out (MODE 1)
+            base = "mlp_out" if "ELi1EE" in k or ", 1>" in k else "mlp_stats"
         for f in ("launches_per_step", "read_GB_per_step", "write_GB_per_step"):
             cls[base][f] += v[f]
     for c in cls.values():

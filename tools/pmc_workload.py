@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--mode", default="train", choices=["train", "fwd"], help="fwd: forward-only passes in eval mode (the inference schedule)")
 args = ap.parse_args()
 
 from bench import make_batch, nonzero_grn_  # noqa: E402
@@ -42,7 +43,15 @@ opt = FlatAdamW(eng, lr=2e-4, schedule="WarmupCosine", warmup_steps=3, t_total=1
 ddp = FlatDataParallel(eng, opt)
 step = TrainStep(model, MixedLoss(0.5, 0.0, 0.5), opt, ddp, use_graph=False)
 x, tgt = make_batch(args.batch, 256, 256, dev, seed=42)
-for _ in range(args.steps):
-    loss = step(x, tgt)
-torch.cuda.synchronize()
-print("loss", float(loss), "steps", args.steps, "batch", args.batch)
+if args.mode == "fwd":
+    model.eval()
+    with torch.no_grad():
+        for _ in range(args.steps):
+            y = model(x)
+    torch.cuda.synchronize()
+    print("fwd mean", float(y.mean()), "passes", args.steps, "batch", args.batch)
+else:
+    for _ in range(args.steps):
+        loss = step(x, tgt)
+    torch.cuda.synchronize()
+    print("loss", float(loss), "steps", args.steps, "batch", args.batch)

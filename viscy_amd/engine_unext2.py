@@ -395,7 +395,7 @@ class Engine:
         o.unprep_grad(dW1f, g(blk.mlp.fc1.weight), 4 * C, C, 1, gamma=blk.norm.weight, W=blk.mlp.fc1.weight,
                       dgamma=g(blk.norm.weight), u=db1f, beta=blk.norm.bias)
         o.matvec_t_add(blk.mlp.fc1.weight, db1f, g(blk.norm.bias), 4 * C, C)
-        g(blk.mlp.fc1.bias).add_(db1f)
+        o.transpose_f32(db1f, g(blk.mlp.fc1.bias), 4 * C, 1, True)  # g(b1) += db1f (a [4C, 1] "transpose": no ATen launch in the step)
         dy = o.ln_bwd(dxh, xh, None, rstd, None, None, None, None, M, C)
         del dxh
         if rows is not None:
