@@ -14,7 +14,9 @@
  *              VSX_BF16 (1) = bf16 storage + bf16 MFMA, fp32 accumulation / statistics.
  *   - activations inside the trunk are channels-last: [B, H, W, C] ("pixel rows x channels").
  *   - return 0 on success; non-zero → vsx_last_error() (thread-local) has the message.
- *   - re-entrant, no global mutable state besides read-only tables and vsx_set_flag knobs.
+ *   - re-entrant; the only mutable global state is the set of kernel-selection flags behind vsx_set_flag (plain ints read at
+ *     launch time: set them before launching from several threads, not while launches are in flight) and the thread-local
+ *     error string.
  */
 #ifndef VSX_H
 #define VSX_H
@@ -286,6 +288,10 @@ int32_t vsx_mlp_pack(const void* W1, const void* W2, void* img, int32_t C, vsx_s
 int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1, const float* grn_s, const float* grn_b, const float* b2,
     const void* res, const float* rscale, void* out, float* colsq, const float* gelu_table, int64_t M, int32_t C, int32_t hw,
     int32_t mode, int32_t dtype, vsx_stream_t stream);
+/* training fc1 on the same kernel: h = bf16(xh . W1'^T + b1) and g = bf16(gelu(h)) stored ([M, 4C] each), colsq[b, 4C] +=
+ * sum_hw g^2 — the outputs of vsx_gemm_nt with VSX_EPI_BIAS_GELU_SQ */
+int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1, float* colsq, const float* gelu_table, void* h, void* g,
+    int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
 /* GELU of a bf16 value through a table (csrc/mlp.hip): vsx_mlp_gelu_table fills `tab` (vsx_mlp_gelu_table_len() floats) with
  * a * Phi(-a) for every bf16 magnitude a in [2^-24, 16); gelu(h) = max(h, 0) - tab[bits(|h|)]. */
 int32_t vsx_mlp_gelu_table_len(void);
@@ -333,6 +339,11 @@ int32_t vsx_prep_head_dgrad(const float* W, void* dst, int32_t Cmid, int32_t C3,
  * (viscy_transforms/_normalize.py:72-80): (x - sub)/(div + 1e-8). */
 int32_t vsx_stem_im2col(const float* x, void* P, const float* sub, const float* div, int32_t B, int32_t Cin,
     int32_t Z, int32_t H, int32_t W, int32_t kz, int32_t ky, int32_t kx, int32_t dtype, vsx_stream_t stream);
+/* the same gather with rows of ldp >= patch-size elements (tail zero-filled), and the matching weight-space helper
+ * dst[r][k] = k < K ? src[r][k] : 0: K = 80 of the 5x4x4 stem becomes 96 = a whole number of 32-deep MFMA slabs */
+int32_t vsx_stem_im2col_ld(const float* x, void* P, const float* sub, const float* div, int32_t B, int32_t Cin, int32_t Z,
+    int32_t H, int32_t W, int32_t kz, int32_t ky, int32_t kx, int32_t ldp, int32_t dtype, vsx_stream_t stream);
+int32_t vsx_pad_cols(const void* src, void* dst, int32_t R, int32_t K, int32_t Kp, int32_t dtype, vsx_stream_t stream);
 
 /* K10: MONAI UpSample(mode="pixelshuffle", pre_conv=None) + torch.cat([up, skip], 1) (viscy_models/components/blocks.py:138-146,170-171). */
 int32_t vsx_pixel_shuffle_cat_fwd(const void* low, const void* skip, void* out, int32_t B, int32_t h,

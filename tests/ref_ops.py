@@ -188,7 +188,16 @@ def dwconv7_bwd_weight(dy, x, dw, db, B, H, W, Cc):
         db += dy.float().view(-1, Cc).sum(0)
 
 
-def stem_im2col(x, kernel, dtype, sub=None, div=None):
+def pad_cols(src, Kp):
+    R, K = src.shape
+    dst = torch.zeros((R, Kp), dtype=src.dtype)
+    dst[:, :K] = src
+    return dst
+
+
+def stem_im2col(x, kernel, dtype, sub=None, div=None, ld=None):
+    if ld is not None:
+        return pad_cols(stem_im2col(x, kernel, dtype, sub, div), ld)
     B, Cin, Z, H, W = x.shape
     kz, ky, kx = kernel
     if sub is not None:

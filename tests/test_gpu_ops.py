@@ -458,6 +458,16 @@ def test_stem_im2col_and_normalize_fusion(dt):
         x = rnd(B, Cin, Z, Hh, Ww, seed=1) * 10 + 3
         sub, div = torch.tensor([1.0, 2.0][:B]), torch.tensor([3.0, 0.5][:B])
         close(H.stem_im2col(x.to(DEV), (5, 4, 4), dt), R.stem_im2col(x, (5, 4, 4), dt), dt, "im2col")
+        # rows padded to a whole number of 32-deep MFMA slabs (K = 80 -> 96): zero tail, same head; matching weight helper
+        Pr = R.stem_im2col(x, (5, 4, 4), dt)
+        KT = Pr.shape[1]
+        ldp = (KT + 31) // 32 * 32 + (32 if KT % 32 == 0 else 0)
+        Pp = H.stem_im2col(x.to(DEV), (5, 4, 4), dt, ld=ldp)
+        assert Pp.shape[1] == ldp > KT and float(Pp[:, KT:].abs().max()) == 0.0
+        close(Pp[:, :KT], Pr, dt, "im2col padded")
+        wsrc = rnd(24, 80, dt=dt, seed=9)
+        wp = H.pad_cols(wsrc.to(DEV), 96)
+        assert torch.equal(wp[:, :80].cpu(), wsrc) and float(wp[:, 80:].abs().max()) == 0.0
         close(H.stem_im2col(x.to(DEV), (5, 4, 4), dt, sub.to(DEV), div.to(DEV)), R.stem_im2col(x, (5, 4, 4), dt, sub, div), dt,
               "im2col+normalize")
 
@@ -795,7 +805,7 @@ def test_fused_grn_mlp_matches_unfused_kernels_and_reference(C, hw, B, drop_path
         assert ops.mlp_supported(C, hw, M, dt)
         _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops)
     finally:
-        L.lib().vsx_set_flag(b"mlp_fused", 1)
+        L.lib().vsx_set_flag(b"mlp_fused", 3)
 
 
 def _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops):
@@ -829,6 +839,19 @@ def _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops):
     ops.gemm("nt", xh, W1, hh, M, H4, C, C, C, H4, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=b1, red0=csq2, hw=hw, C2=gg)
     assert torch.equal(gg.float(), g.to(dt).float()) or (gg.float() - g).abs().max().item() <= 0.02 * g.abs().max().item()
     close(colsq, csq2, torch.float32, "colsq vs unfused", scale=csq2.abs().max().item() * 5)
+    # training fc1 on the fused kernel (MODE 2): the same h / g / colsq as the GEMM with the GELU epilogue (the table GELU is
+    # the correctly rounded erf GELU, the epilogue's Abramowitz-Stegun evaluation may differ from it by one bf16 ulp)
+    csq3 = torch.zeros_like(colsq)
+    h3, g3 = ops.mlp_fc1(xh, img, b1, csq3, M, C, hw)
+    assert (h3.float() - hh.float()).abs().max().item() <= 0.008 * hh.float().abs().max().item()   # accumulation order: 1 ulp
+    assert ((h3 != hh).float().mean().item()) < 0.02
+    same_h = h3 == hh
+    dg = (g3.float() - gg.float()).abs()
+    assert dg[same_h].max().item() <= 0.008 * gg.float().abs().max().item() and (dg[same_h] > 0).float().mean().item() < 0.01
+    gref = torch.nn.functional.gelu(h3.float().double()).float().to(dt).float()  # erf GELU in double, rounded to bf16
+    dgr = (g3.float() - gref).abs()
+    assert (dgr > 0).float().mean().item() < 2e-3 and dgr.max().item() <= 0.008 * gref.abs().max().item()  # (double rounding)
+    close(csq3, csq2, torch.float32, "colsq (fc1 fused) vs unfused", scale=csq2.abs().max().item() * 5)
     out2 = torch.empty((M, C), dtype=dt, device="cuda")
     ops.gemm("nt", gg, W2, out2, M, C, H4, H4, H4, C, dtype=dt, pro=L.PRO_GRN, grn_s=ops.grn_scale(csq2, gamma), grn_b=beta,
              hw=hw, epi=L.EPI_BIAS_RES, bias=b2, res=res, ldr=C, rscale=rs)

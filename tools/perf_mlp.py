@@ -50,6 +50,8 @@ for C, hw, nblk in SHAPES:
     t_out = timeit(lambda: ops.mlp_out(xh, img, b1, s, beta, b2, res, None, M, C, hw))
     t_fc1_inf = timeit(lambda: ops.gemm("nt", xh, W1, None, M, H4, C, C, C, H4, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=b1, red0=colsq, hw=hw, C2=g))
     t_fc1_tr = timeit(lambda: ops.gemm("nt", xh, W1, h, M, H4, C, C, C, H4, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=b1, red0=colsq, hw=hw, C2=g))
+    t_fc1_fused = timeit(lambda: ops.mlp_fc1(xh, img, b1, colsq, M, C, hw), n=5)
+    print(f"      fc1(train): unfused GEMM {t_fc1_tr:8.1f} us | fused kernel + h/g stores {t_fc1_fused:8.1f} us ({2 * M * H4 * 2 / t_fc1_fused / 1e3:6.0f} GB/s stored)")
     t_fc2 = timeit(lambda: ops.gemm("nt", g, W2, out, M, C, H4, H4, H4, C, dtype=dt, pro=L.PRO_GRN, grn_s=s, grn_b=beta, hw=hw, epi=L.EPI_BIAS_RES, bias=b2, res=res, ldr=C))
     Ws = ops.scale_weight_samples(W2.float(), s, dt) if hw % 128 == 0 and hw // 128 >= 8 else None
     t_fc2f = timeit(lambda: ops.gemm("nt", g, Ws, out, M, C, H4, H4, H4, C, dtype=dt, hw=hw, b_bstride=C * H4, epi=L.EPI_BIAS_RES, bias=b2, res=res, ldr=C)) if Ws is not None else float("nan")

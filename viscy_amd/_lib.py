@@ -59,6 +59,8 @@ _SIGS = {
     "vsx_dwconv7_bwd_data": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_dwconv7_bwd_weight": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_stem_im2col": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "vsx_stem_im2col_ld": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "vsx_pad_cols": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_pixel_shuffle_cat_fwd": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_pixel_shuffle_cat_bwd": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_head_shuffle_fwd": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
@@ -77,6 +79,7 @@ _SIGS = {
     "vsx_mlp_image_bytes": (_I64, [_I32]),
     "vsx_mlp_pack": (_I32, [_P, _P, _P, _I32, _P]),
     "vsx_mlp_fwd": (_I32, [_P] * 11 + [_I64, _I32, _I32, _I32, _I32, _P]),
+    "vsx_mlp_fc1": (_I32, [_P] * 7 + [_I64, _I32, _I32, _I32, _P]),
     "vsx_mlp_gelu_table_len": (_I32, []),
     "vsx_mlp_gelu_table": (_I32, [_P, _P]),
     "vsx_prep_weight": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),

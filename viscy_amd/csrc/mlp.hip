@@ -6,6 +6,9 @@
 // in TWO passes over the C-wide LayerNorm output, with the 4C-wide hidden activation never leaving the CU:
 //   MODE 0 (statistics): fc1 -> +bias -> GELU -> per-sample column sums of g^2 (the GRN statistics), nothing stored;
 //   MODE 1 (output)    : fc1 recomputed -> +bias -> GELU -> g * s[b] + beta -> fc2 -> +bias -> * drop-path scale -> + shortcut.
+//   MODE 2 (training fc1): MODE 0 that also stores the pre-activation h and the activation g (bf16) for the backward — the
+//                        same outputs as the unfused fc1 GEMM, whose 3-slab K loop pays one HBM round trip per slab and per
+//                        tile (its waves sit in s_waitcnt 41 % of the time); here the activation rows are loaded once.
 // (SURVEY §7 step 4 / VERDICT r1 "what's missing" 1.  The unfused schedule moved 8 of its 15 C-units per pixel as 4C-wide
 // h / g tensors through HBM in inference; this one moves 1 + 3.)
 //
@@ -43,7 +46,9 @@ struct MlpArgs {
   const bf16_t* res;    // [M, C]  shortcut                      (MODE 1)
   const float* rscale;  // [B] stochastic-depth scale or NULL    (MODE 1)
   bf16_t* out;          // [M, C]                                (MODE 1)
-  float* colsq;         // [B, 4C] += sum_hw gelu(h)^2           (MODE 0)
+  float* colsq;         // [B, 4C] += sum_hw gelu(h)^2           (MODE 0, 2)
+  bf16_t* hout;         // [M, 4C] pre-activation                (MODE 2)
+  bf16_t* gout;         // [M, 4C] activation                    (MODE 2)
   const float* gtab;    // [MLP_GT_N] r(a) = a * Phi(-a) for every bf16 a in [2^-24, 16)  (vsx_mlp_gelu_table)
   int M, hw;
 };
@@ -67,13 +72,13 @@ struct MlpGeom {
   static constexpr int H4 = 4 * C, NHS = H4 / 32, KK = C / 32, NF = C / 16;
   static constexpr int WM = 16 * MF, BM = NW * WM;
   static constexpr int W1_PIECES = 2 * KK, IMG_PIECES = 2 * KK + NF;   // KiB per hidden sub-chunk in the image
-  static constexpr int NP = MODE == 0 ? W1_PIECES : IMG_PIECES;        // pieces staged per sub-chunk
+  static constexpr int NP = MODE != 1 ? W1_PIECES : IMG_PIECES;        // pieces staged per sub-chunk
   static constexpr int STAGE_BYTES = NP * 1024;
   static constexpr int OB_COLS = 64;                                   // output leaves in blocks of 64 columns
   static constexpr int OB_RS = OB_COLS * 2 + 16;                       // staging row stride (bytes)
-  static constexpr int OUT_BYTES = MODE == 1 ? NW * WM * OB_RS : 16;
-  static constexpr int VEC_FLOATS = MODE == 0 ? H4 : 3 * H4 + C;
-  static constexpr int RED_FLOATS = MODE == 0 ? 2 * NW * 32 : 4;
+  static constexpr int OUT_BYTES = MODE == 1 ? NW * WM * OB_RS : (MODE == 2 ? NW * 2 * WM * OB_RS : 16);
+  static constexpr int VEC_FLOATS = MODE != 1 ? H4 : 3 * H4 + C;
+  static constexpr int RED_FLOATS = MODE != 1 ? 2 * NW * 32 : 4;
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES + OUT_BYTES + (VEC_FLOATS + RED_FLOATS) * 4;
 };
 
@@ -81,7 +86,7 @@ template <int C, int MF, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
   typedef MlpGeom<C, MF, NW, MODE> G;
   constexpr int H4 = G::H4, NHS = G::NHS, KK = G::KK, NF = G::NF, WM = G::WM;
-  constexpr int VALU_OPS = MF * (MODE == 1 ? 80 : 64);  // VALU instructions of one sub-chunk's bias / GELU / GRN (from the ISA)
+  constexpr bool STATS = MODE != 1, STORE = MODE == 2;
   // SEPARATE LDS objects, on purpose: the two weight stages, the per-channel vectors and the output staging are distinct
   // variables, so the compiler's alias scopes let fragment / vector reads proceed while the LDS-DMA prefetch of the OTHER
   // stage is in flight (through one array every ds_read behind a global_load_lds costs an s_waitcnt vmcnt(0): no overlap)
@@ -145,6 +150,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
   };
   // bias, GELU, GRN in registers (same rounding points as the unfused kernels: h and g are bf16 values); MODE 0 adds g^2
   // into sq, MODE 1 packs z = g * s + beta as the fc2 A fragments
+  // MODE 2: h / g of two consecutive sub-chunks are parked in a wave-private LDS tile [2 outputs][WM rows][64 hidden] and
+  // leave as 16-byte vectors, 128-byte row segments (8-byte stores straight from the accumulator layout — 32-byte segments —
+  // ran at 2.4-2.8 TB/s and made this pass slower than the unfused GEMM)
+  char* sb = obuf + wave * (2 * WM * G::OB_RS);
   auto activate = [&](int hs, const mlp_f32x4 (&acc)[2][MF], mlp_bf16x8 (&zf)[MF], float (&sq)[2][4]) {
     const float* vb = vec + hs * 32 + kq * 4;
     float b1v[2][4], sv[2][4], bv[2][4];
@@ -188,9 +197,14 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
         for (int r = 0; r < 4; r += 2) {
           const uint32_t Pq = P[hf * 2 + r / 2];
           const float h0 = __uint_as_float(Pq << 16), h1 = __uint_as_float(Pq & 0xFFFF0000u);
-          const float g0 = round_bf16(fmaxf(h0, 0.f) - rr[hf * 4 + r]);
-          const float g1 = round_bf16(fmaxf(h1, 0.f) - rr[hf * 4 + r + 1]);
-          if constexpr (MODE == 0) {
+          const uint32_t Gq = f32x2_to_bf16x2_bits(fmaxf(h0, 0.f) - rr[hf * 4 + r], fmaxf(h1, 0.f) - rr[hf * 4 + r + 1]);
+          const float g0 = __uint_as_float(Gq << 16), g1 = __uint_as_float(Gq & 0xFFFF0000u);
+          if constexpr (STORE) {
+            char* d = sb + (mf * 16 + p16) * G::OB_RS + ((hs & 1) * 32 + hf * 16 + kq * 4 + r) * 2;
+            *reinterpret_cast<uint32_t*>(d) = Pq;
+            *reinterpret_cast<uint32_t*>(d + WM * G::OB_RS) = Gq;
+          }
+          if constexpr (STATS) {
             sq[hf][r] = fmaf(g0, g0, sq[hf][r]);
             sq[hf][r + 1] = fmaf(g1, g1, sq[hf][r + 1]);
           } else {
@@ -222,6 +236,23 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
                                        (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
     }
   };
+  // MODE 2: lane (p, q) owns hidden q*4 .. q*4+3 of pixel p in each 16-column half: two 8-byte stores per output and
+  // fragment; the two halves of a sub-chunk complete a 64-byte row segment, consecutive sub-chunks the cache lines
+  auto store_pending = [&](int hs) {  // hs = the ODD sub-chunk of the pair (hs - 1, hs) parked in the staging tile
+    if constexpr (STORE) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int idx = lane; idx < 2 * WM * 8; idx += 64) {
+        const int o = idx / (WM * 8), rem = idx - o * (WM * 8);
+        const int row = rem >> 3, ch = rem & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(sb + (o * WM + row) * G::OB_RS + ch * 16);
+        bf16_t* dst = (o ? a.gout : a.hout) + (size_t)(row0 + row) * H4 + (hs - 1) * 32 + ch * 8;
+        *reinterpret_cast<uint4*>(dst) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
   mlp_f32x4 hcur[2][MF], hnxt[2][MF];
   // prologue: W1 of sub-chunk 0 goes where "stage -1" would sit (buffer 1)
   {
@@ -237,9 +268,13 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
 
   auto step = [&](int hs, const char* Sb, char* other) {
     // stage hs has landed for everyone (waited + barrier by the caller); every wave is done with stage hs - 1 in `other`
+    if constexpr (STORE) {
+      if (hs > 0 && (hs & 1) == 0) store_pending(hs - 1);  // issued BEFORE the prefetch: the next vmcnt(0) then waits for
+                                                           // stores that have had a whole sub-chunk to complete
+    }
     if (hs + 1 < NHS) stage_load2(hs + 1, other);
     const char* S = Sb + lane * 16;
-    if constexpr (MODE == 0) {
+    if constexpr (STATS) {
       if (hs > 0 && wave == (hs - 1) % NW && lane < 32) {  // column sums of the previous sub-chunk (parked before the barrier)
         const float* r = red + ((hs - 1) & 1) * NW * 32 + lane;
         float t = 0.f;
@@ -265,7 +300,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     activate(hs, hcur, zf, sq);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (MODE == 0) {
+    if constexpr (STATS) {
       // sum over this wave's pixels: the 16 lanes of a DPP row share q, i.e. the same 8 hidden columns
       float* rw = red + (hs & 1) * NW * 32 + wave * 32;
 #pragma unroll
@@ -310,7 +345,8 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
     step(hs + 1, buf1, buf0);
   }
 
-  if constexpr (MODE == 0) {
+  if constexpr (STATS) {
+    store_pending(NHS - 1);
     __syncthreads();
     if (wave == (NHS - 1) % NW && lane < 32) {
       const float* r = red + ((NHS - 1) & 1) * NW * 32 + lane;
@@ -454,6 +490,9 @@ static int mlp_dispatch(const MlpCfg* c, const MlpArgs& a, hipStream_t s) {
   return mlp_launch<384, 2, 4, MODE>(a, s);
 }
 
+extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1, float* colsq, const float* gtab, void* h,
+                               void* g, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
+
 /* mode 0: colsq[b, 4C] += sum over the sample's pixels of gelu(fc1(xh))^2 (bf16-rounded g, as the unfused fc1 epilogue);
  * mode 1: out = res + rscale[b] * (fc2(gelu(fc1(xh)) * s[b] + beta) + b2). */
 extern "C" int32_t vsx_mlp_gelu_table_len(void) { return MLP_GT_N; }
@@ -485,6 +524,7 @@ extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1
   MlpArgs a;
   a.xh = (const bf16_t*)xh; a.wimg = (const char*)wimg; a.b1 = b1; a.grn_s = grn_s; a.grn_b = grn_b; a.b2 = b2;
   a.res = (const bf16_t*)res; a.rscale = rscale; a.out = (bf16_t*)out; a.colsq = colsq; a.gtab = gtab; a.M = (int)M; a.hw = hw;
+  a.hout = nullptr; a.gout = nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) {
     VSX_CHECK(colsq != nullptr, "vsx_mlp_fwd: mode 0 needs colsq");
@@ -492,4 +532,20 @@ extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1
   }
   VSX_CHECK(mode == 1 && grn_s && grn_b && b2 && res && out, "vsx_mlp_fwd: mode 1 needs s, beta, b2, res, out");
   return mlp_dispatch<1>(c, a, s);
+}
+
+/* training fc1 (MODE 2): h = bf16(xh . W1'^T + b1), g = bf16(gelu(h)) stored for the backward, colsq[b, 4C] += sum_hw g^2 —
+ * the outputs of vsx_gemm_nt with VSX_EPI_BIAS_GELU_SQ, from the kernel that keeps its activation rows in registers */
+extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1, float* colsq, const float* gtab, void* h,
+                               void* g, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_fc1: bf16 only");
+  VSX_CHECK(xh && wimg && b1 && colsq && gtab && h && g && M > 0 && hw > 0, "vsx_mlp_fc1: bad arguments");
+  const MlpCfg* c = mlp_cfg(C, hw, M);
+  VSX_CHECK(c != nullptr, "vsx_mlp_fc1: unsupported shape C=%d hw=%d M=%ld (query vsx_mlp_supported first)", C, hw, (long)M);
+  VSX_CHECK(M < (1ll << 31), "vsx_mlp_fc1: M too large");
+  MlpArgs a;
+  a.xh = (const bf16_t*)xh; a.wimg = (const char*)wimg; a.b1 = b1; a.grn_s = nullptr; a.grn_b = nullptr; a.b2 = nullptr;
+  a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = colsq; a.gtab = gtab; a.hout = (bf16_t*)h; a.gout = (bf16_t*)g;
+  a.M = (int)M; a.hw = hw;
+  return mlp_dispatch<2>(c, a, (hipStream_t)stream);
 }

@@ -12,12 +12,12 @@
 template <typename T>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ P,
                                                           const float* __restrict__ sub, const float* __restrict__ dv,
-                                                          int B, int Cin, int Z, int H, int W, int kz, int ky, int kx) {
+                                                          int B, int Cin, int Z, int H, int W, int kz, int ky, int kx, int ldp) {
   constexpr int VN = VT<T>::N;
   const int h = H / ky, w = W / kx, D = Z / kz;
   const int K = Cin * kz * ky * kx;
   const int KT = D * K;
-  const int nch = KT / VN;
+  const int nch = ldp / VN;  // ldp >= KT: the columns [KT, ldp) of a row are zero (K padded to the GEMM's slab width)
   const long total = (long)B * h * w * nch;
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
@@ -36,6 +36,10 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < VN; ++j) {
     int col = ch * VN + j;
+    if (col >= KT) {
+      o[j] = 0.f;
+      continue;
+    }
     int d = col / K, k = col - d * K;
     int dx = k % kx;
     int t = k / kx;
@@ -46,30 +50,66 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
     float v = x[((((size_t)b * Cin + ci) * Z + d * kz + dz) * H + yo * ky + dy) * W + xo * kx + dx];
     o[j] = sub ? (v - s) * inv : v;
   }
-  stvec<T>(P + ((size_t)(b * h + yo) * w + xo) * KT + ch * VN, pack<T>(o));
+  stvec<T>(P + ((size_t)(b * h + yo) * w + xo) * ldp + ch * VN, pack<T>(o));
 }
 
 /* K1 gather half of UNeXt2Stem (viscy_models/components/stems.py:26-50): the Conv3d with
  * kernel = stride = (kz,ky,kx) is a GEMM over non-overlapping patches; this writes the patch
  * matrix, vsx_gemm_nt does the projection.  Optional per-sample (sub, div) fuses
  * NormalizeSampled (viscy_transforms/_normalize.py:72-80) into the load. */
-extern "C" int32_t vsx_stem_im2col(const float* x, void* P, const float* sub, const float* div, int32_t B, int32_t Cin,
-                                   int32_t Z, int32_t H, int32_t W, int32_t kz, int32_t ky, int32_t kx, int32_t dtype,
-                                   vsx_stream_t stream) {
+static int stem_im2col_launch(const float* x, void* P, const float* sub, const float* div, int32_t B, int32_t Cin, int32_t Z,
+                              int32_t H, int32_t W, int32_t kz, int32_t ky, int32_t kx, int32_t ldp, int32_t dtype,
+                              vsx_stream_t stream) {
   int vn = dtype == VSX_BF16 ? 8 : 4;
   VSX_CHECK(x && P && B > 0 && Cin > 0, "vsx_stem_im2col: bad arguments");
   VSX_CHECK(Z % kz == 0 && H % ky == 0 && W % kx == 0, "vsx_stem_im2col: (%d,%d,%d) not divisible by kernel (%d,%d,%d)",
             Z, H, W, kz, ky, kx);
-  VSX_CHECK((Cin * kz * ky * kx) % vn == 0, "vsx_stem_im2col: patch size must be a multiple of %d", vn);
+  const int KT = (Z / kz) * Cin * kz * ky * kx;
+  VSX_CHECK(KT % vn == 0, "vsx_stem_im2col: patch size must be a multiple of %d", vn);
+  VSX_CHECK(ldp >= KT && ldp % vn == 0, "vsx_stem_im2col: row length %d must be >= %d and a multiple of %d", ldp, KT, vn);
   VSX_CHECK((sub == nullptr) == (div == nullptr), "vsx_stem_im2col: sub/div must both be set or both NULL");
-  long total = (long)B * (H / ky) * (W / kx) * ((Z / kz) * Cin * kz * ky * kx / vn);
+  long total = (long)B * (H / ky) * (W / kx) * (ldp / vn);
   dim3 grid(vsx_cdiv(total, 256));
   if (dtype == VSX_BF16)
     hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)P, sub, div, B,
-                       Cin, Z, H, W, kz, ky, kx);
+                       Cin, Z, H, W, kz, ky, kx, ldp);
   else
     hipLaunchKernelGGL(stem_im2col_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)P, sub, div, B,
-                       Cin, Z, H, W, kz, ky, kx);
+                       Cin, Z, H, W, kz, ky, kx, ldp);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t vsx_stem_im2col(const float* x, void* P, const float* sub, const float* div, int32_t B, int32_t Cin,
+                                   int32_t Z, int32_t H, int32_t W, int32_t kz, int32_t ky, int32_t kx, int32_t dtype,
+                                   vsx_stream_t stream) {
+  return stem_im2col_launch(x, P, sub, div, B, Cin, Z, H, W, kz, ky, kx, (Z / (kz > 0 ? kz : 1)) * Cin * kz * ky * kx, dtype, stream);
+}
+
+/* the same gather with rows of `ldp` >= patch-size elements, the tail zero-filled: K = 80 (the 5x4x4 single-channel stem)
+ * becomes 96, a whole number of 32-deep MFMA slabs, and the projection runs on the lean GEMM instead of the generic one
+ * (2.9 ms -> the launch's HBM time at B = 512) */
+extern "C" int32_t vsx_stem_im2col_ld(const float* x, void* P, const float* sub, const float* div, int32_t B, int32_t Cin,
+                                      int32_t Z, int32_t H, int32_t W, int32_t kz, int32_t ky, int32_t kx, int32_t ldp,
+                                      int32_t dtype, vsx_stream_t stream) {
+  return stem_im2col_launch(x, P, sub, div, B, Cin, Z, H, W, kz, ky, kx, ldp, dtype, stream);
+}
+
+// dst[r][k] = k < K ? src[r][k] : 0   (row length K -> Kp; weight-space helper of the padded stem GEMM)
+template <typename T>
+__global__ __launch_bounds__(256) void pad_cols_kernel(const T* __restrict__ src, T* __restrict__ dst, int R, int K, int Kp) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)R * Kp) return;
+  const int k = (int)(gid % Kp), r = (int)(gid / Kp);
+  dst[gid] = k < K ? src[(size_t)r * K + k] : from_f32<T>(0.f);
+}
+extern "C" int32_t vsx_pad_cols(const void* src, void* dst, int32_t R, int32_t K, int32_t Kp, int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(src && dst && R > 0 && K > 0 && Kp >= K, "vsx_pad_cols: bad arguments");
+  dim3 grid(vsx_cdiv((long)R * Kp, 256));
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(pad_cols_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, R, K, Kp);
+  else
+    hipLaunchKernelGGL(pad_cols_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, R, K, Kp);
   VSX_LAUNCH_CHECK();
   return 0;
 }

@@ -223,6 +223,10 @@ class Engine:
         Dp = cfg["ratio"]
         if Dp == 1:
             W["stem_W"], _ = o.prep_weight(sw, co3, K, 1, dt)
+            if dt == torch.bfloat16 and K % 32:
+                # K = 80 (the 5x4x4 single-channel stem) is not a whole number of 32-deep MFMA slabs: the projection fell to
+                # the generic GEMM (2.9 ms at B = 512, 250 GB/s).  Zero-padded to 96 on both operands it runs on the lean one.
+                W["stem_W"] = o.pad_cols(W["stem_W"], (K + 31) // 32 * 32)
             W["stem_b"] = m.stem.conv.bias
         else:  # rare configuration (Z = 15): tiny weight-space expansion done with tensor ops
             we = torch.zeros((co3, Dp, Dp, K), dtype=torch.float32, device=self.device)
@@ -280,13 +284,13 @@ class Engine:
     # ------------------------------------------------------------------ block forward / backward
     def _mlp_mode(self, C, hw, M, dt, training: bool) -> bool:
         """fused GRN-MLP kernel available for this block shape (bf16, C a supported width, whole workgroup tiles per sample)
-        and enabled (``mlp_fused`` flag, bit 0; the training forward keeps the unfused pair: it has to store h anyway and
-        the backward consumes the stored activation)"""
+        and enabled (``mlp_fused`` flag: bit 0 = inference forward (statistics + output passes), bit 1 = training fc1 (the
+        statistics pass that also stores h and g; fc2 stays the unfused GEMM, which reads the stored g))"""
         o = self.ops
         if dt != torch.bfloat16 or not o.mlp_supported(C, hw, M, dt):
             return False
         flag = L.lib().vsx_get_flag(b"mlp_fused") if o.__name__.endswith("viscy_amd.ops") else 0
-        return bool(flag & 1) and not training
+        return bool(flag & (2 if training else 1))
 
     def _block_fwd(self, x, w, B, H, Wd, dt, save, rows=None):
         """One ConvNeXt-V2 block on a dense channels-last map [B*H*W, C].  ``rows = (idx, inv, keep, L)`` selects the FCMAE
@@ -328,10 +332,16 @@ class Engine:
         # fc1 writes the pre-activation h (needed for gelu' in backward) AND the activation g = gelu(h):
         # fc2, the fc2 weight gradient and the GRN statistics path all consume g, so GELU is evaluated once
         # (inference keeps the activation only: C = NULL skips the pre-activation store, a third of the block's 4C-wide traffic)
-        h = torch.empty((M, 4 * C), dtype=dt, device=x.device) if save is not None else None
-        gact = torch.empty((M, 4 * C), dtype=dt, device=x.device)
-        o.gemm("nt", xh, w.W1f, h, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=w.b1f, red0=colsq,
-               hw=hw, C2=gact)
+        if save is not None and self._mlp_mode(C, hw, M, dt, True):
+            # training fc1 on the fused kernel's statistics pass, which also stores h and g (csrc/mlp.hip MODE 2)
+            if w.img is None:
+                w.img = o.mlp_pack(w.W1f, w.W2, C)
+            h, gact = o.mlp_fc1(xh, w.img, w.b1f, colsq, M, C, hw)
+        else:
+            h = torch.empty((M, 4 * C), dtype=dt, device=x.device) if save is not None else None
+            gact = torch.empty((M, 4 * C), dtype=dt, device=x.device)
+            o.gemm("nt", xh, w.W1f, h, M, 4 * C, C, C, C, 4 * C, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=w.b1f, red0=colsq,
+                   hw=hw, C2=gact)
         s = o.grn_scale(colsq, w.grn_w)
         out = torch.empty((M, C), dtype=dt, device=x.device)
         if dt == torch.bfloat16 and C > 64 and hw % 128 == 0 and hw // 128 >= 8:
@@ -431,7 +441,7 @@ class Engine:
         if need_bwd:
             self._pending_bwd += 1
         # ---- stem: patch gather + projection GEMM, then encoder stem_1 LayerNorm2d
-        P = o.stem_im2col(x.contiguous(), (kz, ky, kx), dt)
+        P = o.stem_im2col(x.contiguous(), (kz, ky, kx), dt, ld=W["stem_W"].shape[1])
         M0, K0 = B * h * w, P.shape[1]
         f = torch.empty((M0, C0), dtype=dt, device=x.device)
         o.gemm("nt", P, W["stem_W"], f, M0, C0, K0, K0, K0, C0, dtype=dt, epi=L.EPI_BIAS, bias=W["stem_b"])
@@ -735,7 +745,8 @@ class Engine:
         df = o.ln_bwd(d, f, mean, rstd, ln1.weight, None, g(ln1.weight), g(ln1.bias), M0, C0)
         Dp = cfg["ratio"]
         if Dp == 1:
-            o.gemm("tn", P, df, g(m.stem.conv.weight), M0, C0, K0, K0, C0, K0, dtype=dt, colsum=g(m.stem.conv.bias))
+            Kw = m.stem.conv.weight[0].numel()  # the patch matrix may carry zero-padded tail columns (lda = K0 >= Kw)
+            o.gemm("tn", P, df, g(m.stem.conv.weight), M0, C0, Kw, K0, C0, Kw, dtype=dt, colsum=g(m.stem.conv.bias))
         else:
             co3 = C0 // Dp
             K = K0 // Dp

@@ -172,15 +172,26 @@ def dwconv7_bwd_weight(dy: Tensor, x: Tensor, dw: Tensor, db: Tensor | None, B: 
 
 
 def stem_im2col(x: Tensor, kernel: tuple[int, int, int], dtype: torch.dtype, sub: Tensor | None = None,
-                div: Tensor | None = None) -> Tensor:
+                div: Tensor | None = None, ld: int | None = None) -> Tensor:
+    """patch matrix of the stem; ``ld`` > patch size pads every row with zeros (see vsx_stem_im2col_ld)"""
     if x.dtype != torch.float32:
         raise TypeError("input stacks are float32")
     B, Cin, Z, H, W = x.shape
     kz, ky, kx = kernel
-    P = torch.empty((B * (H // ky) * (W // kx), (Z // kz) * Cin * kz * ky * kx), dtype=dtype, device=x.device)
-    check(lib().vsx_stem_im2col(ptr(x), ptr(P), ptr(sub), ptr(div), B, Cin, Z, H, W, kz, ky, kx, dtype_code(dtype),
-                                stream()), "stem_im2col")
+    K = (Z // kz) * Cin * kz * ky * kx
+    ld = K if ld is None else ld
+    P = torch.empty((B * (H // ky) * (W // kx), ld), dtype=dtype, device=x.device)
+    check(lib().vsx_stem_im2col_ld(ptr(x), ptr(P), ptr(sub), ptr(div), B, Cin, Z, H, W, kz, ky, kx, ld, dtype_code(dtype),
+                                   stream()), "stem_im2col")
     return P
+
+
+def pad_cols(src: Tensor, Kp: int) -> Tensor:
+    """[R, K] -> [R, Kp] with zero-filled tail columns"""
+    R, K = src.shape
+    dst = torch.empty((R, Kp), dtype=src.dtype, device=src.device)
+    check(lib().vsx_pad_cols(ptr(src), ptr(dst), R, K, Kp, dtype_code(src.dtype), stream()), "pad_cols")
+    return dst
 
 
 def pixel_shuffle_cat_fwd(low: Tensor, skip: Tensor | None, B: int, h: int, w: int, c: int, cs: int) -> Tensor:
@@ -316,6 +327,15 @@ def mlp_stats(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int
     """colsq[b, 4C] += per-sample column sums of gelu(fc1(xh))^2 — nothing 4C-wide is written"""
     check(lib().vsx_mlp_fwd(ptr(xh), ptr(img), ptr(b1), None, None, None, None, None, None, ptr(colsq), ptr(_gelu_table(xh.device)),
                             M, C, hw, 0, dtype_code(xh.dtype), stream()), "mlp_stats")
+
+
+def mlp_fc1(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int):
+    """training fc1 on the fused kernel: returns (h, g) [M, 4C] and accumulates the GRN statistics into colsq"""
+    h = torch.empty((M, 4 * C), dtype=xh.dtype, device=xh.device)
+    g = torch.empty((M, 4 * C), dtype=xh.dtype, device=xh.device)
+    check(lib().vsx_mlp_fc1(ptr(xh), ptr(img), ptr(b1), ptr(colsq), ptr(_gelu_table(xh.device)), ptr(h), ptr(g), M, C, hw,
+                            dtype_code(xh.dtype), stream()), "mlp_fc1")
+    return h, g
 
 
 def mlp_out(xh: Tensor, img: Tensor, b1: Tensor, s: Tensor, beta: Tensor, b2: Tensor, res: Tensor, rscale: Tensor | None,
