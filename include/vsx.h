@@ -91,7 +91,10 @@ typedef struct VsxGemm {
                            inference keeps only the activation) */
   int64_t b_bstride;    /* NT: element stride between PER-SAMPLE weight matrices B[b] (b = m / hw); 0 = one shared B.
                          * Needs hw % 128 == 0, plain row operands, N > 64, K % 32 == 0 (the lean instantiation). Used to
-                         * fold the GRN scale into fc2: a·W2^T with a = g·s[b] + beta  ==  g·(W2·diag(s[b]))^T + W2·beta */
+                         * fold the GRN scale into fc2: a·W2^T with a = g·s[b] + beta  ==  g·(W2·diag(s[b]))^T + W2·beta
+                         * TN: element stride between PER-SAMPLE OUTPUT matrices C[b] (and colsum rows [b][N]): one product
+                         * X_b^T·Y_b per sample of hw rows, plain stores (bf16, no prologue, hw % 64 == 0).  The block backward
+                         * derives the fc2 weight gradient and the GRN statistics from these (vsx_grn_q_reduce) */
   const float* rscale;  /* NT, EPI_BIAS_RES: per-sample scale of the branch, c = (acc + bias) * rscale[m / hw] + res — stochastic
                          * depth (timm DropPath: 0 or 1 / keep_prob per sample), NULL = 1.  Needs hw > 0. */
 } VsxGemm;
@@ -292,6 +295,24 @@ int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1, const flo
  * sum_hw g^2 — the outputs of vsx_gemm_nt with VSX_EPI_BIAS_GELU_SQ */
 int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1, float* colsq, const float* gelu_table, void* h, void* g,
     int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
+/* GRN statistics and fc2 weight gradient from the per-sample products Q[b] = dout_b^T . g_b ([C, 4C] fp32 each, vsx_gemm_tn
+ * with b_bstride) and the per-sample column sums cs[b][C] of dout — dz = dout . W2 is linear in dout, so
+ *   P[b, j] = sum_hw dz*g = sum_c W2[c, j] * Q[b, c, j]          S[b, j] = sum_hw dz = sum_c W2[c, j] * cs[b, c]
+ *   dW2[c, j] += sum_b s[b, j] * Q[b, c, j] + beta[j] * sum_b cs[b, c]        db2[c] += sum_b cs[b, c]
+ * (W2 = the bf16 GEMM operand [C, 4C]): neither dz nor a pass over the 4C-wide activations is needed for the statistics. */
+int32_t vsx_grn_q_reduce(const float* Q, const float* cs, const void* W2, const float* s, const float* beta, float* P, float* S,
+    float* dW2, float* db2, int32_t nb, int32_t C, int32_t dtype, vsx_stream_t stream);
+/* Block backward without a stored dz (csrc/mlp.hip MODE 3 / 4; wimg = vsx_mlp_pack with W2^T [4C, C] in the place of W1'):
+ *   vsx_mlp_bwd_stats: P[b, 4C] += sum_hw dz * g, S[b, 4C] += sum_hw dz with dz = bf16(dout . W2) recomputed tile by tile —
+ *                      what vsx_gemm_nt(VSX_EPI_DZ) accumulates, minus its 4C-wide output
+ *   vsx_mlp_bwd_dh   : dh = (dz * s[b] + gelu(h) * t[b]) * gelu'(h) stored [M, 4C] (dz recomputed), colsum[4C] += sum of dh over
+ *                      all rows through the caller-owned workspace ws [ws_rows >= M / vsx_mlp_rows_per_workgroup, 4C] —
+ *                      vsx_gemm_nt(VSX_EPI_DZ) + vsx_grn_gelu_bwd with ONE 4C-wide write instead of two */
+int32_t vsx_mlp_bwd_stats(const void* dout, const void* wimg, const void* g, float* P, float* S, int64_t M, int32_t C, int32_t hw,
+    int32_t dtype, vsx_stream_t stream);
+int32_t vsx_mlp_bwd_dh(const void* dout, const void* wimg, const void* h, const float* s, const float* t, void* dh, float* ws,
+    int64_t ws_rows, float* colsum, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
+int32_t vsx_mlp_rows_per_workgroup(int32_t C, int32_t hw, int64_t M);
 /* GELU of a bf16 value through a table (csrc/mlp.hip): vsx_mlp_gelu_table fills `tab` (vsx_mlp_gelu_table_len() floats) with
  * a * Phi(-a) for every bf16 magnitude a in [2^-24, 16); gelu(h) = max(h, 0) - tab[bits(|h|)]. */
 int32_t vsx_mlp_gelu_table_len(void);

@@ -859,3 +859,69 @@ def _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops):
     assert err <= 1e-2, err  # one bf16 ulp of the output scale: the two schedules differ in accumulation order only
     if drop_path:  # a dropped sample is exactly its shortcut
         assert torch.equal(out[:hw], res[:hw])
+
+
+@pytest.mark.parametrize("C,hw,B", [(96, 256, 3), (96, 1024, 2), (192, 256, 2), (224, 512, 2), (96, 4096, 2), (224, 8192, 1)])
+def test_fused_block_backward_without_stored_dz(C, hw, B):
+    """csrc/mlp.hip MODE 3 / 4 (dz recomputed on chip: GRN statistics pass, then dh written once) against the unfused pair
+    vsx_gemm_nt(VSX_EPI_DZ) + vsx_grn_gelu_bwd on the same operands: same dz rounding points, same GELU arithmetic"""
+    if SELF_CHECK:
+        pytest.skip("HIP-only kernel")
+    from viscy_amd import _lib as L
+    from viscy_amd import ops
+
+    dt = torch.bfloat16
+    M, H4 = B * hw, 4 * C
+    assert ops.mlp_supported(C, hw, M, dt)
+    dout = rnd(M, C, dt=dt, seed=1).cuda()
+    W2 = rnd(C, H4, dt=dt, seed=2, scale=H4 ** -0.5).cuda()
+    W2T = W2.t().contiguous()
+    h = rnd(M, H4, dt=dt, seed=3).cuda()
+    g = torch.nn.functional.gelu(h.float()).to(dt)
+    s = (1 + 0.2 * rnd(B, H4, seed=4)).cuda()
+    t = (0.05 * rnd(B, H4, seed=5)).cuda()
+    # unfused
+    PS = torch.zeros((2, B, H4), dtype=torch.float32, device="cuda")
+    dz = torch.empty((M, H4), dtype=dt, device="cuda")
+    ops.gemm("nt", dout, W2T, dz, M, H4, C, C, C, H4, dtype=dt, epi=L.EPI_DZ, aux=g, ldx=H4, red0=PS[0], red1=PS[1], hw=hw)
+    db = torch.zeros(H4, dtype=torch.float32, device="cuda")
+    dh_ref = dz.clone()
+    ops.grn_gelu_bwd(dh_ref, h, s, t, db, M, H4, hw)
+    # fused
+    img2 = ops.mlp_pack(W2T, W2, C)
+    PS2 = torch.zeros_like(PS)
+    ops.mlp_bwd_stats(dout, img2, g, PS2[0], PS2[1], M, C, hw)
+    close(PS2[0], PS[0], torch.float32, "P = sum dz*g", scale=PS[0].abs().max().item() * 5)
+    close(PS2[1], PS[1], torch.float32, "S = sum dz", scale=PS[1].abs().max().item() * 5)
+    # the same statistics AND the fc2 weight gradient from the per-sample products Q_b = dout_b^T g_b (dz is linear in dout)
+    beta = (0.1 * rnd(H4, seed=6)).cuda()
+    Qb = torch.full((B, C, H4), float("nan"), dtype=torch.float32, device="cuda")   # plain stores: no zero-fill needed
+    csb = torch.full((B, C), float("nan"), dtype=torch.float32, device="cuda")
+    ops.gemm("tn", g, dout, Qb, M, C, H4, H4, C, H4, dtype=dt, hw=hw, colsum=csb, b_bstride=C * H4)
+    Qref = torch.einsum("bpc,bpj->bcj", dout.float().view(B, hw, C), g.float().view(B, hw, H4))
+    close(Qb, Qref, torch.float32, "per-sample TN products", scale=Qref.abs().max().item() * 5)
+    close(csb, dout.float().view(B, hw, C).sum(1), torch.float32, "per-sample column sums", scale=float(hw) ** 0.5)
+    PS3 = torch.zeros_like(PS)
+    dW2q, db2q = torch.zeros((C, H4), device="cuda"), torch.zeros(C, device="cuda")
+    ops.grn_q_reduce(Qb, csb, W2, s, beta, PS3[0], PS3[1], dW2q, db2q)
+    # (the unfused P / S round dz to bf16 element by element before summing: agreement to that rounding noise)
+    close(PS3[0], PS[0], torch.float32, "P from Q", scale=PS[0].abs().max().item() * 4)
+    close(PS3[1], PS[1], torch.float32, "S from cs", scale=PS[1].abs().max().item() * 4)
+    dW2r, db2r = torch.zeros((C, H4), device="cuda"), torch.zeros(C, device="cuda")
+    ops.gemm("tn", g, dout, dW2r, M, C, H4, H4, C, H4, dtype=dt, pro=L.PRO_GRN, grn_s=s, grn_b=beta, hw=hw, colsum=db2r)
+    close(dW2q, dW2r, dt, "dW2 from Q vs GRN-prologue TN")   # the prologue form rounds z = g*s + beta to bf16
+    close(db2q, db2r, torch.float32, "db2", scale=db2r.abs().max().item() * 5)
+    db2 = torch.zeros_like(db)
+    dh = ops.mlp_bwd_dh(dout, img2, h, s, t, db2, M, C, hw)
+    # dz is recomputed with another accumulation order: one bf16 ulp of dz here and there, propagated through the product
+    err = (dh.float() - dh_ref.float()).abs().max().item() / dh_ref.float().abs().max().item()
+    assert err <= 1.5e-2, err
+    assert ((dh != dh_ref).float().mean().item()) < 0.05
+    close(db2, db, torch.float32, "colsum dh", scale=db.abs().max().item() * 5)
+    # against the fp32 statement
+    dzf = (dout.float() @ W2.float()).to(dt).float()
+    x = h.float()
+    cdf = 0.5 * (1 + torch.erf(x * 0.7071067811865476))
+    pdf = torch.exp(-0.5 * x * x) * 0.3989422804014327
+    ref = ((dzf.view(B, hw, H4) * s[:, None] + (x * cdf).view(B, hw, H4) * t[:, None]).view(M, H4) * (cdf + x * pdf)).to(dt)
+    close(dh, ref, dt, "dh vs fp32 statement")

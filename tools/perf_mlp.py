@@ -52,6 +52,29 @@ for C, hw, nblk in SHAPES:
     t_fc1_tr = timeit(lambda: ops.gemm("nt", xh, W1, h, M, H4, C, C, C, H4, dtype=dt, epi=L.EPI_BIAS_GELU_SQ, bias=b1, red0=colsq, hw=hw, C2=g))
     t_fc1_fused = timeit(lambda: ops.mlp_fc1(xh, img, b1, colsq, M, C, hw), n=5)
     print(f"      fc1(train): unfused GEMM {t_fc1_tr:8.1f} us | fused kernel + h/g stores {t_fc1_fused:8.1f} us ({2 * M * H4 * 2 / t_fc1_fused / 1e3:6.0f} GB/s stored)")
+    # block backward: unfused dz GEMM (EPI_DZ) + grn_gelu_bwd vs the two recompute passes (MODE 3 / 4)
+    dout = torch.randn(M, C, device="cuda").to(dt)
+    W2T = W2.t().contiguous()
+    tt = torch.randn(B, H4, device="cuda") * 0.05
+    PS = torch.zeros((2, B, H4), device="cuda")
+    dzb = torch.empty((M, H4), dtype=dt, device="cuda")
+    dbb = torch.zeros(H4, device="cuda")
+    img2 = ops.mlp_pack(W2T, W2, C)
+    t_dz = timeit(lambda: ops.gemm("nt", dout, W2T, dzb, M, H4, C, C, C, H4, dtype=dt, epi=L.EPI_DZ, aux=g, ldx=H4, red0=PS[0], red1=PS[1], hw=hw), n=5)
+    t_ggb = timeit(lambda: ops.grn_gelu_bwd(dzb, h, s, tt, dbb, M, H4, hw), n=5)
+    t_b3 = timeit(lambda: ops.mlp_bwd_stats(dout, img2, g, PS[0], PS[1], M, C, hw), n=5)
+    t_b4 = timeit(lambda: ops.mlp_bwd_dh(dout, img2, h, s, tt, dbb, M, C, hw), n=5)
+    Qb = torch.empty((B, C, H4), device="cuda")
+    csb = torch.empty((B, C), device="cuda")
+    dW2 = torch.zeros((C, H4), device="cuda")
+    db2 = torch.zeros(C, device="cuda")
+    t_tn_pro = timeit(lambda: ops.gemm("tn", g, dout, dW2, M, C, H4, H4, C, H4, dtype=dt, pro=L.PRO_GRN, grn_s=s, grn_b=beta, hw=hw, colsum=db2), n=5)
+    t_tn_ps = timeit(lambda: ops.gemm("tn", g, dout, Qb, M, C, H4, H4, C, H4, dtype=dt, hw=hw, colsum=csb, b_bstride=C * H4), n=5)
+    t_qr = timeit(lambda: ops.grn_q_reduce(Qb, csb, W2, s, beta, PS[0], PS[1], dW2, db2), n=5)
+    print(f"      dW2: TN with GRN prologue {t_tn_pro:8.1f} us | per-sample TN {t_tn_ps:8.1f} + q_reduce {t_qr:8.1f} us (also yields P, S)")
+    del Qb
+    print(f"      backward: dz GEMM {t_dz:8.1f} + grn_gelu_bwd {t_ggb:8.1f} = {t_dz + t_ggb:8.1f} us | recompute passes: stats {t_b3:8.1f} + dh {t_b4:8.1f} = {t_b3 + t_b4:8.1f} us")
+    del dzb
     t_fc2 = timeit(lambda: ops.gemm("nt", g, W2, out, M, C, H4, H4, H4, C, dtype=dt, pro=L.PRO_GRN, grn_s=s, grn_b=beta, hw=hw, epi=L.EPI_BIAS_RES, bias=b2, res=res, ldr=C))
     Ws = ops.scale_weight_samples(W2.float(), s, dt) if hw % 128 == 0 and hw // 128 >= 8 else None
     t_fc2f = timeit(lambda: ops.gemm("nt", g, Ws, out, M, C, H4, H4, H4, C, dtype=dt, hw=hw, b_bstride=C * H4, epi=L.EPI_BIAS_RES, bias=b2, res=res, ldr=C)) if Ws is not None else float("nan")

@@ -1250,7 +1250,12 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
     }
   }
 
-  float* W = reinterpret_cast<float*>(p.C) + p.c_coff[z];
+  // per-sample mode (b_bstride != 0, set up by launch_tn): split `by` IS sample `by` (one contiguous step range per sample, one
+  // workgroup per (sample, tile)), its product goes to its own output matrix with plain stores
+  const bool per_sample = p.b_bstride != 0;
+  const bool ps_atomic = (p.pro & 4096) != 0;  // several splits per sample (few samples, large maps): atomics into zeroed outputs
+  const int sample = per_sample ? (int)(((long)sbase * BMS) / p.hw) : 0;
+  float* W = reinterpret_cast<float*>(p.C) + p.c_coff[z] + (per_sample ? (size_t)sample * (size_t)p.b_bstride : 0);
 #pragma unroll
   for (int i = 0; i < FN_; ++i)
 #pragma unroll
@@ -1259,9 +1264,22 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + (wn * FN_ + i) * 16 + kq * 4 + r;
         const int k = k0 + (wk * FK_ + j) * 16 + p16;
-        if (n < p.N && k < p.K) atomicAdd(W + (size_t)n * p.ldc + k, acc[i][j][r]);
+        if (n < p.N && k < p.K) {
+          if (per_sample && !ps_atomic) W[(size_t)n * p.ldc + k] = acc[i][j][r];
+          else atomicAdd(W + (size_t)n * p.ldc + k, acc[i][j][r]);
+        }
       }
-  if (do_colsum && n0 + tid < p.N) atomicAdd(p.colsum + n0 + tid, csum);
+  if (do_colsum && n0 + tid < p.N) {
+    if (per_sample && !ps_atomic) p.colsum[(size_t)sample * p.N + n0 + tid] = csum;
+    else atomicAdd(p.colsum + (per_sample ? (size_t)sample * p.N : 0) + n0 + tid, csum);
+  }
+}
+
+// zero fill as an ordinary kernel node (the captured step stays free of memset nodes)
+__global__ __launch_bounds__(256) void tn_zero_kernel(float* __restrict__ p, long n) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) *reinterpret_cast<float4*>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  else for (; i < n; ++i) p[i] = 0.f;
 }
 
 template <typename T, int BT, bool TR>
@@ -1280,6 +1298,44 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
   int rpb = 0;
   if (splits > vsx_cdiv(p->M, 32)) splits = vsx_cdiv(p->M, 32);
   if (splits >= 8) splits &= ~7;  // multiple of 8: the kernel maps whole splits onto XCDs
+  if (p->b_bstride != 0) {
+    // one product PER SAMPLE: C[b] (b_bstride elements apart) = X_b^T . Y_b over the hw rows of sample b, colsum[b][N] likewise
+    // (plain stores: the caller need not zero the outputs).  Used by the block backward: the per-sample products dout_b^T g_b
+    // give the fc2 weight gradient AND the GRN statistics P, S without ever forming dz (vsx_grn_q_reduce).
+    if constexpr (sizeof(T) == 2 && BT == 128 && TR) {
+      VSX_CHECK(g_vsx_nt_fast && p->a_mode == VSX_A_ROWS && p->pro == VSX_PRO_NONE && p->hw > 0 && p->hw % 64 == 0 && p->M % p->hw == 0 &&
+                    nz == 1 && (unsigned long long)64 * (p->lda > p->ldb ? p->lda : p->ldb) * sizeof(T) < (1ull << 31),
+                "vsx_gemm_tn: per-sample outputs (b_bstride) need plain bf16 row operands, no prologue, hw %% 64 == 0");
+      VsxGemm pq = *p;
+      pq.pro |= 1024;  // contiguous step range per split: a whole sample, or 1 / ks of one
+      const int nb = p->M / p->hw;
+      const bool n_full = p->N >= 224 && p->N <= 256 && p->K >= 128;
+      const int t2 = n_full ? vsx_cdiv(p->N, 256) * vsx_cdiv(p->K, 128) : tiles;
+      // few samples with large maps (the 2048^2 gate shape: 8 samples of 262 144 rows): ks splits per sample so that the launch
+      // still fills the chip; their partial products meet in zero-filled outputs through atomics (<= ks adds per address)
+      int ks = 1;
+      const int spp = p->hw / 64;  // 64-row steps per sample
+      while ((long)nb * ks * t2 < 768 && ks < 64 && spp % (2 * ks) == 0) ks *= 2;
+      if (ks > 1) {
+        pq.pro |= 4096;
+        const long nq = (long)nb * p->b_bstride, nc = p->colsum ? (long)nb * p->N : 0;
+        hipLaunchKernelGGL(tn_zero_kernel, dim3(vsx_cdiv(nq, 1024L)), dim3(256), 0, s, reinterpret_cast<float*>(p->C) + p->c_coff[0], nq);
+        if (nc) hipLaunchKernelGGL(tn_zero_kernel, dim3(vsx_cdiv(nc, 1024L)), dim3(256), 0, s, p->colsum, nc);
+      }
+      if (n_full) {
+        dim3 g2(t2, nb * ks, 1);
+        hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, false, 64, 1, 128>), g2, dim3(256), 0, s, pq);
+      } else {
+        dim3 g2(tiles, nb * ks, 1);
+        hipLaunchKernelGGL((gemm_tn_fast_kernel<T, BT, TR, false, 64, 1>), g2, dim3(256), 0, s, pq);
+      }
+      VSX_LAUNCH_CHECK();
+      return 0;
+    } else {
+      vsx_set_error("vsx_gemm_tn: per-sample outputs (b_bstride) exist for bf16 operands with outputs of at least 96 x 96 only");
+      return 1;
+    }
+  }
   dim3 grid(tiles, splits, nz);
   const bool fast = g_vsx_nt_fast && p->a_mode == VSX_A_ROWS && p->M % 32 == 0 && p->N >= VT<T>::N && p->K >= VT<T>::N &&
                     (p->pro == VSX_PRO_NONE || (p->pro == VSX_PRO_GRN && p->hw > 0 && p->hw % 32 == 0)) &&
@@ -1350,6 +1406,7 @@ extern "C" int32_t vsx_gemm_tn(const VsxGemm* p, int32_t dtype, vsx_stream_t str
   // and there are enough pixel rows to split; 64x64 only for genuinely small weight matrices
   long t128 = (long)vsx_cdiv(p->N, 128) * vsx_cdiv(p->K, 128);
   bool small = (p->N < 96 || p->K < 96) || (t128 < 24 && p->M < 65536);
+  if (p->b_bstride != 0) small = false;  // per-sample outputs live on the 128-wide lean instantiations
   if (dtype == VSX_BF16) {
     if (g_vsx_tn_tr) return small ? launch_tn<bf16_t, 64, true>(p, s) : launch_tn<bf16_t, 128, true>(p, s);
     return small ? launch_tn<bf16_t, 64, false>(p, s) : launch_tn<bf16_t, 128, false>(p, s);

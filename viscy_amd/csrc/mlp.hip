@@ -9,6 +9,14 @@
 //   MODE 2 (training fc1): MODE 0 that also stores the pre-activation h and the activation g (bf16) for the backward — the
 //                        same outputs as the unfused fc1 GEMM, whose 3-slab K loop pays one HBM round trip per slab and per
 //                        tile (its waves sit in s_waitcnt 41 % of the time); here the activation rows are loaded once.
+//   MODE 3 (backward statistics): dz = dout . W2 (recomputed per 32-column sub-chunk), P[b] += sum_hw dz * g, S[b] += sum_hw dz
+//                        — the GRN statistics path of the backward; dz is NOT stored.
+//   MODE 4 (backward dh): dz recomputed, dh = (dz * s[b] + gelu(h) * t[b]) * gelu'(h) stored (the fc1 gradient operand), column
+//                        sums of dh (the fc1 bias gradient) into one workspace row per workgroup.
+//                        Modes 3 + 4 replace the fc2 data-gradient GEMM (which wrote the 4C-wide dz) and the GRN / GELU backward
+//                        pass (which read it back and wrote dh over it): one 4C-wide write instead of two.  HBM writes run
+//                        at ~3.5 TB/s on this part whatever the kernel (measured: every write-dominated launch of the step
+//                        lands on bytes / 3.5 TB/s), so the write is what a pass costs.
 // (SURVEY §7 step 4 / VERDICT r1 "what's missing" 1.  The unfused schedule moved 8 of its 15 C-units per pixel as 4C-wide
 // h / g tensors through HBM in inference; this one moves 1 + 3.)
 //
@@ -49,6 +57,10 @@ struct MlpArgs {
   float* colsq;         // [B, 4C] += sum_hw gelu(h)^2           (MODE 0, 2)
   bf16_t* hout;         // [M, 4C] pre-activation                (MODE 2)
   bf16_t* gout;         // [M, 4C] activation                    (MODE 2)
+  const bf16_t* tin;    // [M, 4C] stored activation g (MODE 3) / stored pre-activation h (MODE 4)
+  float* red0;          // [B, 4C] += sum_hw dz * g  (MODE 3)
+  float* red1;          // [B, 4C] += sum_hw dz      (MODE 3)
+  float* ws;            // [M / BM, 4C] per-workgroup column sums of dh (MODE 4)
   const float* gtab;    // [MLP_GT_N] r(a) = a * Phi(-a) for every bf16 a in [2^-24, 16)  (vsx_mlp_gelu_table)
   int M, hw;
 };
@@ -76,9 +88,10 @@ struct MlpGeom {
   static constexpr int STAGE_BYTES = NP * 1024;
   static constexpr int OB_COLS = 64;                                   // output leaves in blocks of 64 columns
   static constexpr int OB_RS = OB_COLS * 2 + 16;                       // staging row stride (bytes)
-  static constexpr int OUT_BYTES = MODE == 1 ? NW * WM * OB_RS : (MODE == 2 ? NW * 2 * WM * OB_RS : 16);
-  static constexpr int VEC_FLOATS = MODE != 1 ? H4 : 3 * H4 + C;
-  static constexpr int RED_FLOATS = MODE != 1 ? 2 * NW * 32 : 4;
+  static constexpr int OUT_BYTES = MODE == 2 ? NW * 2 * WM * OB_RS : (MODE == 0 ? 16 : NW * WM * OB_RS);
+  static constexpr int VEC_FLOATS = MODE == 1 ? 3 * H4 + C : (MODE == 4 ? 2 * H4 : (MODE == 3 ? 4 : H4));
+  static constexpr int RED_FLOATS = MODE == 1 ? 4 : (MODE == 3 ? 4 * NW * 32 : 2 * NW * 32);
+  static constexpr int GT_FLOATS = MODE <= 2 ? MLP_GT_N : 4;
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES + OUT_BYTES + (VEC_FLOATS + RED_FLOATS) * 4;
 };
 
@@ -86,7 +99,7 @@ template <int C, int MF, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
   typedef MlpGeom<C, MF, NW, MODE> G;
   constexpr int H4 = G::H4, NHS = G::NHS, KK = G::KK, NF = G::NF, WM = G::WM;
-  constexpr bool STATS = MODE != 1, STORE = MODE == 2;
+  constexpr bool STATS = MODE == 0 || MODE == 2, STORE = MODE == 2, BWD = MODE >= 3;
   // SEPARATE LDS objects, on purpose: the two weight stages, the per-channel vectors and the output staging are distinct
   // variables, so the compiler's alias scopes let fragment / vector reads proceed while the LDS-DMA prefetch of the OTHER
   // stage is in flight (through one array every ds_read behind a global_load_lds costs an s_waitcnt vmcnt(0): no overlap)
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
   __shared__ __attribute__((aligned(16))) float vec[G::VEC_FLOATS];
   __shared__ __attribute__((aligned(16))) float red[G::RED_FLOATS];
   __shared__ __attribute__((aligned(16))) char obuf[G::OUT_BYTES];
-  __shared__ __attribute__((aligned(16))) float gt[MLP_GT_N];
+  __shared__ __attribute__((aligned(16))) float gt[G::GT_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,13 +117,22 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
   const int b = m0 / a.hw;
   const int row0 = m0 + wave * WM;
 
-  for (int i = tid; i < MLP_GT_N; i += NW * 64) gt[i] = a.gtab[i];
+  if constexpr (!BWD) {
+    for (int i = tid; i < MLP_GT_N; i += NW * 64) gt[i] = a.gtab[i];
+  }
   // ---- per-channel vectors -> LDS (once)
-  for (int i = tid; i < H4; i += NW * 64) {
-    vec[i] = a.b1[i];
-    if constexpr (MODE == 1) {
-      vec[H4 + i] = a.grn_s[(size_t)b * H4 + i];
-      vec[2 * H4 + i] = a.grn_b[i];
+  if constexpr (!BWD) {
+    for (int i = tid; i < H4; i += NW * 64) {
+      vec[i] = a.b1[i];
+      if constexpr (MODE == 1) {
+        vec[H4 + i] = a.grn_s[(size_t)b * H4 + i];
+        vec[2 * H4 + i] = a.grn_b[i];
+      }
+    }
+  } else if constexpr (MODE == 4) {
+    for (int i = tid; i < H4; i += NW * 64) {  // this sample's GRN scale s and statistics-path factor t
+      vec[i] = a.grn_s[(size_t)b * H4 + i];
+      vec[H4 + i] = a.grn_b[(size_t)b * H4 + i];
     }
   }
   if constexpr (MODE == 1) {
@@ -153,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
   // MODE 2: h / g of two consecutive sub-chunks are parked in a wave-private LDS tile [2 outputs][WM rows][64 hidden] and
   // leave as 16-byte vectors, 128-byte row segments (8-byte stores straight from the accumulator layout — 32-byte segments —
   // ran at 2.4-2.8 TB/s and made this pass slower than the unfused GEMM)
-  char* sb = obuf + wave * (2 * WM * G::OB_RS);
+  char* sb = obuf + wave * ((MODE == 2 ? 2 : 1) * WM * G::OB_RS);
   auto activate = [&](int hs, const mlp_f32x4 (&acc)[2][MF], mlp_bf16x8 (&zf)[MF], float (&sq)[2][4]) {
     const float* vb = vec + hs * 32 + kq * 4;
     float b1v[2][4], sv[2][4], bv[2][4];
@@ -220,6 +242,101 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
     }
   };
 
+  // ---- MODE 3 / 4: the stored activation (MODE 3: g, MODE 4: h) of a PAIR of sub-chunks travels HBM -> registers (16-byte
+  // vectors, 128-byte row segments, issued two sub-chunks ahead) -> a wave-private LDS tile [WM rows][64 hidden], from where
+  // the accumulator layout reads 8 bytes per lane; MODE 4 writes dh over h in that tile and flushes it like MODE 2
+  uint4 tq[BWD ? (WM * 8) / 64 : 1];
+  auto tile_load = [&](int hs) {   // hs even: the pair (hs, hs + 1)
+    if constexpr (BWD) {
+#pragma unroll
+      for (int i = 0; i < (WM * 8) / 64; ++i) {
+        const int idx = lane + 64 * i, row = idx >> 3, ch = idx & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(a.tin + (size_t)(row0 + row) * H4 + hs * 32 + ch * 8);
+        tq[i] = v;
+      }
+    }
+  };
+  auto tile_write = [&]() {
+    if constexpr (BWD) {
+#pragma unroll
+      for (int i = 0; i < (WM * 8) / 64; ++i) {
+        const int idx = lane + 64 * i, row = idx >> 3, ch = idx & 7;
+        const uint4 v = tq[i];  // through a value: a direct array -> LDS aggregate copy keeps the array in scratch
+        *reinterpret_cast<uint4*>(sb + row * G::OB_RS + ch * 16) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  auto tile_flush = [&](int hs) {  // MODE 4: dh of the pair (hs - 1, hs), hs odd
+    if constexpr (MODE == 4) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < (WM * 8) / 64; ++i) {
+        const int idx = lane + 64 * i, row = idx >> 3, ch = idx & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(sb + row * G::OB_RS + ch * 16);
+        *reinterpret_cast<uint4*>(a.hout + (size_t)(row0 + row) * H4 + (hs - 1) * 32 + ch * 8) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  // backward activation of one sub-chunk: acc = dz (fp32) of [WM pixels] x [32 hidden] in the accumulator layout
+  auto bwd_act = [&](int hs, const mlp_f32x4 (&acc)[2][MF], float (&r0)[2][4], float (&r1)[2][4]) {
+    if constexpr (BWD) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { r0[hf][r] = 0.f; r1[hf][r] = 0.f; }
+      float sv[2][4], tv[2][4];
+      if constexpr (MODE == 4) {
+        const float* vb = vec + hs * 32 + kq * 4;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const float4 t2 = *reinterpret_cast<const float4*>(vb + hf * 16);
+          const float4 t3 = *reinterpret_cast<const float4*>(vb + H4 + hf * 16);
+          sv[hf][0] = t2.x; sv[hf][1] = t2.y; sv[hf][2] = t2.z; sv[hf][3] = t2.w;
+          tv[hf][0] = t3.x; tv[hf][1] = t3.y; tv[hf][2] = t3.z; tv[hf][3] = t3.w;
+        }
+      }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          char* tp = sb + (mf * 16 + p16) * G::OB_RS + ((hs & 1) * 32 + hf * 16 + kq * 4) * 2;
+          const uint2 tw = *reinterpret_cast<const uint2*>(tp);   // 4 bf16: g (MODE 3) or h (MODE 4)
+          const float e[4] = {__uint_as_float(tw.x << 16), __uint_as_float(tw.x & 0xFFFF0000u), __uint_as_float(tw.y << 16),
+                              __uint_as_float(tw.y & 0xFFFF0000u)};
+          if constexpr (MODE == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float dz = round_bf16(acc[hf][mf][r]);
+              r0[hf][r] = fmaf(dz, e[r], r0[hf][r]);
+              r1[hf][r] += dz;
+            }
+          } else {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {  // packed fp32 pairs, same arithmetic as grn_gelu_bwd_kernel (norm.hip)
+              const vsx_v2f x = {e[r], e[r + 1]};
+              const vsx_v2f d2 = {round_bf16(acc[hf][mf][r]), round_bf16(acc[hf][mf][r + 1])};
+              const vsx_v2f s2 = {sv[hf][r], sv[hf][r + 1]}, t2 = {tv[hf][r], tv[hf][r + 1]};
+              vsx_v2f cdf, pdf;
+              gelu_parts2(x, cdf, pdf);
+              const vsx_v2f gv = x * cdf, dgv = cdf + x * pdf;
+              const vsx_v2f rr = (d2 * s2 + gv * t2) * dgv;
+              o[r] = round_bf16(rr.x);
+              o[r + 1] = round_bf16(rr.y);
+              r0[hf][r] += o[r];
+              r0[hf][r + 1] += o[r + 1];
+            }
+            *reinterpret_cast<uint2*>(tp) = make_uint2(f32x2_to_bf16x2_bits(o[0], o[1]), f32x2_to_bf16x2_bits(o[2], o[3]));
+          }
+        }
+    }
+  };
+
   // ---- software pipeline over the hidden sub-chunks.  Stage s (buffer s & 1) = [W1 of sub-chunk s + 1 | W2 of sub-chunk s]:
   // while the VALU works through bias / GELU / GRN of sub-chunk s, the SAME wave's MFMA pipe already runs fc1 of sub-chunk
   // s + 1 (independent instructions in one basic block), then fc2 of sub-chunk s.  Without the shift every wave of the
@@ -262,6 +379,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
                                        (__attribute__((address_space(3))) void*)(buf1 + p * 1024), 16, 0, 0);
   }
   stage_load2(0, buf0);
+  tile_load(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   gemm1(buf1 + lane * 16, hcur);
@@ -272,8 +390,33 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
       if (hs > 0 && (hs & 1) == 0) store_pending(hs - 1);  // issued BEFORE the prefetch: the next vmcnt(0) then waits for
                                                            // stores that have had a whole sub-chunk to complete
     }
+    if constexpr (BWD) {
+      if ((hs & 1) == 0) {  // pair boundary: the vmcnt(0) the caller just passed covered this pair's loads and the last stores
+        if (hs > 0) tile_flush(hs - 1);
+        tile_write();
+        if (hs + 2 < NHS) tile_load(hs + 2);
+      }
+    }
     if (hs + 1 < NHS) stage_load2(hs + 1, other);
     const char* S = Sb + lane * 16;
+    if constexpr (MODE == 3) {
+      if (hs > 0 && wave == (hs - 1) % NW) {  // P (lanes 0-31) and S (lanes 32-63) of the previous sub-chunk
+        const float* r = red + ((hs - 1) & 1) * 2 * NW * 32 + (lane >> 5) * NW * 32 + (lane & 31);
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += r[w * 32];
+        atomicAdd((lane < 32 ? a.red0 : a.red1) + (size_t)b * H4 + (hs - 1) * 32 + (lane & 31), t);
+      }
+    }
+    if constexpr (MODE == 4) {
+      if (hs > 0 && wave == (hs - 1) % NW && lane < 32) {  // column sums of dh: one workspace row per workgroup, no atomics
+        const float* r = red + ((hs - 1) & 1) * NW * 32 + lane;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += r[w * 32];
+        a.ws[(size_t)blockIdx.x * H4 + (hs - 1) * 32 + lane] = t;
+      }
+    }
     if constexpr (STATS) {
       if (hs > 0 && wave == (hs - 1) % NW && lane < 32) {  // column sums of the previous sub-chunk (parked before the barrier)
         const float* r = red + ((hs - 1) & 1) * NW * 32 + lane;
@@ -298,9 +441,24 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    activate(hs, hcur, zf, sq);
+    float q0[2][4], q1[2][4];
+    if constexpr (BWD) bwd_act(hs, hcur, q0, q1);
+    else activate(hs, hcur, zf, sq);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (STATS) {
+    if constexpr (BWD) {
+      float* rw = red + (hs & 1) * (MODE == 3 ? 2 : 1) * NW * 32 + wave * 32;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t0 = group_sum<16>(q0[hf][r]);
+          if (p16 == 0) rw[hf * 16 + kq * 4 + r] = t0;
+          if constexpr (MODE == 3) {
+            const float t1 = group_sum<16>(q1[hf][r]);
+            if (p16 == 0) rw[NW * 32 + hf * 16 + kq * 4 + r] = t1;
+          }
+        }
+    } else if constexpr (STATS) {
       // sum over this wave's pixels: the 16 lanes of a DPP row share q, i.e. the same 8 hidden columns
       float* rw = red + (hs & 1) * NW * 32 + wave * 32;
 #pragma unroll
@@ -345,7 +503,28 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
     step(hs + 1, buf1, buf0);
   }
 
-  if constexpr (STATS) {
+  if constexpr (BWD) {
+    tile_flush(NHS - 1);
+    __syncthreads();
+    if constexpr (MODE == 3) {
+      if (wave == (NHS - 1) % NW) {
+        const float* r = red + ((NHS - 1) & 1) * 2 * NW * 32 + (lane >> 5) * NW * 32 + (lane & 31);
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += r[w * 32];
+        atomicAdd((lane < 32 ? a.red0 : a.red1) + (size_t)b * H4 + (NHS - 1) * 32 + (lane & 31), t);
+      }
+    } else {
+      if (wave == (NHS - 1) % NW && lane < 32) {
+        const float* r = red + ((NHS - 1) & 1) * NW * 32 + lane;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += r[w * 32];
+        a.ws[(size_t)blockIdx.x * H4 + (NHS - 1) * 32 + lane] = t;
+      }
+    }
+    return;
+  } else if constexpr (STATS) {
     store_pending(NHS - 1);
     __syncthreads();
     if (wave == (NHS - 1) % NW && lane < 32) {
@@ -524,7 +703,7 @@ extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1
   MlpArgs a;
   a.xh = (const bf16_t*)xh; a.wimg = (const char*)wimg; a.b1 = b1; a.grn_s = grn_s; a.grn_b = grn_b; a.b2 = b2;
   a.res = (const bf16_t*)res; a.rscale = rscale; a.out = (bf16_t*)out; a.colsq = colsq; a.gtab = gtab; a.M = (int)M; a.hw = hw;
-  a.hout = nullptr; a.gout = nullptr;
+  a.hout = nullptr; a.gout = nullptr; a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) {
     VSX_CHECK(colsq != nullptr, "vsx_mlp_fwd: mode 0 needs colsq");
@@ -546,6 +725,59 @@ extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1
   MlpArgs a;
   a.xh = (const bf16_t*)xh; a.wimg = (const char*)wimg; a.b1 = b1; a.grn_s = nullptr; a.grn_b = nullptr; a.b2 = nullptr;
   a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = colsq; a.gtab = gtab; a.hout = (bf16_t*)h; a.gout = (bf16_t*)g;
+  a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr;
   a.M = (int)M; a.hw = hw;
   return mlp_dispatch<2>(c, a, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ backward passes
+__global__ void reduce_rows_kernel(const float* __restrict__ ws, float* __restrict__ out, int R, int N);  // norm.hip
+
+static void mlp_bwd_args(MlpArgs& a, const void* dout, const void* wimg, const void* tin, int64_t M, int32_t hw) {
+  a.xh = (const bf16_t*)dout; a.wimg = (const char*)wimg; a.b1 = nullptr; a.grn_s = nullptr; a.grn_b = nullptr; a.b2 = nullptr;
+  a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = nullptr; a.gtab = nullptr; a.hout = nullptr; a.gout = nullptr;
+  a.tin = (const bf16_t*)tin; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.M = (int)M; a.hw = hw;
+}
+
+/* MODE 3: the GRN statistics path of the block backward without a stored dz: dz = dout . W2 recomputed tile by tile
+ * (wimg = vsx_mlp_pack of W2^T [4C, C] in the place of W1), P[b, 4C] += sum_hw dz * g, S[b, 4C] += sum_hw dz
+ * (what the VSX_EPI_DZ epilogue of vsx_gemm_nt accumulates, minus its 4C-wide output) */
+extern "C" int32_t vsx_mlp_bwd_stats(const void* dout, const void* wimg, const void* g, float* P, float* S, int64_t M, int32_t C,
+                                     int32_t hw, int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_bwd_stats: bf16 only");
+  VSX_CHECK(dout && wimg && g && P && S && M > 0 && hw > 0, "vsx_mlp_bwd_stats: bad arguments");
+  const MlpCfg* c = mlp_cfg(C, hw, M);
+  VSX_CHECK(c != nullptr && M < (1ll << 31), "vsx_mlp_bwd_stats: unsupported shape C=%d hw=%d M=%ld", C, hw, (long)M);
+  MlpArgs a;
+  mlp_bwd_args(a, dout, wimg, g, M, hw);
+  a.red0 = P; a.red1 = S;
+  return mlp_dispatch<3>(c, a, (hipStream_t)stream);
+}
+
+/* MODE 4: dh = (dz * s[b] + gelu(h) * t[b]) * gelu'(h) with dz recomputed, stored [M, 4C]; colsum[4C] += sum over all pixels
+ * of dh through ws ([M / rows-per-workgroup, 4C] floats, caller-owned) — vsx_gemm_nt(VSX_EPI_DZ) + vsx_grn_gelu_bwd in one
+ * pass that writes the 4C-wide tensor once */
+extern "C" int32_t vsx_mlp_bwd_dh(const void* dout, const void* wimg, const void* h, const float* s, const float* t, void* dh,
+                                  float* ws, int64_t ws_rows, float* colsum, int64_t M, int32_t C, int32_t hw, int32_t dtype,
+                                  vsx_stream_t stream) {
+  VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_bwd_dh: bf16 only");
+  VSX_CHECK(dout && wimg && h && s && t && dh && ws && colsum && M > 0 && hw > 0, "vsx_mlp_bwd_dh: bad arguments");
+  const MlpCfg* c = mlp_cfg(C, hw, M);
+  VSX_CHECK(c != nullptr && M < (1ll << 31), "vsx_mlp_bwd_dh: unsupported shape C=%d hw=%d M=%ld", C, hw, (long)M);
+  const int bm = c->NW * 16 * c->MF;
+  VSX_CHECK(ws_rows >= M / bm, "vsx_mlp_bwd_dh: workspace needs %ld rows of %d floats", (long)(M / bm), 4 * C);
+  MlpArgs a;
+  mlp_bwd_args(a, dout, wimg, h, M, hw);
+  a.grn_s = s; a.grn_b = t; a.hout = (bf16_t*)dh; a.ws = ws;
+  if (int e = mlp_dispatch<4>(c, a, (hipStream_t)stream)) return e;
+  const int R = (int)(M / bm), N = 4 * C;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv(N, 64), vsx_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)ws, colsum, R, N);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t vsx_mlp_rows_per_workgroup(int32_t C, int32_t hw, int64_t M) {
+  const MlpCfg* c = mlp_cfg(C, hw, M);
+  return c ? c->NW * 16 * c->MF : 0;
 }

@@ -510,3 +510,55 @@ extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, con
   VSX_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------ statistics + fc2 weight gradient from per-sample products
+// grid (4C / 256, nb + C): rows < nb compute P / S of one sample (loop over c), rows >= nb compute one dW2 row (loop over b)
+template <typename T>
+__global__ __launch_bounds__(256) void grn_q_reduce_kernel(const float* __restrict__ Q, const float* __restrict__ cs,
+                                                           const T* __restrict__ W2, const float* __restrict__ s,
+                                                           const float* __restrict__ beta, float* __restrict__ P,
+                                                           float* __restrict__ S, float* __restrict__ dW2,
+                                                           float* __restrict__ db2, int nb, int C) {
+  const int N = 4 * C;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int row = blockIdx.y;
+  if (row < nb) {
+    if (j >= N) return;
+    const float* q = Q + (size_t)row * C * N + j;
+    const float* c1 = cs + (size_t)row * C;
+    float p = 0.f, sm = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+      const float w = to_f32<T>(W2[(size_t)c * N + j]);
+      p = fmaf(w, q[(size_t)c * N], p);
+      sm = fmaf(w, c1[c], sm);
+    }
+    P[(size_t)row * N + j] += p;
+    S[(size_t)row * N + j] += sm;
+  } else {
+    const int c = row - nb;
+    float ct = 0.f;  // sum_b cs[b][c]
+    for (int b = 0; b < nb; ++b) ct += cs[(size_t)b * C + c];
+    if (blockIdx.x == 0 && threadIdx.x == 0) db2[c] += ct;
+    if (j >= N) return;
+    const float* q = Q + (size_t)c * N + j;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int b = 0; b < nb; ++b) acc = fmaf(s[(size_t)b * N + j], q[(size_t)b * C * N], acc);
+    dW2[(size_t)c * N + j] += acc + beta[j] * ct;
+  }
+}
+
+extern "C" int32_t vsx_grn_q_reduce(const float* Q, const float* cs, const void* W2, const float* s, const float* beta, float* P,
+                                    float* S, float* dW2, float* db2, int32_t nb, int32_t C, int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(Q && cs && W2 && s && beta && P && S && dW2 && db2 && nb > 0 && C > 0, "vsx_grn_q_reduce: bad arguments");
+  dim3 grid(vsx_cdiv(4 * C, 256), nb + C);
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(grn_q_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, Q, cs, (const bf16_t*)W2, s, beta, P, S,
+                       dW2, db2, nb, C);
+  else
+    hipLaunchKernelGGL(grn_q_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, Q, cs, (const float*)W2, s, beta, P, S,
+                       dW2, db2, nb, C);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}

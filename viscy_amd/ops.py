@@ -338,6 +338,30 @@ def mlp_fc1(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, 
     return h, g
 
 
+def grn_q_reduce(Q: Tensor, cs: Tensor, W2: Tensor, s: Tensor, beta: Tensor, P: Tensor, S: Tensor, dW2: Tensor, db2: Tensor) -> None:
+    """GRN statistics P, S and the fc2 weight / bias gradient from the per-sample products Q[b] = dout_b^T g_b and the per-sample
+    column sums cs[b] of dout (see vsx_grn_q_reduce)"""
+    nb, C = cs.shape
+    check(lib().vsx_grn_q_reduce(ptr(Q), ptr(cs), ptr(W2), ptr(s), ptr(beta), ptr(P), ptr(S), ptr(dW2), ptr(db2), nb, C,
+                                 dtype_code(W2.dtype), stream()), "grn_q_reduce")
+
+
+def mlp_bwd_stats(dout: Tensor, img2: Tensor, g: Tensor, P: Tensor, S: Tensor, M: int, C: int, hw: int) -> None:
+    """P[b, 4C] += sum_hw dz * g, S[b, 4C] += sum_hw dz with dz = dout . W2 recomputed on chip (img2 = mlp_pack(W2T, ...))"""
+    check(lib().vsx_mlp_bwd_stats(ptr(dout), ptr(img2), ptr(g), ptr(P), ptr(S), M, C, hw, dtype_code(dout.dtype), stream()),
+          "mlp_bwd_stats")
+
+
+def mlp_bwd_dh(dout: Tensor, img2: Tensor, h: Tensor, s: Tensor, t: Tensor, colsum: Tensor, M: int, C: int, hw: int) -> Tensor:
+    """dh = (dz * s + gelu(h) * t) * gelu'(h), dz recomputed; colsum[4C] += column sums of dh"""
+    dh = torch.empty((M, 4 * C), dtype=dout.dtype, device=dout.device)
+    rows = M // int(lib().vsx_mlp_rows_per_workgroup(C, hw, M))
+    ws = _workspace(dout.device, rows * 4 * C)
+    check(lib().vsx_mlp_bwd_dh(ptr(dout), ptr(img2), ptr(h), ptr(s), ptr(t), ptr(dh), ptr(ws), rows, ptr(colsum), M, C, hw,
+                               dtype_code(dout.dtype), stream()), "mlp_bwd_dh")
+    return dh
+
+
 def mlp_out(xh: Tensor, img: Tensor, b1: Tensor, s: Tensor, beta: Tensor, b2: Tensor, res: Tensor, rscale: Tensor | None,
             M: int, C: int, hw: int) -> Tensor:
     """out = res + rscale * (fc2(gelu(fc1(xh)) * s + beta) + b2), hidden activation kept on chip"""
