@@ -285,7 +285,8 @@ int32_t vsx_adamw(float* p, const float* g, float* m, float* v, const float* hyp
  *                       and W2 [C, 4C] (both bf16, row-major as vsx_prep_weight writes them)
  *   vsx_mlp_fwd mode 0: colsq[b, 4C] += sum_hw gelu(fc1(xh))^2   (GRN statistics; nothing else is stored)
  *               mode 1: out = res + rscale[b] * (fc2(gelu(fc1(xh)) * s[b] + beta) + b2) */
-int32_t vsx_mlp_supported(int32_t C, int32_t hw, int64_t M, int32_t dtype);
+int32_t vsx_mlp_supported(int32_t C, int32_t hw, int64_t M, int32_t dtype);   /* the inference pair (modes 0 and 1) */
+int32_t vsx_mlp_mode_supported(int32_t C, int32_t hw, int64_t M, int32_t mode, int32_t dtype);  /* one pass (mode 0..4) */
 int64_t vsx_mlp_image_bytes(int32_t C);
 int32_t vsx_mlp_pack(const void* W1, const void* W2, void* img, int32_t C, vsx_stream_t stream);
 int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1, const float* grn_s, const float* grn_b, const float* b2,

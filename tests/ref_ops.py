@@ -376,7 +376,7 @@ def adamw(p, g, m, v, hyper):
     p.addcdiv_(m, v.sqrt() / (bc2**0.5) + eps, value=-lr / bc1)
 
 
-def mlp_supported(C, hw, M, dtype) -> bool:
+def mlp_supported(C, hw, M, dtype, mode=None) -> bool:
     """the fused GRN-MLP exists only as a HIP kernel; this backend states the unfused schedule"""
     return False
 

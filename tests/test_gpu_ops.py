@@ -788,7 +788,7 @@ def test_layer_scale_fold_unfold():
 
 
 # ------------------------------------------------------------------ fused GRN-MLP (csrc/mlp.hip)
-@pytest.mark.parametrize("C,hw,B", [(96, 256, 3), (96, 1024, 2), (192, 256, 2), (224, 512, 2), (384, 128, 3), (384, 256, 2)])
+@pytest.mark.parametrize("C,hw,B", [(96, 256, 3), (96, 1024, 2), (192, 256, 2), (224, 512, 2), (384, 256, 3), (384, 256, 2)])
 @pytest.mark.parametrize("drop_path", [False, True], ids=["plain", "droppath"])
 def test_fused_grn_mlp_matches_unfused_kernels_and_reference(C, hw, B, drop_path):
     """vsx_mlp_fwd (hidden activation on chip, fc1 recomputed in the output pass) against (a) the fp32 statement with the
@@ -800,12 +800,12 @@ def test_fused_grn_mlp_matches_unfused_kernels_and_reference(C, hw, B, drop_path
 
     dt = torch.bfloat16
     M, H4 = B * hw, 4 * C
-    L.lib().vsx_set_flag(b"mlp_fused", 7)  # bit 2: the C = 384 instantiation too (off by default: measured slower)
+    L.lib().vsx_set_flag(b"mlp_fused", 15)  # bit 2: the C = 384 instantiations too
     try:
         assert ops.mlp_supported(C, hw, M, dt)
         _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops)
     finally:
-        L.lib().vsx_set_flag(b"mlp_fused", 3)
+        L.lib().vsx_set_flag(b"mlp_fused", 11)
 
 
 def _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops):
@@ -861,7 +861,8 @@ def _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops):
         assert torch.equal(out[:hw], res[:hw])
 
 
-@pytest.mark.parametrize("C,hw,B", [(96, 256, 3), (96, 1024, 2), (192, 256, 2), (224, 512, 2), (96, 4096, 2), (224, 8192, 1)])
+@pytest.mark.parametrize("C,hw,B", [(96, 256, 3), (96, 1024, 2), (192, 256, 2), (224, 512, 2), (96, 4096, 2), (224, 8192, 1),
+                                    (384, 256, 3)])
 def test_fused_block_backward_without_stored_dz(C, hw, B):
     """csrc/mlp.hip MODE 3 / 4 (dz recomputed on chip: GRN statistics pass, then dh written once) against the unfused pair
     vsx_gemm_nt(VSX_EPI_DZ) + vsx_grn_gelu_bwd on the same operands: same dz rounding points, same GELU arithmetic"""
@@ -872,7 +873,16 @@ def test_fused_block_backward_without_stored_dz(C, hw, B):
 
     dt = torch.bfloat16
     M, H4 = B * hw, 4 * C
-    assert ops.mlp_supported(C, hw, M, dt)
+    if C == 384:
+        L.lib().vsx_set_flag(b"mlp_fused", 15)
+    try:
+        assert ops.mlp_supported(C, hw, M, dt, 3) and ops.mlp_supported(C, hw, M, dt, 4)
+        _fused_bwd_case(C, hw, B, dt, M, H4, L, ops)
+    finally:
+        L.lib().vsx_set_flag(b"mlp_fused", 11)
+
+
+def _fused_bwd_case(C, hw, B, dt, M, H4, L, ops):
     dout = rnd(M, C, dt=dt, seed=1).cuda()
     W2 = rnd(C, H4, dt=dt, seed=2, scale=H4 ** -0.5).cuda()
     W2T = W2.t().contiguous()

@@ -76,6 +76,7 @@ _SIGS = {
     "vsx_adamw": (_I32, [_P, _P, _P, _P, _P, _I64, _P]),
     "vsx_adamw_advance": (_I32, [_P, _P, _P, _P]),
     "vsx_mlp_supported": (_I32, [_I32, _I32, _I64, _I32]),
+    "vsx_mlp_mode_supported": (_I32, [_I32, _I32, _I64, _I32, _I32]),
     "vsx_mlp_image_bytes": (_I64, [_I32]),
     "vsx_mlp_pack": (_I32, [_P, _P, _P, _I32, _P]),
     "vsx_mlp_fwd": (_I32, [_P] * 11 + [_I64, _I32, _I32, _I32, _I32, _P]),

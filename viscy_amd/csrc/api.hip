@@ -20,7 +20,7 @@ int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup i
 int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x splits)
 int g_vsx_ln_stream = 0;  // OFF (as nt_stream; measured with the value 3) —  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
 int g_vsx_tn_contig = 1;  // lean TN kernel: contiguous step range per split
-int g_vsx_mlp_fused = 11;  // fused GRN-MLP kernels (csrc/mlp.hip) on the C = 96 / 192 / 224 blocks: bit 0 = inference forward (statistics + output passes, hidden activation on chip), bit 1 = training fc1 (statistics pass that also stores h and g), bit 3 = block backward without a stored dz (statistics from the per-sample weight-gradient products or MODE 3, then MODE 4 writes dh once), bit 2 = also the C = 384 blocks (measured slower: off)
+int g_vsx_mlp_fused = 11;  // fused GRN-MLP kernels (csrc/mlp.hip) on the C = 96 / 192 / 224 blocks: bit 0 = inference forward (statistics + output passes, hidden activation on chip), bit 1 = training fc1 (statistics pass that also stores h and g), bit 3 = block backward without a stored dz (statistics from the per-sample weight-gradient products or MODE 3, then MODE 4 writes dh once), bit 2 = also the C = 384 blocks (fc1 -12 %, backward -4 %, inference forward slower, step unchanged: off)
 int g_vsx_nt_tall = 0;  // 256x128 NT tiles: -5..-9 % on isolated wide-output launches, nothing on the whole step (measured) -> off
 
 void vsx_set_error(const char* fmt, ...) {

@@ -621,25 +621,32 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
-struct MlpCfg { int C, MF, NW; };
+struct MlpCfg { int C, MF, NW, modes; };  // modes: bit m set = this geometry serves MODE m
 // rows per workgroup must divide the pixels of a sample; the large maps take 256-row workgroups (8 waves x 32 rows: weight
-// traffic L2 -> LDS per flop is 1 / rows).  C = 384 (16 x 16 maps: 128-row workgroups, one wave per SIMD at 256 + 212
-// registers) measured 875 us against 614 us for the unfused pair at B = 512 and is left to the unfused schedule unless
-// bit 2 of the mlp_fused flag asks for it (tools/perf_mlp.py)
+// traffic L2 -> LDS per flop is 1 / rows).  C = 384 lives on 16 x 16 maps (256 rows = one sample): the passes without fc2
+// accumulators (MODE 0, 2, 3, 4) fit 8 waves at <= 256 registers, the output pass (MODE 1, 192 accumulator registers) only
+// 4 waves x 32 rows (one wave per SIMD: measured 875 us against 614 us for the unfused pair at B = 512).  All C = 384
+// geometries sit behind bit 2 of the mlp_fused flag (tools/perf_mlp.py).
 extern int g_vsx_mlp_fused;
-static const MlpCfg kMlpCfgs[] = {{96, 2, 8}, {192, 2, 8}, {224, 2, 8}, {384, 2, 4}};
+static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 31}, {192, 2, 8, 31}, {224, 2, 8, 31}, {384, 2, 8, 1 | 4 | 8 | 16}, {384, 2, 4, 2}};
 
-static const MlpCfg* mlp_cfg(int C, int hw, long M) {
+static const MlpCfg* mlp_cfg(int C, int hw, long M, int mode) {
   for (const MlpCfg& c : kMlpCfgs) {
     const int bm = c.NW * 16 * c.MF;
+    if (!(c.modes & (1 << mode))) continue;
     if (c.C == 384 && !(g_vsx_mlp_fused & 4)) continue;
     if (c.C == C && hw % bm == 0 && M % bm == 0) return &c;
   }
   return nullptr;
 }
 
+/* inference pair (MODE 0 + 1) available? */
 extern "C" int32_t vsx_mlp_supported(int32_t C, int32_t hw, int64_t M, int32_t dtype) {
-  return dtype == VSX_BF16 && mlp_cfg(C, hw, M) != nullptr;
+  return dtype == VSX_BF16 && mlp_cfg(C, hw, M, 0) != nullptr && mlp_cfg(C, hw, M, 1) != nullptr;
+}
+/* one pass: mode 0 statistics, 1 output, 2 training fc1, 3 backward statistics, 4 backward dh */
+extern "C" int32_t vsx_mlp_mode_supported(int32_t C, int32_t hw, int64_t M, int32_t mode, int32_t dtype) {
+  return dtype == VSX_BF16 && mode >= 0 && mode <= 4 && mlp_cfg(C, hw, M, mode) != nullptr;
 }
 
 extern "C" int64_t vsx_mlp_image_bytes(int32_t C) { return (int64_t)(4 * C / 32) * (2 * (C / 32) + C / 16) * 1024; }
@@ -666,11 +673,9 @@ static int mlp_dispatch(const MlpCfg* c, const MlpArgs& a, hipStream_t s) {
   if (c->C == 96) return mlp_launch<96, 2, 8, MODE>(a, s);
   if (c->C == 192) return mlp_launch<192, 2, 8, MODE>(a, s);
   if (c->C == 224) return mlp_launch<224, 2, 8, MODE>(a, s);
-  return mlp_launch<384, 2, 4, MODE>(a, s);
+  if constexpr (MODE == 1) return mlp_launch<384, 2, 4, MODE>(a, s);
+  else return mlp_launch<384, 2, 8, MODE>(a, s);
 }
-
-extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1, float* colsq, const float* gtab, void* h,
-                               void* g, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
 
 /* mode 0: colsq[b, 4C] += sum over the sample's pixels of gelu(fc1(xh))^2 (bf16-rounded g, as the unfused fc1 epilogue);
  * mode 1: out = res + rscale[b] * (fc2(gelu(fc1(xh)) * s[b] + beta) + b2). */
@@ -697,7 +702,7 @@ extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1
                                vsx_stream_t stream) {
   VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_fwd: bf16 only (the fp32 parity mode runs the unfused schedule)");
   VSX_CHECK(xh && wimg && b1 && gtab && M > 0 && hw > 0, "vsx_mlp_fwd: bad arguments");
-  const MlpCfg* c = mlp_cfg(C, hw, M);
+  const MlpCfg* c = mlp_cfg(C, hw, M, mode == 0 ? 0 : 1);
   VSX_CHECK(c != nullptr, "vsx_mlp_fwd: unsupported shape C=%d hw=%d M=%ld (query vsx_mlp_supported first)", C, hw, (long)M);
   VSX_CHECK(M < (1ll << 31), "vsx_mlp_fwd: M too large");
   MlpArgs a;
@@ -719,7 +724,7 @@ extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1
                                void* g, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream) {
   VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_fc1: bf16 only");
   VSX_CHECK(xh && wimg && b1 && colsq && gtab && h && g && M > 0 && hw > 0, "vsx_mlp_fc1: bad arguments");
-  const MlpCfg* c = mlp_cfg(C, hw, M);
+  const MlpCfg* c = mlp_cfg(C, hw, M, 2);
   VSX_CHECK(c != nullptr, "vsx_mlp_fc1: unsupported shape C=%d hw=%d M=%ld (query vsx_mlp_supported first)", C, hw, (long)M);
   VSX_CHECK(M < (1ll << 31), "vsx_mlp_fc1: M too large");
   MlpArgs a;
@@ -746,7 +751,7 @@ extern "C" int32_t vsx_mlp_bwd_stats(const void* dout, const void* wimg, const v
                                      int32_t hw, int32_t dtype, vsx_stream_t stream) {
   VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_bwd_stats: bf16 only");
   VSX_CHECK(dout && wimg && g && P && S && M > 0 && hw > 0, "vsx_mlp_bwd_stats: bad arguments");
-  const MlpCfg* c = mlp_cfg(C, hw, M);
+  const MlpCfg* c = mlp_cfg(C, hw, M, 3);
   VSX_CHECK(c != nullptr && M < (1ll << 31), "vsx_mlp_bwd_stats: unsupported shape C=%d hw=%d M=%ld", C, hw, (long)M);
   MlpArgs a;
   mlp_bwd_args(a, dout, wimg, g, M, hw);
@@ -762,7 +767,7 @@ extern "C" int32_t vsx_mlp_bwd_dh(const void* dout, const void* wimg, const void
                                   vsx_stream_t stream) {
   VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_bwd_dh: bf16 only");
   VSX_CHECK(dout && wimg && h && s && t && dh && ws && colsum && M > 0 && hw > 0, "vsx_mlp_bwd_dh: bad arguments");
-  const MlpCfg* c = mlp_cfg(C, hw, M);
+  const MlpCfg* c = mlp_cfg(C, hw, M, 4);
   VSX_CHECK(c != nullptr && M < (1ll << 31), "vsx_mlp_bwd_dh: unsupported shape C=%d hw=%d M=%ld", C, hw, (long)M);
   const int bm = c->NW * 16 * c->MF;
   VSX_CHECK(ws_rows >= M / bm, "vsx_mlp_bwd_dh: workspace needs %ld rows of %d floats", (long)(M / bm), 4 * C);
@@ -778,6 +783,6 @@ extern "C" int32_t vsx_mlp_bwd_dh(const void* dout, const void* wimg, const void
 }
 
 extern "C" int32_t vsx_mlp_rows_per_workgroup(int32_t C, int32_t hw, int64_t M) {
-  const MlpCfg* c = mlp_cfg(C, hw, M);
+  const MlpCfg* c = mlp_cfg(C, hw, M, 4);
   return c ? c->NW * 16 * c->MF : 0;
 }

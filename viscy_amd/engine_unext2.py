@@ -282,23 +282,29 @@ class Engine:
         return dt
 
     # ------------------------------------------------------------------ block forward / backward
+    def _mlp_flag(self) -> int:
+        return L.lib().vsx_get_flag(b"mlp_fused") if self.ops.__name__.endswith("viscy_amd.ops") else 0
+
     def _mlp_mode(self, C, hw, M, dt, training: bool) -> bool:
         """fused GRN-MLP kernel available for this block shape (bf16, C a supported width, whole workgroup tiles per sample)
         and enabled (``mlp_fused`` flag: bit 0 = inference forward (statistics + output passes), bit 1 = training fc1 (the
         statistics pass that also stores h and g; fc2 stays the unfused GEMM, which reads the stored g))"""
-        o = self.ops
-        if dt != torch.bfloat16 or not o.mlp_supported(C, hw, M, dt):
+        if dt != torch.bfloat16:
             return False
-        flag = L.lib().vsx_get_flag(b"mlp_fused") if o.__name__.endswith("viscy_amd.ops") else 0
-        return bool(flag & (2 if training else 1))
+        flag = self._mlp_flag()
+        if training:
+            return bool(flag & 2) and self.ops.mlp_supported(C, hw, M, dt, 2)
+        return bool(flag & 1) and self.ops.mlp_supported(C, hw, M, dt)
 
-    def _mlp_bwd_fused(self, C, hw, M, dt) -> bool:
-        """``mlp_fused`` bit 3: the block backward recomputes dz on chip instead of storing it (csrc/mlp.hip MODE 3 / 4)"""
-        o = self.ops
-        if dt != torch.bfloat16 or not o.mlp_supported(C, hw, M, dt):
-            return False
-        flag = L.lib().vsx_get_flag(b"mlp_fused") if o.__name__.endswith("viscy_amd.ops") else 0
-        return bool(flag & 8)
+    def _mlp_bwd_fused(self, C, hw, M, dt, B) -> int:
+        """``mlp_fused`` bit 3: the block backward writes dh once (csrc/mlp.hip MODE 4) instead of dz and then dh.  Returns
+        0 (unfused), 1 (GRN statistics and fc2 weight gradient from the per-sample products dout_b^T g_b) or 2 (statistics
+        from the MODE 3 pass: when the B per-sample [C, 4C] fp32 products would be larger than 512 MB)"""
+        if dt != torch.bfloat16 or not (self._mlp_flag() & 8) or not self.ops.mlp_supported(C, hw, M, dt, 4):
+            return 0
+        if B * C * 4 * C * 4 <= (512 << 20) and C >= 96 and hw % 64 == 0:
+            return 1
+        return 2 if self.ops.mlp_supported(C, hw, M, dt, 3) else 0
 
     def _block_fwd(self, x, w, B, H, Wd, dt, save, rows=None):
         """One ConvNeXt-V2 block on a dense channels-last map [B*H*W, C].  ``rows = (idx, inv, keep, L)`` selects the FCMAE
@@ -390,9 +396,9 @@ class Engine:
         else:
             dW2, db2 = g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias)
             dgw, dgb = g(blk.mlp.grn.weight), g(blk.mlp.grn.bias)
-        fused_bwd = self._mlp_bwd_fused(C, hw, M, dt)
+        fused_bwd = self._mlp_bwd_fused(C, hw, M, dt, B)
         PS = self._za.take(2, B, 4 * C)
-        if fused_bwd:
+        if fused_bwd == 1:
             # dz = dout·W2 is LINEAR in dout, so everything the backward needs from "Σ over the sample of dz·(something)" comes
             # out of the per-sample products Q_b = dout_bᵀ·g_b that the weight gradient computes anyway:
             #   P_b = Σ_hw dz·g = Σ_c W2[c,:]·Q_b[c,:],  S_b = Σ_hw dz = Σ_c W2[c,:]·cs_b[c],  dW2 = Σ_b s_b·Q_b + cs⊗β
@@ -416,6 +422,8 @@ class Engine:
             # dz = dout·W2 tile by tile (K = C is short) and writes dh directly (csrc/mlp.hip MODE 4) — one 4C-wide write
             # where the unfused pair (dz GEMM, then GRN / GELU backward over it) has two
             img2 = o.mlp_pack(w.W2T, w.W2, C)
+            if fused_bwd == 2:  # statistics by recomputing dz tile by tile (P = Σ dz·g, S = Σ dz), nothing stored
+                o.mlp_bwd_stats(dout, img2, gact, PS[0], PS[1], M, C, hw)
             t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw, Sb=PS[1], dbeta=dgb)
             dz = o.mlp_bwd_dh(dout, img2, h, s, t, db1f, M, C, hw)  # (named dz below: it holds dH)
         else:

@@ -299,8 +299,14 @@ def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor) -> None:
 
 
 # ------------------------------------------------------------------ fused GRN-MLP (csrc/mlp.hip)
-def mlp_supported(C: int, hw: int, M: int, dtype: torch.dtype) -> bool:
-    return dtype == torch.bfloat16 and bool(lib().vsx_mlp_supported(C, hw, M, dtype_code(dtype)))
+def mlp_supported(C: int, hw: int, M: int, dtype: torch.dtype, mode: int | None = None) -> bool:
+    """fused GRN-MLP kernel available: the inference pair (mode None), or one pass — 2 training fc1, 3 backward statistics,
+    4 backward dh"""
+    if dtype != torch.bfloat16:
+        return False
+    if mode is None:
+        return bool(lib().vsx_mlp_supported(C, hw, M, dtype_code(dtype)))
+    return bool(lib().vsx_mlp_mode_supported(C, hw, M, mode, dtype_code(dtype)))
 
 
 def mlp_pack(W1f: Tensor, W2: Tensor, C: int) -> Tensor:
