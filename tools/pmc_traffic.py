@@ -12,7 +12,12 @@ def load(path, counter):
     rows = []
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            rows.append((re.sub(r"[<(].*", "", r["Kernel_Name"]).replace("void ", "").strip(), float(r["Counter_Value"])))
+            kn = r["Kernel_Name"]
+            m = re.search(r"mlp_fused_kernel<\s*\d+,\s*\d+,\s*\d+,\s*(\d)>", kn) or re.search(r"mlp_fused_kernelILi\d+ELi\d+ELi\d+ELi(\d)EE", kn)
+            if m:  # the pass (template MODE) is what the op classes of bench.py distinguish
+                rows.append((f"mlp_fused_kernel_mode{m.group(1)}", float(r["Counter_Value"])))
+                continue
+            rows.append((re.sub(r"[<(].*", "", kn).replace("void ", "").strip(), float(r["Counter_Value"])))
     return rows
 
 
@@ -54,8 +59,8 @@ def main(fetch_csv, write_csv, steps, batch, out):
         base = re.sub(r"^_Z\d+", "", k)
         base = re.sub(r"_kernel.*", "", base)
         base = {"gemm_nt_fast": "gemm_nt", "gemm_tn_fast": "gemm_tn"}.get(base, base)
-        if base.startswith("mlp_fused"):  # bench.py's OpTimer classes: mlp_stats (MODE 0) / mlp_out (MODE 1)
-            base = "mlp_out" if "ELi1EE" in k or ", 1>" in k else "mlp_stats"
+        if base.startswith("mlp_fused"):  # bench.py's OpTimer classes = the ops wrappers of the five passes
+            base = {"0": "mlp_stats", "1": "mlp_out", "2": "mlp_fc1", "3": "mlp_bwd_stats", "4": "mlp_bwd_dh"}.get(k[-1], "mlp_fused")
         for f in ("launches_per_step", "read_GB_per_step", "write_GB_per_step"):
             cls[base][f] += v[f]
     for c in cls.values():
