@@ -278,6 +278,52 @@ def g4b_transform_pins():
     print("G4b transforms: BatchedRandGaussianNoise (2e-6), BatchedRandFlip (exact), BatchedRandWeightedCropd weights / starts / gather (exact)")
 
 
+def g5_unet2d():
+    """BASELINE configs[0] (the CPU plumbing model): the reference's own Unet2d / ConvBlock2D
+    (viscy_models/unet/unet2d.py, components/conv_block_2d.py) against viscy_amd.unet2d — same state-dict keys in the same
+    order, same initial weights from the same seed, bit-identical train- and eval-mode outputs and gradients; the small
+    residual configuration is committed as tests/golden/unet2d.pt."""
+    from viscy_amd.unet2d import Unet2d
+
+    for n in ("viscy_models", "viscy_models.components", "viscy_models.unet"):
+        if n not in sys.modules:
+            _stub(n)
+    src = os.path.join(REF, "viscy-models", "src", "viscy_models")
+    _load("viscy_models.components.conv_block_2d", os.path.join(src, "components", "conv_block_2d.py"))
+    ref_cls = _load("viscy_models.unet.unet2d", os.path.join(src, "unet", "unet2d.py")).Unet2d
+    cases = [dict(task="reg"), dict(residual=True, task="reg", num_blocks=3),
+             dict(residual=True, num_blocks=2, num_filters=(4, 8, 12), in_channels=2, out_channels=3, task="reg")]
+    gold = None
+    for kw in cases:
+        torch.manual_seed(5)
+        ref = ref_cls(**kw)
+        torch.manual_seed(5)
+        mine = Unet2d(**kw)
+        rs, ms = ref.state_dict(), mine.state_dict()
+        assert list(rs) == list(ms), "state-dict keys / order differ"
+        assert all(torch.equal(rs[k], ms[k]) for k in rs), "initial weights differ for the same seed"
+        initial = {k: v.clone() for k, v in rs.items()}  # before the train-mode passes move the BatchNorm statistics
+        x = torch.randn(2, kw.get("in_channels", 1), 1, 32, 32)
+        outs = {}
+        for train in (True, False):
+            ref.train(train), mine.train(train)
+            a, b = ref(x), mine(x)
+            assert torch.equal(a, b), f"Unet2d forward differs (train={train}, {kw})"
+            outs[train] = a.detach().clone()
+        ref.train(), mine.train()
+        ref(x).square().mean().backward()
+        mine(x).square().mean().backward()
+        for (k, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+            if pr.grad is None:
+                assert pm.grad is None, k
+            else:
+                assert torch.equal(pr.grad, pm.grad), f"gradient of {k} differs"
+        gold = {"kwargs": kw, "state_dict": initial, "x": x, "y_train": outs[True],
+                "y_eval": outs[False], "grad_first_conv": ref.down_conv_block_0.Conv2d_0.weight.grad.clone()}
+    torch.save(gold, os.path.join(GOLD, "unet2d.pt"))
+    print(f"G5  Unet2d ('2D' plumbing model): {len(cases)} configurations bit-identical to the reference (keys, init, fwd, bwd)")
+
+
 def g6_hf_convnext():
     from transformers import ConvNextV2Config
     from transformers.models.convnextv2.modeling_convnextv2 import ConvNextV2Layer, ConvNextV2Stage
@@ -707,6 +753,7 @@ if __name__ == "__main__":
     g2_loss()
     g3_normalize()
     g4b_transform_pins()
+    g5_unet2d()
     g8_wiring()
     g9_fcmae()
     g10_contrastive()

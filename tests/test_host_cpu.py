@@ -598,7 +598,7 @@ data:
     assert set(skipped) == {"lightning.pytorch.callbacks.LearningRateMonitor", "lightning.pytorch.loggers.TensorBoardLogger",
                             "trainer.strategy=ddp_find_unused_parameters_true"}
     with pytest.raises(KeyError, match="no viscy_amd counterpart"):
-        C.instantiate({"class_path": "viscy_models.unet.Unet2d", "init_args": {}})
+        C.instantiate({"class_path": "viscy_models.unet.Unet25d", "init_args": {}})
 
 
 def test_mmap_preload_with_unequal_time_axes(tmp_path):

@@ -46,6 +46,8 @@ CLASS_MAP = {
     "viscy_models.unet.UNeXt2": "viscy_amd.unext2.UNeXt2",
     "viscy_models.unet.unext2.UNeXt2": "viscy_amd.unext2.UNeXt2",
     "viscy_models.unet.FullyConvolutionalMAE": "viscy_amd.fcmae.FullyConvolutionalMAE",
+    "viscy_models.unet.Unet2d": "viscy_amd.unet2d.Unet2d",  # CPU plumbing model (BASELINE configs[0]); plain PyTorch
+    "viscy_models.unet.unet2d.Unet2d": "viscy_amd.unet2d.Unet2d",
     "viscy_models.unet.fcmae.FullyConvolutionalMAE": "viscy_amd.fcmae.FullyConvolutionalMAE",
 }
 for _t in ("NormalizeSampled", "MinMaxSampled", "RandWeightedCropd", "CenterSpatialCropd", "BatchedCenterSpatialCropd",

@@ -54,8 +54,11 @@ class Trainer:
         train_dl = datamodule.train_dataloader()
         steps_per_epoch = 1 if self.fast_dev_run else min(len(train_dl), self.limit_train_batches or len(train_dl))
         opt = module.configure_optimizers(t_total=steps_per_epoch * (1 if self.fast_dev_run else self.max_epochs))
+        native = hasattr(module.model, "engine")  # False: the plain-PyTorch "2D" plumbing model (single process, CPU or GPU)
+        if dist.is_initialized() and not native:
+            raise NotImplementedError("data-parallel training is built for the flat-engine models (UNeXt2 / fcmae) only")
         ddp = FlatDataParallel(module.model.engine(), opt) if dist.is_initialized() else None
-        use_bf16 = self.precision.startswith("bf16")
+        use_bf16 = self.precision.startswith("bf16") and self.device.type == "cuda"
         from .data.combined import CombinedLoader
 
         for epoch in range(1 if self.fast_dev_run else self.max_epochs):
@@ -99,7 +102,8 @@ class Trainer:
                         break
             datamodule.training = True
             module.on_validation_epoch_end()
-        torch.cuda.synchronize()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
         self.finished = True
         if self.default_root_dir is not None and (not dist.is_initialized() or dist.get_rank() == 0):
             self.save_checkpoint(module)

@@ -33,9 +33,32 @@ except Exception:  # noqa: BLE001
     _HAVE_LIGHTNING = False
 
 from .fcmae import FullyConvolutionalMAE  # noqa: E402
+from .unet2d import Unet2d  # noqa: E402
 
-# cytoland.engine._UNET_ARCHITECTURE (engine.py:36-43): the entries on the accelerated path
-_UNET_ARCHITECTURE = {"UNeXt2": UNeXt2, "fcmae": FullyConvolutionalMAE}
+# cytoland.engine._UNET_ARCHITECTURE (engine.py:36-43): "UNeXt2" / "fcmae" are the accelerated path; "2D" is the reference's
+# CPU plumbing case (BASELINE configs[0]) as a plain-PyTorch module (viscy_amd.unet2d) with torch.optim.AdamW — no kernels
+_UNET_ARCHITECTURE = {"UNeXt2": UNeXt2, "fcmae": FullyConvolutionalMAE, "2D": Unet2d}
+
+
+class _TorchOptimizer:
+    """optimizer + per-step scheduler pair for the plain-PyTorch "2D" model, with the two calls viscy_amd.trainer makes"""
+
+    def __init__(self, params, lr, schedule, warmup_steps, t_total, warmup_multiplier):
+        from .optim import warmup_cosine_lambda
+
+        self.opt = torch.optim.AdamW(params, lr=lr)
+        if schedule == "WarmupCosine":
+            self.sched = torch.optim.lr_scheduler.LambdaLR(
+                self.opt, lambda s: warmup_cosine_lambda(s, warmup_steps, t_total, warmup_multiplier))
+        else:
+            self.sched = torch.optim.lr_scheduler.ConstantLR(self.opt, factor=1, total_iters=1)
+
+    def zero_grad(self):
+        self.opt.zero_grad(set_to_none=True)
+
+    def step(self):
+        self.opt.step()
+        self.sched.step()
 
 
 def _divisible_pad_amounts(shape_yx: Sequence[int], k: int) -> list[tuple[int, int]]:
@@ -82,7 +105,7 @@ def blend_in(old_stack: Tensor, new_stack: Tensor, z_slice: slice) -> Tensor:
 class VSUNet(_Base):
     def __init__(
         self,
-        architecture: Literal["UNeXt2", "fcmae"] = "UNeXt2",
+        architecture: Literal["UNeXt2", "fcmae", "2D"] = "UNeXt2",
         model_config: dict | None = None,
         loss_function: nn.Module | None = None,
         lr: float = 1e-3,
@@ -109,8 +132,11 @@ class VSUNet(_Base):
             raise ValueError(f"Architecture {architecture} not in {_UNET_ARCHITECTURE.keys()} (this build accelerates the "
                              "UNeXt2 path only)")
         self.model = net_class(**model_config)
+        self._native = hasattr(self.model, "engine")  # False: the plain-PyTorch "2D" plumbing model
         if freeze_encoder:  # engine.py:204-206; only the FCMAE network has `.encoder` (as in the reference)
             self.model.encoder.requires_grad_(False)
+        if loss_function is None and not self._native:
+            loss_function = nn.MSELoss()  # engine.py:197
         if loss_function is None:
             from .losses import MixedLoss
 
@@ -293,6 +319,9 @@ class VSUNet(_Base):
                 sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: warmup_cosine_lambda(s, self.warmup_steps, tt, self.warmup_multiplier))
                 return [opt], [{"scheduler": sch, "interval": "step"}]
             return [opt], [torch.optim.lr_scheduler.ConstantLR(opt, factor=1, total_iters=1)]
+        if not self._native:
+            return _TorchOptimizer(self.model.parameters(), self.lr, self.schedule, self.warmup_steps, t_total or 0,
+                                   self.warmup_multiplier)
         from .optim import FlatAdamW
 
         self.model.grad_mode = "flat"
