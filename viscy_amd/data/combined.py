@@ -244,19 +244,19 @@ class ConcatDataModule(_DMBase):
             dm.prepare_data()
 
     def setup(self, stage: str):
+        """Fit-only container (as the reference's): every child is set up, their train / val datasets are concatenated, and
+        the children that multi-sample (``train_patches_per_stack`` > 0) must agree on that count."""
         if stage != "fit":
             raise NotImplementedError("Only fit stage is supported")
-        self.train_patches_per_stack = 0
-        for dm in self.data_modules:
-            dm.trainer = self.trainer
-            dm.setup(stage)
-            if patches := getattr(dm, "train_patches_per_stack", 0):
-                if self.train_patches_per_stack == 0:
-                    self.train_patches_per_stack = patches
-                elif self.train_patches_per_stack != patches:
-                    raise ValueError("Inconsistent patches per stack")
-        self.train_dataset = self._ConcatDataset([dm.train_dataset for dm in self.data_modules])
-        self.val_dataset = self._ConcatDataset([dm.val_dataset for dm in self.data_modules])
+        for child in self.data_modules:
+            child.trainer = self.trainer
+            child.setup(stage)
+        counts = {int(n) for n in (getattr(child, "train_patches_per_stack", 0) for child in self.data_modules) if n}
+        if len(counts) > 1:
+            raise ValueError("Inconsistent patches per stack")
+        self.train_patches_per_stack = counts.pop() if counts else 0
+        self.train_dataset, self.val_dataset = (self._ConcatDataset([getattr(child, name) for child in self.data_modules])
+                                                for name in ("train_dataset", "val_dataset"))
 
     def _dataloader_kwargs(self) -> dict:
         return {"num_workers": self.num_workers, "persistent_workers": self.persistent_workers and self.num_workers > 0,

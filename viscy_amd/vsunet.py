@@ -341,16 +341,15 @@ class FcmaeUNet(VSUNet):
     module that yields ``Sample`` dicts (or a list of them, merged like ``CombinedLoader`` batches) works."""
 
     def __init__(self, fit_mask_ratio: float = 0.0, encoder_only: bool = False, **kwargs):
-        if encoder_only:
-            if "ckpt_path" not in kwargs or kwargs["ckpt_path"] is None:
-                raise ValueError("encoder_only=True requires ckpt_path")
-            ckpt_path = kwargs.pop("ckpt_path")
-        else:
-            ckpt_path = None
+        # encoder_only: the checkpoint is withheld from the base constructor (which would load it whole and strictly) and only
+        # its encoder entries are loaded afterwards
+        encoder_ckpt = kwargs.pop("ckpt_path", None) if encoder_only else None
+        if encoder_only and encoder_ckpt is None:
+            raise ValueError("encoder_only=True requires ckpt_path")
         super().__init__(architecture="fcmae", **kwargs)
         self.fit_mask_ratio = fit_mask_ratio
-        if ckpt_path is not None:
-            self._load_encoder_weights(ckpt_path)
+        if encoder_ckpt is not None:
+            self._load_encoder_weights(encoder_ckpt)
 
     def _load_encoder_weights(self, ckpt_path: str) -> None:
         """``encoder_only=True``: of a pre-trained Lightning checkpoint only the ``model.encoder.*`` entries are loaded, strictly
