@@ -109,16 +109,31 @@ def test_forward_backward_bf16_tracks_fp32():
     y = ref(x)
     dout = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
     y.backward(dout)
+    gr = torch.cat([p.grad.flatten() for p in ref.parameters()]).double()
+    # yardstick: the reference's OWN mixed-precision arithmetic — the same module under torch.autocast(bfloat16) (bf16
+    # convolution / linear operands, fp32 LayerNorm statistics and residual sums), i.e. what Lightning's bf16-mixed runs —
+    # measured against the same fp32 result.  The bf16 engine keeps the residual stream in bf16; the bar is that
+    # this costs nothing measurable next to the rounding the reference's autocast already has.
+    ref.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ya = ref(x)
+    ya.float().backward(dout)
+    ga = torch.cat([p.grad.flatten() for p in ref.parameters()]).double()
+    ymax = y.detach().abs().max().item()
+    ac_fwd = (ya.float().detach() - y.detach()).abs().max().item() / ymax
+    ac_cos = torch.nn.functional.cosine_similarity(ga, gr, dim=0).item()
     mine.compute_dtype = torch.bfloat16
     out = mine(x.cuda())
     assert out.dtype == torch.float32
-    torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-2, atol=0.02 * y.detach().abs().max().item())
+    hip_fwd = (out.cpu() - y.detach()).abs().max().item() / ymax
     out.backward(dout.cuda())
-    # cosine similarity of the full gradient vector (bf16 activations, fp32 accumulation)
-    gm = torch.cat([p.grad.flatten().cpu() for p in mine.parameters()])
-    gr = torch.cat([p.grad.flatten() for p in ref.parameters()])
+    gm = torch.cat([p.grad.flatten().cpu() for p in mine.parameters()]).double()
     cos = torch.nn.functional.cosine_similarity(gm, gr, dim=0).item()
-    assert cos > 0.995, cos
+    print(f"bf16 vs fp32 oracle: forward {hip_fwd:.4f} (reference autocast {ac_fwd:.4f}), gradient 1-cos {1 - cos:.2e} "
+          f"(reference autocast {1 - ac_cos:.2e})")
+    # measured (tools/bf16_gate.py, MI355X): forward 0.0107 vs 0.0112, 1-cos 1.70e-3 vs 1.88e-3
+    assert hip_fwd <= max(1.25 * ac_fwd, 0.005) and hip_fwd <= 0.015, (hip_fwd, ac_fwd)
+    assert 1 - cos <= 1.25 * (1 - ac_cos) and cos > 0.9975, (cos, ac_cos)
     # autocast contract: bf16 is selected by torch.autocast like Lightning's bf16-mixed
     mine.compute_dtype = None
     with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -163,16 +178,21 @@ def test_mixed_loss_vs_reference_golden(tag):
     g = p.grad.cpu()
     sample = g.flatten()[:: max(1, g.numel() // 4096)]
     scale = c["grad_absmax"].item()
-    # bf16 rounding inside the SSIM window means makes individual pixels flip by one bf16 ulp between
-    # implementations; compare the gradient field in aggregate and per-sample loosely
-    assert (sample - c["grad_sample"]).abs().mean().item() <= 2e-2 * c["grad_sample"].abs().mean().item()
+    # per element against the reference's own gradient (the golden's strided sample).  Measured on MI355X
+    # (tools/bf16_gate.py): worst element 3.4e-3 of the gradient's absolute maximum, mean |Δ| ≤ 2.2e-4 of mean |g|
+    d = (sample - c["grad_sample"]).abs()
+    assert d.max().item() <= 1e-2 * scale, (d.max().item(), scale)
+    assert d.mean().item() <= 1e-3 * c["grad_sample"].abs().mean().item()
     assert abs(g.double().sum().item() - c["grad_sum"].item()) <= 2e-2 * max(abs(c["grad_sum"].item()), scale)
-    # full-tensor comparison against the oracle run here (same seeds)
+    # every element against the oracle run here (same seeds)
     pr = pred.clone().requires_grad_(True)
     lr = loss_ref.mixed_loss(pr, target, 0.5, 0.0, 0.5)
     lr.backward()
-    cos = torch.nn.functional.cosine_similarity(g.flatten(), pr.grad.flatten(), dim=0).item()
-    assert cos > 0.999, cos
+    dfull = (g - pr.grad).abs() / pr.grad.abs().max()
+    assert dfull.max().item() <= 1e-2, dfull.max().item()
+    assert (dfull > 5e-3).float().mean().item() <= 1e-3  # measured: the 99.9th percentile is ≤ 2.7e-3
+    cos = torch.nn.functional.cosine_similarity(g.flatten().double(), pr.grad.flatten().double(), dim=0).item()
+    assert cos > 0.99999, cos
 
 
 def test_mixed_loss_branches_and_errors():
