@@ -450,6 +450,51 @@ def test_dwconv7(dt, B, Hh, Ww, C):
         close(a, b, dt, name)
 
 
+@pytest.mark.parametrize("B,Hh,Ww,C", [(2, 64, 64, 96), (3, 32, 32, 192), (2, 16, 16, 384), (1, 40, 72, 224), (1, 33, 19, 24),
+                                       (2, 16, 24, 40), (5, 48, 16, 64)])
+def test_dwconv7_matrix_core_path(B, Hh, Ww, C):
+    """bf16 forward / data gradient on the matrix cores (banded Toeplitz tiles, dwconv_mfma.hip; flag dw_mfma) against the
+    VALU stencil (flag off) and the fp32 reference: whole / partial tiles, one and two x tiles, partial channel slabs,
+    several tiles per persistent workgroup.  The MFMA operand is the bf16-rounded weight (the reference's autocast
+    precision), so the tight comparison uses bf16-representable weights, where both kernels compute the same products."""
+    from viscy_amd._lib import lib
+
+    def set_flag(v):
+        assert lib().vsx_set_flag(b"dw_mfma", v) == 0
+
+    H = _hip()
+    dt = torch.bfloat16
+    M = B * Hh * Ww
+    x, dy, add = rnd(M, C, dt=dt, seed=1), rnd(M, C, dt=dt, seed=2), rnd(M, C, dt=dt, seed=3)
+    bias = rnd(C, seed=5)
+    assert lib().vsx_get_flag(b"dw_mfma") == 1  # shipped default
+    for wkind in ("bf16_exact", "fp32"):
+        w = rnd(49, C, seed=4, scale=0.2)
+        if wkind == "bf16_exact":
+            w = w.to(torch.bfloat16).float()
+        outs = {}
+        for flag in (1, 0):
+            set_flag(flag)
+            try:
+                outs[flag] = (H.dwconv7_fwd(x.to(DEV), w.to(DEV), bias.to(DEV), B, Hh, Ww, C).float().cpu(),
+                              H.dwconv7_fwd(x.to(DEV), w.to(DEV), None, B, Hh, Ww, C).float().cpu(),
+                              H.dwconv7_bwd_data(dy.to(DEV), w.to(DEV), add.to(DEV), B, Hh, Ww, C).float().cpu(),
+                              H.dwconv7_bwd_data(dy.to(DEV), w.to(DEV), None, B, Hh, Ww, C).float().cpu())
+            finally:
+                set_flag(1)
+        ref = (R.dwconv7_fwd(x, w, bias, B, Hh, Ww, C).float(), R.dwconv7_fwd(x, w, None, B, Hh, Ww, C).float(),
+               R.dwconv7_bwd_data(dy, w, add, B, Hh, Ww, C).float(), R.dwconv7_bwd_data(dy, w, None, B, Hh, Ww, C).float())
+        for name, a, b, r in zip(["y", "y_nobias", "dx_add", "dx"], outs[1], outs[0], ref):
+            assert torch.isfinite(a).all(), name
+            scale = r.abs().max().item()
+            close(a, r, dt, f"{name} vs reference ({wkind})")
+            if wkind == "bf16_exact":
+                # same products, fp32 accumulation in a different order, one bf16 rounding (two with `add`): a few ulps apart
+                d = (a - b).abs()
+                assert d.max().item() <= (1.6e-2 if name == "dx_add" else 8e-3) * scale, (name, d.max().item() / scale)
+                assert (d > 0).float().mean().item() < (0.5 if name == "dx_add" else 0.2), (name, (d > 0).float().mean().item())
+
+
 # ------------------------------------------------------------------ data movement
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 def test_stem_im2col_and_normalize_fusion(dt):

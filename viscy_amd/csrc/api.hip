@@ -13,6 +13,7 @@ int g_vsx_tn_wide = 1;
 int g_vsx_ggb_blocks = 2048;  // grn_gelu_bwd: target workgroup count (tuning knob, see norm.hip)
 int g_vsx_tn_rect = 3;  // rectangular TN tiles: bit 0 = when N or K is 224..256 wide, bit 1 = 256x128 when 256 divides N (no prologue), bit 2 = 128x256 when 256 divides K (slower: off)
 int g_vsx_dw_rows2 = 0;  // depthwise 7x7: two output rows per thread — measured +3..8 % (fwd) / +18 % (dgrad) SLOWER: off
+int g_vsx_dw_mfma = 1;   // depthwise forward / data gradient on the matrix cores (banded Toeplitz tiles, dwconv_mfma.hip); 0: VALU stencil
 int g_vsx_dw_wg16 = 1;   // depthwise weight gradient: 8x16-pixel tiles (35 KB of LDS, 4 workgroups / CU) instead of 8x32 (63 KB, 2)
 int g_vsx_nt_stream = 0;  // OFF (rare NaN in long runs not yet explained; measured gains below are with the value 3) —  // lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B)
 int g_vsx_grn_stream = 0;  // OFF (as nt_stream; measured with the value 2) —  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
@@ -48,6 +49,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "tn_rect")) { g_vsx_tn_rect = value; return 0; }
   if (name && !strcmp(name, "dw_rows2")) { g_vsx_dw_rows2 = value; return 0; }
   if (name && !strcmp(name, "dw_wg16")) { g_vsx_dw_wg16 = value; return 0; }
+  if (name && !strcmp(name, "dw_mfma")) { g_vsx_dw_mfma = value; return 0; }
   if (name && !strcmp(name, "mlp_fused")) { g_vsx_mlp_fused = value; return 0; }
   vsx_set_error("vsx_set_flag: unknown flag '%s'", name ? name : "(null)");
   return 1;
@@ -68,6 +70,7 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "tn_rect")) return g_vsx_tn_rect;
   if (name && !strcmp(name, "dw_rows2")) return g_vsx_dw_rows2;
   if (name && !strcmp(name, "dw_wg16")) return g_vsx_dw_wg16;
+  if (name && !strcmp(name, "dw_mfma")) return g_vsx_dw_mfma;
   if (name && !strcmp(name, "mlp_fused")) return g_vsx_mlp_fused;
   return -1;
 }

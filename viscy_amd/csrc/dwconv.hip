@@ -427,9 +427,14 @@ static int dw_launch(const void* x, const float* w, const float* bias, const voi
                      int C, bool flip, hipStream_t s);
 extern int g_vsx_dw_rows2;
 extern int g_vsx_dw_wg16;
+int vsx_dwconv7_mfma_try(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W, int C,
+                         bool flip, hipStream_t s, int* taken);  // dwconv_mfma.hip
 template <>
 int dw_launch<bf16_t>(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W,
                       int C, bool flip, hipStream_t s) {
+  int taken = 0;  // matrix-core Toeplitz path (flag dw_mfma, images >= 16 x 16): memory-bound instead of VALU-bound
+  if (int rc = vsx_dwconv7_mfma_try(x, w, bias, add, y, B, H, W, C, flip, s, &taken)) return rc;
+  if (taken) return 0;
   if (g_vsx_dw_rows2 && W >= 24 && H >= 16) {  // 32 ch x 16x32 px, two output rows per thread
     constexpr int CB = 4 * VT<bf16_t>::N;
     long blocks = (long)B * vsx_cdiv(H, 16) * vsx_cdiv(W, 32) * vsx_cdiv(C, CB);

@@ -1,0 +1,276 @@
+// Depthwise 7x7 convolution on the matrix cores (bf16 production path) — forward and data gradient.
+//
+// The VALU stencil in dwconv.hip is compute-bound: 49 FMAs + bf16 unpacks per output keep it at 1.3–1.6 TB/s where a
+// streaming kernel reaches 3.5.  A depthwise convolution has no channel contraction, but for ONE channel a tap row is a
+// banded (Toeplitz) matrix product along x:
+//
+//     out_c[x, y] = sum_ky  sum_k  T_c,ky[x, k] * in_c[k, y + ky],      T_c,ky[x, k] = w_c[ky][k - x]  (0 <= k - x < 7)
+//
+// i.e. 7 MFMAs v_mfma_f32_16x16x32_bf16 per (channel, 16 x 16 output tile): A = T (16 output columns x 32 input columns,
+// of which 22 matter), B = the input columns of 16 image rows shifted by ky, D accumulates in fp32.  22 % of the MFMA's
+// MACs are useful — still > 5x the VALU rate, which makes the kernel memory-bound.  What it costs is layout: the tensor is
+// channels-last in HBM and the MFMA wants x contiguous per channel, so tiles are transposed through LDS
+// (16-byte global accesses, 2-byte LDS accesses on both sides) into per-channel planes.
+//
+// Structure (one persistent workgroup of 16 waves per CU):
+//   * a workgroup owns one 32-channel slab and a contiguous range of 16 x (16*NXT)-pixel tiles; wave w owns channels
+//     2w, 2w+1 of the slab and keeps their 2 x 7 Toeplitz fragments in registers for the whole launch (built once from the
+//     fp32 tap-major weights, rounded to bf16 — the operand precision of the reference's autocast convolution);
+//   * tiles are double-buffered: the global loads of tile i+1 are issued before the MFMAs of tile i and land in the other
+//     LDS buffer afterwards; a channel's outputs overwrite its own input plane (only its wave reads it), then all threads
+//     gather 16-byte channel vectors back out of the planes for the global store (+ the optional residual `add`).
+//
+// LDS plane of channel ch: [22 rows][PITCH] bf16 at ch * PLANE + (ch / 8) * 16 elements.  PITCH = 48 (NXT = 2) / 40
+// (NXT = 1) keeps the ds_read_b128 of a B fragment 16-byte aligned and conflict-free; the (ch / 8) * 16 skew spreads the
+// four 8-channel vectors of a pixel over distinct banks for the 2-byte transposing accesses.  Columns past the staged
+// 16*NXT + 6 are read by the K = 32 window of the last x tile: they are zeroed once per launch (A is zero there, but
+// 0 * garbage must not be NaN).
+#include "vsx_common.h"
+#include "../../include/vsx.h"
+
+typedef __attribute__((ext_vector_type(4))) float dwm_f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 dwm_bf16x8;
+
+namespace {
+
+constexpr int DWM_THREADS = 1024;
+constexpr int DWM_CB = 32;      // channels per slab
+constexpr int DWM_ROWS = 22;    // 16 output rows + 6 halo rows
+
+template <int NXT>
+struct DwmGeom {
+  static constexpr int TW = 16 * NXT;
+  static constexpr int IW = TW + 6;                       // staged columns
+  static constexpr int PITCH = NXT == 1 ? 40 : 16 * NXT + 16;  // elements per plane row (>= 16*(NXT-1) + 32, rows 16-B aligned)
+  static constexpr int PLANE = DWM_ROWS * PITCH;          // elements per channel plane (multiple of 8)
+  static constexpr int BUF = DWM_CB * PLANE + (DWM_CB / 8) * 16;  // elements per buffer
+};
+
+__device__ __forceinline__ int dwm_plane_base(int ch, int plane) { return ch * plane + (ch >> 3) * 16; }
+
+template <int NXT, bool FLIP>
+__global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias,
+                                                                   const bf16_t* __restrict__ add, bf16_t* __restrict__ y,
+                                                                   int B, int H, int W, int C, int nslab, int tiles_total,
+                                                                   int tiles_per_wg) {
+  typedef DwmGeom<NXT> G;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2][G::BUF];
+
+  // XCD-aware order (workgroups are dealt round-robin to the 8 XCDs): one XCD gets a contiguous range of logical ids, so
+  // the slabs of one tile range — which split every 128-byte line of a pixel between them — meet in one L2
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int slab = bid % nslab;
+  const int chunk = bid / nslab;
+  const int t_begin = chunk * tiles_per_wg;
+  const int t_end = min(tiles_total, t_begin + tiles_per_wg);
+  if (t_begin >= t_end) return;
+  const int c_base = slab * DWM_CB;
+  const int tiles_x = (W + G::TW - 1) / G::TW, tiles_y = (H + 15) / 16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int p16 = lane & 15, kq = lane >> 4;
+
+  // ---- Toeplitz fragments of this wave's two channels: A[i = p16][k = kq*8 + e] = w[ky][k - i]
+  dwm_bf16x8 afrag[2][7];
+  float bias_v[2];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int ch = c_base + wave * 2 + cc;
+    bias_v[cc] = (bias && ch < C) ? bias[ch] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      uint32_t pk[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int t = kq * 8 + e2 * 2 + h - p16;
+          const int tap = FLIP ? 48 - (ky * 7 + t) : ky * 7 + t;
+          v[h] = (t >= 0 && t < 7 && ch < C) ? w[(size_t)tap * C + ch] : 0.f;
+        }
+        pk[e2] = f32x2_to_bf16x2_bits(v[0], v[1]);
+      }
+      uint4 q = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      afrag[cc][ky] = __builtin_bit_cast(dwm_bf16x8, q);
+    }
+  }
+
+  // ---- zero the pad columns of both buffers once (never written afterwards)
+  {
+    constexpr int PADW = G::PITCH - G::IW;
+    for (int i = tid; i < 2 * DWM_CB * DWM_ROWS * PADW; i += DWM_THREADS) {
+      const int col = G::IW + i % PADW;
+      int r = i / PADW;
+      const int row = r % DWM_ROWS; r /= DWM_ROWS;
+      const int ch = r % DWM_CB;
+      const int buf = r / DWM_CB;
+      lds[buf][dwm_plane_base(ch, G::PLANE) + row * G::PITCH + col] = 0;
+    }
+  }
+
+  // staging items: (pixel of the 22 x IW halo tile, 8-channel vector): consecutive lanes = the 4 vectors of a pixel
+  constexpr int ITEMS = DWM_ROWS * G::IW * 4;
+  constexpr int NIT = (ITEMS + DWM_THREADS - 1) / DWM_THREADS;
+  uint4 stage[NIT];
+
+  auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    b = t / tiles_y;
+    y0 = ty * 16;
+    x0 = tx * G::TW;
+  };
+  auto load_tile = [&](int t) {
+    int b, y0, x0;
+    tile_origin(t, b, y0, x0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * DWM_THREADS;
+      const int cv = i & 3, p = i >> 2;
+      const int col = p % G::IW, row = p / G::IW;
+      const int gy = y0 + row - 3, gx = x0 + col - 3;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (i < ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cv * 8 < C)
+        v = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + gy) * W + gx) * C + c_base + cv * 8);
+      stage[it] = v;
+    }
+  };
+  auto store_tile_lds = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * DWM_THREADS;
+      if (i < ITEMS) {
+        const int cv = i & 3, p = i >> 2;
+        const int col = p % G::IW, row = p / G::IW;
+        unsigned short* dst = &lds[buf][dwm_plane_base(cv * 8, G::PLANE) + row * G::PITCH + col];
+        const uint32_t d[4] = {stage[it].x, stage[it].y, stage[it].z, stage[it].w};
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          dst[(e2 * 2) * G::PLANE] = (unsigned short)(d[e2] & 0xffffu);
+          dst[(e2 * 2 + 1) * G::PLANE] = (unsigned short)(d[e2] >> 16);
+        }
+      }
+    }
+  };
+
+  load_tile(t_begin);
+  __syncthreads();  // pad zeroing done
+  store_tile_lds(0);
+  __syncthreads();
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = (t - t_begin) & 1;
+    const bool more = t + 1 < t_end;
+    if (more) load_tile(t + 1);  // in flight under the MFMAs
+
+    // ---- compute: this wave's two channels, NXT x tiles of 16 columns, 16 rows
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int chl = wave * 2 + cc;
+      const unsigned short* plane = &lds[cur][dwm_plane_base(chl, G::PLANE)];
+      dwm_f32x4 acc[NXT];
+#pragma unroll
+      for (int xt = 0; xt < NXT; ++xt) acc[xt] = dwm_f32x4{bias_v[cc], bias_v[cc], bias_v[cc], bias_v[cc]};
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+        for (int xt = 0; xt < NXT; ++xt) {
+          const uint4 q = *reinterpret_cast<const uint4*>(plane + (p16 + ky) * G::PITCH + xt * 16 + kq * 8);
+          acc[xt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[cc][ky], __builtin_bit_cast(dwm_bf16x8, q), acc[xt], 0, 0, 0);
+        }
+      }
+      // D: lane (row j = p16, columns kq*4 .. +3) -> the channel's own plane, row j, tile-local column
+#pragma unroll
+      for (int xt = 0; xt < NXT; ++xt) {
+        uint2 o;
+        o.x = f32x2_to_bf16x2_bits(acc[xt][0], acc[xt][1]);
+        o.y = f32x2_to_bf16x2_bits(acc[xt][2], acc[xt][3]);
+        *reinterpret_cast<uint2*>(const_cast<unsigned short*>(plane) + p16 * G::PITCH + xt * 16 + kq * 4) = o;
+      }
+    }
+    if (more) store_tile_lds(cur ^ 1);
+    __syncthreads();
+
+    // ---- gather channel vectors back and store
+    {
+      int b, y0, x0;
+      tile_origin(t, b, y0, x0);
+      constexpr int OITEMS = 16 * G::TW * 4;
+#pragma unroll
+      for (int it = 0; it < (OITEMS + DWM_THREADS - 1) / DWM_THREADS; ++it) {
+        const int i = tid + it * DWM_THREADS;
+        const int cv = i & 3, p = i >> 2;
+        const int col = p % G::TW, row = p / G::TW;
+        const int gy = y0 + row, gx = x0 + col;
+        if (i < OITEMS && gy < H && gx < W && c_base + cv * 8 < C) {
+          const unsigned short* src = &lds[cur][dwm_plane_base(cv * 8, G::PLANE) + row * G::PITCH + col];
+          uint32_t d[4];
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2)
+            d[e2] = (uint32_t)src[(e2 * 2) * G::PLANE] | ((uint32_t)src[(e2 * 2 + 1) * G::PLANE] << 16);
+          const size_t off = (((size_t)b * H + gy) * W + gx) * C + c_base + cv * 8;
+          uint4 o = make_uint4(d[0], d[1], d[2], d[3]);
+          if (add) {
+            float a[8], f[8];
+            unpack<bf16_t>(*reinterpret_cast<const uint4*>(add + off), a);
+            unpack<bf16_t>(o, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += a[j];
+            o = pack<bf16_t>(f);
+          }
+          *reinterpret_cast<uint4*>(y + off) = o;
+        }
+      }
+    }
+    __syncthreads();  // the planes of `cur` are overwritten by the staging of tile t + 2
+  }
+}
+
+}  // namespace
+
+extern int g_vsx_dw_mfma;
+
+// *taken = 1 when the launch went to the MFMA path, 0 when the caller should use the VALU stencil; returns 0 or an error code
+int vsx_dwconv7_mfma_try(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W, int C,
+                         bool flip, hipStream_t s, int* taken) {
+  *taken = 0;
+  if (!g_vsx_dw_mfma || H < 16 || W < 16 || (C & 7)) return 0;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int nxt = W >= 24 ? 2 : 1;
+  const int tw = 16 * nxt;
+  const int nslab = vsx_cdiv(C, DWM_CB);
+  const long tiles_l = (long)B * vsx_cdiv(H, 16) * vsx_cdiv(W, tw);
+  if (tiles_l > 0x7fffffffL) return 0;
+  const int tiles = (int)tiles_l;
+  int chunks = n_cu / nslab;
+  if (chunks < 1) chunks = 1;
+  if (chunks > tiles) chunks = tiles;
+  const int per = vsx_cdiv(tiles, chunks);
+  chunks = vsx_cdiv(tiles, per);
+  int grid = chunks * nslab;
+  // keep the XCD remap valid: pad the grid to a multiple of 8 (surplus workgroups exit at once)
+  grid = (grid + 7) & ~7;
+#define DWM_LAUNCH(NXT, FLIP)                                                                                          \
+  hipLaunchKernelGGL((dwconv7_mfma_kernel<NXT, FLIP>), dim3(grid), dim3(DWM_THREADS), 0, s, (const bf16_t*)x, w, bias,  \
+                     (const bf16_t*)add, (bf16_t*)y, B, H, W, C, nslab, tiles, per)
+  if (nxt == 2) {
+    if (flip) DWM_LAUNCH(2, true); else DWM_LAUNCH(2, false);
+  } else {
+    if (flip) DWM_LAUNCH(1, true); else DWM_LAUNCH(1, false);
+  }
+#undef DWM_LAUNCH
+  VSX_LAUNCH_CHECK();
+  *taken = 1;
+  return 0;
+}
