@@ -467,21 +467,21 @@ def test_dwconv7_matrix_core_path(B, Hh, Ww, C):
     M = B * Hh * Ww
     x, dy, add = rnd(M, C, dt=dt, seed=1), rnd(M, C, dt=dt, seed=2), rnd(M, C, dt=dt, seed=3)
     bias = rnd(C, seed=5)
-    assert lib().vsx_get_flag(b"dw_mfma") == 1  # shipped default
+    assert lib().vsx_get_flag(b"dw_mfma") == 7  # shipped default: forward / data gradient (bit 0), weight gradient (bits 1, 2)
     for wkind in ("bf16_exact", "fp32"):
         w = rnd(49, C, seed=4, scale=0.2)
         if wkind == "bf16_exact":
             w = w.to(torch.bfloat16).float()
         outs = {}
         for flag in (1, 0):
-            set_flag(flag)
+            set_flag(7 * flag)
             try:
                 outs[flag] = (H.dwconv7_fwd(x.to(DEV), w.to(DEV), bias.to(DEV), B, Hh, Ww, C).float().cpu(),
                               H.dwconv7_fwd(x.to(DEV), w.to(DEV), None, B, Hh, Ww, C).float().cpu(),
                               H.dwconv7_bwd_data(dy.to(DEV), w.to(DEV), add.to(DEV), B, Hh, Ww, C).float().cpu(),
                               H.dwconv7_bwd_data(dy.to(DEV), w.to(DEV), None, B, Hh, Ww, C).float().cpu())
             finally:
-                set_flag(1)
+                set_flag(7)
         ref = (R.dwconv7_fwd(x, w, bias, B, Hh, Ww, C).float(), R.dwconv7_fwd(x, w, None, B, Hh, Ww, C).float(),
                R.dwconv7_bwd_data(dy, w, add, B, Hh, Ww, C).float(), R.dwconv7_bwd_data(dy, w, None, B, Hh, Ww, C).float())
         for name, a, b, r in zip(["y", "y_nobias", "dx_add", "dx"], outs[1], outs[0], ref):
@@ -493,6 +493,27 @@ def test_dwconv7_matrix_core_path(B, Hh, Ww, C):
                 d = (a - b).abs()
                 assert d.max().item() <= (1.6e-2 if name == "dx_add" else 8e-3) * scale, (name, d.max().item() / scale)
                 assert (d > 0).float().mean().item() < (0.5 if name == "dx_add" else 0.2), (name, (d > 0).float().mean().item())
+
+
+    # weight gradient: row contraction on the matrix cores (transpose reads) vs the VALU kernel and the fp32 reference —
+    # the products are exact in both, only the fp32 summation order differs
+    res = {}
+    for flag in (7, 3, 0):  # 16-column tiles (shipped), 32-column tiles where the width allows, VALU kernel
+        set_flag(flag)
+        try:
+            dw, db = torch.zeros(49, C, device=DEV), torch.zeros(C, device=DEV)
+            H.dwconv7_bwd_weight(dy.to(DEV), x.to(DEV), dw, db, B, Hh, Ww, C)
+            H.dwconv7_bwd_weight(dy.to(DEV), x.to(DEV), dw, db, B, Hh, Ww, C)  # accumulates
+            res[flag] = (dw.cpu() / 2, db.cpu() / 2)
+        finally:
+            set_flag(7)
+    dwr, dbr = torch.zeros(49, C), torch.zeros(C)
+    R.dwconv7_bwd_weight(dy, x, dwr, dbr, B, Hh, Ww, C)
+    for name, a, a32, b, r in zip(["dw", "db"], res[7], res[3], res[0], (dwr, dbr)):
+        scale = r.abs().max().item()
+        bar = 2e-4 * scale + 1e-5 * scale * (M ** 0.5)
+        for what, other in (("reference", r), ("VALU kernel", b), ("32-column tiles", a32)):
+            assert (a - other).abs().max().item() <= bar, (name, what, (a - other).abs().max().item() / scale)
 
 
 # ------------------------------------------------------------------ data movement

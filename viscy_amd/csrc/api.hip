@@ -13,7 +13,7 @@ int g_vsx_tn_wide = 1;
 int g_vsx_ggb_blocks = 2048;  // grn_gelu_bwd: target workgroup count (tuning knob, see norm.hip)
 int g_vsx_tn_rect = 3;  // rectangular TN tiles: bit 0 = when N or K is 224..256 wide, bit 1 = 256x128 when 256 divides N (no prologue), bit 2 = 128x256 when 256 divides K (slower: off)
 int g_vsx_dw_rows2 = 0;  // depthwise 7x7: two output rows per thread — measured +3..8 % (fwd) / +18 % (dgrad) SLOWER: off
-int g_vsx_dw_mfma = 1;   // depthwise forward / data gradient on the matrix cores (banded Toeplitz tiles, dwconv_mfma.hip); 0: VALU stencil
+int g_vsx_dw_mfma = 7;   // depthwise conv on the matrix cores (dwconv_mfma.hip): bit 0 forward / data gradient (banded Toeplitz tiles), bit 1 weight gradient (row contraction, transpose reads), bit 2 16-column weight-gradient tiles at every width (the 32-column variant spills: 471 vs 285 us at 64x64x96, B = 512); 0: VALU stencils
 int g_vsx_dw_wg16 = 1;   // depthwise weight gradient: 8x16-pixel tiles (35 KB of LDS, 4 workgroups / CU) instead of 8x32 (63 KB, 2)
 int g_vsx_nt_stream = 0;  // OFF (rare NaN in long runs not yet explained; measured gains below are with the value 3) —  // lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B)
 int g_vsx_grn_stream = 0;  // OFF (as nt_stream; measured with the value 2) —  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)

@@ -429,6 +429,8 @@ extern int g_vsx_dw_rows2;
 extern int g_vsx_dw_wg16;
 int vsx_dwconv7_mfma_try(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W, int C,
                          bool flip, hipStream_t s, int* taken);  // dwconv_mfma.hip
+int vsx_dwconv7_wgrad_mfma_try(const void* dy, const void* x, float* ws, int ws_rows, int B, int H, int W, int C,
+                               hipStream_t s, int* taken);  // dwconv_mfma.hip
 template <>
 int dw_launch<bf16_t>(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W,
                       int C, bool flip, hipStream_t s) {
@@ -505,6 +507,14 @@ extern "C" int32_t vsx_dwconv7_bwd_weight(const void* dy, const void* x, float* 
             "vsx_dwconv7_bwd_weight: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VSX_BF16) {
+    int rows = 0;  // matrix-core path (flag dw_mfma bit 1): one workspace row per tile range, folded by the same second kernel
+    if (int rc = vsx_dwconv7_wgrad_mfma_try(dy, x, ws, ws_rows, B, H, W, C, st, &rows)) return rc;
+    if (rows > 0) {
+      hipLaunchKernelGGL(dw_reduce_rows_kernel, dim3(vsx_cdiv(50 * C, 64), vsx_cdiv(rows, 64)), dim3(256), 0, st, ws, dw, db, rows,
+                         C);
+      VSX_LAUNCH_CHECK();
+      return 0;
+    }
     if (W >= 24 && g_vsx_dw_wg16) return dw_wgrad_cfg<bf16_t, 4, 8, 16>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
     if (W >= 24) return dw_wgrad_cfg<bf16_t, 4, 8, 32>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
     return dw_wgrad_cfg<bf16_t, 4, 8, 8>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);

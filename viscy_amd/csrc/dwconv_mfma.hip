@@ -231,6 +231,165 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient on the matrix cores.  dw_c[ky][kx] = sum_{y,x} dy_c[y][x] * in_c[y + ky - 3][x + kx - 3]: for one
+// channel and one ky, contract over 16 image ROWS with v_mfma_f32_16x16x16_bf16:
+//
+//     G_ky[u][v] += sum_{row} in_c[row + ky][vb + u] * dy_c[row][vb + v]          (plane coordinates, block start vb)
+//
+// and dw_c[ky][kx] is the kx-th diagonal of G_ky (u - v = kx).  Blocks start every 8 columns and all accumulate into the
+// SAME G_ky (the diagonals of columns v < 8 of each block are complete, u = v + kx <= 14; columns v >= 8 belong to the next
+// block and are ignored at the end), so a channel needs 7 accumulators (+ 1 with an all-ones A for db = sum dy), kept in
+// registers for the whole launch; the diagonals are extracted once, at the end, through LDS atomics into one workspace
+// row per tile range — no global atomics, a fixed summation order.
+// Both operands are row-major [row][x] planes whose fragments run along the contraction (row) axis: they are fetched
+// with the gfx950 transpose read ds_read_b64_tr_b16 (lane (r, cseg) of a 16-lane group supplies the address of 4
+// contiguous columns of row r; lane l receives column l & 15 of the group's 4 rows) — the shift by ky is a row offset of
+// the address, never a misaligned access.  Same persistent 16-wave workgroups and 2-byte LDS transposition as the forward;
+// one LDS buffer (in + dy planes of 32 channels = 117 KB), the next tile's global loads are in flight under the MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef short dwm_s16x4 __attribute__((ext_vector_type(4)));
+constexpr int DWM_WPITCH = 48;  // elements per plane row: tr reads of 4 rows x 16 columns (and of the paired group) hit distinct banks
+
+template <int NXT>
+__global__ __launch_bounds__(DWM_THREADS) void dwconv7_wgrad_mfma_kernel(const bf16_t* __restrict__ dy,
+                                                                         const bf16_t* __restrict__ x, float* __restrict__ ws,
+                                                                         int B, int H, int W, int C, int nslab, int tiles_total,
+                                                                         int tiles_per_wg) {
+  constexpr int TW = 16 * NXT, IW = TW + 6, P = DWM_WPITCH;
+  constexpr int XPLANE = DWM_ROWS * P, DPLANE = 16 * P;
+  constexpr int XBUF = DWM_CB * XPLANE + (DWM_CB / 8) * 16, DBUF = DWM_CB * DPLANE + (DWM_CB / 8) * 16;
+  __shared__ __attribute__((aligned(16))) unsigned short xl[XBUF];
+  __shared__ __attribute__((aligned(16))) unsigned short dl[DBUF];
+  __shared__ float red[DWM_CB * 50];
+
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int slab = bid % nslab;
+  const int chunk = bid / nslab;
+  const int t_begin = chunk * tiles_per_wg;
+  const int t_end = min(tiles_total, t_begin + tiles_per_wg);
+  if (t_begin >= t_end) return;
+  const int c_base = slab * DWM_CB;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + 15) / 16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int p16 = lane & 15, kq = lane >> 4;
+  const int tr_r = (lane & 15) >> 2, tr_c = (lane & 3) * 4;  // this lane's address role in a transpose read
+
+  for (int i = tid; i < XBUF; i += DWM_THREADS) xl[i] = 0;   // pads (and everything else) finite before the first MFMA
+  for (int i = tid; i < DBUF; i += DWM_THREADS) dl[i] = 0;
+  for (int i = tid; i < DWM_CB * 50; i += DWM_THREADS) red[i] = 0.f;
+
+  constexpr int XITEMS = DWM_ROWS * IW * 4, DITEMS = 16 * TW * 4, ITEMS = XITEMS + DITEMS;
+  constexpr int NIT = (ITEMS + DWM_THREADS - 1) / DWM_THREADS;
+  uint4 stage[NIT];
+
+  auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    b = t / tiles_y;
+    y0 = ty * 16;
+    x0 = tx * TW;
+  };
+  auto load_tile = [&](int t) {
+    int b, y0, x0;
+    tile_origin(t, b, y0, x0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * DWM_THREADS;
+      const bool is_x = i < XITEMS;
+      const int k = is_x ? i : i - XITEMS;
+      const int cv = k & 3, p = k >> 2;
+      const int wdt = is_x ? IW : TW;
+      const int col = p % wdt, row = p / wdt;
+      const int gy = y0 + row - (is_x ? 3 : 0), gx = x0 + col - (is_x ? 3 : 0);
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (i < ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cv * 8 < C)
+        v = *reinterpret_cast<const uint4*>((is_x ? x : dy) + (((size_t)b * H + gy) * W + gx) * C + c_base + cv * 8);
+      stage[it] = v;
+    }
+  };
+  auto store_tile_lds = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * DWM_THREADS;
+      if (i < ITEMS) {
+        const bool is_x = i < XITEMS;
+        const int k = is_x ? i : i - XITEMS;
+        const int cv = k & 3, p = k >> 2;
+        const int wdt = is_x ? IW : TW;
+        const int col = p % wdt, row = p / wdt;
+        const int plane = is_x ? XPLANE : DPLANE;
+        unsigned short* dst = (is_x ? xl : dl) + dwm_plane_base(cv * 8, plane) + row * P + col;
+        const uint32_t d[4] = {stage[it].x, stage[it].y, stage[it].z, stage[it].w};
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          dst[(e2 * 2) * plane] = (unsigned short)(d[e2] & 0xffffu);
+          dst[(e2 * 2 + 1) * plane] = (unsigned short)(d[e2] >> 16);
+        }
+      }
+    }
+  };
+
+  dwm_f32x4 acc[2][8];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[cc][k] = dwm_f32x4{0.f, 0.f, 0.f, 0.f};
+  const dwm_s16x4 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
+
+  load_tile(t_begin);
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    store_tile_lds();
+    __syncthreads();
+    if (t + 1 < t_end) load_tile(t + 1);  // in flight under the MFMAs
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      const int chl = wave * 2 + cc;
+      const unsigned short* xp = xl + dwm_plane_base(chl, XPLANE) + (kq * 4 + tr_r) * P + tr_c;
+      const unsigned short* dp = dl + dwm_plane_base(chl, DPLANE) + (kq * 4 + tr_r) * P + tr_c;
+#pragma unroll
+      for (int vb = 0; vb < TW; vb += 8) {
+        const dwm_s16x4 bfr = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) dwm_s16x4*)(dp + vb));
+        acc[cc][7] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones, bfr, acc[cc][7], 0, 0, 0);
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+          const dwm_s16x4 afr = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) dwm_s16x4*)(xp + ky * P + vb));
+          acc[cc][ky] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(afr, bfr, acc[cc][ky], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // planes are rewritten by the next tile
+  }
+
+  // ---- diagonals: lane holds G[u = kq*4 + r][v = p16]; column v < 8, kx = u - v in [0, 7)
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int chl = wave * 2 + cc;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kx = kq * 4 + r - p16;
+        if (p16 < 8 && kx >= 0 && kx < 7) atomicAdd(&red[chl * 50 + ky * 7 + kx], acc[cc][ky][r]);
+      }
+    if (p16 < 8 && kq == 0) atomicAdd(&red[chl * 50 + 49], acc[cc][7][0]);  // every row u of the ones product = column sum
+  }
+  __syncthreads();
+  float* row = ws + (size_t)chunk * 50 * C;
+  for (int i = tid; i < DWM_CB * 50; i += DWM_THREADS) {
+    const int chl = i % DWM_CB, n = i / DWM_CB;
+    if (c_base + chl < C) row[(size_t)n * C + c_base + chl] = red[chl * 50 + n];
+  }
+}
+
 }  // namespace
 
 extern int g_vsx_dw_mfma;
@@ -239,7 +398,7 @@ extern int g_vsx_dw_mfma;
 int vsx_dwconv7_mfma_try(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W, int C,
                          bool flip, hipStream_t s, int* taken) {
   *taken = 0;
-  if (!g_vsx_dw_mfma || H < 16 || W < 16 || (C & 7)) return 0;
+  if (!(g_vsx_dw_mfma & 1) || H < 16 || W < 16 || (C & 7)) return 0;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -272,5 +431,40 @@ int vsx_dwconv7_mfma_try(const void* x, const float* w, const float* bias, const
 #undef DWM_LAUNCH
   VSX_LAUNCH_CHECK();
   *taken = 1;
+  return 0;
+}
+
+// *taken = number of workspace rows written (to be folded by the caller), 0 when the VALU kernel should run instead
+int vsx_dwconv7_wgrad_mfma_try(const void* dy, const void* x, float* ws, int ws_rows, int B, int H, int W, int C,
+                               hipStream_t s, int* taken) {
+  *taken = 0;
+  if (!(g_vsx_dw_mfma & 2) || H < 16 || W < 16 || (C & 7)) return 0;
+  int dev = 0;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int nxt = (W >= 24 && !(g_vsx_dw_mfma & 4)) ? 2 : 1;  // bit 2: 16-column tiles at every width (A/B knob)
+  const int nslab = vsx_cdiv(C, DWM_CB);
+  const long tiles_l = (long)B * vsx_cdiv(H, 16) * vsx_cdiv(W, 16 * nxt);
+  if (tiles_l > 0x7fffffffL) return 0;
+  const int tiles = (int)tiles_l;
+  int chunks = n_cu / nslab;
+  if (chunks < 1) chunks = 1;
+  if (chunks > tiles) chunks = tiles;
+  if (chunks > ws_rows) chunks = ws_rows;
+  const int per = vsx_cdiv(tiles, chunks);
+  chunks = vsx_cdiv(tiles, per);
+  const int grid = (chunks * nslab + 7) & ~7;
+  if (nxt == 2)
+    hipLaunchKernelGGL((dwconv7_wgrad_mfma_kernel<2>), dim3(grid), dim3(DWM_THREADS), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                       ws, B, H, W, C, nslab, tiles, per);
+  else
+    hipLaunchKernelGGL((dwconv7_wgrad_mfma_kernel<1>), dim3(grid), dim3(DWM_THREADS), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                       ws, B, H, W, C, nslab, tiles, per);
+  VSX_LAUNCH_CHECK();
+  *taken = chunks;
   return 0;
 }
