@@ -508,10 +508,15 @@ def g9_fcmae():
             yr, yo = r(x), o(x)
         d = maxrel(yo, yr)
         assert d == 0.0, (tag, d)
-        golden[tag] = {"kwargs": kw, "seed": 11, "x_seed": 43, "x_shape": tuple(x.shape), "y": yo, "n_keys": len(o.state_dict()),
+        with torch.no_grad():  # Z == 1 input: the Conv2d stem branch (fcmae.py:369-370)
+            yr2, yo2 = r(x[:, :, :1]), o(x[:, :, :1])
+        assert yr2.shape == yr.shape and maxrel(yo2, yr2) == 0.0, tag
+        golden[tag] = {"kwargs": kw, "seed": 11, "x_seed": 43, "x_shape": tuple(x.shape), "y": yo, "y_2d": yo2,
+                       "n_keys": len(o.state_dict()),
                        "keys": list(o.state_dict().keys()),
                        "param_checksum": sum(p.double().sum() for p in o.parameters()).item()}
-        print(f"G9 fcmae {tag}: reference dense forward on stubbed timm/monai == oracle (exact); keys={len(o.state_dict())}")
+        print(f"G9 fcmae {tag}: reference dense forward (Z-stack and Z == 1 input) on stubbed timm/monai == oracle (exact); "
+              f"keys={len(o.state_dict())}")
     torch.save(golden, os.path.join(GOLD, "fcmae_forward.pt"))
 
     # ---- masked pre-training path: the reference draws the mask (generate_mask, fcmae.py:40-66); the oracle gets the same

@@ -349,12 +349,15 @@ def test_fcmae_forward_matches_reference_golden_fp32(tag):
     x = torch.randn(g["x_shape"], generator=torch.Generator().manual_seed(g["x_seed"]))
     with torch.no_grad():
         y = mine(x.cuda())
+        y2d = mine(x[:, :, :1].contiguous().cuda())  # Z == 1 input: the Conv2d stem branch (fcmae.py:369-370)
     assert y.shape == g["y"].shape and y.dtype == torch.float32
     assert relerr(y, g["y"]) <= 1e-3
+    assert y2d.shape == g["y_2d"].shape and relerr(y2d, g["y_2d"]) <= 1e-3
 
 
+@pytest.mark.parametrize("flat_input", [False, True], ids=["zstack", "z1"])
 @pytest.mark.parametrize("tag", ["small_z5", "head_conv_z5"])
-def test_fcmae_forward_backward_vs_oracle_fp32(tag):
+def test_fcmae_forward_backward_vs_oracle_fp32(tag, flat_input):
     from oracle import fcmae_ref
     from viscy_amd.fcmae import FullyConvolutionalMAE
 
@@ -368,7 +371,8 @@ def test_fcmae_forward_backward_vs_oracle_fp32(tag):
     mine.load_state_dict(ref.state_dict(), strict=True)
     mine = mine.cuda()
     mine.compute_dtype = torch.float32
-    x = torch.randn(2, kw["in_channels"], kw["in_stack_depth"], 64, 96, generator=torch.Generator().manual_seed(5))
+    x = torch.randn(2, kw["in_channels"], 1 if flat_input else kw["in_stack_depth"], 64, 96,
+                    generator=torch.Generator().manual_seed(5))
     y = ref(x)
     dout = torch.randn(y.shape, generator=torch.Generator().manual_seed(6))
     y.backward(dout)
@@ -378,8 +382,9 @@ def test_fcmae_forward_backward_vs_oracle_fp32(tag):
     worst = 0.0
     for (name, pr), (n2, pm) in zip(ref.named_parameters(), mine.named_parameters()):
         assert name == n2
-        if pr.grad is None:  # the 2-D stem branch is not on the Z > 1 path
-            assert "conv2d" in name and pm.grad is None
+        if pr.grad is None:  # the stem branch that is not on this input's path (Conv2d for a Z-stack, Conv3d for Z == 1)
+            assert ("conv3d" if flat_input else "conv2d") in name
+            assert pm.grad is None or float(pm.grad.abs().max()) == 0.0
             continue
         if name == "head.conv.0.conv.bias":
             continue

@@ -142,6 +142,8 @@ class Engine:
         for i in (1, 0):
             ps += self._stage_params_rev(getattr(m.encoder_stages, f"stages_{i}"))
         ps += [m.encoder_stages.stem_1.weight, m.encoder_stages.stem_1.bias, m.stem.conv.weight, m.stem.conv.bias]
+        if getattr(m, "stem2d", None) is not None:  # FCMAE: the Conv2d stem of Z == 1 inputs
+            ps += [m.stem2d.weight, m.stem2d.bias]
         self._bucket_marks.append(len(ps))  # bucket 2 = encoder stages 1, 0 + stem
         return ps
 
@@ -234,6 +236,13 @@ class Engine:
                 we[:, d, d, :] = sw.detach().reshape(co3, K)
             W["stem_W"] = we.reshape(co3 * Dp, Dp * K).to(dt).contiguous()
             W["stem_b"] = m.stem.conv.bias.detach().repeat_interleave(Dp).contiguous()
+        s2 = getattr(m, "stem2d", None)
+        if s2 is not None:  # FCMAE: Conv2d stem of Z == 1 inputs (fcmae.py:348-353,369-370) — the same patch GEMM with kz = 1
+            K2 = s2.weight[0].numel()
+            W["stem2d_W"], _ = o.prep_weight(s2.weight, s2.weight.shape[0], K2, 1, dt)
+            if dt == torch.bfloat16 and K2 % 32:
+                W["stem2d_W"] = o.pad_cols(W["stem2d_W"], (K2 + 31) // 32 * 32)
+            W["stem2d_b"] = s2.bias
         enc = []
         for i in range(4):
             st = getattr(m.encoder_stages, f"stages_{i}")
@@ -464,7 +473,8 @@ class Engine:
         B, Cin, Z, H, Wd = x.shape
         za_key = ("fwd", B, H, Wd, masks is not None)
         self._za = za = _ZeroArena(x.device, self._za_need.get(za_key, 0))
-        if Cin != cfg["in_channels"] or Z != cfg["in_stack_depth"]:
+        flat_stem = Z == 1 and cfg["in_stack_depth"] != 1 and "stem2d_W" in W  # FCMAE 2-D branch: x.squeeze(2) -> conv2d
+        if Cin != cfg["in_channels"] or (Z != cfg["in_stack_depth"] and not flat_stem):
             raise ValueError(f"expected input (B,{cfg['in_channels']},{cfg['in_stack_depth']},Y,X), got {tuple(x.shape)}")
         kz, ky, kx = cfg["stem_kernel"]
         if H % (8 * ky) or Wd % (8 * kx):
@@ -478,14 +488,16 @@ class Engine:
         if need_bwd:
             self._pending_bwd += 1
         # ---- stem: patch gather + projection GEMM, then encoder stem_1 LayerNorm2d
-        P = o.stem_im2col(x.contiguous(), (kz, ky, kx), dt, ld=W["stem_W"].shape[1])
+        stem_W, stem_b = (W["stem2d_W"], W["stem2d_b"]) if flat_stem else (W["stem_W"], W["stem_b"])
+        P = o.stem_im2col(x.contiguous(), (1 if flat_stem else kz, ky, kx), dt, ld=stem_W.shape[1])
         M0, K0 = B * h * w, P.shape[1]
         f = torch.empty((M0, C0), dtype=dt, device=x.device)
-        o.gemm("nt", P, W["stem_W"], f, M0, C0, K0, K0, K0, C0, dtype=dt, epi=L.EPI_BIAS, bias=W["stem_b"])
+        o.gemm("nt", P, stem_W, f, M0, C0, K0, K0, K0, C0, dtype=dt, epi=L.EPI_BIAS, bias=stem_b)
         ln1 = m.encoder_stages.stem_1
         cur, mean, rstd = o.ln_fwd(f, ln1.weight, ln1.bias, M0, C0)
         if need_bwd:
             sv["stem"] = (P, f, mean, rstd)
+            sv["flat_stem"] = flat_stem
         else:
             del P, f
         # ---- encoder
@@ -781,7 +793,10 @@ class Engine:
         M0, C0, K0 = f.shape[0], f.shape[1], P.shape[1]
         df = o.ln_bwd(d, f, mean, rstd, ln1.weight, None, g(ln1.weight), g(ln1.bias), M0, C0)
         Dp = cfg["ratio"]
-        if Dp == 1:
+        if sv.get("flat_stem"):
+            Kw = m.stem2d.weight[0].numel()
+            o.gemm("tn", P, df, g(m.stem2d.weight), M0, C0, Kw, K0, C0, Kw, dtype=dt, colsum=g(m.stem2d.bias))
+        elif Dp == 1:
             Kw = m.stem.conv.weight[0].numel()  # the patch matrix may carry zero-padded tail columns (lda = K0 >= Kw)
             o.gemm("tn", P, df, g(m.stem.conv.weight), M0, C0, Kw, K0, C0, Kw, dtype=dt, colsum=g(m.stem.conv.bias))
         else:

@@ -32,6 +32,11 @@ class _FcmaeCore(_Core):
     def __init__(self, in_channels, out_channels, encoder_blocks, dims, stem_kernel_size, in_stack_depth, decoder_conv_blocks,
                  head_conv, head_conv_expansion_ratio, head_conv_pool):
         super().__init__()
+        # MaskedAdaptiveProjection.conv2d (fcmae.py:348-353): the stem of Z == 1 inputs.  A parameter of the core, so it lives
+        # in the engine's flat buffers and trains like the rest; registered FIRST = next to the 3-D stem at the tail of the
+        # (reverse-forward-order) flat buffer, i.e. in the gradient bucket that is reduced last.
+        self.stem2d = _Conv((dims[0], in_channels, stem_kernel_size[1], stem_kernel_size[2]))
+        nn.init.trunc_normal_(self.stem2d.weight, std=0.02)
         self._build(in_channels=in_channels, out_channels=out_channels, in_stack_depth=in_stack_depth,
                     out_stack_depth=in_stack_depth, depths=tuple(encoder_blocks), dims=tuple(dims), conv_mlp=False,
                     stem_kernel_size=stem_kernel_size, decoder_conv_blocks=decoder_conv_blocks,
@@ -132,8 +137,7 @@ class FullyConvolutionalMAE(nn.Module):
         object.__setattr__(self, "_core", core)  # NOT a registered submodule: its parameters appear below, under reference names
         enc, stem = _Holder(), _Holder()
         stem.conv3d = _share(core.stem.conv)
-        stem.conv2d = _Conv((dims[0], in_channels, stem_kernel_size[1], stem_kernel_size[2]))  # Z == 1 inputs: kept for the key set
-        nn.init.trunc_normal_(stem.conv2d.weight, std=0.02)
+        stem.conv2d = _share(core.stem2d)  # Z == 1 inputs (fcmae.py:369-370)
         stem.norm = _share(core.encoder_stages.stem_1)
         enc.stem = stem
         enc.stages = nn.ModuleList(_StageView(getattr(core.encoder_stages, f"stages_{i}")) for i in range(4))
@@ -186,8 +190,6 @@ class FullyConvolutionalMAE(nn.Module):
     def forward(self, x: Tensor, mask_ratio: float = 0.0, mask: Tensor | None = None):
         """fcmae.py:541-560.  ``mask`` (B,1,H/stride,W/stride bool, True = masked) is an extension for tests: it injects the
         draw ``generate_mask`` would make; every sample must mask the same number of cells."""
-        if x.ndim == 5 and x.shape[2] == 1:
-            raise NotImplementedError("the 2-D stem branch (Z == 1 inputs) is not built")
         masks = None
         if mask is None and mask_ratio > 0.0:
             mask = generate_mask(x.shape, self.total_stride, mask_ratio, x.device)
