@@ -367,6 +367,13 @@ int32_t vsx_stem_im2col_ld(const float* x, void* P, const float* sub, const floa
     int32_t H, int32_t W, int32_t kz, int32_t ky, int32_t kx, int32_t ldp, int32_t dtype, vsx_stream_t stream);
 int32_t vsx_pad_cols(const void* src, void* dst, int32_t R, int32_t K, int32_t Kp, int32_t dtype, vsx_stream_t stream);
 
+/* Dense 3x3 convolution (padding 1) of a channels-last map as a GEMM — MONAI SubpixelUpsample's pre-convolution, selected by
+ * UNeXt2(decoder_upsample_pre_conv=True) (/root/reference/packages/viscy-models/src/viscy_models/components/blocks.py:138-146).
+ * vsx_im2col3x3: col[m][t*C + c] = x[b, y + t/3 - 1, x + t%3 - 1, c], zero outside the image (t = 3*ky + kx: the K order of
+ * vsx_prep_weight(conv.weight, Cout, C, 9)).  vsx_col2im3x3: its transpose, dx[m][c] = sum_t dcol[m - shift(t)][t*C + c]. */
+int32_t vsx_im2col3x3(const void* x, void* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, vsx_stream_t stream);
+int32_t vsx_col2im3x3(const void* dcol, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, vsx_stream_t stream);
+
 /* K10: MONAI UpSample(mode="pixelshuffle", pre_conv=None) + torch.cat([up, skip], 1) (viscy_models/components/blocks.py:138-146,170-171). */
 int32_t vsx_pixel_shuffle_cat_fwd(const void* low, const void* skip, void* out, int32_t B, int32_t h,
     int32_t w, int32_t c, int32_t cs, int32_t dtype, vsx_stream_t stream);

@@ -14,8 +14,8 @@ What it restates (reference file:line, all under /root/reference/packages/viscy-
     follows the in-repo restatement unet/fcmae.py:174-221 (dense path) and the stage
     logic unet/fcmae.py:260-274, and is cross-checked against
     ``transformers.models.convnextv2`` (oracle/validate_against_reference.py).
-  * MONAI 1.5.2 (uv.lock:3358) pieces: ``UpSample(mode="pixelshuffle", pre_conv=None)``
-    (= plain pixel shuffle + optional pad-pool) and ``Convolution`` (Conv3d → InstanceNorm3d
+  * MONAI 1.5.2 (uv.lock:3358) pieces: ``UpSample(mode="pixelshuffle", pre_conv=None | "default")``
+    (= [3x3 convolution +] pixel shuffle + optional pad-pool) and ``Convolution`` (Conv3d → InstanceNorm3d
     → PReLU, "NDA" ordering).
 
 Parity pinning: see oracle/validate_against_reference.py (run in the build container where
@@ -233,14 +233,23 @@ class UNeXt2Stem(nn.Module):
 
 
 class PixelShuffleUp(nn.Module):
-    """MONAI UpSample(mode="pixelshuffle", pre_conv=None[, apply_pad_pool]) — parameter free."""
+    """MONAI ``SubpixelUpsample`` as ``UpSample(mode="pixelshuffle", pre_conv=None | "default"[, apply_pad_pool])`` builds it
+    (MONAI 1.5.2 is not in this image: restated from its published source).  ``pre_conv=None``: parameter free.
+    ``pre_conv="default"``: ``conv_block = Conv2d(in_channels, out_channels * scale², 3, stride 1, padding 1, bias)`` with
+    ICNR-initialised weights in front of the shuffle — what ``UNeXt2(decoder_upsample_pre_conv=True)`` selects
+    (components/blocks.py:138-146; there ``out_channels * scale² == in_channels``)."""
 
-    def __init__(self, scale: int, pad_pool: bool):
+    def __init__(self, scale: int, pad_pool: bool, in_channels: int | None = None, pre_conv: bool = False):
         super().__init__()
         self.scale, self.pad_pool = scale, pad_pool
+        if pre_conv:
+            self.conv_block = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1, bias=True)
+            icnr_init(self.conv_block, scale, upsample_dims=2)
+        else:
+            self.conv_block = nn.Identity()
 
     def forward(self, x: Tensor) -> Tensor:
-        x = F.pixel_shuffle(x, self.scale)
+        x = F.pixel_shuffle(self.conv_block(x), self.scale)
         if self.pad_pool:
             s = self.scale
             x = F.avg_pool2d(F.pad(x, (s - 1, 0, s - 1, 0)), kernel_size=s, stride=1)
@@ -248,15 +257,19 @@ class PixelShuffleUp(nn.Module):
 
 
 class UNeXt2UpStage(nn.Module):
-    """components/blocks.py:77-172 (pixelshuffle mode, upsample_pre_conv=None)."""
+    """components/blocks.py:77-172 (pixelshuffle mode).  MONAI's ``UpSample`` is an ``nn.Sequential`` whose pixel-shuffle
+    child is registered as ``pixelshuffle`` — the pre-convolution's keys are ``upsample.pixelshuffle.conv_block.*``."""
 
-    def __init__(self, in_channels: int, skip_channels: int, out_channels: int, scale_factor: int, conv_blocks: int):
+    def __init__(self, in_channels: int, skip_channels: int, out_channels: int, scale_factor: int, conv_blocks: int,
+                 pre_conv: bool = False):
         super().__init__()
         mid = in_channels // scale_factor**2
-        self.upsample = PixelShuffleUp(scale_factor, pad_pool=False)
+        self.upsample = nn.Sequential()
+        self.upsample.add_module("pixelshuffle", PixelShuffleUp(scale_factor, False, in_channels, pre_conv))
         self.conv = ConvNeXtStage(mid + skip_channels, out_channels, 1, conv_blocks, conv_mlp=True)
         self.conv.apply(timm_init_weights)
-        icnr_init(self.conv.blocks[-1].mlp.fc2, scale_factor, upsample_dims=2)
+        if not pre_conv:  # blocks.py:147: conv_weight_init_factor = None if upsample_pre_conv else scale_factor
+            icnr_init(self.conv.blocks[-1].mlp.fc2, scale_factor, upsample_dims=2)
 
     def forward(self, inp: Tensor, skip: Tensor) -> Tensor:
         return self.conv(torch.cat([self.upsample(inp), skip], dim=1))
@@ -265,10 +278,10 @@ class UNeXt2UpStage(nn.Module):
 class UNeXt2Decoder(nn.Module):
     """components/blocks.py:175-243."""
 
-    def __init__(self, num_channels: list[int], conv_blocks: int, strides: list[int]):
+    def __init__(self, num_channels: list[int], conv_blocks: int, strides: list[int], pre_conv: bool = False):
         super().__init__()
         self.decoder_stages = nn.ModuleList(
-            UNeXt2UpStage(num_channels[i], num_channels[i] // 2, num_channels[i + 1], strides[i], conv_blocks)
+            UNeXt2UpStage(num_channels[i], num_channels[i] // 2, num_channels[i + 1], strides[i], conv_blocks, pre_conv)
             for i in range(len(num_channels) - 1)
         )
 
@@ -354,8 +367,8 @@ class UNeXt2(nn.Module):
             raise ValueError(
                 f"Input stack depth {in_stack_depth} is not divisible by stem kernel depth {stem_kernel_size[0]}."
             )
-        if decoder_mode != "pixelshuffle" or decoder_upsample_pre_conv or pretrained:
-            raise NotImplementedError("oracle covers the pixelshuffle / no-pre-conv path only")
+        if decoder_mode != "pixelshuffle" or pretrained:
+            raise NotImplementedError("oracle covers the pixelshuffle path only")
         if out_stack_depth is None:
             out_stack_depth = in_stack_depth
         enc = ConvNeXtFeatures(backbone, drop_path_rate=drop_path_rate)
@@ -367,7 +380,8 @@ class UNeXt2(nn.Module):
         dec = num_channels
         dec.reverse()
         dec[-1] = (out_stack_depth + 2) * out_channels * 2**2 * head_expansion_ratio
-        self.decoder = UNeXt2Decoder(dec, decoder_conv_blocks, [2] * (len(num_channels) - 1) + [stem_kernel_size[-1]])
+        self.decoder = UNeXt2Decoder(dec, decoder_conv_blocks, [2] * (len(num_channels) - 1) + [stem_kernel_size[-1]],
+                                     pre_conv=bool(decoder_upsample_pre_conv))
         self.head = PixelToVoxelHead(dec[-1], out_channels, out_stack_depth, head_expansion_ratio, pool=head_pool)
         self.out_stack_depth = out_stack_depth
 

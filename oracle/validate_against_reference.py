@@ -403,9 +403,11 @@ def g8_wiring():
     timm.layers = sys.modules["timm.layers"]
 
     def up_sample(spatial_dims, in_channels, out_channels, scale_factor, mode, pre_conv, apply_pad_pool):
-        assert spatial_dims == 2 and mode == "pixelshuffle" and pre_conv is None
+        assert spatial_dims == 2 and mode == "pixelshuffle" and pre_conv in (None, "default")
         assert out_channels * scale_factor**2 == in_channels
-        return R.PixelShuffleUp(scale_factor, apply_pad_pool)
+        up = nn.Sequential()  # MONAI's UpSample is a Sequential whose shuffle block is registered as "pixelshuffle"
+        up.add_module("pixelshuffle", R.PixelShuffleUp(scale_factor, apply_pad_pool, in_channels, pre_conv == "default"))
+        return up
 
     def convolution(spatial_dims, in_channels, out_channels, kernel_size, padding):
         assert spatial_dims == 3 and kernel_size == 3 and tuple(padding) == (0, 1, 1)
@@ -440,6 +442,10 @@ def g8_wiring():
         ("atto_pool", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_atto", head_pool=True), 64),
         ("femto_z15", dict(in_channels=2, out_channels=3, in_stack_depth=15, out_stack_depth=5, backbone="convnextv2_femto"), 64),
         ("tiny_pool", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True), 64),
+        # decoder_upsample_pre_conv=True: the reference's own wiring (unext2.py -> blocks.py:138-147: pre_conv="default", no
+        # ICNR on the stage) around the restated MONAI SubpixelUpsample convolution
+        ("femto_preconv", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_femto",
+                               decoder_upsample_pre_conv=True), 64),
     ]:
         r = ref.UNeXt2(**kw)
         o = R.UNeXt2(**kw)

@@ -188,6 +188,21 @@ def dwconv7_bwd_weight(dy, x, dw, db, B, H, W, Cc):
         db += dy.float().view(-1, Cc).sum(0)
 
 
+def im2col3x3(x, B, H, W, Cc):
+    img = F.pad(x.float().view(B, H, W, Cc), (0, 0, 1, 1, 1, 1))
+    cols = [img[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)]
+    return torch.stack(cols, dim=3).reshape(B * H * W, 9 * Cc).to(x.dtype)
+
+
+def col2im3x3(dcol, B, H, W, Cc):
+    d = dcol.float().view(B, H, W, 9, Cc)
+    out = torch.zeros(B, H + 2, W + 2, Cc)
+    for t in range(9):
+        ky, kx = divmod(t, 3)
+        out[:, ky:ky + H, kx:kx + W, :] += d[:, :, :, t, :]
+    return out[:, 1:H + 1, 1:W + 1, :].reshape(B * H * W, Cc).to(dcol.dtype)
+
+
 def pad_cols(src, Kp):
     R, K = src.shape
     dst = torch.zeros((R, Kp), dtype=src.dtype)

@@ -28,7 +28,7 @@ def _pair(kw, seed=7):
     return ref, mine.cuda()
 
 
-@pytest.mark.parametrize("tag", ["atto_pool", "femto_z15", "tiny_pool"])
+@pytest.mark.parametrize("tag", ["atto_pool", "femto_z15", "tiny_pool", "femto_preconv"])
 def test_forward_matches_reference_golden_fp32(tag):
     """fixtures were produced by the REFERENCE's own unext2.py/blocks.py/heads.py (oracle/validate_against_reference.py G8)"""
     g = load_golden("unext2_forward.pt")[tag]
@@ -45,6 +45,9 @@ CASES = [
     ("atto_pool", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_atto", head_pool=True), (2, 64, 96)),
     ("femto_z15", dict(in_channels=2, out_channels=2, in_stack_depth=15, out_stack_depth=5, backbone="convnextv2_femto"), (1, 64, 64)),
     ("tiny_pool", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True), (2, 128, 128)),
+    # decoder_upsample_pre_conv=True (blocks.py:138-146): a dense 3x3 convolution in front of every decoder pixel shuffle
+    ("femto_preconv", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_femto",
+                           decoder_upsample_pre_conv=True), (2, 64, 96)),
 ]
 
 

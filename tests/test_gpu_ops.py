@@ -516,6 +516,27 @@ def test_dwconv7_matrix_core_path(B, Hh, Ww, C):
             assert (a - other).abs().max().item() <= bar, (name, what, (a - other).abs().max().item() / scale)
 
 
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("B,Hh,Ww,C", [(2, 8, 8, 96), (1, 5, 7, 40), (3, 16, 12, 24), (1, 1, 1, 8)])
+def test_conv3x3_patch_gather_and_scatter(dt, B, Hh, Ww, C):
+    """vsx_im2col3x3 / vsx_col2im3x3 (the decoder pre-convolution as a GEMM): exact data movement, and together with the
+    GEMMs a Conv2d(C, Cout, 3, padding=1) forward / data gradient"""
+    H = _hip()
+    M = B * Hh * Ww
+    x = rnd(M, C, dt=dt, seed=1)
+    col = H.im2col3x3(x.to(DEV), B, Hh, Ww, C).cpu()
+    assert torch.equal(col, R.im2col3x3(x, B, Hh, Ww, C))
+    dcol = rnd(M, 9 * C, dt=dt, seed=2)
+    close(H.col2im3x3(dcol.to(DEV), B, Hh, Ww, C), R.col2im3x3(dcol, B, Hh, Ww, C), dt, "col2im")
+    # against torch's convolution: K order t*C + c with t = 3*ky + kx == prep_weight(conv.weight, Cout, C, 9)
+    Cout = 16
+    w = rnd(Cout, C, 3, 3, seed=3, scale=0.1)
+    Wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * C)
+    y = col.float() @ Wp.t()
+    yr = torch.nn.functional.conv2d(x.float().view(B, Hh, Ww, C).permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    torch.testing.assert_close(y, yr.reshape(M, Cout), rtol=1e-4, atol=1e-4)
+
+
 # ------------------------------------------------------------------ data movement
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 def test_stem_im2col_and_normalize_fusion(dt):

@@ -41,7 +41,7 @@ def test_bad_depth_raises():
         unext2_ref.UNeXt2(in_stack_depth=7)
 
 
-@pytest.mark.parametrize("tag", ["atto_pool", "femto_z15", "tiny_pool"])
+@pytest.mark.parametrize("tag", ["atto_pool", "femto_z15", "tiny_pool", "femto_preconv"])
 def test_forward_golden(tag):
     g = load_golden("unext2_forward.pt")[tag]
     m = unext2_ref.randomize_(unext2_ref.UNeXt2(**g["kwargs"]), seed=g["seed"]).eval()

@@ -25,6 +25,9 @@ CASES = [
     ("atto_pool", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_atto", head_pool=True), (2, 64, 96)),
     ("femto_z15", dict(in_channels=2, out_channels=2, in_stack_depth=15, out_stack_depth=5, backbone="convnextv2_femto"), (1, 64, 64)),
     ("tiny_nopool", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny"), (1, 64, 64)),
+    # decoder_upsample_pre_conv=True: MONAI SubpixelUpsample's 3x3 convolution in front of every pixel shuffle (blocks.py:138-146)
+    ("femto_preconv", dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_femto",
+                           decoder_upsample_pre_conv=True), (2, 64, 96)),
 ]
 
 
@@ -68,6 +71,18 @@ def test_state_dict_compat():
                 "head.conv.1.weight", "head.conv.0.adn.A.weight"]:
         assert key in sd
     assert m.num_blocks == 6 and m.out_stack_depth == 5
+    # decoder_upsample_pre_conv=True adds one Conv2d(C, C, 3) per decoder stage under MONAI's module names, ICNR-initialised
+    # (identical 2x2 sub-kernels), and leaves the stage's last fc2 on timm's init (blocks.py:147)
+    ref = unext2_ref.UNeXt2(backbone="convnextv2_atto", decoder_upsample_pre_conv=True)
+    mp = UNeXt2(backbone="convnextv2_atto", decoder_upsample_pre_conv=True)
+    assert list(mp.state_dict()) == list(ref.state_dict()) and len(mp.state_dict()) == 213 + 6
+    assert [tuple(v.shape) for v in mp.state_dict().values()] == [tuple(v.shape) for v in ref.state_dict().values()]
+    w = mp.state_dict()["decoder.decoder_stages.1.upsample.pixelshuffle.conv_block.weight"]
+    assert w.shape == (160, 160, 3, 3)
+    groups = w.view(40, 4, 160, 3, 3)
+    assert torch.equal(groups[:, 0], groups[:, 3]) and not torch.equal(groups[0, 0], groups[1, 0])
+    fc2 = mp.state_dict()["decoder.decoder_stages.1.conv.blocks.1.mlp.fc2.weight"]
+    assert not torch.equal(fc2[0], fc2[1])  # no ICNR on the stage when the pre-convolution carries it
 
 
 def test_bad_depth_and_cpu_forward_raise():

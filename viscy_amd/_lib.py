@@ -61,6 +61,8 @@ _SIGS = {
     "vsx_stem_im2col": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_stem_im2col_ld": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_pad_cols": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _P]),
+    "vsx_im2col3x3": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "vsx_col2im3x3": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_pixel_shuffle_cat_fwd": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_pixel_shuffle_cat_bwd": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vsx_head_shuffle_fwd": (_I32, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),

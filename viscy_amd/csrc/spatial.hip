@@ -114,6 +114,83 @@ extern "C" int32_t vsx_pad_cols(const void* src, void* dst, int32_t R, int32_t K
   return 0;
 }
 
+// ------------------------------------------------------------------ dense 3x3 convolution as a GEMM: patch gather / scatter
+// (decoder_upsample_pre_conv: MONAI SubpixelUpsample's Conv2d(C, C, 3, padding=1) in front of the pixel shuffle,
+// blocks.py:138-146).  col[m][t*C + c] = x[b, y + t/3 - 1, x + t%3 - 1, c] (zero outside the image); the transpose
+// gathers the nine shifted contributions of a pixel (no atomics): dx[m][c] = sum_t dcol[m - shift(t)][t*C + c].
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ x, T* __restrict__ col, int B, int H, int W, int C) {
+  constexpr int VN = VT<T>::N;
+  const int nch = C / VN;
+  const long total = (long)B * H * W * 9 * nch;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int cv = (int)(gid % nch);
+  long r = gid / nch;
+  const int t = (int)(r % 9);
+  const long m = r / 9;
+  const int xx = (int)(m % W);
+  const int yy = (int)((m / W) % H);
+  const int sy = yy + t / 3 - 1, sx = xx + t % 3 - 1;
+  typename VT<T>::vec v = vzero<T>();
+  if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = ldvec<T>(x + ((m - (long)yy * W - xx) + (long)sy * W + sx) * C + cv * VN);
+  stvec<T>(col + (m * 9 + t) * C + cv * VN, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int B, int H, int W, int C) {
+  constexpr int VN = VT<T>::N;
+  const int nch = C / VN;
+  const long total = (long)B * H * W * nch;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int cv = (int)(gid % nch);
+  const long m = gid / nch;
+  const int xx = (int)(m % W);
+  const int yy = (int)((m / W) % H);
+  float acc[VN];
+#pragma unroll
+  for (int j = 0; j < VN; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    // output pixel (oy, ox) read this pixel through tap t when oy + t/3 - 1 == yy, ox + t%3 - 1 == xx
+    const int oy = yy - (t / 3 - 1), ox = xx - (t % 3 - 1);
+    if (oy >= 0 && oy < H && ox >= 0 && ox < W) {
+      float f[VN];
+      unpack<T>(ldvec<T>(dcol + (((m - (long)yy * W - xx) + (long)oy * W + ox) * 9 + t) * C + cv * VN), f);
+#pragma unroll
+      for (int j = 0; j < VN; ++j) acc[j] += f[j];
+    }
+  }
+  stvec<T>(dx + m * C + cv * VN, pack<T>(acc));
+}
+
+extern "C" int32_t vsx_im2col3x3(const void* x, void* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                 vsx_stream_t stream) {
+  const int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(x && col && B > 0 && H > 0 && W > 0 && C > 0 && C % vn == 0, "vsx_im2col3x3: bad arguments (C=%d)", C);
+  dim3 grid(vsx_cdiv((long)B * H * W * 9 * (C / vn), 256));
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)col, B, H, W, C);
+  else
+    hipLaunchKernelGGL(im2col3x3_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)col, B, H, W, C);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t vsx_col2im3x3(const void* dcol, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                                 vsx_stream_t stream) {
+  const int vn = dtype == VSX_BF16 ? 8 : 4;
+  VSX_CHECK(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % vn == 0, "vsx_col2im3x3: bad arguments (C=%d)", C);
+  dim3 grid(vsx_cdiv((long)B * H * W * (C / vn), 256));
+  if (dtype == VSX_BF16)
+    hipLaunchKernelGGL(col2im3x3_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcol, (bf16_t*)dx, B, H, W, C);
+  else
+    hipLaunchKernelGGL(col2im3x3_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dcol, (float*)dx, B, H, W, C);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------ pixel shuffle x2 + concat (K10)
 // out[b, Y, X, j] = j < c ? low[b, Y/2, X/2, 4j + 2(Y&1) + (X&1)] : skip[b, Y, X, j - c]
 template <typename T>

@@ -135,6 +135,8 @@ class Engine:
         else:
             for st in reversed(list(m.decoder.decoder_stages)):
                 ps += self._stage_params_rev(st.conv)
+                if getattr(st, "pre_conv", None) is not None:  # decoder_upsample_pre_conv: runs before the stage in the forward
+                    ps += [st.pre_conv.weight, st.pre_conv.bias]
         self._bucket_marks.append(len(ps))  # bucket 0 = head + decoder (or the embedding tail)
         for i in (3, 2):
             ps += self._stage_params_rev(getattr(m.encoder_stages, f"stages_{i}"))
@@ -269,6 +271,16 @@ class Engine:
                 st = us.conv
                 proj = self._prep_proj(st.downsample[0], st.downsample[1], dt, need_bwd)
                 dec.append((proj, [self._prep_block(b, dt, need_bwd) for b in st.blocks]))
+            # decoder_upsample_pre_conv: Conv2d(C, C, 3, padding 1) in front of each pixel shuffle = patch matrix x [C, 9C]
+            pre = []
+            for us in m.decoder.decoder_stages:
+                pc = getattr(us, "pre_conv", None)
+                if pc is None:
+                    pre.append(None)
+                else:
+                    cpc = pc.weight.shape[0]
+                    pre.append((pc, *o.prep_weight(pc.weight, cpc, cpc, 9, dt, want=True, want_t=need_bwd)))
+            W["dec_pre"] = pre
         W["dec"] = dec
         if cfg.get("head", "conv") == "conv":
             hc = m.head.conv[0].conv
@@ -537,6 +549,15 @@ class Engine:
             skip, sh, sw_, sc = feats[2 - k]
             assert sh == 2 * fh and sw_ == 2 * fw
             c_up = fc // 4
+            pre = W["dec_pre"][k]
+            low_in = None
+            if pre is not None:  # MONAI SubpixelUpsample conv_block: dense 3x3 convolution at the low resolution
+                pc, Wp, _ = pre
+                col = o.im2col3x3(feat, B, fh, fw, fc)
+                low_in = feat
+                feat = torch.empty((B * fh * fw, fc), dtype=dt, device=x.device)
+                o.gemm("nt", col, Wp, feat, B * fh * fw, fc, 9 * fc, 9 * fc, 9 * fc, fc, dtype=dt, epi=L.EPI_BIAS, bias=pc.bias)
+                del col
             cat = o.pixel_shuffle_cat_fwd(feat, skip, B, fh, fw, c_up, sc)
             fh, fw = sh, sw_
             Mk, ccat = B * fh * fw, c_up + sc
@@ -544,7 +565,7 @@ class Engine:
             cur = torch.empty((Mk, proj.cout), dtype=dt, device=x.device)
             o.gemm("nt", xn, proj.W, cur, Mk, proj.cout, ccat, ccat, ccat, proj.cout, dtype=dt, epi=L.EPI_BIAS,
                    bias=proj.conv.bias)
-            st_sv = {"proj": (cat, xn, mean, rstd, c_up, sc), "blocks": []}
+            st_sv = {"proj": (cat, xn, mean, rstd, c_up, sc), "blocks": [], "pre_in": low_in}
             for bw in blocks:
                 cur = self._block_fwd(cur, bw, B, fh, fw, dt, st_sv["blocks"] if need_bwd else None)
             feat, fc = cur, proj.cout
@@ -758,6 +779,20 @@ class Engine:
             del dxn
             d, dskips[2 - k] = o.pixel_shuffle_cat_bwd(dcat, B, sh // 2, sw_ // 2, c_up, sc)
             del dcat
+            pre = W["dec_pre"][k]
+            if pre is not None:  # pre-convolution: weight gradient from the re-gathered patch matrix, data gradient through its transpose
+                pc, _, WpT = pre
+                lh, lw, cpc = sh // 2, sw_ // 2, 4 * c_up
+                Ml = B * lh * lw
+                col = o.im2col3x3(st_sv["pre_in"], B, lh, lw, cpc)
+                dWp = self._za.take(cpc, 9 * cpc)
+                o.gemm("tn", col, d, dWp, Ml, cpc, 9 * cpc, 9 * cpc, cpc, 9 * cpc, dtype=dt, colsum=g(pc.bias))
+                o.unprep_grad(dWp, g(pc.weight), cpc, cpc, 9)
+                del col
+                dcol = torch.empty((Ml, 9 * cpc), dtype=dt, device=dev)
+                o.gemm("nt", d, WpT, dcol, Ml, 9 * cpc, cpc, cpc, cpc, 9 * cpc, dtype=dt)
+                d = o.col2im3x3(dcol, B, lh, lw, cpc)
+                del dcol
         yield 0
         if self.encoder_frozen():  # nothing below the decoder needs a gradient: skip ~40 % of the backward
             self._za_need[za_key] = za.used

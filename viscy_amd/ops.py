@@ -186,6 +186,20 @@ def stem_im2col(x: Tensor, kernel: tuple[int, int, int], dtype: torch.dtype, sub
     return P
 
 
+def im2col3x3(x: Tensor, B: int, H: int, W: int, Cc: int) -> Tensor:
+    """[B*H*W, C] channels-last map -> [B*H*W, 9*C] patch matrix of a 3x3 / padding-1 convolution (tap-major columns)"""
+    col = torch.empty((B * H * W, 9 * Cc), dtype=x.dtype, device=x.device)
+    check(lib().vsx_im2col3x3(ptr(x), ptr(col), B, H, W, Cc, dtype_code(x.dtype), stream()), "im2col3x3")
+    return col
+
+
+def col2im3x3(dcol: Tensor, B: int, H: int, W: int, Cc: int) -> Tensor:
+    """transpose of im2col3x3: [B*H*W, 9*C] -> [B*H*W, C]"""
+    dx = torch.empty((B * H * W, Cc), dtype=dcol.dtype, device=dcol.device)
+    check(lib().vsx_col2im3x3(ptr(dcol), ptr(dx), B, H, W, Cc, dtype_code(dcol.dtype), stream()), "col2im3x3")
+    return dx
+
+
 def pad_cols(src: Tensor, Kp: int) -> Tensor:
     """[R, K] -> [R, Kp] with zero-filled tail columns"""
     R, K = src.shape

@@ -133,17 +133,30 @@ class _Stem(_Holder):
 
 
 class _UpStage(_Holder):
-    def __init__(self, cin, cskip, cout, depth):
+    """``pre_conv``: MONAI SubpixelUpsample's Conv2d(cin, cin, 3, padding 1) in front of the pixel shuffle
+    (``decoder_upsample_pre_conv=True``, blocks.py:138-146); MONAI's ``UpSample`` registers the shuffle block as
+    ``pixelshuffle``, hence the key ``upsample.pixelshuffle.conv_block.{weight,bias}``."""
+
+    def __init__(self, cin, cskip, cout, depth, pre_conv=False):
         super().__init__()
-        self.upsample = nn.Identity()
+        if pre_conv:
+            self.upsample = _Holder()
+            self.upsample.pixelshuffle = _Holder()
+            self.upsample.pixelshuffle.conv_block = _Conv((cin, cin, 3, 3))
+        else:
+            self.upsample = nn.Identity()
         self.conv = _Stage(cin // 4 + cskip, cout, 1, depth, conv_mlp=True)
+
+    @property
+    def pre_conv(self):
+        return None if isinstance(self.upsample, nn.Identity) else self.upsample.pixelshuffle.conv_block
 
 
 class _Decoder(_Holder):
-    def __init__(self, chans, depth):
+    def __init__(self, chans, depth, pre_conv=False):
         super().__init__()
         self.decoder_stages = nn.ModuleList(
-            _UpStage(chans[i], chans[i] // 2, chans[i + 1], depth) for i in range(len(chans) - 1)
+            _UpStage(chans[i], chans[i] // 2, chans[i + 1], depth, pre_conv) for i in range(len(chans) - 1)
         )
 
 
@@ -195,7 +208,8 @@ class _Core(nn.Module):
     engine's naming, flat-buffer engine, HIP-only forward."""
 
     def _build(self, *, in_channels, out_channels, in_stack_depth, out_stack_depth, depths, dims, conv_mlp, stem_kernel_size,
-               decoder_conv_blocks, head: str, head_channels_from: int, head_pool: bool, head_expansion_ratio: int) -> None:
+               decoder_conv_blocks, head: str, head_channels_from: int, head_pool: bool, head_expansion_ratio: int,
+               decoder_upsample_pre_conv: bool = False) -> None:
         stem_kernel_size = tuple(stem_kernel_size)
         if stem_kernel_size[1] != 4 or stem_kernel_size[2] != 4:
             raise NotImplementedError("stem_kernel_size must be (k, 4, 4)")
@@ -218,7 +232,8 @@ class _Core(nn.Module):
         else:               # PixelToVoxelShuffleHead: C_out * D * s^2, s = stem XY kernel
             dec[-1] = out_channels * out_stack_depth * stem_kernel_size[-1] ** 2
         self.cfg["decoder_channels"] = dec
-        self.decoder = _Decoder(dec, decoder_conv_blocks)
+        self.cfg["pre_conv"] = bool(decoder_upsample_pre_conv)
+        self.decoder = _Decoder(dec, decoder_conv_blocks, bool(decoder_upsample_pre_conv))
         if head == "conv":
             c3 = dec[-1] // 4 // (out_stack_depth + 2)
             cmid = out_channels * head_expansion_ratio * 4
@@ -245,7 +260,13 @@ class _Core(nn.Module):
         bound = 1 / math.sqrt(w[0].numel())
         nn.init.uniform_(self.stem.conv.bias, -bound, bound)
         for st in self.decoder.decoder_stages:
-            _icnr_(st.conv.blocks[-1].mlp.fc2.weight, 2)
+            pc = st.pre_conv
+            if pc is None:
+                _icnr_(st.conv.blocks[-1].mlp.fc2.weight, 2)
+            else:  # MONAI SubpixelUpsample: torch Conv2d default bias, ICNR weight; the stage keeps timm's init (blocks.py:147)
+                _icnr_(pc.weight, 2)
+                bound = 1 / math.sqrt(pc.weight[0].numel())
+                nn.init.uniform_(pc.bias, -bound, bound)
         if self.cfg["head"] == "conv":
             nn.init.normal_(self.head.conv[0].conv.weight, 0.0, 0.02)
             nn.init.zeros_(self.head.conv[0].conv.bias)
@@ -329,8 +350,6 @@ class UNeXt2(_Core):
             raise ValueError(f"backbone {backbone!r} not available; choose from {sorted(CONVNEXTV2_CFGS)}")
         if decoder_mode != "pixelshuffle":
             raise NotImplementedError("only decoder_mode='pixelshuffle' is built (deconv is broken upstream too)")
-        if decoder_upsample_pre_conv:
-            raise NotImplementedError("decoder_upsample_pre_conv=True is not built")
         if pretrained:
             raise NotImplementedError("pretrained timm weights cannot be downloaded here; load a state_dict instead")
         if not 0.0 <= float(drop_path_rate) < 1.0:
@@ -341,7 +360,8 @@ class UNeXt2(_Core):
         self._build(in_channels=in_channels, out_channels=out_channels, in_stack_depth=in_stack_depth,
                     out_stack_depth=out_stack_depth, depths=depths, dims=dims, conv_mlp=conv_mlp,
                     stem_kernel_size=stem_kernel_size, decoder_conv_blocks=decoder_conv_blocks, head="conv",
-                    head_channels_from=out_channels, head_pool=head_pool, head_expansion_ratio=head_expansion_ratio)
+                    head_channels_from=out_channels, head_pool=head_pool, head_expansion_ratio=head_expansion_ratio,
+                    decoder_upsample_pre_conv=decoder_upsample_pre_conv)
         if drop_path_rate:
             # timm ConvNeXt: stochastic-depth rates rise linearly over all encoder blocks (torch.linspace(0, rate, sum(depths)));
             # the decoder stages are built without drop path (blocks.py:54-74)
