@@ -31,8 +31,6 @@
 typedef __attribute__((ext_vector_type(4))) float dwm_f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 dwm_bf16x8;
 
-namespace {
-
 constexpr int DWM_THREADS = 1024;
 constexpr int DWM_CB = 32;      // channels per slab
 constexpr int DWM_ROWS = 22;    // 16 output rows + 6 halo rows
@@ -46,7 +44,7 @@ struct DwmGeom {
   static constexpr int BUF = DWM_CB * PLANE + (DWM_CB / 8) * 16;  // elements per buffer
 };
 
-__device__ __forceinline__ int dwm_plane_base(int ch, int plane) { return ch * plane + (ch >> 3) * 16; }
+static __device__ __forceinline__ int dwm_plane_base(int ch, int plane) { return ch * plane + (ch >> 3) * 16; }
 
 template <int NXT, bool FLIP>
 __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
@@ -389,8 +387,6 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_wgrad_mfma_kernel(const b
     if (c_base + chl < C) row[(size_t)n * C + c_base + chl] = red[chl * 50 + n];
   }
 }
-
-}  // namespace
 
 extern int g_vsx_dw_mfma;
 
