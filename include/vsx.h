@@ -246,6 +246,15 @@ int32_t vsx_ssim_scale_bwd(const float* P, const float* T, const float* tmax, co
     const float* gout, int32_t has_ssim, vsx_stream_t stream);
 
 /* ms_ssim_25d combination with clamp(min=1e-4) (metrics.py:326-349) + MixedLoss weights (mixed_loss.py:56-69); writes loss, MS-SSIM and the per-(scale, sample) map-pixel gradients. */
+/* Training variant of the two calls above with one pass over the stack less: vsx_ssim_scale_fwd_dmu = the sums of
+ * vsx_ssim_scale_fwd plus the UNSCALED gradient field dmu [3][B*C][H-10][W-10] of this scale (last != 0: the SSIM map, else
+ * the contrast map — what ms_ssim_25d uses of it, metrics.py:326-349), kept by the caller; vsx_ssim_scale_bwd_in = the
+ * second half of vsx_ssim_scale_bwd, applying this scale's per-sample coef [B][2] (vsx_loss_finalize) to the stored field. */
+int32_t vsx_ssim_scale_fwd_dmu(const float* P, const float* T, const float* tmax, float* sum_ssim, float* sum_cs, float* dmu,
+                               int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, int32_t last, vsx_stream_t stream);
+int32_t vsx_ssim_scale_bwd_in(const float* P, const float* T, const float* dmu, const float* coef, const float* dPnext,
+                              float* dP, int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, float l1c, float l2c,
+                              const float* gout, int32_t has_ssim, int32_t last, vsx_stream_t stream);
 int32_t vsx_loss_finalize(const float* sum_ssim, const float* sum_cs, const float* l1sum, const float* l2sum,
     const float* npix, float nelem, int32_t B, int32_t nscale, float a1, float a2, float a3, const float* gout,
     float* loss, float* coef, float* ms_out, vsx_stream_t stream);

@@ -75,6 +75,8 @@ _SIGS = {
     "vsx_ssim_scale_fwd": (_I32, [_P] * 5 + [_I32] * 5 + [_P]),
     "vsx_ssim_scale_bwd": (_I32, [_P] * 7 + [_I32] * 5 + [_F32, _F32, _P, _I32, _P]),
     "vsx_loss_finalize": (_I32, [_P] * 5 + [_F32, _I32, _I32, _F32, _F32, _F32, _P, _P, _P, _P, _P]),
+    "vsx_ssim_scale_fwd_dmu": (_I32, [_P] * 6 + [_I32] * 6 + [_P]),
+    "vsx_ssim_scale_bwd_in": (_I32, [_P] * 6 + [_I32] * 5 + [_F32, _F32, _P, _I32, _I32, _P]),
     "vsx_adamw": (_I32, [_P, _P, _P, _P, _P, _I64, _P]),
     "vsx_adamw_advance": (_I32, [_P, _P, _P, _P]),
     "vsx_mlp_supported": (_I32, [_I32, _I32, _I64, _I32]),

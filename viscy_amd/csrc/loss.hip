@@ -128,7 +128,7 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict__ P, const float* __restrict__ T,
                                                         const float* __restrict__ tmax_p, int C, int D, int H, int W,
                                                         float* __restrict__ sum_ssim, float* __restrict__ sum_cs,
-                                                        const float* __restrict__ coef, float* __restrict__ dmu) {
+                                                        const float* __restrict__ coef, float* __restrict__ dmu, int last) {
   // The five window means are produced one quantity at a time through ONE pair of LDS planes (13 KB instead of 63 KB:
   // the kernel ran at 2 workgroups per CU and was latency-bound); the plane sums of this thread's halo pixels and the
   // finished means of its output pixels wait in registers.
@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
   }
   float acc_s = 0.f, acc_c = 0.f;
   float gs = 0.f, gc = 0.f;
-  if (BWD) { gs = coef[2 * b]; gc = coef[2 * b + 1]; }
+  // coef == nullptr: the UNSCALED gradient field of this scale (the loss weights the SSIM map of the last scale and the
+  // contrast map of the others, by one factor per sample that is known only after every scale has been summed:
+  // ssim_bwd_in_kernel applies it) — lets the value pass and the map-gradient pass be one pass
+  if (BWD) { gs = coef ? coef[2 * b] : (last ? 1.f : 0.f); gc = coef ? coef[2 * b + 1] : (last ? 0.f : 1.f); }
 #pragma unroll
   for (int i = 0; i < NOUT; ++i) {
     const int idx = threadIdx.x + i * 256;
@@ -218,12 +221,11 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
       dmu[o] = round_bf16(px.dmx);
       dmu[nbc * plane + o] = round_bf16(px.dmxx);
       dmu[2 * nbc * plane + o] = round_bf16(px.dmxy);
-    } else {
-      acc_s += px.ssim;
-      acc_c += px.cs;
     }
+    acc_s += px.ssim;
+    acc_c += px.cs;
   }
-  if (!BWD) {
+  if (sum_ssim != nullptr) {
     float s = block_sum_256(acc_s, sh);
     float c = block_sum_256(acc_c, sh);
     if (threadIdx.x == 0) {
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void ssim_bwd_in_kernel(const float* __restrict__ P, const float* __restrict__ T,
                                                           const float* __restrict__ dmu, const float* __restrict__ dPn,
                                                           float* __restrict__ dP, int D, int H, int W, float l1c_,
-                                                          float l2c_, const float* __restrict__ gout_p, int has_ssim) {
+                                                          float l2c_, const float* __restrict__ gout_p, int has_ssim,
+                                                          const float* __restrict__ coef, int C, int last) {
   __shared__ float S[3][SI][SLD];
   __shared__ float R[3][SI][ST];
   const TileId tl = xcd_tile();
@@ -252,15 +255,17 @@ __global__ __launch_bounds__(256) void ssim_bwd_in_kernel(const float* __restric
   if (has_ssim) {
     const size_t plane = (size_t)Ho * Wo;
     const size_t nbc = (size_t)gridDim.z;
+    // dmu of an unscaled field (see ssim_tile_kernel): this sample's factor for the map the loss uses at this scale
+    const float gsample = coef ? coef[2 * (bc / C) + (last ? 0 : 1)] : 1.f;
     for (int idx = threadIdx.x; idx < SI * SI; idx += 256) {
       const int iy = idx / SI, ix = idx - iy * SI;
       const int oy = iy0 - 10 + iy, ox = ix0 - 10 + ix;
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
       if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
         const size_t o = (size_t)bc * plane + (size_t)oy * Wo + ox;
-        v0 = dmu[o];
-        v1 = dmu[nbc * plane + o];
-        v2 = dmu[2 * nbc * plane + o];
+        v0 = dmu[o] * gsample;
+        v1 = dmu[nbc * plane + o] * gsample;
+        v2 = dmu[2 * nbc * plane + o] * gsample;
       }
       S[0][iy][ix] = v0; S[1][iy][ix] = v1; S[2][iy][ix] = v2;
     }
@@ -376,7 +381,7 @@ extern "C" int32_t vsx_ssim_scale_fwd(const float* P, const float* T, const floa
   VSX_CHECK(H >= 11 && W >= 11 && D >= 1, "vsx_ssim_scale_fwd: plane %dx%d smaller than the 11x11 window", H, W);
   dim3 grid(vsx_cdiv(W - 10, ST), vsx_cdiv(H - 10, ST), B * C);
   hipLaunchKernelGGL(ssim_tile_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, P, T, tmax, C, D, H, W, sum_ssim,
-                     sum_cs, (const float*)nullptr, (float*)nullptr);
+                     sum_cs, (const float*)nullptr, (float*)nullptr, 0);
   VSX_LAUNCH_CHECK();
   return 0;
 }
@@ -393,12 +398,45 @@ extern "C" int32_t vsx_ssim_scale_bwd(const float* P, const float* T, const floa
     VSX_CHECK(tmax && coef && dmu && H >= 11 && W >= 11, "vsx_ssim_scale_bwd: SSIM term needs tmax/coef/dmu and a >=11 plane");
     dim3 g1(vsx_cdiv(W - 10, ST), vsx_cdiv(H - 10, ST), B * C);
     hipLaunchKernelGGL(ssim_tile_kernel<true>, g1, dim3(256), 0, (hipStream_t)stream, P, T, tmax, C, D, H, W,
-                       (float*)nullptr, (float*)nullptr, coef, dmu);
+                       (float*)nullptr, (float*)nullptr, coef, dmu, 0);
     VSX_LAUNCH_CHECK();
   }
   dim3 g2(vsx_cdiv(W, ST), vsx_cdiv(H, ST), B * C);
   hipLaunchKernelGGL(ssim_bwd_in_kernel, g2, dim3(256), 0, (hipStream_t)stream, P, T, dmu, dPnext, dP, D, H, W, l1c, l2c,
-                     gout, has_ssim);
+                     gout, has_ssim, (const float*)nullptr, C, 0);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+/* Training forward of one scale: the sums of vsx_ssim_scale_fwd AND, in the same pass over the stack, the gradient field
+ * w.r.t. the window means for a unit upstream gradient on the map this scale contributes (SSIM for the last scale,
+ * contrast for the others): dmu [3][B*C][H-10][W-10], kept until the backward.  The per-sample factor (known once all
+ * scales are summed: vsx_loss_finalize) is applied by vsx_ssim_scale_bwd_in — one pass over the full-resolution stack less
+ * than vsx_ssim_scale_fwd + vsx_ssim_scale_bwd.  The bf16 rounding of the field happens before the factor (the reference
+ * rounds after): a change of the rounding point of one intermediate, covered by the parity tolerances. */
+extern "C" int32_t vsx_ssim_scale_fwd_dmu(const float* P, const float* T, const float* tmax, float* sum_ssim, float* sum_cs,
+                                          float* dmu, int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, int32_t last,
+                                          vsx_stream_t stream) {
+  VSX_CHECK(P && T && tmax && sum_ssim && sum_cs && dmu, "vsx_ssim_scale_fwd_dmu: null pointer");
+  VSX_CHECK(H >= 11 && W >= 11 && D >= 1, "vsx_ssim_scale_fwd_dmu: plane %dx%d smaller than the 11x11 window", H, W);
+  dim3 grid(vsx_cdiv(W - 10, ST), vsx_cdiv(H - 10, ST), B * C);
+  hipLaunchKernelGGL(ssim_tile_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, P, T, tmax, C, D, H, W, sum_ssim,
+                     sum_cs, (const float*)nullptr, dmu, last ? 1 : 0);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+/* Backward of one scale from a stored unscaled field: dP = transposed box filter of coef_b * dmu + chain to the stack +
+ * 0.25 * dPnext + L1 / L2 terms (as vsx_ssim_scale_bwd).  coef [B][2] from vsx_loss_finalize for this scale. */
+extern "C" int32_t vsx_ssim_scale_bwd_in(const float* P, const float* T, const float* dmu, const float* coef,
+                                         const float* dPnext, float* dP, int32_t B, int32_t C, int32_t D, int32_t H, int32_t W,
+                                         float l1c, float l2c, const float* gout, int32_t has_ssim, int32_t last,
+                                         vsx_stream_t stream) {
+  VSX_CHECK(P && T && dP && B > 0 && C > 0, "vsx_ssim_scale_bwd_in: null pointer");
+  if (has_ssim) VSX_CHECK(dmu && coef && H >= 11 && W >= 11, "vsx_ssim_scale_bwd_in: SSIM term needs dmu / coef and a >=11 plane");
+  dim3 g2(vsx_cdiv(W, ST), vsx_cdiv(H, ST), B * C);
+  hipLaunchKernelGGL(ssim_bwd_in_kernel, g2, dim3(256), 0, (hipStream_t)stream, P, T, dmu, dPnext, dP, D, H, W, l1c, l2c,
+                     gout, has_ssim, coef, C, last ? 1 : 0);
   VSX_LAUNCH_CHECK();
   return 0;
 }

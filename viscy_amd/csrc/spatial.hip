@@ -33,6 +33,31 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
     inv = 1.f / (dv[b] + 1e-8f);
   }
   float o[VN];
+  if (kx == 4) {
+    // the XY kernel of every built stem is 4 wide: 4 consecutive patch columns are 4 consecutive pixels of one input row —
+    // one 16-byte load and one index decode per quad instead of four scalar loads with their own div / mod chains
+    // (1.10 ms -> see DESIGN §3 at B = 512: the gather was instruction-bound at 1 TB/s)
+#pragma unroll
+    for (int q = 0; q < VN / 4; ++q) {
+      const int col = ch * VN + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col < KT) {
+        const int d = col / K, k = col - d * K;
+        int t = k >> 2;
+        const int dy = t % ky;
+        t /= ky;
+        const int dz = t % kz;
+        const int ci = t / kz;
+        v = *reinterpret_cast<const float4*>(x + ((((size_t)b * Cin + ci) * Z + d * kz + dz) * H + yo * ky + dy) * W + xo * 4);
+        if (sub) {
+          v.x = (v.x - s) * inv; v.y = (v.y - s) * inv; v.z = (v.z - s) * inv; v.w = (v.w - s) * inv;
+        }
+      }
+      o[q * 4] = v.x; o[q * 4 + 1] = v.y; o[q * 4 + 2] = v.z; o[q * 4 + 3] = v.w;
+    }
+    stvec<T>(P + ((size_t)(b * h + yo) * w + xo) * ldp + ch * VN, pack<T>(o));
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < VN; ++j) {
     int col = ch * VN + j;

@@ -69,16 +69,28 @@ class _MixedLossFn(torch.autograd.Function):
                 Ts.append(To)
                 dims.append((h // 2, w // 2))
         npix_d = _npix_cached(tuple(dims), C, dev)
+        # a forward that will be differentiated also stores each scale's unscaled gradient field in the same pass over the stack
+        # (vsx_ssim_scale_fwd_dmu): the backward is then one pass per scale instead of two
+        need_grad = bool(getattr(ctx, "needs_input_grad", (True,))[0])
+        dmus = []
         for sc in range(ns):
             h, w = dims[sc]
-            check(l.vsx_ssim_scale_fwd(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc : sc + 1]), ptr(sum_ssim[sc * B : (sc + 1) * B]),
-                                       ptr(sum_cs[sc * B : (sc + 1) * B]), B, C, D, h, w, s), "ssim_scale_fwd")
+            if need_grad:
+                dmu = torch.empty(3 * B * C * (h - 10) * (w - 10), dtype=torch.float32, device=dev)
+                check(l.vsx_ssim_scale_fwd_dmu(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc : sc + 1]),
+                                               ptr(sum_ssim[sc * B : (sc + 1) * B]), ptr(sum_cs[sc * B : (sc + 1) * B]), ptr(dmu),
+                                               B, C, D, h, w, 1 if sc == ns - 1 else 0, s), "ssim_scale_fwd_dmu")
+                dmus.append(dmu)
+            else:
+                check(l.vsx_ssim_scale_fwd(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc : sc + 1]), ptr(sum_ssim[sc * B : (sc + 1) * B]),
+                                           ptr(sum_cs[sc * B : (sc + 1) * B]), B, C, D, h, w, s), "ssim_scale_fwd")
         out = torch.empty(2, dtype=torch.float32, device=dev)
         coef = torch.empty(max(ns, 1) * B * 2, dtype=torch.float32, device=dev)
         nelem = float(P0.numel())
         check(l.vsx_loss_finalize(ptr(sum_ssim), ptr(sum_cs), ptr(l1sum), ptr(l2sum), ptr(npix_d), nelem, B, max(ns, 1),
                                   a1, a2, a3, None, ptr(out[0:1]), ptr(coef), ptr(out[1:2]), s), "loss_finalize")
         ctx.saved = (Ps, Ts, dims, tmax, scal, npix_d, (B, C, D), (a1, a2, a3), ns, nelem, preds.dtype)
+        ctx.dmus = dmus
         ctx.ms_ssim = out[1]
         return out[0]
 
@@ -94,17 +106,17 @@ class _MixedLossFn(torch.autograd.Function):
         tmp = torch.empty(2, dtype=torch.float32, device=dev)
         check(l.vsx_loss_finalize(ptr(sum_ssim), ptr(sum_cs), ptr(scal[0:1]), ptr(scal[1:2]), ptr(npix_d), nelem, B,
                                   max(ns, 1), a1, a2, a3, ptr(go), ptr(tmp[0:1]), ptr(coef), ptr(tmp[1:2]), s), "loss_finalize")
-        h0, w0 = dims[0]
-        dmu = torch.empty(3 * B * C * max(h0 - 10, 1) * max(w0 - 10, 1), dtype=torch.float32, device=dev) if ns else None
+        dmus = getattr(ctx, "dmus", None) or []
         dnext = None
         for sc in range(max(ns, 1) - 1, -1, -1):
             h, w = dims[sc]
             dP = torch.empty((B, C, D, h, w), dtype=torch.float32, device=dev)
             l1c = a1 / nelem if sc == 0 else 0.0
             l2c = a2 / nelem if sc == 0 else 0.0
-            check(l.vsx_ssim_scale_bwd(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc : sc + 1]) if ns else None,
-                                       ptr(coef[sc * B * 2 : (sc + 1) * B * 2]) if ns else None, ptr(dmu), ptr(dnext),
-                                       ptr(dP), B, C, D, h, w, l1c, l2c, ptr(go), 1 if ns else 0, s), "ssim_scale_bwd")
+            check(l.vsx_ssim_scale_bwd_in(ptr(Ps[sc]), ptr(Ts[sc]), ptr(dmus[sc]) if ns else None,
+                                          ptr(coef[sc * B * 2 : (sc + 1) * B * 2]) if ns else None, ptr(dnext), ptr(dP),
+                                          B, C, D, h, w, l1c, l2c, ptr(go), 1 if ns else 0, 1 if sc == ns - 1 else 0, s),
+                  "ssim_scale_bwd_in")
             dnext = dP
         return dnext.to(in_dtype), None, None, None, None
 
