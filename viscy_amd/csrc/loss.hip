@@ -218,9 +218,13 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
       const size_t plane = (size_t)Ho * Wo;
       const size_t nbc = (size_t)gridDim.z;
       const size_t o = (size_t)bc * plane + (size_t)gy * Wo + gx;
-      dmu[o] = round_bf16(px.dmx);
-      dmu[nbc * plane + o] = round_bf16(px.dmxx);
-      dmu[2 * nbc * plane + o] = round_bf16(px.dmxy);
+      // the reference casts these gradients to bf16 AFTER the upstream factor is in them, and the three terms they feed
+      // (G_x + 2 p G_xx + t G_xy) nearly cancel: rounding the unscaled field instead moves the final gradient by up to 8 %
+      // of its maximum (measured) — bf16 noise of the same size as the reference's own, but not the SAME noise.  The
+      // unscaled field is therefore kept in fp32 and rounded by ssim_bwd_in_kernel once the factor is applied.
+      dmu[o] = coef ? round_bf16(px.dmx) : px.dmx;
+      dmu[nbc * plane + o] = coef ? round_bf16(px.dmxx) : px.dmxx;
+      dmu[2 * nbc * plane + o] = coef ? round_bf16(px.dmxy) : px.dmxy;
     }
     acc_s += px.ssim;
     acc_c += px.cs;
@@ -263,9 +267,10 @@ __global__ __launch_bounds__(256) void ssim_bwd_in_kernel(const float* __restric
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
       if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
         const size_t o = (size_t)bc * plane + (size_t)oy * Wo + ox;
-        v0 = dmu[o] * gsample;
-        v1 = dmu[nbc * plane + o] * gsample;
-        v2 = dmu[2 * nbc * plane + o] * gsample;
+        v0 = dmu[o];
+        v1 = dmu[nbc * plane + o];
+        v2 = dmu[2 * nbc * plane + o];
+        if (coef) { v0 = round_bf16(v0 * gsample); v1 = round_bf16(v1 * gsample); v2 = round_bf16(v2 * gsample); }
       }
       S[0][iy][ix] = v0; S[1][iy][ix] = v1; S[2][iy][ix] = v2;
     }
@@ -412,8 +417,8 @@ extern "C" int32_t vsx_ssim_scale_bwd(const float* P, const float* T, const floa
  * w.r.t. the window means for a unit upstream gradient on the map this scale contributes (SSIM for the last scale,
  * contrast for the others): dmu [3][B*C][H-10][W-10], kept until the backward.  The per-sample factor (known once all
  * scales are summed: vsx_loss_finalize) is applied by vsx_ssim_scale_bwd_in — one pass over the full-resolution stack less
- * than vsx_ssim_scale_fwd + vsx_ssim_scale_bwd.  The bf16 rounding of the field happens before the factor (the reference
- * rounds after): a change of the rounding point of one intermediate, covered by the parity tolerances. */
+ * than vsx_ssim_scale_fwd + vsx_ssim_scale_bwd.  The field is stored unrounded (fp32); vsx_ssim_scale_bwd_in rounds it to
+ * bf16 after the factor, where the reference's autograd casts it. */
 extern "C" int32_t vsx_ssim_scale_fwd_dmu(const float* P, const float* T, const float* tmax, float* sum_ssim, float* sum_cs,
                                           float* dmu, int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, int32_t last,
                                           vsx_stream_t stream) {
