@@ -77,6 +77,8 @@ GEMM_CASES = [
     (512, 384, 256, 256),   # lean instantiation, 128-byte K slabs (BK = 64, single LDS buffer), 3 N tiles
     (1024, 224, 512, 512),  # lean, BK = 64, ragged last N tile
     (384, 192, 224, 128),   # lean, BK = 32 (K % 64 != 0)
+    (448, 384, 256, 64),    # lean with TWO samples per 128-row tile (8 x 8 feature maps), odd sample count, BK = 64
+    (512, 192, 96, 64),     # the same, BK = 32
 ]
 
 
@@ -142,8 +144,9 @@ def test_gemm_nt_gelu_sq_without_preactivation_store(dt, M, N, K, hw):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("M,N,K,hw", [(192, 40, 160, 64), (768, 224, 384, 256), (512, 128, 96, 128)],
-                         ids=["generic", "lean_bk64", "lean_bk32"])
+@pytest.mark.parametrize("M,N,K,hw", [(192, 40, 160, 64), (768, 224, 384, 256), (512, 128, 96, 128), (448, 768, 384, 64),
+                                      (256, 192, 96, 64)],
+                         ids=["generic", "lean_bk64", "lean_bk32", "lean_two_samples_per_tile", "lean_two_samples_bk32"])
 def test_gemm_nt_grn_prologue(dt, M, N, K, hw):
     H = _hip()
     A, Bw = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, seed=2, scale=K**-0.5)

@@ -530,6 +530,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
     ldsB[i] = BM * RS + row * RS + ch * 16;
   }
   const float* grn_s = PRO ? p.grn_s + (size_t)b_tile * p.K : nullptr;
+  // hw % 128 == 64 (8 x 8 feature maps): a 128-row tile holds two samples, one per 64-row epilogue pass; the GRN prologue
+  // picks the scale row of the sample its A row belongs to, the column reductions are flushed after every pass
+  const bool split_tile = BM == 128 && p.hw > 0 && (p.hw % 128) != 0;
 
   vec ar[NA], br[NB];
   auto gload = [&](int kt, vec* ar, vec* br) {
@@ -547,11 +550,16 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
       vec v = ar[i];
       if constexpr (PRO) {  // a = g * s[b, k] + beta[k]
         const int k = kt * BK + ((tid + i * 256) % CPR) * VN;
+        const float* grn_row = grn_s;
+        if (split_tile) {
+          const int m = m0 + (tid + i * 256) / CPR;
+          grn_row = p.grn_s + (size_t)((m < p.M ? m : p.M - 1) / p.hw) * p.K;
+        }
         float f[VN];
         unpack<T>(v, f);
 #pragma unroll
         for (int j = 0; j < VN; j += 4) {
-          const float4 sv = *reinterpret_cast<const float4*>(grn_s + k + j);
+          const float4 sv = *reinterpret_cast<const float4*>(grn_row + k + j);
           const float4 bv = *reinterpret_cast<const float4*>(p.grn_b + k + j);
           f[j] = fmaf(f[j], sv.x, bv.x); f[j + 1] = fmaf(f[j + 1], sv.y, bv.y);
           f[j + 2] = fmaf(f[j + 2], sv.z, bv.z); f[j + 3] = fmaf(f[j + 3], sv.w, bv.w);
@@ -705,6 +713,33 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
         }
       }
     }
+    if constexpr (REDUCE) {
+      if (split_tile && half + 1 < NPASS && m0 + half * HR < p.M) {
+        // this pass was one whole sample: its column sums go out now (same park-and-add as below)
+        __syncthreads();
+        if (ncol_ok) {
+#pragma unroll
+          for (int j = 0; j < VN; ++j) {
+            Cs[rr * CS_LD + cc * VN + j] = r0[j];
+            Cs[(rr + RSTEP) * CS_LD + cc * VN + j] = r1[j];
+            r0[j] = 0.f;
+            r1[j] = 0.f;
+          }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+          float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+          for (int r = 0; r < RSTEP; ++r) {
+            a0 += Cs[r * CS_LD + tid];
+            a1 += Cs[(r + RSTEP) * CS_LD + tid];
+          }
+          const size_t bs = (size_t)((m0 + half * HR) / p.hw);
+          atomicAdd(p.red0 + bs * p.N + n0 + tid, a0);
+          if constexpr (EPI == VSX_EPI_DZ) atomicAdd(p.red1 + bs * p.N + n0 + tid, a1);
+        }
+      }
+    }
   }
   if constexpr (REDUCE) {
     // column sums of the tile: park the per-thread partials in the (dead) staging rows, then BN threads add them
@@ -724,8 +759,10 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
         a0 += Cs[r * CS_LD + tid];
         a1 += Cs[(r + RSTEP) * CS_LD + tid];
       }
-      atomicAdd(p.red0 + (size_t)b_tile * p.N + n0 + tid, a0);
-      if constexpr (EPI == VSX_EPI_DZ) atomicAdd(p.red1 + (size_t)b_tile * p.N + n0 + tid, a1);
+      // (split_tile: what is left in r0 / r1 is the LAST pass = the tile's last sample)
+      const size_t bs = split_tile ? (size_t)((m0 + (NPASS - 1) * HR < p.M ? m0 + (NPASS - 1) * HR : p.M - 1) / p.hw) : (size_t)b_tile;
+      atomicAdd(p.red0 + bs * p.N + n0 + tid, a0);
+      if constexpr (EPI == VSX_EPI_DZ) atomicAdd(p.red1 + bs * p.N + n0 + tid, a1);
     }
   }
 }
@@ -780,7 +817,10 @@ static bool nt_fast_ok(const VsxGemm* p, int es) {
   if (!g_vsx_nt_fast || p->N <= 64 || p->a_mode != VSX_A_ROWS || p->c_mode != VSX_A_ROWS || p->K % 32 != 0) return false;
   if (p->epi == VSX_EPI_BIAS_STATS) return false;
   const bool reduce = p->epi == VSX_EPI_BIAS_GELU_SQ || p->epi == VSX_EPI_DZ;
-  if ((reduce || p->pro == VSX_PRO_GRN || p->b_bstride != 0) && (p->hw <= 0 || p->hw % 128 != 0)) return false;
+  if (p->b_bstride != 0 && (p->hw <= 0 || p->hw % 128 != 0)) return false;
+  // reductions / the GRN prologue need every 64-row epilogue pass inside one sample: hw a multiple of 128, or exactly 64
+  // (8 x 8 feature maps: two samples per tile, handled per pass)
+  if ((reduce || p->pro == VSX_PRO_GRN) && (p->hw <= 0 || (p->hw % 128 != 0 && p->hw != 64))) return false;
   if ((unsigned long long)256 * p->lda * es >= (1ull << 32) || (unsigned long long)p->N * p->ldb * es >= (1ull << 32)) return false;
   return true;
 }
