@@ -54,14 +54,32 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16_t* __rest
   const int p16 = lane & 15, kq = lane >> 4;
   const int b = blockIdx.z, ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
   const size_t img = (size_t)b * H2 * W2;
-  for (int c = tid; c < 18 * 18 * HC_D7; c += 256) {
-    const int pix = c / HC_D7, zc = c - pix * HC_D7;
-    const int py = pix / 18, px = pix - py * 18;
-    const int y = ty0 + py - 1, x = tx0 + px - 1;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (y >= 0 && y < H2 && x >= 0 && x < W2)
-      v = *reinterpret_cast<const uint4*>(hin + (img + (size_t)y * W2 + x) * (HC_D7 * HC_C3) + zc * HC_C3);
-    *reinterpret_cast<uint4*>(tile + pix * HF_PS + zc * 16) = v;
+  {
+    // staging: every thread's loads first, then its LDS stores.  Written as `load; store` in one strided loop the compiler
+    // kept a real loop with `s_waitcnt vmcnt(0)` in front of each store — one memory round trip per iteration, 9–15 per tile
+    // (rocprofv3: the data-gradient kernel ran at 1.6 TB/s with its MFMAs idle 3/4 of the time)
+    constexpr int NST = (18 * 18 * HC_D7 + 255) / 256;
+    uint4 sv[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int c = tid + it * 256;
+      const int pix = c / HC_D7, zc = c - pix * HC_D7;
+      const int py = pix / 18, px = pix - py * 18;
+      const int y = ty0 + py - 1, x = tx0 + px - 1;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (c < 18 * 18 * HC_D7 && y >= 0 && y < H2 && x >= 0 && x < W2)
+        v = *reinterpret_cast<const uint4*>(hin + (img + (size_t)y * W2 + x) * (HC_D7 * HC_C3) + zc * HC_C3);
+      sv[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int c = tid + it * 256;
+      if (c < 18 * 18 * HC_D7) {
+        const int pix = c / HC_D7, zc = c - pix * HC_D7;
+        const uint4 v = sv[it];
+        *reinterpret_cast<uint4*>(tile + pix * HF_PS + zc * 16) = v;
+      }
+    }
   }
   // weights: 2 channel fragments x 7 K-steps (4 taps each; tap 27 does not exist -> zero), resident in registers
   bf16x8 wf[2][7];
@@ -192,20 +210,43 @@ __global__ __launch_bounds__(256) void head_conv_wgrad_kernel(const bf16_t* __re
     const int ty0 = (rem / tiles_x) * 8, tx0 = (rem % tiles_x) * 16;
     const size_t img = (size_t)b * H2 * W2;
     __syncthreads();  // previous tile fully consumed
-    for (int c = tid; c < 128 * 20; c += 256) {  // dU tile: 128 pixels x 20 chunks
-      const int pix = c / 20, ch = c - pix * 20;
-      const int y = ty0 + (pix >> 4), x = tx0 + (pix & 15);
-      *reinterpret_cast<uint4*>(du_t + pix * HW_DS + ch * 16) =
-          *reinterpret_cast<const uint4*>(dU + (img + (size_t)y * W2 + x) * (HC_ZO * HC_CMID) + ch * 8);
-    }
-    for (int c = tid; c < 180 * HC_D7; c += 256) {
-      const int pix = c / HC_D7, zc = c - pix * HC_D7;
-      const int py = pix / 18, px = pix - py * 18;
-      const int y = ty0 + py - 1, x = tx0 + px - 1;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (y >= 0 && y < H2 && x >= 0 && x < W2)
-        v = *reinterpret_cast<const uint4*>(hin + (img + (size_t)y * W2 + x) * (HC_D7 * HC_C3) + zc * HC_C3);
-      *reinterpret_cast<uint4*>(hin_t + pix * HF_PS + zc * 16) = v;
+    {  // all loads of the tile in flight together, then the LDS stores (see head_conv_fwd_kernel)
+      constexpr int NDU = 128 * 20 / 256, NHI = (180 * HC_D7 + 255) / 256;
+      uint4 dv[NDU], hv[NHI];
+#pragma unroll
+      for (int it = 0; it < NDU; ++it) {  // dU tile: 128 pixels x 20 chunks
+        const int c = tid + it * 256;
+        const int pix = c / 20, ch = c - pix * 20;
+        const int y = ty0 + (pix >> 4), x = tx0 + (pix & 15);
+        dv[it] = *reinterpret_cast<const uint4*>(dU + (img + (size_t)y * W2 + x) * (HC_ZO * HC_CMID) + ch * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < NHI; ++it) {
+        const int c = tid + it * 256;
+        const int pix = c / HC_D7, zc = c - pix * HC_D7;
+        const int py = pix / 18, px = pix - py * 18;
+        const int y = ty0 + py - 1, x = tx0 + px - 1;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (c < 180 * HC_D7 && y >= 0 && y < H2 && x >= 0 && x < W2)
+          v = *reinterpret_cast<const uint4*>(hin + (img + (size_t)y * W2 + x) * (HC_D7 * HC_C3) + zc * HC_C3);
+        hv[it] = v;
+      }
+#pragma unroll
+      for (int it = 0; it < NDU; ++it) {
+        const int c = tid + it * 256;
+        const int pix = c / 20, ch = c - pix * 20;
+        const uint4 v = dv[it];
+        *reinterpret_cast<uint4*>(du_t + pix * HW_DS + ch * 16) = v;
+      }
+#pragma unroll
+      for (int it = 0; it < NHI; ++it) {
+        const int c = tid + it * 256;
+        if (c < 180 * HC_D7) {
+          const int pix = c / HC_D7, zc = c - pix * HC_D7;
+          const uint4 v = hv[it];
+          *reinterpret_cast<uint4*>(hin_t + pix * HF_PS + zc * 16) = v;
+        }
+      }
     }
     __syncthreads();
 #pragma unroll 1
@@ -305,14 +346,29 @@ __global__ __launch_bounds__(256) void head_conv_dgrad_kernel(const bf16_t* __re
   const int p16 = lane & 15, kq = lane >> 4;
   const int b = blockIdx.z, ty0 = blockIdx.y * 8, tx0 = blockIdx.x * 16;
   const size_t img = (size_t)b * H2 * W2;
-  for (int c = tid; c < 180 * 20; c += 256) {
-    const int pix = c / 20, ch = c - pix * 20;
-    const int py = pix / 18, px = pix - py * 18;
-    const int y = ty0 + py - 1, x = tx0 + px - 1;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (y >= 0 && y < H2 && x >= 0 && x < W2)
-      v = *reinterpret_cast<const uint4*>(dU + (img + (size_t)y * W2 + x) * (HC_ZO * HC_CMID) + ch * 8);
-    *reinterpret_cast<uint4*>(halo + pix * HD_PS + ch * 16) = v;
+  {  // all loads of the halo tile in flight together, then the LDS stores (see head_conv_fwd_kernel)
+    constexpr int NST = (180 * 20 + 255) / 256;
+    uint4 sv[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int c = tid + it * 256;
+      const int pix = c / 20, ch = c - pix * 20;
+      const int py = pix / 18, px = pix - py * 18;
+      const int y = ty0 + py - 1, x = tx0 + px - 1;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (c < 180 * 20 && y >= 0 && y < H2 && x >= 0 && x < W2)
+        v = *reinterpret_cast<const uint4*>(dU + (img + (size_t)y * W2 + x) * (HC_ZO * HC_CMID) + ch * 8);
+      sv[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int c = tid + it * 256;
+      if (c < 180 * 20) {
+        const int pix = c / 20, ch = c - pix * 20;
+        const uint4 v = sv[it];
+        *reinterpret_cast<uint4*>(halo + pix * HD_PS + ch * 16) = v;
+      }
+    }
   }
   f32x4 acc[2][4];
 #pragma unroll

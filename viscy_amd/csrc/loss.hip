@@ -275,18 +275,31 @@ __global__ __launch_bounds__(256) void ssim_bwd_in_kernel(const float* __restric
     const size_t nbc = (size_t)gridDim.z;
     // dmu of an unscaled field (see ssim_tile_kernel): this sample's factor for the map the loss uses at this scale
     const float gsample = coef ? coef[2 * (bc / C) + (last ? 0 : 1)] : 1.f;
-    for (int idx = threadIdx.x; idx < SI * SI; idx += 256) {
+    constexpr int NIN = (SI * SI + 255) / 256;
+    float hv[NIN][3];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {  // every halo load of the thread in flight before the first LDS store
+      const int idx = threadIdx.x + i * 256;
       const int iy = idx / SI, ix = idx - iy * SI;
       const int oy = iy0 - 10 + iy, ox = ix0 - 10 + ix;
       float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
+      if (idx < SI * SI && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
         const size_t o = (size_t)bc * plane + (size_t)oy * Wo + ox;
         v0 = dmu[o];
         v1 = dmu[nbc * plane + o];
         v2 = dmu[2 * nbc * plane + o];
-        if (coef) { v0 = round_bf16(v0 * gsample); v1 = round_bf16(v1 * gsample); v2 = round_bf16(v2 * gsample); }
       }
-      S[0][iy][ix] = v0; S[1][iy][ix] = v1; S[2][iy][ix] = v2;
+      hv[i][0] = v0; hv[i][1] = v1; hv[i][2] = v2;
+    }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      if (idx < SI * SI) {
+        const int iy = idx / SI, ix = idx - iy * SI;
+        float v0 = hv[i][0], v1 = hv[i][1], v2 = hv[i][2];
+        if (coef) { v0 = round_bf16(v0 * gsample); v1 = round_bf16(v1 * gsample); v2 = round_bf16(v2 * gsample); }
+        S[0][iy][ix] = v0; S[1][iy][ix] = v1; S[2][iy][ix] = v2;
+      }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < SI * ST; idx += 256) {
