@@ -512,29 +512,62 @@ extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, con
 }
 
 // ------------------------------------------------------------------ statistics + fc2 weight gradient from per-sample products
-// grid (4C / 256, nb + C): rows < nb compute P / S of one sample (loop over c), rows >= nb compute one dW2 row (loop over b)
+// grid (4C / 1024, nb + C): rows < nb compute P / S of one sample (loop over c), rows >= nb compute one dW2 row (loop over b).
+// A thread owns 4 consecutive columns (16-byte loads) and keeps 8 loop iterations of loads in flight: with one column per
+// thread and 4 scalar loads in flight the kernel ran at 1.2–1.4 TB/s (latency-bound), 2.2 ms per step.
 template <typename T>
 __global__ __launch_bounds__(256) void grn_q_reduce_kernel(const float* __restrict__ Q, const float* __restrict__ cs,
                                                            const T* __restrict__ W2, const float* __restrict__ s,
                                                            const float* __restrict__ beta, float* __restrict__ P,
                                                            float* __restrict__ S, float* __restrict__ dW2,
                                                            float* __restrict__ db2, int nb, int C) {
-  const int N = 4 * C;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int N = 4 * C;  // a multiple of 4: every thread's 4 columns are all inside or all outside
+  const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
   const int row = blockIdx.y;
+  auto w4 = [&](int c) -> float4 {
+    if constexpr (sizeof(T) == 2) {
+      const uint2 u = *reinterpret_cast<const uint2*>(W2 + (size_t)c * N + j);
+      return make_float4(bf16_bits_to_f32(u.x & 0xffffu), bf16_bits_to_f32(u.x >> 16), bf16_bits_to_f32(u.y & 0xffffu),
+                         bf16_bits_to_f32(u.y >> 16));
+    } else {
+      return *reinterpret_cast<const float4*>(W2 + (size_t)c * N + j);
+    }
+  };
   if (row < nb) {
     if (j >= N) return;
     const float* q = Q + (size_t)row * C * N + j;
     const float* c1 = cs + (size_t)row * C;
-    float p = 0.f, sm = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < C; ++c) {
-      const float w = to_f32<T>(W2[(size_t)c * N + j]);
-      p = fmaf(w, q[(size_t)c * N], p);
-      sm = fmaf(w, c1[c], sm);
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), sm = p;
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+      float4 qv[8], wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        qv[u] = *reinterpret_cast<const float4*>(q + (size_t)(c + u) * N);
+        wv[u] = w4(c + u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float cc = c1[c + u];
+        p.x = fmaf(wv[u].x, qv[u].x, p.x); p.y = fmaf(wv[u].y, qv[u].y, p.y);
+        p.z = fmaf(wv[u].z, qv[u].z, p.z); p.w = fmaf(wv[u].w, qv[u].w, p.w);
+        sm.x = fmaf(wv[u].x, cc, sm.x); sm.y = fmaf(wv[u].y, cc, sm.y);
+        sm.z = fmaf(wv[u].z, cc, sm.z); sm.w = fmaf(wv[u].w, cc, sm.w);
+      }
     }
-    P[(size_t)row * N + j] += p;
-    S[(size_t)row * N + j] += sm;
+    for (; c < C; ++c) {
+      const float4 qv = *reinterpret_cast<const float4*>(q + (size_t)c * N), wv = w4(c);
+      const float cc = c1[c];
+      p.x = fmaf(wv.x, qv.x, p.x); p.y = fmaf(wv.y, qv.y, p.y); p.z = fmaf(wv.z, qv.z, p.z); p.w = fmaf(wv.w, qv.w, p.w);
+      sm.x = fmaf(wv.x, cc, sm.x); sm.y = fmaf(wv.y, cc, sm.y); sm.z = fmaf(wv.z, cc, sm.z); sm.w = fmaf(wv.w, cc, sm.w);
+    }
+    float4* Pp = reinterpret_cast<float4*>(P + (size_t)row * N + j);
+    float4* Sp = reinterpret_cast<float4*>(S + (size_t)row * N + j);
+    float4 a = *Pp, b = *Sp;
+    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    b.x += sm.x; b.y += sm.y; b.z += sm.z; b.w += sm.w;
+    *Pp = a;
+    *Sp = b;
   } else {
     const int c = row - nb;
     float ct = 0.f;  // sum_b cs[b][c]
@@ -542,17 +575,38 @@ __global__ __launch_bounds__(256) void grn_q_reduce_kernel(const float* __restri
     if (blockIdx.x == 0 && threadIdx.x == 0) db2[c] += ct;
     if (j >= N) return;
     const float* q = Q + (size_t)c * N + j;
-    float acc = 0.f;
-#pragma unroll 4
-    for (int b = 0; b < nb; ++b) acc = fmaf(s[(size_t)b * N + j], q[(size_t)b * C * N], acc);
-    dW2[(size_t)c * N + j] += acc + beta[j] * ct;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int b = 0;
+    for (; b + 8 <= nb; b += 8) {
+      float4 qv[8], sv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        qv[u] = *reinterpret_cast<const float4*>(q + (size_t)(b + u) * C * N);
+        sv[u] = *reinterpret_cast<const float4*>(s + (size_t)(b + u) * N + j);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc.x = fmaf(sv[u].x, qv[u].x, acc.x); acc.y = fmaf(sv[u].y, qv[u].y, acc.y);
+        acc.z = fmaf(sv[u].z, qv[u].z, acc.z); acc.w = fmaf(sv[u].w, qv[u].w, acc.w);
+      }
+    }
+    for (; b < nb; ++b) {
+      const float4 qv = *reinterpret_cast<const float4*>(q + (size_t)b * C * N);
+      const float4 sv = *reinterpret_cast<const float4*>(s + (size_t)b * N + j);
+      acc.x = fmaf(sv.x, qv.x, acc.x); acc.y = fmaf(sv.y, qv.y, acc.y); acc.z = fmaf(sv.z, qv.z, acc.z); acc.w = fmaf(sv.w, qv.w, acc.w);
+    }
+    const float4 bt = *reinterpret_cast<const float4*>(beta + j);
+    float4* dp = reinterpret_cast<float4*>(dW2 + (size_t)c * N + j);
+    float4 d = *dp;
+    d.x += acc.x + bt.x * ct; d.y += acc.y + bt.y * ct; d.z += acc.z + bt.z * ct; d.w += acc.w + bt.w * ct;
+    *dp = d;
   }
 }
 
 extern "C" int32_t vsx_grn_q_reduce(const float* Q, const float* cs, const void* W2, const float* s, const float* beta, float* P,
                                     float* S, float* dW2, float* db2, int32_t nb, int32_t C, int32_t dtype, vsx_stream_t stream) {
   VSX_CHECK(Q && cs && W2 && s && beta && P && S && dW2 && db2 && nb > 0 && C > 0, "vsx_grn_q_reduce: bad arguments");
-  dim3 grid(vsx_cdiv(4 * C, 256), nb + C);
+  dim3 grid(vsx_cdiv(4 * C, 1024), nb + C);
   if (dtype == VSX_BF16)
     hipLaunchKernelGGL(grn_q_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, Q, cs, (const bf16_t*)W2, s, beta, P, S,
                        dW2, db2, nb, C);
