@@ -14,6 +14,8 @@ int g_vsx_ggb_blocks = 2048;  // grn_gelu_bwd: target workgroup count (tuning kn
 int g_vsx_tn_rect = 3;  // rectangular TN tiles: bit 0 = when N or K is 224..256 wide, bit 1 = 256x128 when 256 divides N (no prologue), bit 2 = 128x256 when 256 divides K (slower: off)
 int g_vsx_dw_rows2 = 0;  // depthwise 7x7: two output rows per thread — measured +3..8 % (fwd) / +18 % (dgrad) SLOWER: off
 int g_vsx_dw_mfma = 7;   // depthwise conv on the matrix cores (dwconv_mfma.hip): bit 0 forward / data gradient (banded Toeplitz tiles), bit 1 weight gradient (row contraction, transpose reads), bit 2 16-column weight-gradient tiles at every width (the 32-column variant spills: 471 vs 285 us at 64x64x96, B = 512); 0: VALU stencils
+int g_vsx_ln_fblk = 32768;  // LayerNorm forward: cap on workgroups per launch (each sweeps rows / cap windows).  Measured at B = 512 (64x64x96 / x224): 2048 -> 209 / 438 us, 8192 -> 172 / 351, 32768 -> 162 / 331 (a grid-stride sweep by few workgroups streams at 5.0 TB/s where one vector per thread reaches 6.8: tools/micro/write_rate.hip)
+int g_vsx_ln_bblk = 8192;   // LayerNorm backward WITHOUT affine gradients (the block LayerNorms): cap on workgroups (with dgamma: 512, same-address atomics).  512 -> 319 / 651 us, 2048 -> 254 / 586, 8192 -> 240 / 541 (16x16x384: 83 -> 61), 32768 -> 225 / 516 but 78 at 16x16x384
 int g_vsx_dw_wg16 = 1;   // depthwise weight gradient: 8x16-pixel tiles (35 KB of LDS, 4 workgroups / CU) instead of 8x32 (63 KB, 2)
 int g_vsx_nt_stream = 0;  // OFF (rare NaN in long runs not yet explained; measured gains below are with the value 3) —  // lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B)
 int g_vsx_grn_stream = 0;  // OFF (as nt_stream; measured with the value 2) —  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
@@ -50,6 +52,8 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "dw_rows2")) { g_vsx_dw_rows2 = value; return 0; }
   if (name && !strcmp(name, "dw_wg16")) { g_vsx_dw_wg16 = value; return 0; }
   if (name && !strcmp(name, "dw_mfma")) { g_vsx_dw_mfma = value; return 0; }
+  if (name && !strcmp(name, "ln_fblk") && value > 0) { g_vsx_ln_fblk = value; return 0; }
+  if (name && !strcmp(name, "ln_bblk") && value > 0) { g_vsx_ln_bblk = value; return 0; }
   if (name && !strcmp(name, "mlp_fused")) { g_vsx_mlp_fused = value; return 0; }
   vsx_set_error("vsx_set_flag: unknown flag '%s'", name ? name : "(null)");
   return 1;
@@ -71,6 +75,8 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "dw_rows2")) return g_vsx_dw_rows2;
   if (name && !strcmp(name, "dw_wg16")) return g_vsx_dw_wg16;
   if (name && !strcmp(name, "dw_mfma")) return g_vsx_dw_mfma;
+  if (name && !strcmp(name, "ln_fblk")) return g_vsx_ln_fblk;
+  if (name && !strcmp(name, "ln_bblk")) return g_vsx_ln_bblk;
   if (name && !strcmp(name, "mlp_fused")) return g_vsx_mlp_fused;
   return -1;
 }

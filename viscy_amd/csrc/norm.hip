@@ -220,6 +220,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
+extern int g_vsx_ln_fblk;
+extern int g_vsx_ln_bblk;
 template <typename T, int G, int CPL>
 static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float* mean, float* rstd,
                      const float* gamma, const float* beta, const void* add, float* dgamma, float* dbeta, int rows,
@@ -227,12 +229,14 @@ static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float*
   constexpr int RPI = 256 / G;
   if (fwd) {
     constexpr int R = CPL == 1 ? 4 : (CPL == 2 ? 2 : 1);  // rows per lane group (see the kernel)
-    int iters = vsx_cdiv(rows, RPI * R * 2048);           // <= 2048 workgroups, each sweeping `iters` windows
+    int iters = vsx_cdiv(rows, RPI * R * g_vsx_ln_fblk);  // <= ln_fblk workgroups, each sweeping `iters` windows
     if (iters < 1) iters = 1;
     hipLaunchKernelGGL((ln_fwd_kernel<T, G, CPL>), dim3(vsx_cdiv(rows, RPI * R * iters)), dim3(256), 0, s, (const T*)a0,
                        (T*)out, mean, rstd, gamma, beta, rows, C, eps, iters, g_vsx_ln_stream & 2);
   } else {
-    int iters = vsx_cdiv(rows, RPI * 512);  // <= 512 blocks → <= 512 same-address atomics on dgamma / dbeta
+    // with an affine LayerNorm: <= 512 blocks → <= 512 same-address atomics on dgamma / dbeta; the block LayerNorms have no
+    // affine here (folded into fc1) and no such limit — their cap is the flag ln_bblk
+    int iters = vsx_cdiv(rows, RPI * (dgamma ? 512 : g_vsx_ln_bblk));
     if (iters < 1) iters = 1;
     int grid = vsx_cdiv(rows, RPI * iters);
     size_t sh = dgamma ? 2 * (size_t)C * sizeof(float) : 0;
