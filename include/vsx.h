@@ -333,7 +333,7 @@ int32_t vsx_mlp_gelu_table(float* tab, vsx_stream_t stream);
  * warmup_steps, t_total, warmup_multiplier, cycles} and the int32 step counter, writes the 8 scalars vsx_adamw reads for
  * THIS step and increments the counter.  No host memory is touched: a captured step replays correctly however far the
  * host runs ahead. */
-int32_t vsx_adamw_advance(const float* cfg, int32_t* step, float* hyper, vsx_stream_t stream);
+int32_t vsx_adamw_advance(const double* cfg, int32_t* step, float* hyper, vsx_stream_t stream);
 
 /* fp32 parameter viewed as [R, Cs, Tn] (out, in, taps) → GEMM operand dst [R, Tn*Cs] and/or dstT [Tn*Cs, R] in `dtype`, optionally scaled per
  * input channel by gamma (LayerNorm fold).  tapmode 1 = head Conv3d tap order (kz,ky,kx) → (ky,kx,kz). */

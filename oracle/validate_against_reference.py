@@ -755,6 +755,93 @@ def g10_contrastive():
     torch.save(golden, os.path.join(GOLD, "contrastive.pt"))
 
 
+def g11_hcs_sampling():
+    """The reference's own ``SlidingWindowDataset`` (viscy_data/sliding_window.py:21-286) + ``ForegroundMaskSupport``
+    (foreground_masks.py) executed unchanged over THIS package's OME-Zarr position objects (iohub / imageio are absent: they
+    are type annotations and a PNG reader on this path, stubbed empty), against ``viscy_amd.data.SlidingWindowDataset`` on
+    the same plate, same torch seed: window order, (t, z) indices, images, foreground masks and the non-zero rejection
+    sampling draws must agree exactly.  Writes tests/golden/hcs_sampling.pt (inputs + the reference's outputs)."""
+    import tempfile
+
+    import numpy as np
+
+    for n in ("iohub", "imageio", "monai", "monai.data", "monai.transforms"):
+        if n not in sys.modules:
+            _stub(n)
+    _stub("iohub.ngff", ImageArray=object, Position=object)
+    sys.modules["imageio"].imread = None
+    _stub("monai.data.utils", collate_meta_tensor=None)
+    mt = sys.modules["monai.transforms"]
+    for name in ("CenterSpatialCrop", "Cropd"):
+        if not hasattr(mt, name):
+            setattr(mt, name, type(name, (), {}))
+    base = "/root/reference/packages/viscy-data/src/viscy_data"
+    _stub("viscy_data")
+    # _typing.py holds type aliases only (and needs typing.NotRequired, Python >= 3.11): stubbed
+    _stub("viscy_data._typing", ChannelMap=dict, DictTransform=object, HCSStackIndex=tuple, NormMeta=dict, Sample=dict)
+    _load("viscy_data._utils", f"{base}/_utils.py")
+    _load("viscy_data.foreground_masks", f"{base}/foreground_masks.py")
+    ref = _load("viscy_data.sliding_window", f"{base}/sliding_window.py")
+
+    from viscy_amd.data import SlidingWindowDataset, open_ome_zarr, write_hcs_plate
+
+    from tests.conftest import build_sampling_plate
+
+    d = tempfile.mkdtemp()
+    path = os.path.join(d, "p.zarr")
+    pos, ch = build_sampling_plate(path)
+    positions = [p_ for _, p_ in open_ome_zarr(path).positions()]
+    golden = {"plate_seed": 7, "channels": ch, "cases": {}}
+    cases = {
+        "plain": dict(channels={"source": ["Phase"], "target": ["Nuclei"]}, z_window_size=3),
+        "two_targets_masks": dict(channels={"source": ["Phase"], "target": ["Membrane", "Nuclei"]}, z_window_size=4, fg_mask_key="fg_mask"),
+        "reject_intensity": dict(channels={"source": ["Phase"], "target": ["Nuclei"]}, z_window_size=3, min_nonzero_fraction=0.8,
+                                 nonzero_threshold=0.05, max_nonzero_retries=6),
+        "reject_mask_channel": dict(channels={"source": ["Phase"], "target": ["Membrane", "Nuclei"]}, z_window_size=2, fg_mask_key="fg_mask",
+                                    min_nonzero_fraction=0.45, nonzero_channel="Nuclei", max_nonzero_retries=3),
+        "reject_source_channel": dict(channels={"source": ["Phase"], "target": ["Nuclei"]}, z_window_size=5, min_nonzero_fraction=0.7,
+                                      nonzero_threshold=0.3, nonzero_channel="Phase", max_nonzero_retries=2),
+    }
+    for tag, kw in cases.items():
+        r = ref.SlidingWindowDataset(positions, **kw)
+        m = SlidingWindowDataset(positions, **kw)
+        assert len(r) == len(m), tag
+        order = torch.randperm(len(r), generator=torch.Generator().manual_seed(3)).tolist()[:24]
+        out = []
+        torch.manual_seed(11)
+        rs = [r[i] for i in order]
+        torch.manual_seed(11)
+        ms = [m[i] for i in order]
+        for a, b in zip(rs, ms):
+            assert a["index"] == b["index"], (tag, a["index"], b["index"])
+            assert set(a) == set(b), (tag, set(a), set(b))
+            for k in ("source", "target", "fg_mask"):
+                if k in a:
+                    assert torch.equal(a[k], b[k]), (tag, k)
+            for c_, levels in a["norm_meta"].items():
+                for lv, st in levels.items():
+                    for sk, v in st.items():
+                        assert torch.equal(v, b["norm_meta"][c_][lv][sk]), (tag, c_, lv, sk)
+            out.append({"index": a["index"], "source_sum": a["source"].double().sum().item(), "target_sum": a["target"].double().sum().item(),
+                        "fg_sum": a["fg_mask"].double().sum().item() if "fg_mask" in a else None,
+                        "tp_mean": float(a["norm_meta"]["Phase"]["timepoint_statistics"]["mean"])})
+        golden["cases"][tag] = {"kwargs": kw, "order": order, "seed": 11, "samples": out}
+        moved = sum(1 for i, a in zip(order, rs) if (a["index"]) != m._index_of(i)) if hasattr(m, "_index_of") else None
+        print(f"G11 hcs sampling {tag}: reference SlidingWindowDataset on this package's zarr objects == viscy_amd dataset "
+              f"(exact, {len(order)} draws{'' if moved is None else f', {moved} re-sampled'})")
+    # missing mask array -> the reference's error type
+    plain = os.path.join(d, "nomask.zarr")
+    write_hcs_plate(plain, {"A/1/0": pos["A/1/0"]}, ch)
+    pp = [p_ for _, p_ in open_ome_zarr(plain).positions()]
+    for cls in (ref.SlidingWindowDataset, SlidingWindowDataset):
+        try:
+            cls(pp, channels={"source": ["Phase"], "target": ["Nuclei"]}, z_window_size=3, fg_mask_key="fg_mask")
+            raise AssertionError("missing mask array accepted")
+        except FileNotFoundError:
+            pass
+    torch.save(golden, os.path.join(GOLD, "hcs_sampling.pt"))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -768,4 +855,5 @@ if __name__ == "__main__":
     g8_wiring()
     g9_fcmae()
     g10_contrastive()
+    g11_hcs_sampling()
     print("oracle pinned; fixtures written to tests/golden/")

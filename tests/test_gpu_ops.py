@@ -124,6 +124,102 @@ def test_gemm_nt_rows(dt, M, N, K, hw, epi):
         close(r1g, r1r, dt, "red1")
 
 
+NT2_CASES = [
+    # M, N, K, hw  (second-generation NT kernel, csrc/gemm_nt2.hip: 256 x 128 tiles, LDS-DMA operands, wave-private epilogue)
+    (512, 128, 96, 256),
+    (768, 224, 512, 256),    # ragged last N tile
+    (512, 96, 384, 512),     # one partial N tile
+    (1024, 384, 256, 64),    # four samples per tile (8 x 8 feature maps): per-wave statistics
+    (512, 192, 96, 128),     # two samples per tile
+    (256, 1536, 384, 256),   # the C = 384 fc1 / dz shape of one sample
+    (1024, 384, 1536, 1024),
+]
+
+
+@pytest.mark.parametrize("M,N,K,hw", NT2_CASES)
+@pytest.mark.parametrize("epi", [R.EPI_NONE, R.EPI_BIAS, R.EPI_BIAS_GELU_SQ, R.EPI_BIAS_RES, R.EPI_DZ])
+def test_gemm_nt2_kernel(M, N, K, hw, epi):
+    """the second-generation NT kernel (forced on for every tile count) against the plain-PyTorch statement AND against the
+    first-generation kernels on the same inputs (bit-identical outputs: same MFMA order per output element)"""
+    if SELF_CHECK:
+        pytest.skip("self-check")
+    from viscy_amd import _lib
+
+    H, dt = _hip(), torch.bfloat16
+    nb = M // hw
+    A = rnd(M, K, dt=dt, seed=1)
+    Bw = rnd(N, K, dt=dt, seed=2, scale=K**-0.5)
+    bias, res, aux = rnd(N, seed=3), rnd(M, N, dt=dt, seed=4), rnd(M, N, dt=dt, seed=5)
+    rscale = (torch.arange(nb) % 2).float() * 1.25
+    kw = dict(dtype=dt, hw=hw, epi=epi)
+    if epi in (R.EPI_BIAS, R.EPI_BIAS_GELU_SQ, R.EPI_BIAS_RES):
+        kw["bias"] = bias
+    if epi == R.EPI_BIAS_RES:
+        kw.update(res=res, ldr=N, rscale=rscale)
+    if epi == R.EPI_DZ:
+        kw.update(aux=aux, ldx=N)
+
+    def run(ops, dev):
+        k2 = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+        C = torch.full((M, N), float("nan"), dtype=dt, device=dev)
+        r0, r1 = torch.zeros(nb, N, device=dev), torch.zeros(nb, N, device=dev)
+        if epi in (R.EPI_BIAS_GELU_SQ, R.EPI_DZ):
+            k2.update(red0=r0, red1=r1)
+        C2 = torch.zeros(M, N, dtype=dt, device=dev)
+        if epi == R.EPI_BIAS_GELU_SQ:
+            k2.update(C2=C2)
+        ops.gemm("nt", A.to(dev), Bw.to(dev), C, M, N, K, K, K, N, **k2)
+        return C, r0, r1, C2
+
+    l = _lib.lib()
+    old = l.vsx_get_flag(b"nt2")
+    try:
+        l.vsx_set_flag(b"nt2", 3)
+        Cg, r0g, r1g, C2g = run(H, DEV)
+        l.vsx_set_flag(b"nt2", 0)
+        C1, r01, r11, C21 = run(H, DEV)
+    finally:
+        l.vsx_set_flag(b"nt2", old)
+    Cr, r0r, r1r, C2r = run(R, "cpu")
+    close(Cg, Cr, dt, "C")
+    close(C2g, C2r, dt, "C2", scale=1.0)
+    if epi in (R.EPI_BIAS_GELU_SQ, R.EPI_DZ):
+        close(r0g, r0r, dt, "red0")
+        torch.testing.assert_close(r0g, r01, rtol=1e-4, atol=1e-3 * float(r01.abs().max()))
+    if epi == R.EPI_DZ:
+        close(r1g, r1r, dt, "red1")
+    assert torch.equal(Cg, C1), "first- and second-generation kernels differ"
+    assert torch.equal(C2g, C21)
+
+
+def test_gemm_nt2_per_sample_weights():
+    """VsxGemm.b_bstride on the second-generation kernel (the fc2 of the large feature maps)"""
+    if SELF_CHECK:
+        pytest.skip("self-check")
+    from viscy_amd import _lib
+
+    H, dt = _hip(), torch.bfloat16
+    M, N, K, hw = 1024, 96, 384, 256
+    nb = M // hw
+    A = rnd(M, K, dt=dt, seed=1).to(DEV)
+    Ws = rnd(nb, N, K, dt=dt, seed=2, scale=K**-0.5).to(DEV)
+    res, bias = rnd(M, N, dt=dt, seed=5).to(DEV), rnd(N, seed=6).to(DEV)
+    l = _lib.lib()
+    old = l.vsx_get_flag(b"nt2")
+    outs = []
+    try:
+        for flag in (3, 0):
+            l.vsx_set_flag(b"nt2", flag)
+            C = torch.zeros(M, N, dtype=dt, device=DEV)
+            H.gemm("nt", A, Ws, C, M, N, K, K, K, N, dtype=dt, hw=hw, b_bstride=N * K, epi=R.EPI_BIAS_RES, bias=bias, res=res, ldr=N)
+            outs.append(C)
+    finally:
+        l.vsx_set_flag(b"nt2", old)
+    ref = torch.cat([A[b * hw:(b + 1) * hw].float() @ Ws[b].float().T for b in range(nb)]) + bias + res.float()
+    close(outs[0], ref, dt, "per-sample weights")
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K,hw", [(200, 40, 48, 100), (512, 384, 256, 256), (384, 192, 224, 128)],
                          ids=["generic", "lean_bk64", "lean_bk32"])

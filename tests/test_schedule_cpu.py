@@ -170,6 +170,42 @@ def test_masked_schedule_matches_reference_golden(tag):
     print(tag, "masked max rel grad err", worst)
 
 
+def test_fcmae_2d_model_runs_on_its_conv2d_stem():
+    """in_stack_depth = 1 (a 2-D FCMAE): the reference takes the conv2d branch whenever x.shape[2] == 1 (fcmae.py:369-370),
+    so the trained stem of such a checkpoint is conv2d — forward == oracle, the gradient lands on conv2d, conv3d gets none
+    (the engine used to run these models on the untrained conv3d weights)"""
+    from oracle import fcmae_ref
+    from viscy_amd.fcmae import FullyConvolutionalMAE
+
+    kw = dict(in_channels=2, out_channels=2, encoder_blocks=[1, 1, 1, 1], dims=[16, 32, 64, 128], decoder_conv_blocks=1,
+              stem_kernel_size=(1, 4, 4), in_stack_depth=1)
+    ref = unext2_ref.randomize_(fcmae_ref.FullyConvolutionalMAE(**kw), seed=11)
+    mine = FullyConvolutionalMAE(**kw)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    x = torch.randn(2, 2, 1, 64, 64, generator=torch.Generator().manual_seed(5))
+    eng = Engine(mine._core, ops=ref_ops)
+    with torch.no_grad():
+        out, sv = eng.forward(x, torch.float32, need_bwd=True)
+    y, _ = ref(x)
+    torch.testing.assert_close(out, y, rtol=2e-4, atol=1e-4 * y.abs().max().item())
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(6))
+    y.backward(dy)
+    with torch.no_grad():
+        eng.backward(sv, dy)
+    named = dict(mine.named_parameters())
+    g2 = eng.g(named["encoder.stem.conv2d.weight"])
+    gr = dict(ref.named_parameters())["encoder.stem.conv2d.weight"].grad
+    assert ((g2 - gr).abs().max() / gr.abs().max()).item() < 2e-3
+    assert float(eng.g(named["encoder.stem.conv3d.weight"]).abs().max()) == 0.0
+    # and the forward really reads conv2d: perturbing it changes the output, perturbing conv3d does not
+    with torch.no_grad():
+        named["encoder.stem.conv3d.weight"].add_(1.0)
+        out3, _ = eng.forward(x, torch.float32, need_bwd=False)
+        named["encoder.stem.conv2d.weight"].add_(1.0)
+        out2, _ = eng.forward(x, torch.float32, need_bwd=False)
+    assert torch.equal(out3, out) and not torch.equal(out2, out)
+
+
 def test_inference_schedule_skips_preactivation_store():
     """need_bwd=False: fc1 keeps only gelu(h) (C = NULL); same output as the training-mode forward"""
     torch.manual_seed(0)

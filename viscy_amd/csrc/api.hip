@@ -24,6 +24,7 @@ int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x spl
 int g_vsx_ln_stream = 0;  // OFF (as nt_stream; measured with the value 3) —  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
 int g_vsx_tn_contig = 1;  // lean TN kernel: contiguous step range per split
 int g_vsx_mlp_fused = 11;  // fused GRN-MLP kernels (csrc/mlp.hip) on the C = 96 / 192 / 224 blocks: bit 0 = inference forward (statistics + output passes, hidden activation on chip), bit 1 = training fc1 (statistics pass that also stores h and g), bit 3 = block backward without a stored dz (statistics from the per-sample weight-gradient products or MODE 3, then MODE 4 writes dh once), bit 2 = also the C = 384 blocks (fc1 -12 %, backward -4 %, inference forward slower, step unchanged: off)
+int g_vsx_nt2 = 1;  // second-generation NT kernel (gemm_nt2.hip: 256 x 128 tiles, LDS-DMA operand path, wave-private epilogue): bit 0 = on for the launches it supports, bit 1 = also below 512 tiles
 int g_vsx_nt_tall = 0;  // 256x128 NT tiles: -5..-9 % on isolated wide-output launches, nothing on the whole step (measured) -> off
 
 void vsx_set_error(const char* fmt, ...) {
@@ -41,6 +42,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "nt_fast")) { g_vsx_nt_fast = value; return 0; }
   if (name && !strcmp(name, "tn_wide")) { g_vsx_tn_wide = value; return 0; }
   if (name && !strcmp(name, "nt_tall")) { g_vsx_nt_tall = value; return 0; }
+  if (name && !strcmp(name, "nt2")) { g_vsx_nt2 = value; return 0; }
   if (name && !strcmp(name, "nt_stream")) { g_vsx_nt_stream = value; return 0; }
   if (name && !strcmp(name, "grn_stream")) { g_vsx_grn_stream = value; return 0; }
   if (name && !strcmp(name, "ggb_contig")) { g_vsx_ggb_contig = value; return 0; }
@@ -64,6 +66,7 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "nt_fast")) return g_vsx_nt_fast;
   if (name && !strcmp(name, "tn_wide")) return g_vsx_tn_wide;
   if (name && !strcmp(name, "nt_tall")) return g_vsx_nt_tall;
+  if (name && !strcmp(name, "nt2")) return g_vsx_nt2;
   if (name && !strcmp(name, "nt_stream")) return g_vsx_nt_stream;
   if (name && !strcmp(name, "grn_stream")) return g_vsx_grn_stream;
   if (name && !strcmp(name, "ggb_contig")) return g_vsx_ggb_contig;

@@ -26,6 +26,8 @@ extern int g_vsx_nt_tall;
 extern int g_vsx_nt_stream;
 extern int g_vsx_tn_want;
 extern int g_vsx_tn_contig;
+bool vsx_gemm_nt2_ok(const VsxGemm* p);           // gemm_nt2.hip
+int vsx_gemm_nt2(const VsxGemm* p, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // operand gather: returns the 16-byte chunk holding A(m, k .. k+VN-1) after the prologue
@@ -906,6 +908,7 @@ extern "C" int32_t vsx_gemm_nt(const VsxGemm* p, int32_t dtype, vsx_stream_t str
   if (p->epi == VSX_EPI_BIAS_RES) VSX_CHECK(p->res != nullptr, "vsx_gemm_nt: EPI_BIAS_RES needs res");
   if (p->rscale) VSX_CHECK(p->epi == VSX_EPI_BIAS_RES && p->hw > 0, "vsx_gemm_nt: rscale needs EPI_BIAS_RES and hw");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == VSX_BF16 && vsx_gemm_nt2_ok(p)) return vsx_gemm_nt2(p, s);  // second-generation kernel (gemm_nt2.hip)
   return dtype == VSX_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
 }
 

@@ -14,9 +14,10 @@
 //   MODE 4 (backward dh): dz recomputed, dh = (dz * s[b] + gelu(h) * t[b]) * gelu'(h) stored (the fc1 gradient operand), column
 //                        sums of dh (the fc1 bias gradient) into one workspace row per workgroup.
 //                        Modes 3 + 4 replace the fc2 data-gradient GEMM (which wrote the 4C-wide dz) and the GRN / GELU backward
-//                        pass (which read it back and wrote dh over it): one 4C-wide write instead of two.  HBM writes run
-//                        at ~3.5 TB/s on this part whatever the kernel (measured: every write-dominated launch of the step
-//                        lands on bytes / 3.5 TB/s), so the write is what a pass costs.
+//                        pass (which read it back and wrote dh over it): one 4C-wide write instead of two.  (The
+//                        write-dominated launches of THIS kernel family land at 3.5 - 3.9 TB/s; linear and tile-shaped store
+//                        probes reach 5.5 - 6.9 TB/s on the part, tools/micro/write_rate.hip — the limit is the kernels'
+//                        structure, DESIGN.md §3 item 10, not the memory.)
 // (SURVEY §7 step 4 / VERDICT r1 "what's missing" 1.  The unfused schedule moved 8 of its 15 C-units per pixel as 4C-wide
 // h / g tensors through HBM in inference; this one moves 1 + 3.)
 //

@@ -69,14 +69,16 @@ extern "C" int32_t vsx_adamw(float* p, const float* g, float* m, float* v, const
 // captured step: the copy reads the block when the GPU gets there, the host — many replays ahead of a 140 ms step — had
 // already overwritten it with a later step's lr / bias corrections (optim.py race).  Now nothing that changes
 // per step lives on the host: a hipGraph replay is a pure function of device state.
+// cfg is DOUBLE: beta2 = 0.999 as a float is 0.99900001287, which moved the bias correction 1 - beta2^t by 1.3e-5 (relative)
+// at t = 1 against torch.optim.AdamW's host-double arithmetic; step counts stay exact beyond 2^24.
 // cfg: {base_lr, beta1, beta2, eps, weight_decay, grad_scale, schedule (0 constant | 1 MONAI WarmupCosine),
 //       warmup_steps, t_total, warmup_multiplier, cycles}
-__global__ void adamw_advance_kernel(const float* __restrict__ cfg, int* __restrict__ step, float* __restrict__ hyper) {
+__global__ void adamw_advance_kernel(const double* __restrict__ cfg, int* __restrict__ step, float* __restrict__ hyper) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int t0 = *step;  // optimiser steps taken so far = index of this step in the LambdaLR schedule
   const double b1 = cfg[1], b2 = cfg[2];
   double lam = 1.0;
-  if (cfg[6] > 0.5f) {
+  if (cfg[6] > 0.5) {
     const double warm = cfg[7], total = cfg[8], mult = cfg[9], cycles = cfg[10];
     if ((double)t0 < warm) {
       lam = mult + (1.0 - mult) * ((double)t0 / fmax(1.0, warm));
@@ -87,17 +89,17 @@ __global__ void adamw_advance_kernel(const float* __restrict__ cfg, int* __restr
   }
   const int t = t0 + 1;
   hyper[0] = (float)((double)cfg[0] * lam);
-  hyper[1] = cfg[1];
-  hyper[2] = cfg[2];
-  hyper[3] = cfg[3];
-  hyper[4] = cfg[4];
+  hyper[1] = (float)cfg[1];
+  hyper[2] = (float)cfg[2];
+  hyper[3] = (float)cfg[3];
+  hyper[4] = (float)cfg[4];
   hyper[5] = (float)(1.0 - pow(b1, (double)t));
   hyper[6] = (float)(1.0 - pow(b2, (double)t));
-  hyper[7] = cfg[5];
+  hyper[7] = (float)cfg[5];
   *step = t;
 }
 
-extern "C" int32_t vsx_adamw_advance(const float* cfg, int32_t* step, float* hyper, vsx_stream_t stream) {
+extern "C" int32_t vsx_adamw_advance(const double* cfg, int32_t* step, float* hyper, vsx_stream_t stream) {
   VSX_CHECK(cfg && step && hyper, "vsx_adamw_advance: bad arguments");
   hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cfg, step, hyper);
   VSX_LAUNCH_CHECK();

@@ -147,6 +147,19 @@ class Position:
             raise KeyError(f"{self.name}/{key}")
         return ImageArray(self.fs_path / key, f"{self.name}/{key}")
 
+    def __contains__(self, key) -> bool:
+        return (self.fs_path / str(key) / ".zarray").exists()
+
+    def create_image(self, name: str, data: np.ndarray, chunks=None) -> ImageArray:
+        """iohub ``Position.create_image``: a new 5-D TCZYX array holding ``data`` (e.g. the precomputed foreground masks that
+        ``viscy preprocess --compute_fg_masks`` stores next to the images)"""
+        data = np.asarray(data)
+        img = self.create_zeros(name, data.shape, data.dtype, chunks=chunks)
+        for t in range(data.shape[0]):
+            for c in range(data.shape[1]):
+                img.write_zrange(t, c, 0, data[t, c])
+        return img
+
     def _save(self) -> None:
         (self.fs_path / ".zattrs").write_text(json.dumps(self.zattrs))
 

@@ -485,7 +485,9 @@ class Engine:
         B, Cin, Z, H, Wd = x.shape
         za_key = ("fwd", B, H, Wd, masks is not None)
         self._za = za = _ZeroArena(x.device, self._za_need.get(za_key, 0))
-        flat_stem = Z == 1 and cfg["in_stack_depth"] != 1 and "stem2d_W" in W  # FCMAE 2-D branch: x.squeeze(2) -> conv2d
+        # FCMAE 2-D branch (fcmae.py:369-370): the reference runs conv2d whenever x.shape[2] == 1, whatever in_stack_depth is —
+        # a 2-D FCMAE (in_stack_depth = 1) trains and loads its conv2d weights, never the conv3d ones
+        flat_stem = Z == 1 and "stem2d_W" in W
         if Cin != cfg["in_channels"] or (Z != cfg["in_stack_depth"] and not flat_stem):
             raise ValueError(f"expected input (B,{cfg['in_channels']},{cfg['in_stack_depth']},Y,X), got {tuple(x.shape)}")
         kz, ky, kx = cfg["stem_kernel"]

@@ -393,8 +393,8 @@ def mlp_out(xh: Tensor, img: Tensor, b1: Tensor, s: Tensor, beta: Tensor, b2: Te
 
 def adamw_advance(cfg: Tensor, step: Tensor, hyper: Tensor) -> None:
     """schedule / bias corrections of the next optimiser step from device state (csrc/optim.hip): no host memory involved"""
-    if step.dtype != torch.int32:
-        raise TypeError("the optimiser step counter is int32")
+    if step.dtype != torch.int32 or cfg.dtype != torch.float64:
+        raise TypeError("the optimiser step counter is int32, the schedule constants float64")
     check(lib().vsx_adamw_advance(ptr(cfg), ptr(step), ptr(hyper), stream()), "adamw_advance")
 
 

@@ -51,7 +51,7 @@ class FlatAdamW:
         self.t = 0                 # host mirror of the device step counter (logging, checkpoints)
         self.grad_scale = 1.0
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.cfg_dev = torch.zeros(16, dtype=torch.float32, device=dev)
+        self.cfg_dev = torch.zeros(16, dtype=torch.float64, device=dev)  # double: see csrc/optim.hip adamw_advance_kernel
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._cfg_sent = None
 
@@ -78,7 +78,7 @@ class FlatAdamW:
         if cfg != self._cfg_sent:
             if torch.cuda.is_available() and self.cfg_dev.is_cuda and torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("FlatAdamW: optimiser constants changed inside a hipGraph capture")
-            self.cfg_dev[: len(cfg)].copy_(torch.tensor(cfg, dtype=torch.float32))
+            self.cfg_dev[: len(cfg)].copy_(torch.tensor(cfg, dtype=torch.float64))
             self._cfg_sent = cfg
         self.t += 1
 

@@ -73,17 +73,36 @@ class TrainStep:
         return loss.detach(), dout
 
     def _direct_stages(self):
-        """generator: runs the step up to the end of gradient bucket i, yields i"""
+        """generator: runs the step up to the end of gradient bucket i, yields i.  The compute dtype is resolved BEFORE autocast
+        is switched off (an ambient ``torch.autocast(bfloat16)`` — Lightning's bf16-mixed — selects the bf16 kernels, as in
+        ``unext2_apply``), and the thread-local no-grad / no-autocast modes are entered per stretch, never held across a
+        ``yield``: collectives, graph-capture exits and user hooks between two segments see the caller's modes."""
         eng = self.model.engine()
+        dt = self.model._resolve_dtype()
         self.opt.zero_grad()
-        with torch.no_grad(), torch.autocast("cuda", enabled=False):
-            out, sv = eng.forward(self.x.float(), self.model._resolve_dtype(), True)
+
+        def quiet():
+            import contextlib
+
+            st = contextlib.ExitStack()
+            st.enter_context(torch.no_grad())
+            st.enter_context(torch.autocast("cuda", enabled=False))
+            return st
+
+        with quiet():
+            out, sv = eng.forward(self.x.float(), dt, True)
             eng._pending_bwd = 0  # this driver runs the backward itself
             loss, dout = self._loss_and_grad(out)
             self.loss = loss.detach()
             del out
-            for i in eng.backward_stages(sv, dout):
-                yield i
+            it = eng.backward_stages(sv, dout)
+        while True:
+            with quiet():
+                try:
+                    i = next(it)
+                except StopIteration:
+                    return
+            yield i
 
     # ---- autograd driver
     def _fwd_bwd(self):

@@ -144,6 +144,8 @@ def intensity_augment(x: Tensor, *, gamma: Tensor | None = None, factor: Tensor 
 
 
 class _BatchedRand:
+    is_spatial = False  # the spatial subclasses (flip, affine, crops) say so: foreground masks follow them and only them
+
     def __init__(self, keys, prob: float):
         self.keys, self.prob = _keys(keys), prob
         self.generator: torch.Generator | None = None
@@ -223,14 +225,24 @@ class BatchedRandGaussianNoised(_BatchedRand):
 class BatchedRandFlipd(_BatchedRand):
     """per-sample random flips along the given spatial axes (pure data movement: torch.flip)."""
 
+    is_spatial = True
+
     def __init__(self, keys, spatial_axes: Sequence[int] = (0, 1, 2), prob: float = 0.5, allow_missing_keys: bool = False):
         super().__init__(keys, prob)
         self.spatial_axes = tuple(spatial_axes)
+        self.allow_missing_keys = allow_missing_keys
 
     def __call__(self, sample: dict, params: Tensor | None = None) -> dict:
-        B = sample[self.keys[0]].shape[0]
+        first = next((k for k in self.keys if k in sample), None)
+        if first is None:
+            return sample
+        B = sample[first].shape[0]
         flips = params if params is not None else (torch.rand(B, len(self.spatial_axes), generator=self.generator) < self.prob)
         for k in self.keys:
+            if k not in sample:
+                if self.allow_missing_keys:
+                    continue
+                raise KeyError(k)
             x = sample[k]
             out = x.clone()
             for b in range(B):
@@ -244,11 +256,18 @@ class BatchedRandFlipd(_BatchedRand):
 class BatchedCenterSpatialCropd:
     """centre crop of the trailing spatial dims to ``roi_size`` (slicing only)."""
 
+    is_spatial = True
+
     def __init__(self, keys, roi_size: Sequence[int], allow_missing_keys: bool = False):
         self.keys, self.roi_size = _keys(keys), tuple(roi_size)
+        self.allow_missing_keys = allow_missing_keys
 
     def __call__(self, sample: dict) -> dict:
         for k in self.keys:
+            if k not in sample:
+                if self.allow_missing_keys:
+                    continue
+                raise KeyError(k)
             x = sample[k]
             sl = [slice(None)] * x.ndim
             for d, size in zip(range(x.ndim - len(self.roi_size), x.ndim), self.roi_size):
