@@ -466,6 +466,72 @@ def g8_wiring():
     torch.save(golden, os.path.join(GOLD, "unext2_forward.pt"))
 
 
+def g8b_baseline_size():
+    """tests/golden/unext2_tiny_256.pt — the BASELINE configuration at the BASELINE patch size, from the reference's own
+    wiring (g8_wiring must have run: the reference unext2.py is loaded on the stub timm / monai modules): tiny, B = 4,
+    Z = 5, 256 x 256, 1 -> 2 ch.  fp32 forward (strided sample), MixedLoss(0.5, 0, 0.5) value, a strided sample of every
+    parameter gradient, and the SAME module under ``torch.autocast(bfloat16)`` — the arithmetic Lightning's bf16-mixed runs —
+    as the yardstick for the production bf16 kernels: forward error and per-stage gradient error of autocast against fp32.
+    The GPU test (tests/test_gpu_model.py) holds the fp32 engine to 1e-3 and the bf16 engine to 1.25 x that yardstick."""
+    import time
+
+    R = unext2_ref
+    ref = sys.modules["viscy_models.unet.unext2"]
+    kw = dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True, head_expansion_ratio=4,
+              decoder_conv_blocks=2)
+    r = ref.UNeXt2(**kw)
+    o = R.UNeXt2(**kw)
+    R.randomize_(o, seed=13)
+    r.load_state_dict(o.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(2024)
+    B, S = 4, 256
+    x = torch.randn((B, 1, 5, S, S), generator=g)
+    smooth = torch.nn.functional.avg_pool3d(x, (1, 5, 5), stride=1, padding=(0, 2, 2))
+    tgt = (0.5 * smooth.repeat(1, 2, 1, 1, 1) + 0.1 * torch.randn((B, 2, 5, S, S), generator=g)).contiguous()
+
+    def group_of(name: str) -> str:
+        p = name.split(".")
+        if p[0] == "encoder_stages":
+            return "enc_" + p[1]
+        if p[0] == "decoder":
+            return "dec_" + p[2]
+        return p[0]
+
+    def run(autocast: bool):
+        for p in r.parameters():
+            p.grad = None
+        t0 = time.time()
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            y = r(x)
+        loss = loss_ref.mixed_loss(y.float(), tgt, 0.5, 0.0, 0.5)
+        loss.backward()
+        print(f"   {'autocast(bf16)' if autocast else 'fp32'} forward + backward: {time.time() - t0:.0f} s, loss {loss.item():.6f}")
+        return y.detach().float(), loss.item(), {n: p.grad.detach().clone() for n, p in r.named_parameters()}
+
+    y32, l32, g32 = run(False)
+    yac, lac, gac = run(True)
+    groups = {}
+    for n in g32:
+        groups.setdefault(group_of(n), []).append(n)
+    yard = {"forward_max_rel": ((yac - y32).abs().max() / y32.abs().max()).item(), "loss_rel": abs(lac - l32) / abs(l32), "grad": {}}
+    for gname, names in groups.items():
+        a = torch.cat([g32[n].flatten() for n in names]).double()
+        b = torch.cat([gac[n].flatten() for n in names]).double()
+        yard["grad"][gname] = {"one_minus_cos": 1.0 - torch.nn.functional.cosine_similarity(a, b, dim=0).item(),
+                               "rel_l2": ((a - b).norm() / a.norm()).item()}
+    samples = {}
+    for n, gr in g32.items():
+        f = gr.flatten()
+        st = max(1, f.numel() // 1024)
+        samples[n] = (st, f[::st].clone())
+    gold = {"kwargs": kw, "seed": 13, "x_seed": 2024, "shape": (B, S), "y_stride": 4, "y": y32[..., ::4, ::4].clone(), "y_absmax": y32.abs().max().item(),
+            "loss": l32, "grad_samples": samples, "grad_group_norm": {gn: torch.cat([g32[n].flatten() for n in ns]).double().norm().item() for gn, ns in groups.items()},
+            "groups": groups, "autocast_yardstick": yard}
+    torch.save(gold, os.path.join(GOLD, "unext2_tiny_256.pt"))
+    print(f"G8b baseline size: reference tiny B=4 256x256 fp32 + autocast yardstick written "
+          f"(autocast forward err {yard['forward_max_rel']:.3e}, worst stage 1-cos {max(v['one_minus_cos'] for v in yard['grad'].values()):.3e})")
+
+
 def g9_fcmae():
     """Run the reference's own fcmae.py (dense path) on stubbed timm / monai modules == oracle/fcmae_ref.py."""
     from oracle import fcmae_ref as F
@@ -853,6 +919,7 @@ if __name__ == "__main__":
     g4b_transform_pins()
     g5_unet2d()
     g8_wiring()
+    g8b_baseline_size()
     g9_fcmae()
     g10_contrastive()
     g11_hcs_sampling()

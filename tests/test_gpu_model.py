@@ -337,6 +337,67 @@ def test_full_size_mixed_loss_identities():
 
 
 # ------------------------------------------------------------------------------------------------ FCMAE dense path (§8 f2)
+def test_baseline_size_fp32_and_bf16_engines_vs_reference_golden():
+    """the production bf16 kernels (matrix-core depthwise, fused GRN-MLP passes, direct head convolution,
+    lean GEMMs) pinned at the BASELINE patch size.  tests/golden/unext2_tiny_256.pt holds what the REFERENCE's own wiring
+    (G8b, oracle/validate_against_reference.py) computes for tiny, B = 4, 256 x 256: fp32 forward, MixedLoss value, a
+    strided sample of every parameter gradient, and the errors of the same module under ``torch.autocast(bfloat16)`` — the
+    reference's bf16-mixed arithmetic — per stage.  fp32 engine: forward <= 1e-3 of the output maximum, loss <= 1e-3,
+    per-stage gradient direction 1 - cos < 2e-4 (PReLU kink: DESIGN §5); bf16 engine: forward and every stage within
+    1.25 x the autocast yardstick."""
+    from oracle import unext2_ref
+    from viscy_amd.losses import MixedLoss
+    from viscy_amd.unext2 import UNeXt2
+
+    gold = load_golden("unext2_tiny_256.pt")
+    kw = gold["kwargs"]
+    B, S = gold["shape"]
+    ref = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=gold["seed"])
+    g = torch.Generator().manual_seed(gold["x_seed"])
+    x = torch.randn((B, 1, 5, S, S), generator=g)
+    smooth = torch.nn.functional.avg_pool3d(x, (1, 5, 5), stride=1, padding=(0, 2, 2))
+    tgt = (0.5 * smooth.repeat(1, 2, 1, 1, 1) + 0.1 * torch.randn((B, 2, 5, S, S), generator=g)).contiguous()
+    yard = gold["autocast_yardstick"]
+    st = gold["y_stride"]
+
+    def run(dt):
+        m = UNeXt2(**kw)
+        m.load_state_dict(ref.state_dict(), strict=True)
+        m = m.cuda()
+        m.compute_dtype, m.grad_mode = dt, "flat"
+        eng = m.engine()
+        eng.flat_grad.zero_()
+        y = m(x.cuda())
+        loss = MixedLoss(0.5, 0.0, 0.5)(y, tgt.cuda())
+        loss.backward()
+        named = dict(m.named_parameters())
+        fwd = ((y.detach().float().cpu()[..., ::st, ::st] - gold["y"]).abs().max() / gold["y_absmax"]).item()
+        stages = {}
+        for gname, names in gold["groups"].items():
+            a, b = [], []
+            for n in names:
+                stride, sample = gold["grad_samples"][n]
+                a.append(sample.double())
+                b.append(eng.g(named[n]).flatten()[::stride].double().cpu())
+            a, b = torch.cat(a), torch.cat(b)
+            stages[gname] = (1.0 - torch.nn.functional.cosine_similarity(a, b, dim=0).item(), ((a - b).norm() / a.norm()).item())
+        return fwd, abs(loss.item() - gold["loss"]) / abs(gold["loss"]), stages
+
+    fwd, lrel, stages = run(torch.float32)
+    print("fp32 engine @256: forward", f"{fwd:.2e}", "loss", f"{lrel:.2e}", {k: f"{v[0]:.1e}/{v[1]:.1e}" for k, v in stages.items()})
+    assert fwd <= 1e-3 and lrel <= 1e-3
+    for gname, (omc, rel) in stages.items():
+        assert omc < 2e-4 and rel < 2e-2, (gname, omc, rel)
+    fwd, lrel, stages = run(torch.bfloat16)
+    print("bf16 engine @256: forward", f"{fwd:.2e}", "(autocast", f"{yard['forward_max_rel']:.2e})", "loss", f"{lrel:.2e}",
+          {k: f"{v[0]:.1e} (ac {yard['grad'][k]['one_minus_cos']:.1e})" for k, v in stages.items()})
+    assert fwd <= 1.25 * yard["forward_max_rel"]
+    assert lrel <= max(1.25 * yard["loss_rel"], 2e-3)
+    for gname, (omc, rel) in stages.items():
+        assert omc <= 1.25 * yard["grad"][gname]["one_minus_cos"] + 1e-4, (gname, omc, yard["grad"][gname])
+        assert rel <= 1.25 * yard["grad"][gname]["rel_l2"] + 1e-2, (gname, rel, yard["grad"][gname])
+
+
 @pytest.mark.parametrize("tag", ["small_z5", "vscyto3d_z15", "head_conv_z5"])
 def test_fcmae_forward_matches_reference_golden_fp32(tag):
     """fixtures produced by the REFERENCE's own fcmae.py (oracle/validate_against_reference.py G9)"""

@@ -131,8 +131,11 @@ NT2_CASES = [
     (512, 96, 384, 512),     # one partial N tile
     (1024, 384, 256, 64),    # four samples per tile (8 x 8 feature maps): per-wave statistics
     (512, 192, 96, 128),     # two samples per tile
-    (256, 1536, 384, 256),   # the C = 384 fc1 / dz shape of one sample
-    (1024, 384, 1536, 1024),
+    (256, 1536, 384, 256),   # the C = 384 fc1 / dz shape of one sample: four 384-wide column tiles
+    (1024, 384, 1536, 1024), # one 384-wide tile
+    (512, 3072, 96, 64),     # eight 384-wide tiles, four samples per tile
+    (512, 448, 64, 256),     # 384 + ragged 64: two 256-wide tiles
+    (256, 896, 224, 256),    # 256-wide tiles, ragged last (128 used)
 ]
 
 
@@ -986,12 +989,13 @@ def test_fused_grn_mlp_matches_unfused_kernels_and_reference(C, hw, B, drop_path
 
     dt = torch.bfloat16
     M, H4 = B * hw, 4 * C
-    L.lib().vsx_set_flag(b"mlp_fused", 15)  # bit 2: the C = 384 instantiations too
+    saved = L.lib().vsx_get_flag(b"mlp_fused")
+    L.lib().vsx_set_flag(b"mlp_fused", 31)  # bits 2 / 4: the C = 384 instantiations too (training passes / inference pair)
     try:
         assert ops.mlp_supported(C, hw, M, dt)
         _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops)
     finally:
-        L.lib().vsx_set_flag(b"mlp_fused", 11)
+        L.lib().vsx_set_flag(b"mlp_fused", saved)
 
 
 def _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops):
@@ -1059,13 +1063,13 @@ def test_fused_block_backward_without_stored_dz(C, hw, B):
 
     dt = torch.bfloat16
     M, H4 = B * hw, 4 * C
-    if C == 384:
-        L.lib().vsx_set_flag(b"mlp_fused", 15)
+    saved = L.lib().vsx_get_flag(b"mlp_fused")
+    L.lib().vsx_set_flag(b"mlp_fused", 31)
     try:
         assert ops.mlp_supported(C, hw, M, dt, 3) and ops.mlp_supported(C, hw, M, dt, 4)
         _fused_bwd_case(C, hw, B, dt, M, H4, L, ops)
     finally:
-        L.lib().vsx_set_flag(b"mlp_fused", 11)
+        L.lib().vsx_set_flag(b"mlp_fused", saved)
 
 
 def _fused_bwd_case(C, hw, B, dt, M, H4, L, ops):

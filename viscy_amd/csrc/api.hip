@@ -17,13 +17,13 @@ int g_vsx_dw_mfma = 7;   // depthwise conv on the matrix cores (dwconv_mfma.hip)
 int g_vsx_ln_fblk = 32768;  // LayerNorm forward: cap on workgroups per launch (each sweeps rows / cap windows).  Measured at B = 512 (64x64x96 / x224): 2048 -> 209 / 438 us, 8192 -> 172 / 351, 32768 -> 162 / 331 (a grid-stride sweep by few workgroups streams at 5.0 TB/s where one vector per thread reaches 6.8: tools/micro/write_rate.hip)
 int g_vsx_ln_bblk = 8192;   // LayerNorm backward WITHOUT affine gradients (the block LayerNorms): cap on workgroups (with dgamma: 512, same-address atomics).  512 -> 319 / 651 us, 2048 -> 254 / 586, 8192 -> 240 / 541 (16x16x384: 83 -> 61), 32768 -> 225 / 516 but 78 at 16x16x384
 int g_vsx_dw_wg16 = 1;   // depthwise weight gradient: 8x16-pixel tiles (35 KB of LDS, 4 workgroups / CU) instead of 8x32 (63 KB, 2)
-int g_vsx_nt_stream = 0;  // OFF (rare NaN in long runs not yet explained; measured gains below are with the value 3) —  // lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B)
-int g_vsx_grn_stream = 0;  // OFF (as nt_stream; measured with the value 2) —  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
+int g_vsx_nt_stream = 3;  // lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B).  ON since round 3: the streaming stores are compiler builtins now (round 1 used inline asm, see vsx_common.h stvec_stream), soak / determinism / poison tests run with them
+int g_vsx_grn_stream = 2;  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
 int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup instead of grid-strided rows
 int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x splits)
-int g_vsx_ln_stream = 0;  // OFF (as nt_stream; measured with the value 3) —  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
+int g_vsx_ln_stream = 3;  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
 int g_vsx_tn_contig = 1;  // lean TN kernel: contiguous step range per split
-int g_vsx_mlp_fused = 11;  // fused GRN-MLP kernels (csrc/mlp.hip) on the C = 96 / 192 / 224 blocks: bit 0 = inference forward (statistics + output passes, hidden activation on chip), bit 1 = training fc1 (statistics pass that also stores h and g), bit 3 = block backward without a stored dz (statistics from the per-sample weight-gradient products or MODE 3, then MODE 4 writes dh once), bit 2 = also the C = 384 blocks (fc1 -12 %, backward -4 %, inference forward slower, step unchanged: off)
+int g_vsx_mlp_fused = 15;  // fused GRN-MLP kernels (csrc/mlp.hip): bit 0 = inference forward (statistics + output passes, hidden activation on chip), bit 1 = training fc1 (statistics pass that also stores h and g), bit 3 = block backward without a stored dz (statistics from the per-sample weight-gradient products or MODE 3, then MODE 4 writes dh once) — on the C = 96 / 192 / 224 blocks; bit 2 = the training passes also on the C = 384 blocks (same step time, 7.7 GB less traffic per step); bit 4 = the inference pair also on the C = 384 blocks (slower than the unfused GEMMs there: off)
 int g_vsx_nt2 = 1;  // second-generation NT kernel (gemm_nt2.hip: 256 x 128 tiles, LDS-DMA operand path, wave-private epilogue): bit 0 = on for the launches it supports, bit 1 = also below 512 tiles
 int g_vsx_nt_tall = 0;  // 256x128 NT tiles: -5..-9 % on isolated wide-output launches, nothing on the whole step (measured) -> off
 

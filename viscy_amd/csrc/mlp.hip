@@ -626,8 +626,10 @@ struct MlpCfg { int C, MF, NW, modes; };  // modes: bit m set = this geometry se
 // rows per workgroup must divide the pixels of a sample; the large maps take 256-row workgroups (8 waves x 32 rows: weight
 // traffic L2 -> LDS per flop is 1 / rows).  C = 384 lives on 16 x 16 maps (256 rows = one sample): the passes without fc2
 // accumulators (MODE 0, 2, 3, 4) fit 8 waves at <= 256 registers, the output pass (MODE 1, 192 accumulator registers) only
-// 4 waves x 32 rows (one wave per SIMD: measured 875 us against 614 us for the unfused pair at B = 512).  All C = 384
-// geometries sit behind bit 2 of the mlp_fused flag (tools/perf_mlp.py).
+// 4 waves x 32 rows (one wave per SIMD: measured 875 us against 614 us for the unfused pair at B = 512).  The C = 384
+// training passes (MODE 2 / 3 / 4) sit behind bit 2 of the mlp_fused flag — on since round 3: the step time is unchanged
+// (fc1 -12 %, backward -4 %), the block's backward no longer writes dz and reads it back (-0.7 GB per block and step at
+// B = 512) — the inference pair behind bit 4 (slower than the unfused GEMMs: off).
 extern int g_vsx_mlp_fused;
 static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 31}, {192, 2, 8, 31}, {224, 2, 8, 31}, {384, 2, 8, 1 | 4 | 8 | 16}, {384, 2, 4, 2}};
 
@@ -635,7 +637,7 @@ static const MlpCfg* mlp_cfg(int C, int hw, long M, int mode) {
   for (const MlpCfg& c : kMlpCfgs) {
     const int bm = c.NW * 16 * c.MF;
     if (!(c.modes & (1 << mode))) continue;
-    if (c.C == 384 && !(g_vsx_mlp_fused & 4)) continue;
+    if (c.C == 384 && !(g_vsx_mlp_fused & (mode <= 1 ? 16 : 4))) continue;  // bit 2: training passes, bit 4: inference pair
     if (c.C == C && hw % bm == 0 && M % bm == 0) return &c;
   }
   return nullptr;

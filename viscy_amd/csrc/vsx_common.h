@@ -127,17 +127,23 @@ __device__ __forceinline__ void stvec(T* p, const typename VT<T>::vec& v) {
   *reinterpret_cast<typename VT<T>::vec*>(p) = v;
 }
 
-// 16-byte store that streams past the caches when `nt` is set (outputs a later launch reads, never this one)
+// 16-byte store that streams past the caches when `nt` is set (outputs a later launch reads, never this one).
+// Compiler builtin, NOT inline assembly: round 1 issued `global_store_dwordx4 ... nt` from an asm statement, which hipcc
+// treats as one opaque instruction — it neither counts the store in its s_waitcnt bookkeeping nor pads the wait states a
+// 16-byte store needs before its data registers may be rewritten (the store reads its four data VGPRs over several
+// cycles; hipcc's next instruction could overwrite them).  That is a "rare garbage in a few lanes" hazard by construction
+// and the only thing the streaming-access paths had that the default paths did not; __builtin_nontemporal_store emits the
+// same instruction with the compiler's own hazard handling.
 typedef uint32_t vsx_u32x4 __attribute__((ext_vector_type(4)));
 typedef float vsx_f32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void stvec_stream(bf16_t* p, const uint4& v, bool nt) {
   const vsx_u32x4 w = {v.x, v.y, v.z, v.w};
-  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");  // s_nop 1: the store reads its 4 data registers over two more cycles; hipcc does not pad after inline asm
+  if (nt) __builtin_nontemporal_store(w, reinterpret_cast<vsx_u32x4*>(p));
   else *reinterpret_cast<vsx_u32x4*>(p) = w;
 }
 __device__ __forceinline__ void stvec_stream(float* p, const float4& v, bool nt) {
   const vsx_f32x4s w = {v.x, v.y, v.z, v.w};
-  if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");  // s_nop 1: the store reads its 4 data registers over two more cycles; hipcc does not pad after inline asm
+  if (nt) __builtin_nontemporal_store(w, reinterpret_cast<vsx_f32x4s*>(p));
   else *reinterpret_cast<vsx_f32x4s*>(p) = w;
 }
 

@@ -5,6 +5,13 @@ automatic-optimisation semantics the reference relies on: per ba
 validation logs the mean of per-dataloader mean losses as ``loss/validate``; DDP = one process per GPU,
 gradient all-reduce through ``viscy_amd.parallel.FlatDataParallel`` (RCCL), index sharding with
 ``DistributedSampler`` semantics, ``sync_dist`` → mean all-reduce of logged scalars.
+
+The training step itself is the one ``bench.py`` measures: for the flat-engine models with the stock ``VSUNet.training_step``
+and static batch shapes, ``fit`` drives ``viscy_amd.step.TrainStep`` — the engine's forward / hand-written backward called
+directly (no autograd graph), the whole step captured as hipGraph segments that end where a gradient bucket completes, each
+bucket's RCCL all-reduce issued between two replays, AdamW as its own graph.  Anything else (a list of batches from a
+``CombinedLoader``, a ``fg_mask`` batch, a subclass with its own ``training_step``, a new batch shape after two captured
+ones, the CPU "2D" plumbing model) takes the eager path above; both paths advance the same optimiser / schedule state.
 """
 
 from __future__ import annotations
@@ -18,7 +25,7 @@ from .parallel import FlatDataParallel
 class Trainer:
     def __init__(self, max_epochs: int = 1, fast_dev_run: bool = False, precision: str = "bf16-mixed",
                  accelerator: str = "gpu", seed: int | None = 42, limit_train_batches: int | None = None, callbacks=None,
-                 default_root_dir=None, return_predictions: bool = True):
+                 default_root_dir=None, return_predictions: bool = True, graph_step: bool = True):
         self.max_epochs, self.fast_dev_run, self.precision = max_epochs, fast_dev_run, precision
         self.default_root_dir, self.return_predictions = default_root_dir, return_predictions
         self.callbacks = list(callbacks or [])
@@ -26,6 +33,9 @@ class Trainer:
         self.limit_train_batches = limit_train_batches
         self.finished = False
         self.global_step = 0
+        self.graph_step = graph_step   # False: always the eager zero_grad / training_step / backward / step loop
+        self.graph_steps = 0           # optimisation steps taken through the captured TrainStep (tests, logs)
+        self._train_steps: dict = {}   # batch signature -> TrainStep
         if seed is not None:
             torch.manual_seed(seed)
         self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
@@ -38,6 +48,31 @@ class Trainer:
         if torch.is_tensor(batch):
             return batch.to(self.device, non_blocking=True)
         return batch
+
+    _MAX_CAPTURED_SHAPES = 2  # each captured step owns a memory pool the size of the step's activations
+
+    def _graphed_step(self, module, opt, ddp, batch):
+        """the captured ``TrainStep`` serving this batch, or None (eager path): see the module docstring"""
+        from .vsunet import VSUNet
+
+        if not (self.graph_step and self.device.type == "cuda" and getattr(module, "_native", False)):
+            return None
+        if type(module).training_step is not VSUNet.training_step or type(module)._compute_loss is not VSUNet._compute_loss:
+            return None
+        if not isinstance(batch, dict) or "fg_mask" in batch:
+            return None
+        src, tgt = batch.get("source"), batch.get("target")
+        if not (torch.is_tensor(src) and torch.is_tensor(tgt) and src.is_cuda and tgt.is_cuda):
+            return None
+        key = (tuple(src.shape), tuple(tgt.shape), src.dtype, tgt.dtype)
+        step = self._train_steps.get(key)
+        if step is None:
+            if len(self._train_steps) >= self._MAX_CAPTURED_SHAPES:
+                return None
+            from .step import TrainStep
+
+            step = self._train_steps[key] = TrainStep(module.model, module.loss_function, opt, ddp, use_graph=True)
+        return step
 
     def fit(self, module, datamodule) -> None:
         module.to(self.device)
@@ -58,6 +93,7 @@ class Trainer:
         if dist.is_initialized() and not native:
             raise NotImplementedError("data-parallel training is built for the flat-engine models (UNeXt2 / fcmae) only")
         ddp = FlatDataParallel(module.model.engine(), opt) if dist.is_initialized() else None
+        self._train_steps = {}  # captured steps are bound to THIS fit's optimiser / process group
         use_bf16 = self.precision.startswith("bf16") and self.device.type == "cuda"
         from .data.combined import CombinedLoader
 
@@ -78,13 +114,22 @@ class Trainer:
                 if isinstance(train_dl, CombinedLoader):  # yields (batch, batch_idx, dataloader_idx) like Lightning's
                     batch, _, di = batch
                 batch = datamodule.on_after_batch_transfer(self._to_device(batch), di)
-                opt.zero_grad()
-                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
-                    loss = module.training_step(batch, i)
-                loss.backward()
-                if ddp is not None:
-                    ddp.finish()
-                opt.step()
+                step = self._graphed_step(module, opt, ddp, batch) if native else None
+                if step is not None:
+                    # the benched step: direct engine driver, hipGraph segments, bucketed all-reduce between replays, AdamW
+                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+                        loss = step(batch["source"], batch["target"])
+                    module._log("loss/train", loss.clone(), on_step=True, on_epoch=True, prog_bar=True, logger=True,
+                                sync_dist=True, batch_size=batch["source"].shape[0])  # what VSUNet.training_step logs
+                    self.graph_steps += 1
+                else:
+                    opt.zero_grad()
+                    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+                        loss = module.training_step(batch, i)
+                    loss.backward()
+                    if ddp is not None:
+                        ddp.finish()
+                    opt.step()
                 self.global_step += 1
             module.on_train_epoch_end()
             module.eval()
