@@ -396,7 +396,7 @@ def test_rccl_one_rank_segments_with_interleaved_all_reduce():
     from viscy_amd.parallel import FlatDataParallel
     from viscy_amd.step import TrainStep
 
-    x, t = bench.make_batch(4, 128, 128, "cuda")
+    x, t = bench.make_batch(4, 192, 192, "cuda")
     steps = 24
 
     def run(ddp_on):
