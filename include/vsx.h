@@ -311,7 +311,9 @@ int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1, float* co
  *   dW2[c, j] += sum_b s[b, j] * Q[b, c, j] + beta[j] * sum_b cs[b, c]        db2[c] += sum_b cs[b, c]
  * (W2 = the bf16 GEMM operand [C, 4C]): neither dz nor a pass over the 4C-wide activations is needed for the statistics. */
 int32_t vsx_grn_q_reduce(const float* Q, const float* cs, const void* W2, const float* s, const float* beta, float* P, float* S,
-    float* dW2, float* db2, int32_t nb, int32_t C, int32_t dtype, vsx_stream_t stream);
+    float* dW2, float* db2, float* ws, int64_t ws_floats, int32_t nb, int32_t C, int32_t dtype, vsx_stream_t stream);
+/* floats of caller-owned scratch vsx_grn_q_reduce needs (Q is read ONCE: the per-sample-group partials of dW2 pass through it) */
+int64_t vsx_grn_q_reduce_ws_floats(int32_t nb, int32_t C);
 /* Block backward without a stored dz (csrc/mlp.hip MODE 3 / 4; wimg = vsx_mlp_pack with W2^T [4C, C] in the place of W1'):
  *   vsx_mlp_bwd_stats: P[b, 4C] += sum_hw dz * g, S[b, 4C] += sum_hw dz with dz = bf16(dout . W2) recomputed tile by tile —
  *                      what vsx_gemm_nt(VSX_EPI_DZ) accumulates, minus its 4C-wide output

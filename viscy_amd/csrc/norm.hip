@@ -515,108 +515,109 @@ extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, con
   return 0;
 }
 
-// ------------------------------------------------------------------ statistics + fc2 weight gradient from per-sample products
-// grid (4C / 1024, nb + C): rows < nb compute P / S of one sample (loop over c), rows >= nb compute one dW2 row (loop over b).
-// A thread owns 4 consecutive columns (16-byte loads) and keeps 8 loop iterations of loads in flight: with one column per
-// thread and 4 scalar loads in flight the kernel ran at 1.2–1.4 TB/s (latency-bound), 2.2 ms per step.
+// GRN statistics and fc2 weight gradient from the per-sample products Q[b] = dout_b^T g_b — ONE pass over Q (round 2 read
+// it twice: once per sample for P / S, once per channel for dW2: 1.3 TB/s of its own traffic, 2 ms per step).
+// A workgroup owns (a group of QR_SB samples) x (a block of QR_CB channels) x (512 columns); a thread owns 4 columns:
+//   per channel c it loads the QR_SB sample rows (16-byte loads, QR_SB in flight), accumulates
+//     p[b]  += W2[c, j] * Q[b, c, j]        (-> P[b, j], atomics: one per channel block)
+//     sm[b] += W2[c, j] * cs[b, c]          (-> S[b, j])
+//     acc   += s[b, j] * Q[b, c, j]         (-> the group's partial of dW2[c, j], plain store into ws[group][c][j])
+// and reduce_rows_kernel folds the groups' partials into dW2 (<= nb / (64 QR_SB) atomics per address).
+constexpr int QR_SB = 8, QR_CB = 32, QR_TH = 128;
 template <typename T>
-__global__ __launch_bounds__(256) void grn_q_reduce_kernel(const float* __restrict__ Q, const float* __restrict__ cs,
-                                                           const T* __restrict__ W2, const float* __restrict__ s,
-                                                           const float* __restrict__ beta, float* __restrict__ P,
-                                                           float* __restrict__ S, float* __restrict__ dW2,
-                                                           float* __restrict__ db2, int nb, int C) {
+__global__ __launch_bounds__(QR_TH) void grn_q_reduce_kernel(const float* __restrict__ Q, const float* __restrict__ cs,
+                                                             const T* __restrict__ W2, const float* __restrict__ s,
+                                                             const float* __restrict__ beta, float* __restrict__ P,
+                                                             float* __restrict__ S, float* __restrict__ ws,
+                                                             float* __restrict__ db2, int nb, int C) {
   const int N = 4 * C;  // a multiple of 4: every thread's 4 columns are all inside or all outside
-  const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
-  const int row = blockIdx.y;
+  const int j = (blockIdx.x * QR_TH + threadIdx.x) * 4;
+  const int g = blockIdx.y;
+  const int b0 = g * QR_SB;
+  const int c0 = blockIdx.z * QR_CB, c1 = min(C, c0 + QR_CB);
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;  // one thread per (group, channel block) owns the bias gradient
+  if (j >= N && !lead) return;
+  const bool live = j < N;
+  const int jj = live ? j : 0;
   auto w4 = [&](int c) -> float4 {
     if constexpr (sizeof(T) == 2) {
-      const uint2 u = *reinterpret_cast<const uint2*>(W2 + (size_t)c * N + j);
+      const uint2 u = *reinterpret_cast<const uint2*>(W2 + (size_t)c * N + jj);
       return make_float4(bf16_bits_to_f32(u.x & 0xffffu), bf16_bits_to_f32(u.x >> 16), bf16_bits_to_f32(u.y & 0xffffu),
                          bf16_bits_to_f32(u.y >> 16));
     } else {
-      return *reinterpret_cast<const float4*>(W2 + (size_t)c * N + j);
+      return *reinterpret_cast<const float4*>(W2 + (size_t)c * N + jj);
     }
   };
-  if (row < nb) {
-    if (j >= N) return;
-    const float* q = Q + (size_t)row * C * N + j;
-    const float* c1 = cs + (size_t)row * C;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), sm = p;
-    int c = 0;
-    for (; c + 8 <= C; c += 8) {
-      float4 qv[8], wv[8];
+  float4 p[QR_SB], sm[QR_SB], sv[QR_SB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        qv[u] = *reinterpret_cast<const float4*>(q + (size_t)(c + u) * N);
-        wv[u] = w4(c + u);
-      }
+  for (int u = 0; u < QR_SB; ++u) {
+    p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    sm[u] = p[u];
+    const int b = b0 + u < nb ? b0 + u : nb - 1;
+    sv[u] = *reinterpret_cast<const float4*>(s + (size_t)b * N + jj);
+  }
+  const float4 bt = *reinterpret_cast<const float4*>(beta + jj);
+  for (int c = c0; c < c1; ++c) {
+    float4 qv[QR_SB];
+    float cc[QR_SB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float cc = c1[c + u];
-        p.x = fmaf(wv[u].x, qv[u].x, p.x); p.y = fmaf(wv[u].y, qv[u].y, p.y);
-        p.z = fmaf(wv[u].z, qv[u].z, p.z); p.w = fmaf(wv[u].w, qv[u].w, p.w);
-        sm.x = fmaf(wv[u].x, cc, sm.x); sm.y = fmaf(wv[u].y, cc, sm.y);
-        sm.z = fmaf(wv[u].z, cc, sm.z); sm.w = fmaf(wv[u].w, cc, sm.w);
-      }
+    for (int u = 0; u < QR_SB; ++u) {
+      const int b = b0 + u < nb ? b0 + u : nb - 1;
+      qv[u] = *reinterpret_cast<const float4*>(Q + ((size_t)b * C + c) * N + jj);
+      cc[u] = b0 + u < nb ? cs[(size_t)b * C + c] : 0.f;
     }
-    for (; c < C; ++c) {
-      const float4 qv = *reinterpret_cast<const float4*>(q + (size_t)c * N), wv = w4(c);
-      const float cc = c1[c];
-      p.x = fmaf(wv.x, qv.x, p.x); p.y = fmaf(wv.y, qv.y, p.y); p.z = fmaf(wv.z, qv.z, p.z); p.w = fmaf(wv.w, qv.w, p.w);
-      sm.x = fmaf(wv.x, cc, sm.x); sm.y = fmaf(wv.y, cc, sm.y); sm.z = fmaf(wv.z, cc, sm.z); sm.w = fmaf(wv.w, cc, sm.w);
-    }
-    float4* Pp = reinterpret_cast<float4*>(P + (size_t)row * N + j);
-    float4* Sp = reinterpret_cast<float4*>(S + (size_t)row * N + j);
-    float4 a = *Pp, b = *Sp;
-    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
-    b.x += sm.x; b.y += sm.y; b.z += sm.z; b.w += sm.w;
-    *Pp = a;
-    *Sp = b;
-  } else {
-    const int c = row - nb;
-    float ct = 0.f;  // sum_b cs[b][c]
-    for (int b = 0; b < nb; ++b) ct += cs[(size_t)b * C + c];
-    if (blockIdx.x == 0 && threadIdx.x == 0) db2[c] += ct;
-    if (j >= N) return;
-    const float* q = Q + (size_t)c * N + j;
+    const float4 wv = w4(c);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int b = 0;
-    for (; b + 8 <= nb; b += 8) {
-      float4 qv[8], sv[8];
+    float ct = 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        qv[u] = *reinterpret_cast<const float4*>(q + (size_t)(b + u) * C * N);
-        sv[u] = *reinterpret_cast<const float4*>(s + (size_t)(b + u) * N + j);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < QR_SB; ++u) {
+      if (b0 + u < nb) {
+        p[u].x = fmaf(wv.x, qv[u].x, p[u].x); p[u].y = fmaf(wv.y, qv[u].y, p[u].y);
+        p[u].z = fmaf(wv.z, qv[u].z, p[u].z); p[u].w = fmaf(wv.w, qv[u].w, p[u].w);
+        sm[u].x = fmaf(wv.x, cc[u], sm[u].x); sm[u].y = fmaf(wv.y, cc[u], sm[u].y);
+        sm[u].z = fmaf(wv.z, cc[u], sm[u].z); sm[u].w = fmaf(wv.w, cc[u], sm[u].w);
         acc.x = fmaf(sv[u].x, qv[u].x, acc.x); acc.y = fmaf(sv[u].y, qv[u].y, acc.y);
         acc.z = fmaf(sv[u].z, qv[u].z, acc.z); acc.w = fmaf(sv[u].w, qv[u].w, acc.w);
+        ct += cc[u];
       }
     }
-    for (; b < nb; ++b) {
-      const float4 qv = *reinterpret_cast<const float4*>(q + (size_t)b * C * N);
-      const float4 sv = *reinterpret_cast<const float4*>(s + (size_t)b * N + j);
-      acc.x = fmaf(sv.x, qv.x, acc.x); acc.y = fmaf(sv.y, qv.y, acc.y); acc.z = fmaf(sv.z, qv.z, acc.z); acc.w = fmaf(sv.w, qv.w, acc.w);
+    if (live) {
+      acc.x = fmaf(bt.x, ct, acc.x); acc.y = fmaf(bt.y, ct, acc.y); acc.z = fmaf(bt.z, ct, acc.z); acc.w = fmaf(bt.w, ct, acc.w);
+      *reinterpret_cast<float4*>(ws + ((size_t)g * C + c) * N + j) = acc;
     }
-    const float4 bt = *reinterpret_cast<const float4*>(beta + j);
-    float4* dp = reinterpret_cast<float4*>(dW2 + (size_t)c * N + j);
-    float4 d = *dp;
-    d.x += acc.x + bt.x * ct; d.y += acc.y + bt.y * ct; d.z += acc.z + bt.z * ct; d.w += acc.w + bt.w * ct;
-    *dp = d;
+    if (lead) atomicAdd(db2 + c, ct);
+  }
+  if (!live) return;
+#pragma unroll
+  for (int u = 0; u < QR_SB; ++u) {
+    if (b0 + u < nb) {
+      float* Pp = P + (size_t)(b0 + u) * N + j;
+      float* Sp = S + (size_t)(b0 + u) * N + j;
+      atomicAdd(Pp + 0, p[u].x); atomicAdd(Pp + 1, p[u].y); atomicAdd(Pp + 2, p[u].z); atomicAdd(Pp + 3, p[u].w);
+      atomicAdd(Sp + 0, sm[u].x); atomicAdd(Sp + 1, sm[u].y); atomicAdd(Sp + 2, sm[u].z); atomicAdd(Sp + 3, sm[u].w);
+    }
   }
 }
 
+extern "C" int64_t vsx_grn_q_reduce_ws_floats(int32_t nb, int32_t C) { return (int64_t)vsx_cdiv(nb, QR_SB) * C * 4 * C; }
+
 extern "C" int32_t vsx_grn_q_reduce(const float* Q, const float* cs, const void* W2, const float* s, const float* beta, float* P,
-                                    float* S, float* dW2, float* db2, int32_t nb, int32_t C, int32_t dtype, vsx_stream_t stream) {
-  VSX_CHECK(Q && cs && W2 && s && beta && P && S && dW2 && db2 && nb > 0 && C > 0, "vsx_grn_q_reduce: bad arguments");
-  dim3 grid(vsx_cdiv(4 * C, 1024), nb + C);
+                                    float* S, float* dW2, float* db2, float* ws, int64_t ws_floats, int32_t nb, int32_t C,
+                                    int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(Q && cs && W2 && s && beta && P && S && dW2 && db2 && ws && nb > 0 && C > 0, "vsx_grn_q_reduce: bad arguments");
+  const int G = vsx_cdiv(nb, QR_SB), N = 4 * C;
+  VSX_CHECK(ws_floats >= (int64_t)G * C * N, "vsx_grn_q_reduce: workspace needs %ld floats (vsx_grn_q_reduce_ws_floats)",
+            (long)((int64_t)G * C * N));
+  VSX_CHECK((int64_t)C * N < (1ll << 31), "vsx_grn_q_reduce: C too large");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(vsx_cdiv(N, QR_TH * 4), G, vsx_cdiv(C, QR_CB));
   if (dtype == VSX_BF16)
-    hipLaunchKernelGGL(grn_q_reduce_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, Q, cs, (const bf16_t*)W2, s, beta, P, S,
-                       dW2, db2, nb, C);
+    hipLaunchKernelGGL(grn_q_reduce_kernel<bf16_t>, grid, dim3(QR_TH), 0, st, Q, cs, (const bf16_t*)W2, s, beta, P, S, ws, db2, nb, C);
   else
-    hipLaunchKernelGGL(grn_q_reduce_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, Q, cs, (const float*)W2, s, beta, P, S,
-                       dW2, db2, nb, C);
+    hipLaunchKernelGGL(grn_q_reduce_kernel<float>, grid, dim3(QR_TH), 0, st, Q, cs, (const float*)W2, s, beta, P, S, ws, db2, nb, C);
+  // dW2[c, j] += sum over the groups' partials (the [C, 4C] matrix seen as one row of C * 4C columns)
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv((long)C * N, 64), vsx_cdiv(G, 64)), dim3(256), 0, st, (const float*)ws, dW2, G,
+                     C * N);
   VSX_LAUNCH_CHECK();
   return 0;
 }

@@ -362,8 +362,10 @@ def grn_q_reduce(Q: Tensor, cs: Tensor, W2: Tensor, s: Tensor, beta: Tensor, P: 
     """GRN statistics P, S and the fc2 weight / bias gradient from the per-sample products Q[b] = dout_b^T g_b and the per-sample
     column sums cs[b] of dout (see vsx_grn_q_reduce)"""
     nb, C = cs.shape
-    check(lib().vsx_grn_q_reduce(ptr(Q), ptr(cs), ptr(W2), ptr(s), ptr(beta), ptr(P), ptr(S), ptr(dW2), ptr(db2), nb, C,
-                                 dtype_code(W2.dtype), stream()), "grn_q_reduce")
+    nws = int(lib().vsx_grn_q_reduce_ws_floats(nb, C))
+    ws = _workspace(Q.device, nws)
+    check(lib().vsx_grn_q_reduce(ptr(Q), ptr(cs), ptr(W2), ptr(s), ptr(beta), ptr(P), ptr(S), ptr(dW2), ptr(db2), ptr(ws), nws,
+                                 nb, C, dtype_code(W2.dtype), stream()), "grn_q_reduce")
 
 
 def mlp_bwd_stats(dout: Tensor, img2: Tensor, g: Tensor, P: Tensor, S: Tensor, M: int, C: int, hw: int) -> None:
