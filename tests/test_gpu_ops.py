@@ -195,6 +195,38 @@ def test_gemm_nt2_kernel(M, N, K, hw, epi):
     assert torch.equal(C2g, C21)
 
 
+@pytest.mark.parametrize("M,N,K,hw", [(512, 384, 1536, 256), (768, 224, 512, 256), (512, 96, 384, 512), (256, 768, 3072, 256)])
+def test_gemm_nt2_grn_prologue(M, N, K, hw):
+    """the fc2 forward with the GRN prologue on the second-generation kernel (A fragments scaled in registers): bit-identical
+    to the first-generation prologue kernel, and equal to the plain-PyTorch statement"""
+    if SELF_CHECK:
+        pytest.skip("self-check")
+    from viscy_amd import _lib
+
+    H, dt = _hip(), torch.bfloat16
+    A, Bw = rnd(M, K, dt=dt, seed=1), rnd(N, K, dt=dt, seed=2, scale=K**-0.5)
+    s, beta = 1 + 0.3 * rnd(M // hw, K, seed=3), 0.1 * rnd(K, seed=4)
+    res, bias = rnd(M, N, dt=dt, seed=5), rnd(N, seed=6)
+
+    def run(ops, dev):
+        C = torch.full((M, N), float("nan"), dtype=dt, device=dev)
+        ops.gemm("nt", A.to(dev), Bw.to(dev), C, M, N, K, K, K, N, dtype=dt, pro=R.PRO_GRN, grn_s=s.to(dev), grn_b=beta.to(dev), hw=hw,
+                 epi=R.EPI_BIAS_RES, bias=bias.to(dev), res=res.to(dev), ldr=N)
+        return C
+
+    l = _lib.lib()
+    old = l.vsx_get_flag(b"nt2")
+    try:
+        l.vsx_set_flag(b"nt2", 3)
+        C2 = run(H, DEV)
+        l.vsx_set_flag(b"nt2", 0)
+        C1 = run(H, DEV)
+    finally:
+        l.vsx_set_flag(b"nt2", old)
+    close(C2, run(R, "cpu"), dt, "grn-prologue gemm (second generation)")
+    assert torch.equal(C2, C1)
+
+
 def test_gemm_nt2_per_sample_weights():
     """VsxGemm.b_bstride on the second-generation kernel (the fc2 of the large feature maps)"""
     if SELF_CHECK:

@@ -34,7 +34,8 @@ def rnd(*s):
 SHAPES = []
 for name, side, C in [("s0", 64, 96), ("s1", 32, 192), ("s2", 16, 384), ("s3", 8, 768), ("d2", 64, 224)]:
     SHAPES += [(f"{name} fc1 e2", side, 4 * C, C, L.EPI_BIAS_GELU_SQ), (f"{name} dz e4", side, 4 * C, C, L.EPI_DZ),
-               (f"{name} fc2 e3", side, C, 4 * C, L.EPI_BIAS_RES), (f"{name} dgrad e0", side, C, 4 * C, L.EPI_NONE)]
+               (f"{name} fc2 e3", side, C, 4 * C, L.EPI_BIAS_RES), (f"{name} dgrad e0", side, C, 4 * C, L.EPI_NONE),
+               (f"{name} fc2 e3 grn", side, C, 4 * C, -L.EPI_BIAS_RES)]
 only = os.environ.get("ONLY")
 flags = [int(f) for f in os.environ.get("NT2", "0,3").split(",")]
 for name, side, N, K, epi in SHAPES:
@@ -45,7 +46,11 @@ for name, side, N, K, epi in SHAPES:
     A, W = rnd(M, K), rnd(N, K) * K**-0.5
     C1, C2 = torch.empty(M, N, device=dev, dtype=dt), torch.empty(M, N, device=dev, dtype=dt)
     bias, r0, r1 = torch.zeros(N, device=dev), torch.zeros(B, N, device=dev), torch.zeros(B, N, device=dev)
+    grn = epi < 0
+    epi = abs(epi)
     kw = dict(dtype=dt, hw=hw, epi=epi)
+    if grn:
+        kw.update(pro=L.PRO_GRN, grn_s=torch.ones(B, K, device=dev), grn_b=torch.zeros(K, device=dev))
     nbytes = (M * K + M * N + N * K) * 2
     if epi == L.EPI_BIAS_GELU_SQ:
         kw.update(bias=bias, red0=r0, C2=C2)

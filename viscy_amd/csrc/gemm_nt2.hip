@@ -57,11 +57,17 @@ struct Nt2Geom {
   static_assert(RED_OFF + 8 * 2 * (BN / 2) * 4 <= LDS_BYTES, "epilogue staging overlays the operand stages");
 };
 
-template <int EPI, int BN>
+// PRO: the GRN prologue a = bf16(g * s[b, k] + beta[k]) of the fc2 forward (VSX_PRO_GRN), applied to the A FRAGMENTS in registers
+// between their ds_read and the MFMAs (80 VALU operations per slab and lane next to 48 MFMAs; the first-generation kernel
+// does it in its ds_write staging pass, which the DMA path no longer has); s[b, :] and beta live in LDS behind the stages
+// (2 K floats).  One sample per tile (dispatch: hw % 256 == 0).  Same arithmetic, same rounding: bit-identical results.
+template <int EPI, int BN, bool PRO = false>
 __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_kernel(const VsxGemm p) {
   typedef Nt2Geom<BN> G;
   constexpr int FN = G::FN, A_BYTES = G::A_BYTES, STAGE = G::STAGE, WN = BN / 2;
+  constexpr int PRO_FLOATS = PRO ? 2 * 3072 : 4;   // s[b, :K] then beta[:K], K <= 3072
   __shared__ __attribute__((aligned(1024))) char smem[G::LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) float gsb[PRO_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -106,6 +112,14 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
                                        (__attribute__((address_space(3))) void*)(S + A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
   };
 
+  if constexpr (PRO) {
+    const float* gs = p.grn_s + (size_t)b_tile * p.K;
+    for (int i = tid; i < p.K; i += 512) {
+      gsb[i] = gs[i];
+      gsb[3072 + i] = p.grn_b[i];
+    }
+  }
+
   nt2_f32x4 acc[4][FN];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -116,11 +130,27 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
   const int fpos = (kq ^ ((p16 >> 2) & 2)) * 16;
   const int fragA = (wm * 64 + p16) * ROWB + fpos;
   const int fragB = A_BYTES + (wn * WN + p16) * ROWB + fpos;
-  auto compute = [&](int st) {
+  auto compute = [&](int st, int kt) {
     const char* S = smem + st * STAGE;
     nt2_bf16x8 af[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const nt2_bf16x8*>(S + fragA + i * 16 * ROWB);
+    if constexpr (PRO) {
+      // lane (p16, kq) holds k = kt * 32 + kq * 8 .. + 7 of its rows
+      const float* sp = gsb + kt * BK + kq * 8;
+      const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(sp + 3072), b1 = *reinterpret_cast<const float4*>(sp + 3076);
+      const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float f[8];
+        unpack<bf16_t>(__builtin_bit_cast(uint4, af[i]), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sv[e], bv[e]);
+        af[i] = __builtin_bit_cast(nt2_bf16x8, pack<bf16_t>(f));
+      }
+    }
 #pragma unroll
     for (int jg = 0; jg < FN; jg += 4) {  // B fragments four at a time (register budget of the 12-fragment geometry)
       nt2_bf16x8 bf[4];
@@ -149,7 +179,7 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
     }
     __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading the stage that is refilled next
     if (kt + 2 < nk) issue(kt + 2, stn);
-    compute(st);
+    compute(st, kt);
     st = st == NST - 1 ? 0 : st + 1;
     stn = stn == NST - 1 ? 0 : stn + 1;
   }
@@ -297,6 +327,13 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
 template <int EPI, int BN>
 int launch_bn(const VsxGemm* p, hipStream_t s) {
   const int tiles = (p->M / BM) * vsx_cdiv(p->N, BN);
+  if constexpr (EPI == VSX_EPI_BIAS_RES || EPI == VSX_EPI_NONE) {
+    if (p->pro == VSX_PRO_GRN) {
+      hipLaunchKernelGGL((gemm_nt2_kernel<EPI, BN, true>), dim3(tiles), dim3(512), 0, s, *p);
+      VSX_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((gemm_nt2_kernel<EPI, BN>), dim3(tiles), dim3(512), 0, s, *p);
   VSX_LAUNCH_CHECK();
   return 0;
@@ -330,7 +367,11 @@ int launch(const VsxGemm* p, hipStream_t s) {
 // true if this kernel family takes the launch (bf16 only; the caller has validated the common fields)
 bool vsx_gemm_nt2_ok(const VsxGemm* p) {
   if (!(g_vsx_nt2 & 1)) return false;
-  if (p->a_mode != VSX_A_ROWS || p->c_mode != VSX_A_ROWS || p->pro != VSX_PRO_NONE || p->nz > 1) return false;
+  if (p->a_mode != VSX_A_ROWS || p->c_mode != VSX_A_ROWS || p->nz > 1) return false;
+  if (p->pro != VSX_PRO_NONE) {  // GRN prologue: one sample per tile, epilogues of the fc2 forward only, s / beta fit the LDS copy
+    if (p->pro != VSX_PRO_GRN || p->hw <= 0 || p->hw % BM != 0 || p->K > 3072) return false;
+    if (p->epi != VSX_EPI_BIAS_RES && p->epi != VSX_EPI_NONE) return false;
+  }
   if (p->K % BK != 0 || p->M % BM != 0 || p->N < 64 || p->N % 8 != 0) return false;
   if (p->epi < VSX_EPI_NONE || p->epi > VSX_EPI_DZ) return false;
   const bool per_sample = p->epi == VSX_EPI_BIAS_GELU_SQ || p->epi == VSX_EPI_DZ || p->rscale != nullptr;
@@ -346,6 +387,7 @@ bool vsx_gemm_nt2_ok(const VsxGemm* p) {
   const int bn = pick_bn(p->N);
   if ((long)(p->M / BM) * vsx_cdiv(p->N, bn) < 256) return false;  // few tiles: the BK = 128 generic path
   if (p->epi == VSX_EPI_DZ) return false;
+  if (p->pro == VSX_PRO_GRN) return p->K >= 768 && p->N >= 192;  // the fc2 forward of the 16 x 16 maps (C = 384)
   if (p->epi == VSX_EPI_BIAS_GELU_SQ) return bn == 384 && p->N % 384 == 0 && p->K >= 384 && p->K <= 768;
   return p->K >= 768 && p->N > 192;
 }
