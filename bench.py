@@ -62,7 +62,7 @@ def build_info() -> dict:
     return info
 
 
-FLAG_NAMES = ["tn_tr", "nt_wide", "nt_fast", "tn_wide", "nt_tall", "nt_stream", "grn_stream", "ggb_contig", "tn_want", "tn_contig",
+FLAG_NAMES = ["tn_tr", "nt_wide", "nt_fast", "tn_wide", "nt_tall", "nt2", "nt_stream", "grn_stream", "ggb_contig", "tn_want", "tn_contig",
               "ln_stream", "ggb_blocks", "tn_rect", "dw_rows2", "dw_wg16", "dw_mfma", "ln_fblk", "ln_bblk", "mlp_fused"]
 
 
@@ -411,10 +411,10 @@ def main():
             roof["strict_frac"] = round(dom["strict_bytes"] / dom["launches"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)  # operands + ONE output only
             # HBM traffic of the dominant kernel class: PMC counters cannot be read from inside this process, so the
             # figure comes from the committed rocprofv3 --pmc passes of the SAME configuration (scripts/pmc_traffic.sh ->
-            # profiles/r02_pmc_traffic_b<batch>.json: FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a launch with
+            # profiles/r03_pmc_traffic_b<batch>.json: FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a launch with
             # a known byte count as MI355X_MICROARCH.md prescribes).  The file records the kernel-source hash and the flag
             # set it was measured with; a file from other sources / flags is refused (traffic stays null).
-            tf_path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_b{B}.json")
+            tf_path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_b{B}.json")
             if args.size == 256 and args.dtype == "bf16" and os.path.exists(tf_path):
                 try:
                     tfj = json.load(open(tf_path))

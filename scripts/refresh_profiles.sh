@@ -4,7 +4,7 @@
 # Run through gpurun, then `bash scripts/refresh_profiles.sh --collect` locally copies gpurun_out/* into profiles/.
 cd "$(dirname "$0")/.."
 if [ "$1" == "--collect" ]; then
-  R=${ROUND:-r02}
+  R=${ROUND:-r03}
   cp gpurun_out/kernel_stats.csv profiles/${R}_kernel_stats.csv
   cp gpurun_out/by_kernel_and_grid.txt profiles/${R}_by_kernel_and_grid.txt
   cp gpurun_out/prof_bench.json profiles/${R}_bench_under_rocprof.json
@@ -22,6 +22,6 @@ rm -rf gpurun_out/prof
 bash scripts/pmc_traffic.sh 512 2 train pmc_traffic > /dev/null 2>&1
 bash scripts/pmc_traffic.sh 512 3 fwd pmc_traffic_fwd > /dev/null 2>&1
 # the bench line needs the traffic file of THIS source state in place to attach roofline.traffic
-cp gpurun_out/pmc_traffic.json profiles/r02_pmc_traffic_b512.json
+cp gpurun_out/pmc_traffic.json profiles/r03_pmc_traffic_b512.json
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 cat gpurun_out/bench_default.json

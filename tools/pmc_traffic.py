@@ -59,6 +59,8 @@ def main(fetch_csv, write_csv, steps, batch, out):
         base = re.sub(r"^_Z\d+", "", k)
         base = re.sub(r"_kernel.*", "", base)
         base = {"gemm_nt_fast": "gemm_nt", "gemm_tn_fast": "gemm_tn"}.get(base, base)
+        if "gemm_nt2" in base:  # second-generation NT kernel (anonymous namespace: _ZN12_GLOBAL__N_1...)
+            base = "gemm_nt"
         if base.startswith("mlp_fused"):  # bench.py's OpTimer classes = the ops wrappers of the five passes
             base = {"0": "mlp_stats", "1": "mlp_out", "2": "mlp_fc1", "3": "mlp_bwd_stats", "4": "mlp_bwd_dh"}.get(k[-1], "mlp_fused")
         for f in ("launches_per_step", "read_GB_per_step", "write_GB_per_step"):

@@ -64,6 +64,8 @@ struct MlpArgs {
   float* ws;            // [M / BM, 4C] per-workgroup column sums of dh (MODE 4)
   const float* gtab;    // [MLP_GT_N] r(a) = a * Phi(-a) for every bf16 a in [2^-24, 16)  (vsx_mlp_gelu_table)
   int M, hw;
+  int nt;               // bit 0: non-temporal stores of h / g / dh (read by a later launch only), bit 1: non-temporal load of the stored
+                        // activation (MODE 3: g, MODE 4: h — this pass is its last reader)
 };
 
 // GELU through a table: the pre-activation h is a bf16 value, so gelu(h) = max(h, 0) - r(|h|) with r(a) = a * Phi(-a) read
@@ -252,8 +254,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
 #pragma unroll
       for (int i = 0; i < (WM * 8) / 64; ++i) {
         const int idx = lane + 64 * i, row = idx >> 3, ch = idx & 7;
-        const uint4 v = *reinterpret_cast<const uint4*>(a.tin + (size_t)(row0 + row) * H4 + hs * 32 + ch * 8);
-        tq[i] = v;
+        tq[i] = ldvec_stream<bf16_t>(a.tin + (size_t)(row0 + row) * H4 + hs * 32 + ch * 8, (a.nt & 2) != 0);
       }
     }
   };
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
       for (int i = 0; i < (WM * 8) / 64; ++i) {
         const int idx = lane + 64 * i, row = idx >> 3, ch = idx & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(sb + row * G::OB_RS + ch * 16);
-        *reinterpret_cast<uint4*>(a.hout + (size_t)(row0 + row) * H4 + (hs - 1) * 32 + ch * 8) = v;
+        stvec_stream(a.hout + (size_t)(row0 + row) * H4 + (hs - 1) * 32 + ch * 8, v, (a.nt & 1) != 0);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
         const int row = rem >> 3, ch = rem & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(sb + (o * WM + row) * G::OB_RS + ch * 16);
         bf16_t* dst = (o ? a.gout : a.hout) + (size_t)(row0 + row) * H4 + (hs - 1) * 32 + ch * 8;
-        *reinterpret_cast<uint4*>(dst) = v;
+        stvec_stream(dst, v, (a.nt & 1) != 0);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -631,6 +632,8 @@ struct MlpCfg { int C, MF, NW, modes; };  // modes: bit m set = this geometry se
 // (fc1 -12 %, backward -4 %), the block's backward no longer writes dz and reads it back (-0.7 GB per block and step at
 // B = 512) — the inference pair behind bit 4 (slower than the unfused GEMMs: off).
 extern int g_vsx_mlp_fused;
+extern int g_vsx_nt_stream;
+static inline int mlp_nt() { return (g_vsx_nt_stream >> 2) & 3; }  // bits 2 / 3 of nt_stream: the fused passes' stores / last-reader loads
 static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 31}, {192, 2, 8, 31}, {224, 2, 8, 31}, {384, 2, 8, 1 | 4 | 8 | 16}, {384, 2, 4, 2}};
 
 static const MlpCfg* mlp_cfg(int C, int hw, long M, int mode) {
@@ -711,7 +714,7 @@ extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1
   MlpArgs a;
   a.xh = (const bf16_t*)xh; a.wimg = (const char*)wimg; a.b1 = b1; a.grn_s = grn_s; a.grn_b = grn_b; a.b2 = b2;
   a.res = (const bf16_t*)res; a.rscale = rscale; a.out = (bf16_t*)out; a.colsq = colsq; a.gtab = gtab; a.M = (int)M; a.hw = hw;
-  a.hout = nullptr; a.gout = nullptr; a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr;
+  a.hout = nullptr; a.gout = nullptr; a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.nt = 0;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) {
     VSX_CHECK(colsq != nullptr, "vsx_mlp_fwd: mode 0 needs colsq");
@@ -733,7 +736,7 @@ extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1
   MlpArgs a;
   a.xh = (const bf16_t*)xh; a.wimg = (const char*)wimg; a.b1 = b1; a.grn_s = nullptr; a.grn_b = nullptr; a.b2 = nullptr;
   a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = colsq; a.gtab = gtab; a.hout = (bf16_t*)h; a.gout = (bf16_t*)g;
-  a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr;
+  a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.nt = mlp_nt();
   a.M = (int)M; a.hw = hw;
   return mlp_dispatch<2>(c, a, (hipStream_t)stream);
 }
@@ -744,7 +747,7 @@ __global__ void reduce_rows_kernel(const float* __restrict__ ws, float* __restri
 static void mlp_bwd_args(MlpArgs& a, const void* dout, const void* wimg, const void* tin, int64_t M, int32_t hw) {
   a.xh = (const bf16_t*)dout; a.wimg = (const char*)wimg; a.b1 = nullptr; a.grn_s = nullptr; a.grn_b = nullptr; a.b2 = nullptr;
   a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = nullptr; a.gtab = nullptr; a.hout = nullptr; a.gout = nullptr;
-  a.tin = (const bf16_t*)tin; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.M = (int)M; a.hw = hw;
+  a.tin = (const bf16_t*)tin; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.M = (int)M; a.hw = hw; a.nt = mlp_nt();
 }
 
 /* MODE 3: the GRN statistics path of the block backward without a stored dz: dz = dout . W2 recomputed tile by tile
