@@ -337,6 +337,10 @@ int32_t vsx_mlp_gelu_table(float* tab, vsx_stream_t stream);
  * host runs ahead. */
 int32_t vsx_adamw_advance(const double* cfg, int32_t* step, float* hyper, vsx_stream_t stream);
 
+/* p[0 .. n) = value (16-byte aligned p): `optimizer.zero_grad()` on the flat gradient buffer, the zero-filled reduction
+ * targets of a pass, start values of running maxima — ordinary kernel nodes in the captured step. */
+int32_t vsx_fill_f32(float* p, int64_t n, float value, vsx_stream_t stream);
+
 /* fp32 parameter viewed as [R, Cs, Tn] (out, in, taps) → GEMM operand dst [R, Tn*Cs] and/or dstT [Tn*Cs, R] in `dtype`, optionally scaled per
  * input channel by gamma (LayerNorm fold).  tapmode 1 = head Conv3d tap order (kz,ky,kx) → (ky,kx,kz). */
 int32_t vsx_prep_weight(const float* src, void* dst, void* dstT, const float* gamma, int32_t R, int32_t Cs,

@@ -469,10 +469,11 @@ def g8_wiring():
 def g8b_baseline_size():
     """tests/golden/unext2_tiny_256.pt — the BASELINE configuration at the BASELINE patch size, from the reference's own
     wiring (g8_wiring must have run: the reference unext2.py is loaded on the stub timm / monai modules): tiny, B = 4,
-    Z = 5, 256 x 256, 1 -> 2 ch.  fp32 forward (strided sample), MixedLoss(0.5, 0, 0.5) value, a strided sample of every
-    parameter gradient, and the SAME module under ``torch.autocast(bfloat16)`` — the arithmetic Lightning's bf16-mixed runs —
-    as the yardstick for the production bf16 kernels: forward error and per-stage gradient error of autocast against fp32.
-    The GPU test (tests/test_gpu_model.py) holds the fp32 engine to 1e-3 and the bf16 engine to 1.25 x that yardstick."""
+    Z = 5, 256 x 256, 1 -> 2 ch.  fp32 forward (strided sample), MixedLoss(0.5, 0, 0.5) value and a strided sample of every
+    parameter gradient.  The GPU test (tests/test_gpu_model.py) holds the fp32 engine to 1e-3 against these values and the
+    production bf16 kernels to 1.25 x the error of the same module under ``torch.autocast(bfloat16)`` — the arithmetic
+    Lightning's bf16-mixed runs — which the TEST computes on the GPU next to the engine: the CPU autocast backward is not
+    reproducible run to run (its stem-stage gradient noise moved between 0.8 % and 1.4 % here), so it cannot be a fixture."""
     import time
 
     R = unext2_ref
@@ -497,39 +498,24 @@ def g8b_baseline_size():
             return "dec_" + p[2]
         return p[0]
 
-    def run(autocast: bool):
-        for p in r.parameters():
-            p.grad = None
-        t0 = time.time()
-        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
-            y = r(x)
-        loss = loss_ref.mixed_loss(y.float(), tgt, 0.5, 0.0, 0.5)
-        loss.backward()
-        print(f"   {'autocast(bf16)' if autocast else 'fp32'} forward + backward: {time.time() - t0:.0f} s, loss {loss.item():.6f}")
-        return y.detach().float(), loss.item(), {n: p.grad.detach().clone() for n, p in r.named_parameters()}
-
-    y32, l32, g32 = run(False)
-    yac, lac, gac = run(True)
+    t0 = time.time()
+    y = r(x)
+    loss = loss_ref.mixed_loss(y, tgt, 0.5, 0.0, 0.5)
+    loss.backward()
+    y32, l32 = y.detach(), loss.item()
+    g32 = {n: p.grad.detach().clone() for n, p in r.named_parameters()}
     groups = {}
     for n in g32:
         groups.setdefault(group_of(n), []).append(n)
-    yard = {"forward_max_rel": ((yac - y32).abs().max() / y32.abs().max()).item(), "loss_rel": abs(lac - l32) / abs(l32), "grad": {}}
-    for gname, names in groups.items():
-        a = torch.cat([g32[n].flatten() for n in names]).double()
-        b = torch.cat([gac[n].flatten() for n in names]).double()
-        yard["grad"][gname] = {"one_minus_cos": 1.0 - torch.nn.functional.cosine_similarity(a, b, dim=0).item(),
-                               "rel_l2": ((a - b).norm() / a.norm()).item()}
     samples = {}
     for n, gr in g32.items():
         f = gr.flatten()
         st = max(1, f.numel() // 1024)
         samples[n] = (st, f[::st].clone())
     gold = {"kwargs": kw, "seed": 13, "x_seed": 2024, "shape": (B, S), "y_stride": 4, "y": y32[..., ::4, ::4].clone(), "y_absmax": y32.abs().max().item(),
-            "loss": l32, "grad_samples": samples, "grad_group_norm": {gn: torch.cat([g32[n].flatten() for n in ns]).double().norm().item() for gn, ns in groups.items()},
-            "groups": groups, "autocast_yardstick": yard}
+            "loss": l32, "grad_samples": samples, "groups": groups}
     torch.save(gold, os.path.join(GOLD, "unext2_tiny_256.pt"))
-    print(f"G8b baseline size: reference tiny B=4 256x256 fp32 + autocast yardstick written "
-          f"(autocast forward err {yard['forward_max_rel']:.3e}, worst stage 1-cos {max(v['one_minus_cos'] for v in yard['grad'].values()):.3e})")
+    print(f"G8b baseline size: reference tiny B=4 256x256 fp32 forward / loss {l32:.6f} / gradient samples written ({time.time() - t0:.0f} s)")
 
 
 def g9_fcmae():

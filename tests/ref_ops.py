@@ -396,6 +396,14 @@ def mlp_supported(C, hw, M, dtype, mode=None) -> bool:
     return False
 
 
+def fill_(t, value=0.0):
+    return t.fill_(value)
+
+
+def zeros(*shape, device):
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 def adamw_advance(cfg, step, hyper):
     import math
 

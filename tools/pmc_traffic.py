@@ -17,6 +17,7 @@ def load(path, counter):
             if m:  # the pass (template MODE) is what the op classes of bench.py distinguish
                 rows.append((f"mlp_fused_kernel_mode{m.group(1)}", float(r["Counter_Value"])))
                 continue
+            kn = kn.replace("(anonymous namespace)::", "")  # gemm_nt2_kernel lives in an anonymous namespace
             rows.append((re.sub(r"[<(].*", "", kn).replace("void ", "").strip(), float(r["Counter_Value"])))
     return rows
 

@@ -79,6 +79,7 @@ _SIGS = {
     "vsx_ssim_scale_bwd_in": (_I32, [_P] * 6 + [_I32] * 5 + [_F32, _F32, _P, _I32, _I32, _P]),
     "vsx_adamw": (_I32, [_P, _P, _P, _P, _P, _I64, _P]),
     "vsx_adamw_advance": (_I32, [_P, _P, _P, _P]),
+    "vsx_fill_f32": (_I32, [_P, _I64, _F32, _P]),
     "vsx_mlp_supported": (_I32, [_I32, _I32, _I64, _I32]),
     "vsx_mlp_mode_supported": (_I32, [_I32, _I32, _I64, _I32, _I32]),
     "vsx_mlp_image_bytes": (_I64, [_I32]),

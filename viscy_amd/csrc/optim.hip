@@ -63,6 +63,23 @@ extern "C" int32_t vsx_adamw(float* p, const float* g, float* m, float* v, const
   return 0;
 }
 
+// ------------------------------------------------------------------ fill (zero_grad, reduction targets, the loss's scalar block)
+// The captured step carries no library launch: gradient zeroing, the zero arenas of the two passes and the loss's running
+// max start value are ordinary kernel nodes of this library (they were ATen fills).
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ p, long n, float v) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) *reinterpret_cast<float4*>(p + i) = make_float4(v, v, v, v);
+  else for (; i < n; ++i) p[i] = v;
+}
+
+extern "C" int32_t vsx_fill_f32(float* p, int64_t n, float value, vsx_stream_t stream) {
+  VSX_CHECK(p != nullptr && n >= 0 && ((uintptr_t)p & 15) == 0, "vsx_fill_f32: null or unaligned pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(vsx_cdiv(n, 1024L)), dim3(256), 0, (hipStream_t)stream, p, (long)n, value);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------ schedule + bias corrections on the device
 // One thread turns (constants, step counter) into the 8 per-step scalars the AdamW launch reads and advances the
 // counter.  The first version refreshed those scalars from a pinned host block with an asynchronous copy inside the

@@ -47,11 +47,16 @@ class _ZeroArena:
     0.74 ms per step in the kernel trace).  Sized from the previous pass with the same key; a pass that needs more than
     was recorded falls back to individual allocations (and records the new size)."""
 
-    def __init__(self, dev, numel: int):
-        self.dev = dev
-        self.buf = torch.zeros(numel, dtype=torch.float32, device=dev) if numel > 0 else None
+    def __init__(self, dev, numel: int, ops=None):
+        self.dev, self.ops = dev, ops
+        self.buf = self._zeros(numel) if numel > 0 else None
         self.off = 0
         self.used = 0
+
+    def _zeros(self, *shape) -> Tensor:
+        if self.ops is not None and hasattr(self.ops, "zeros"):
+            return self.ops.zeros(*shape, device=self.dev)  # vsx_fill_f32: the captured step holds no ATen fill
+        return self._zeros(*shape)
 
     def take(self, *shape) -> Tensor:
         n = 1
@@ -484,7 +489,7 @@ class Engine:
         W = self.prepare(dt, need_bwd)
         B, Cin, Z, H, Wd = x.shape
         za_key = ("fwd", B, H, Wd, masks is not None)
-        self._za = za = _ZeroArena(x.device, self._za_need.get(za_key, 0))
+        self._za = za = _ZeroArena(x.device, self._za_need.get(za_key, 0), self.ops)
         # FCMAE 2-D branch (fcmae.py:369-370): the reference runs conv2d whenever x.shape[2] == 1, whatever in_stack_depth is —
         # a 2-D FCMAE (in_stack_depth = 1) trains and loads its conv2d weights, never the conv3d ones
         flat_stem = Z == 1 and "stem2d_W" in W
@@ -751,7 +756,7 @@ class Engine:
         B, H, Wd = sv["shape"]
         dev = self.device
         za_key = ("bwd", B, H, Wd, sv["masked"])
-        self._za = za = _ZeroArena(dev, self._za_need.get(za_key, 0))
+        self._za = za = _ZeroArena(dev, self._za_need.get(za_key, 0), self.ops)
         if cfg.get("head") == "embed":
             d = self._embed_tail_bwd(sv, dout[0], dout[1], dt, B)
         elif cfg.get("head", "conv") == "shuffle":

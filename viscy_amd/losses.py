@@ -45,12 +45,15 @@ class _MixedLossFn(torch.autograd.Function):
             raise ValueError(f"MS-SSIM with 5 scales needs Y, X >= 176 (got {H}x{W}): the 11x11 window must fit at 1/16 scale")
         l = lib()
         s = stream()
-        scal = torch.zeros(2 + 5 + 10 * B, dtype=torch.float32, device=dev)
+        # [l1sum, l2sum, pad, pad | tmax x 5, pad x 3 | sum_ssim 5B | sum_cs 5B]: zero / -inf by vsx_fill_f32 (16-byte aligned
+        # pieces; the captured step holds no ATen fill)
+        scal = torch.empty(12 + 10 * B, dtype=torch.float32, device=dev)
+        check(l.vsx_fill_f32(ptr(scal), scal.numel(), 0.0, s), "fill")
         l1sum, l2sum = scal[0:1], scal[1:2]
-        tmax = scal[2:7]
-        tmax.fill_(float("-inf"))
-        sum_ssim = scal[7 : 7 + 5 * B]
-        sum_cs = scal[7 + 5 * B : 7 + 10 * B]
+        tmax = scal[4:9]
+        check(l.vsx_fill_f32(ptr(scal[4:12]), 8, float("-inf"), s), "fill")
+        sum_ssim = scal[12 : 12 + 5 * B]
+        sum_cs = scal[12 + 5 * B : 12 + 10 * B]
         Ps, Ts, dims = [P0], [T0], [(H, W)]
         planes = B * C * D
         nlev = max(ns, 1)
@@ -100,8 +103,8 @@ class _MixedLossFn(torch.autograd.Function):
         dev = Ps[0].device
         l, s = lib(), stream()
         go = gout.detach().float().reshape(1).contiguous()  # stays on the device: no host sync
-        sum_ssim = scal[7 : 7 + 5 * B]
-        sum_cs = scal[7 + 5 * B : 7 + 10 * B]
+        sum_ssim = scal[12 : 12 + 5 * B]
+        sum_cs = scal[12 + 5 * B : 12 + 10 * B]
         coef = torch.empty(max(ns, 1) * B * 2, dtype=torch.float32, device=dev)
         tmp = torch.empty(2, dtype=torch.float32, device=dev)
         check(l.vsx_loss_finalize(ptr(sum_ssim), ptr(sum_cs), ptr(scal[0:1]), ptr(scal[1:2]), ptr(npix_d), nelem, B,

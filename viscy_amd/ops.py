@@ -308,6 +308,19 @@ def prep_head_dgrad(W: Tensor, Cmid: int, C3: int, Zout: int, dtype: torch.dtype
     return dst
 
 
+def fill_(t: Tensor, value: float = 0.0) -> Tensor:
+    """t[...] = value for a contiguous fp32 tensor (vsx_fill_f32: a kernel node of this library, not an ATen fill)"""
+    if t.dtype != torch.float32:
+        raise TypeError("fill_ is for float32 buffers")
+    check(lib().vsx_fill_f32(ptr(t), t.numel(), float(value), stream()), "fill_f32")
+    return t
+
+
+def zeros(*shape, device) -> Tensor:
+    """zero-filled fp32 tensor (allocation by the caching allocator, fill by vsx_fill_f32)"""
+    return fill_(torch.empty(shape, dtype=torch.float32, device=device), 0.0)
+
+
 def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, hyper: Tensor) -> None:
     check(lib().vsx_adamw(ptr(p), ptr(g), ptr(m), ptr(v), ptr(hyper), p.numel(), stream()), "adamw")
 

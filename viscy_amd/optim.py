@@ -67,7 +67,10 @@ class FlatAdamW:
         return self.base_lr
 
     def zero_grad(self) -> None:
-        self.engine.flat_grad.zero_()
+        if hasattr(self.ops, "fill_"):
+            self.ops.fill_(self.engine.flat_grad, 0.0)  # vsx_fill_f32 (no ATen launch in the captured step)
+        else:
+            self.engine.flat_grad.zero_()
         if hasattr(self.engine, "_pending_bwd"):
             self.engine._pending_bwd = 0  # a new step: no forward of it is waiting for its backward yet
 

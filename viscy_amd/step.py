@@ -64,8 +64,9 @@ class TrainStep:
             ctx = _Ctx()
             loss = _MixedLossFn.forward(ctx, pred, self.t, float(self.crit.l1_alpha), float(self.crit.l2_alpha),
                                         float(self.crit.ms_dssim_alpha))
-            one = torch.ones((), dtype=torch.float32, device=pred.device)
-            return loss, _MixedLossFn.backward(ctx, one)[0]
+            if getattr(self, "_one", None) is None or self._one.device != pred.device:
+                self._one = torch.ones((), dtype=torch.float32, device=pred.device)  # created once, outside any capture
+            return loss, _MixedLossFn.backward(ctx, self._one)[0]
         p = pred.detach().requires_grad_(True)
         with torch.enable_grad():
             loss = self.crit(p, self.t)
