@@ -370,7 +370,7 @@ def test_baseline_size_fp32_and_bf16_engines_vs_reference_golden():
                 b.append(grad_of(n).flatten()[::stride].double().cpu())
             a, b = torch.cat(a), torch.cat(b)
             stages[gname] = (1.0 - torch.nn.functional.cosine_similarity(a, b, dim=0).item(), ((a - b).norm() / a.norm()).item())
-        return fwd, abs(float(loss) - gold["loss"]) / abs(gold["loss"]), stages
+        return fwd, abs(float(loss.detach()) - gold["loss"]) / abs(gold["loss"]), stages
 
     def run_engine(dt):
         m = UNeXt2(**kw)
@@ -391,10 +391,13 @@ def test_baseline_size_fp32_and_bf16_engines_vs_reference_golden():
         o = o.cuda()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = o(x.cuda())
-        loss = loss_ref.mixed_loss(y.float(), tgt.cuda(), 0.5, 0.0, 0.5)
+        # the loss and its gradient in fp32 on the host (oracle/loss_ref.py is CPU code), as bf16-mixed keeps the loss in fp32
+        yc = y.detach().float().cpu().requires_grad_(True)
+        loss = loss_ref.mixed_loss(yc, tgt, 0.5, 0.0, 0.5)
         loss.backward()
+        y.backward(yc.grad.to(device=y.device, dtype=y.dtype))
         named = dict(o.named_parameters())
-        return score(y, loss, lambda n: named[n].grad)
+        return score(y, loss.detach(), lambda n: named[n].grad)
 
     fwd, lrel, stages = run_engine(torch.float32)
     print("fp32 engine @256: forward", f"{fwd:.2e}", "loss", f"{lrel:.2e}", {k: f"{v[0]:.1e}/{v[1]:.1e}" for k, v in stages.items()})
