@@ -59,6 +59,11 @@ int32_t vsx_get_flag(const char* name);
 #define VSX_EPI_BIAS_RES 3     /* c = acc + bias[n] + res[m, n]   (bias may be NULL)      (fc2 + residual)   */
 #define VSX_EPI_DZ 4           /* c = dz = acc; red0[b, n] += dz * aux[m, n] (aux = g); red1[b, n] += dz  (fc2 dgrad) */
 #define VSX_EPI_BIAS_STATS 5   /* c = acc + bias; red0[b, n] += c; red1[b, n] += c^2      (head conv + IN)   */
+#define VSX_EPI_LN_BWD 6       /* c = rstd[m] * (d - mean_n(d) - xh * mean_n(d * xh)),  d = acc rounded to the storage type:
+                                * the backward of an affine-free LayerNorm over the N columns applied to the GEMM result (fc1 data
+                                * gradient + block LayerNorm backward in one launch).  aux = xh [M, ldx] (the normalised rows),
+                                * grn_s = rstd [M] (fp32).  bf16, plain row operands, N <= 256, M % 256 == 0, K % 32 == 0 only
+                                * (vsx_gemm_nt_ln_bwd_supported). */
 
 typedef struct VsxGemm {
   /* C[M, N] = pro(A)[M, K] * B[N, K]^T  (vsx_gemm_nt)   |   W[N, K] += X[M, N]^T * pro(A)[M, K]  (vsx_gemm_tn) */
@@ -104,6 +109,8 @@ typedef struct VsxGemm {
  * the decoder 1x1 projection (viscy_models/components/blocks.py:54-74) and the head Conv3d
  * (viscy_models/components/heads.py:617-625). */
 int32_t vsx_gemm_nt(const VsxGemm* p, int32_t dtype, vsx_stream_t stream);
+/* 1 if vsx_gemm_nt takes VSX_EPI_LN_BWD for this shape (otherwise: a plain vsx_gemm_nt followed by vsx_ln_bwd) */
+int32_t vsx_gemm_nt_ln_bwd_supported(int64_t M, int32_t N, int32_t K, int32_t dtype);
 /* weight-gradient GEMM (contraction over pixels) for the same layers */
 int32_t vsx_gemm_tn(const VsxGemm* p, int32_t dtype, vsx_stream_t stream);
 

@@ -227,6 +227,35 @@ def test_gemm_nt2_grn_prologue(M, N, K, hw):
     assert torch.equal(C2, C1)
 
 
+@pytest.mark.parametrize("M,C", [(512, 96), (768, 192), (512, 224), (256, 256), (1024, 64)])
+def test_fc1_data_gradient_with_layernorm_backward_epilogue(M, C):
+    """VSX_EPI_LN_BWD (csrc/gemm_nt2.hip): dy = LN_backward(dh . W1; xh, rstd) in one launch against the unfused pair (NT GEMM
+    that stores dx^ in bf16, then vsx_ln_bwd) and against the plain-PyTorch statement with the same rounding point"""
+    if SELF_CHECK:
+        pytest.skip("HIP-only kernel")
+    from viscy_amd import ops
+
+    dt, K = torch.bfloat16, 4 * C
+    dh = rnd(M, K, dt=dt, seed=1).cuda()
+    WT = rnd(C, K, dt=dt, seed=2, scale=K**-0.5).cuda()
+    y = rnd(M, C, seed=3) * (1 + torch.arange(M).float()[:, None] / M) + 0.3
+    mu, var = y.mean(1, keepdim=True), y.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-6).rsqrt()
+    xh = ((y - mu) * rstd).to(dt).cuda()
+    rstd = rstd[:, 0].contiguous().cuda()
+    assert ops.dgrad_ln_bwd(dh, WT, xh, rstd, M + 8, C, K) is None  # M % 256 != 0: not served, the caller falls back
+    dy = ops.dgrad_ln_bwd(dh, WT, xh, rstd, M, C, K)
+    assert dy is not None and dy.shape == (M, C) and dy.dtype == dt
+    dxh = torch.empty((M, C), dtype=dt, device="cuda")
+    ops.gemm("nt", dh, WT, dxh, M, C, K, K, K, C, dtype=dt)
+    dy_unfused = ops.ln_bwd(dxh, xh, None, rstd, None, None, None, None, M, C)
+    d = (dh.float() @ WT.float().T).to(dt).float()   # dx^ as the unfused pair stores it
+    xf = xh.float()
+    ref = rstd[:, None] * (d - d.mean(1, keepdim=True) - xf * (d * xf).mean(1, keepdim=True))
+    close(dy, ref, dt, "fused vs statement")
+    close(dy, dy_unfused, dt, "fused vs unfused pair")
+
+
 def test_gemm_nt2_per_sample_weights():
     """VsxGemm.b_bstride on the second-generation kernel (the fc2 of the large feature maps)"""
     if SELF_CHECK:

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("VSX_LIB", os.path.join(_HERE, "libvsx.so"))  # VSX_LI
 VSX_F32, VSX_BF16 = 0, 1
 A_ROWS, A_PATCH2, A_CONV3 = 0, 1, 2
 PRO_NONE, PRO_GRN = 0, 1
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_SQ, EPI_BIAS_RES, EPI_DZ, EPI_BIAS_STATS = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_SQ, EPI_BIAS_RES, EPI_DZ, EPI_BIAS_STATS, EPI_LN_BWD = 0, 1, 2, 3, 4, 5, 6
 
 _I32, _F32, _P, _I64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
 
@@ -50,6 +50,7 @@ _SIGS = {
     "vsx_get_flag": (_I32, [C.c_char_p]),
     "vsx_gemm_nt": (_I32, [C.POINTER(VsxGemm), _I32, _P]),
     "vsx_gemm_tn": (_I32, [C.POINTER(VsxGemm), _I32, _P]),
+    "vsx_gemm_nt_ln_bwd_supported": (_I32, [_I64, _I32, _I32, _I32]),
     "vsx_ln_fwd": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I32, _F32, _I32, _P]),
     "vsx_ln_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P]),
     "vsx_grn_scale": (_I32, [_P, _P, _P, _I32, _I32, _F32, _P]),

@@ -27,6 +27,7 @@ extern int g_vsx_nt_stream;
 extern int g_vsx_tn_want;
 extern int g_vsx_tn_contig;
 bool vsx_gemm_nt2_ok(const VsxGemm* p);           // gemm_nt2.hip
+bool vsx_gemm_nt2_lnbwd_ok(const VsxGemm* p);
 int vsx_gemm_nt2(const VsxGemm* p, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
@@ -907,9 +908,20 @@ extern "C" int32_t vsx_gemm_nt(const VsxGemm* p, int32_t dtype, vsx_stream_t str
   if (p->epi == VSX_EPI_BIAS_STATS) VSX_CHECK(p->red1 != nullptr, "vsx_gemm_nt: EPI_BIAS_STATS needs red1");
   if (p->epi == VSX_EPI_BIAS_RES) VSX_CHECK(p->res != nullptr, "vsx_gemm_nt: EPI_BIAS_RES needs res");
   if (p->rscale) VSX_CHECK(p->epi == VSX_EPI_BIAS_RES && p->hw > 0, "vsx_gemm_nt: rscale needs EPI_BIAS_RES and hw");
+  if (p->epi == VSX_EPI_LN_BWD)
+    VSX_CHECK(dtype == VSX_BF16 && p->aux && p->grn_s && p->C && vsx_gemm_nt2_lnbwd_ok(p),
+              "vsx_gemm_nt: EPI_LN_BWD needs bf16 row operands, aux = xh, grn_s = rstd, N <= 256, M %% 256 == 0, K %% 32 == 0 "
+              "(query vsx_gemm_nt_ln_bwd_supported)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == VSX_BF16 && vsx_gemm_nt2_ok(p)) return vsx_gemm_nt2(p, s);  // second-generation kernel (gemm_nt2.hip)
   return dtype == VSX_BF16 ? dispatch_nt<bf16_t>(p, s) : dispatch_nt<float>(p, s);
+}
+
+extern "C" int32_t vsx_gemm_nt_ln_bwd_supported(int64_t M, int32_t N, int32_t K, int32_t dtype) {
+  if (dtype != VSX_BF16 || M <= 0 || M >= (1ll << 31)) return 0;
+  VsxGemm q = {};
+  q.M = (int32_t)M; q.N = N; q.K = K; q.lda = K; q.ldb = K; q.ldc = N; q.a_mode = VSX_A_ROWS; q.c_mode = VSX_A_ROWS; q.epi = VSX_EPI_LN_BWD;
+  return vsx_gemm_nt2_lnbwd_ok(&q) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

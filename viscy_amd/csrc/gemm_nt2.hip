@@ -324,6 +324,163 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fc1 data gradient with the block LayerNorm's backward in its epilogue (VSX_EPI_LN_BWD):
+//     dx^ = dh . W1'            (the GEMM: M x C, K = 4C)
+//     dy  = rstd * (dx^ - mean_c(dx^) - x^ * mean_c(dx^ * x^))          (LayerNorm without affine: it is folded into fc1)
+// One column tile spans the whole row (C <= 256), and the waves are laid out 8 (M) x 1 (N) — a wave owns 32 complete rows, so
+// the two row means are sums over the lanes of ONE wave.  dx^ is rounded to bf16 where the unfused pair stored it; it is never
+// written: the launch that wrote it, the LayerNorm-backward launch that read it back with x^, and 2 C-wide passes per block go.
+// ------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p) {
+  typedef Nt2Geom<BN> G;
+  constexpr int FN = BN / 16, A_BYTES = G::A_BYTES, STAGE = G::STAGE, NCG = BN / 64;
+  __shared__ __attribute__((aligned(1024))) char smem[G::LDS_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p16 = lane & 15, kq = lane >> 4;
+  int bid = blockIdx.x;
+  const int m0 = bid * BM;
+
+  const int dr = lane >> 2;
+  const int dc = (lane & 3) ^ ((lane >> 4) & 2);
+  const char* Ab = reinterpret_cast<const char*>(p.A) + (size_t)m0 * (size_t)p.lda * 2;
+  const char* Bb = reinterpret_cast<const char*>(p.B);
+  uint32_t offA[G::NPA], offB[G::NPB];
+#pragma unroll
+  for (int i = 0; i < G::NPA; ++i) offA[i] = (uint32_t)((wave + 8 * i) * 16 + dr) * (uint32_t)(p.lda * 2) + dc * 16;
+#pragma unroll
+  for (int i = 0; i < G::NPB; ++i) {
+    int nb = (wave + 8 * i) * 16 + dr;
+    nb = nb < p.N ? nb : p.N - 1;
+    offB[i] = (uint32_t)nb * (uint32_t)(p.ldb * 2) + dc * 16;
+  }
+  auto issue = [&](int kt, int st) {
+    char* S = smem + st * STAGE;
+    const char* Ak = Ab + (size_t)kt * ROWB;
+    const char* Bk = Bb + (size_t)kt * ROWB;
+#pragma unroll
+    for (int i = 0; i < G::NPA; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ak + offA[i]),
+                                       (__attribute__((address_space(3))) void*)(S + (wave + 8 * i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < G::NPB; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bk + offB[i]),
+                                       (__attribute__((address_space(3))) void*)(S + A_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+  };
+
+  nt2_f32x4 acc[2][FN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = (nt2_f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fpos = (kq ^ ((p16 >> 2) & 2)) * 16;
+  const int fragA = (wave * 32 + p16) * ROWB + fpos;
+  const int fragB = A_BYTES + p16 * ROWB + fpos;
+  auto compute = [&](int st) {
+    const char* S = smem + st * STAGE;
+    nt2_bf16x8 af[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const nt2_bf16x8*>(S + fragA + i * 16 * ROWB);
+#pragma unroll
+    for (int jg = 0; jg < FN; jg += 4) {
+      nt2_bf16x8 bf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const nt2_bf16x8*>(S + fragB + (jg + j) * 16 * ROWB);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][jg + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][jg + j], 0, 0, 0);
+    }
+  };
+
+  const int nk = p.K / BK;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  int st = 0, stn = NST - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      if constexpr (G::PER_SLAB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(kt + 2, stn);
+    compute(st);
+    st = st == NST - 1 ? 0 : st + 1;
+    stn = stn == NST - 1 ? 0 : stn + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: per 16-row fragment, all column groups are read back into registers (dx^ as bf16 values, x^), the row
+  // means are reduced over the 8 lanes that share a row, then dy is formed and stored
+  float* Cw = reinterpret_cast<float*>(smem + wave * CW_BYTES);
+  const int er = lane >> 3, ec = (lane & 7) * 8;
+  const float invC = 1.f / (float)p.N;
+  const bf16_t* XH = reinterpret_cast<const bf16_t*>(p.aux);
+  bf16_t* DY = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float v[NCG][2][8];
+    uint4 xq[NCG][2];
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int cg = 0; cg < NCG; ++cg) {
+      const int n = cg * 64 + ec;
+      const bool ok = n < p.N;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cw[(kq * 4 + r) * CW_LD + j * 16 + p16] = acc[i][cg * 4 + j][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 t0 = *reinterpret_cast<const float4*>(Cw + (er + 8 * h) * CW_LD + ec);
+        const float4 t1 = *reinterpret_cast<const float4*>(Cw + (er + 8 * h) * CW_LD + ec + 4);
+        const float t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        const int m = m0 + wave * 32 + i * 16 + er + 8 * h;
+        xq[cg][h] = ok ? ldvec<bf16_t>(XH + (size_t)m * p.ldx + n) : make_uint4(0u, 0u, 0u, 0u);
+        float xf[8];
+        unpack<bf16_t>(xq[cg][h], xf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = ok ? round_bf16(t[e]) : 0.f;   // dx^ as the unfused pair stored it
+          v[cg][h][e] = d;
+          s1[h] += d;
+          s2[h] = fmaf(d, xf[e], s2[h]);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // the 8 lanes er * 8 .. + 7 hold the row's column groups
+      s1[h] += __shfl_xor(s1[h], 1, 64); s1[h] += __shfl_xor(s1[h], 2, 64); s1[h] += __shfl_xor(s1[h], 4, 64);
+      s2[h] += __shfl_xor(s2[h], 1, 64); s2[h] += __shfl_xor(s2[h], 2, 64); s2[h] += __shfl_xor(s2[h], 4, 64);
+      const int m = m0 + wave * 32 + i * 16 + er + 8 * h;
+      const float rs = p.grn_s[m];
+      const float m1 = s1[h] * invC, m2 = s2[h] * invC;
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        const int n = cg * 64 + ec;
+        if (n < p.N) {
+          float xf[8], o[8];
+          unpack<bf16_t>(xq[cg][h], xf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rs * (v[cg][h][e] - m1 - xf[e] * m2);
+          stvec<bf16_t>(DY + (size_t)m * p.ldc + n, pack<bf16_t>(o));
+        }
+      }
+    }
+  }
+}
+
 template <int EPI, int BN>
 int launch_bn(const VsxGemm* p, hipStream_t s) {
   const int tiles = (p->M / BM) * vsx_cdiv(p->N, BN);
@@ -365,7 +522,15 @@ int launch(const VsxGemm* p, hipStream_t s) {
 }  // namespace
 
 // true if this kernel family takes the launch (bf16 only; the caller has validated the common fields)
+// the fused fc1-data-gradient + LayerNorm-backward launch exists on this kernel family only
+bool vsx_gemm_nt2_lnbwd_ok(const VsxGemm* p) {
+  return p->a_mode == VSX_A_ROWS && p->c_mode == VSX_A_ROWS && p->pro == VSX_PRO_NONE && p->nz <= 1 && p->K % BK == 0 &&
+         p->M % BM == 0 && p->N >= 64 && p->N <= 256 && p->N % 8 == 0 && p->b_bstride == 0 &&
+         (unsigned long long)BM * p->lda * 2 < (1ull << 32) && (unsigned long long)p->N * p->ldb * 2 < (1ull << 32);
+}
+
 bool vsx_gemm_nt2_ok(const VsxGemm* p) {
+  if (p->epi == VSX_EPI_LN_BWD) return vsx_gemm_nt2_lnbwd_ok(p);
   if (!(g_vsx_nt2 & 1)) return false;
   if (p->a_mode != VSX_A_ROWS || p->c_mode != VSX_A_ROWS || p->nz > 1) return false;
   if (p->pro != VSX_PRO_NONE) {  // GRN prologue: one sample per tile, epilogues of the fc2 forward only, s / beta fit the LDS copy
@@ -393,6 +558,13 @@ bool vsx_gemm_nt2_ok(const VsxGemm* p) {
 }
 
 int vsx_gemm_nt2(const VsxGemm* p, hipStream_t s) {
+  if (p->epi == VSX_EPI_LN_BWD) {
+    const int tiles = p->M / BM;
+    if (p->N <= 128) hipLaunchKernelGGL((gemm_nt2_lnbwd_kernel<128>), dim3(tiles), dim3(512), 0, s, *p);
+    else hipLaunchKernelGGL((gemm_nt2_lnbwd_kernel<256>), dim3(tiles), dim3(512), 0, s, *p);
+    VSX_LAUNCH_CHECK();
+    return 0;
+  }
   switch (p->epi) {
     case VSX_EPI_NONE: return launch<VSX_EPI_NONE>(p, s);
     case VSX_EPI_BIAS: return launch<VSX_EPI_BIAS>(p, s);

@@ -459,8 +459,13 @@ class Engine:
                    red1=PS[1], hw=hw)
             t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw, Sb=PS[1], dbeta=dgb)
             o.grn_gelu_bwd(dz, h, s, t, db1f, M, 4 * C, hw)  # dz now holds dH
-        dxh = torch.empty((M, C), dtype=dt, device=dev)
-        o.gemm("nt", dz, w.W1fT, dxh, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt)
+        # fc1 data gradient; where one column tile spans the row (C <= 256) the block LayerNorm's backward rides in the GEMM's
+        # epilogue (VSX_EPI_LN_BWD): dx^ is never written, the LayerNorm-backward launch and two C-wide passes go
+        dy = o.dgrad_ln_bwd(dz, w.W1fT, xh, rstd, M, C, 4 * C) if hasattr(o, "dgrad_ln_bwd") else None
+        dxh = None
+        if dy is None:
+            dxh = torch.empty((M, C), dtype=dt, device=dev)
+            o.gemm("nt", dz, w.W1fT, dxh, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt)
         dW1f = self._za.take(4 * C, C)
         o.gemm("tn", xh, dz, dW1f, M, 4 * C, C, C, 4 * C, C, dtype=dt)
         del dz
@@ -469,7 +474,8 @@ class Engine:
                       dgamma=g(blk.norm.weight), u=db1f, beta=blk.norm.bias)
         o.matvec_t_add(blk.mlp.fc1.weight, db1f, g(blk.norm.bias), 4 * C, C)
         o.transpose_f32(db1f, g(blk.mlp.fc1.bias), 4 * C, 1, True)  # g(b1) += db1f (a [4C, 1] "transpose": no ATen launch in the step)
-        dy = o.ln_bwd(dxh, xh, None, rstd, None, None, None, None, M, C)
+        if dy is None:
+            dy = o.ln_bwd(dxh, xh, None, rstd, None, None, None, None, M, C)
         del dxh
         if rows is not None:
             dy = o.rows_select(dy, inv, B * H * Wd, C)  # adjoint of the gather: zero-filled scatter

@@ -102,6 +102,17 @@ def gemm(
     check(fn(C.byref(p), dtype_code(dtype), stream()), f"gemm_{kind}")
 
 
+def dgrad_ln_bwd(dh: Tensor, WT: Tensor, xh: Tensor, rstd: Tensor, M: int, C: int, K: int) -> Tensor | None:
+    """fc1 data gradient with the block LayerNorm's backward in the GEMM epilogue (VSX_EPI_LN_BWD, csrc/gemm_nt2.hip):
+    dy = LN_backward(dh . WT^T; xh, rstd) [M, C] in ONE launch — dx^ is never written.  None if the shape is not served
+    (the caller then runs the GEMM and vsx_ln_bwd)."""
+    if dh.dtype != torch.bfloat16 or not lib().vsx_gemm_nt_ln_bwd_supported(M, C, K, dtype_code(dh.dtype)):
+        return None
+    dy = torch.empty((M, C), dtype=dh.dtype, device=dh.device)
+    gemm("nt", dh, WT, dy, M, C, K, K, K, C, dtype=dh.dtype, epi=L.EPI_LN_BWD, aux=xh, ldx=C, grn_s=rstd)
+    return dy
+
+
 def gemm_z(kind: str, *args, nz: int, a_coff, b_off, c_coff, **kw) -> None:
     """z-batched GEMM with more than 8 slabs: issue in groups of <= 8."""
     for s in range(0, nz, 8):
