@@ -262,9 +262,20 @@ int32_t vsx_ssim_scale_fwd_dmu(const float* P, const float* T, const float* tmax
 int32_t vsx_ssim_scale_bwd_in(const float* P, const float* T, const float* dmu, const float* coef, const float* dPnext,
                               float* dP, int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, float l1c, float l2c,
                               const float* gout, int32_t has_ssim, int32_t last, vsx_stream_t stream);
+/* One-pass training forward of a scale: vsx_ssim_scale_fwd_dmu + the vsx_loss_pool pass of the NEXT scale (pooled stacks Po / To,
+ * their data range tmax_next, and with l1sum != NULL this scale's L1 / L2 sums) from the same reads of P / T; tmax[0] must be
+ * final (vsx_loss_tmax for scale 0).  tmax, tmax_next, l1sum, l2sum are SLOTTED here: VSX_LOSS_SLOTS partial values,
+ * VSX_LOSS_SLOT_STRIDE floats apart (range = their max, sums = their sum; vsx_loss_finalize takes sum_slots = VSX_LOSS_SLOTS).
+ * Reference: metrics.py:272-305 + 340-341, mixed_loss.py:58-63. */
+#define VSX_LOSS_SLOTS 64        /* partial accumulators per scalar of the one-pass forward (same-address atomics serialise) */
+#define VSX_LOSS_SLOT_STRIDE 32  /* floats between two slots (one 128-byte line each) */
+int32_t vsx_loss_tmax(const float* T, int64_t n, float* tmax, vsx_stream_t stream);
+int32_t vsx_ssim_scale_fwd_fused(const float* P, const float* T, const float* tmax, float* sum_ssim, float* sum_cs, float* dmu,
+                                 float* Po, float* To, float* tmax_next, float* l1sum, float* l2sum, int32_t B, int32_t C,
+                                 int32_t D, int32_t H, int32_t W, int32_t last, vsx_stream_t stream);
 int32_t vsx_loss_finalize(const float* sum_ssim, const float* sum_cs, const float* l1sum, const float* l2sum,
-    const float* npix, float nelem, int32_t B, int32_t nscale, float a1, float a2, float a3, const float* gout,
-    float* loss, float* coef, float* ms_out, vsx_stream_t stream);
+    const float* npix, float nelem, int32_t B, int32_t nscale, int32_t sum_slots, float a1, float a2, float a3,
+    const float* gout, float* loss, float* coef, float* ms_out, vsx_stream_t stream);  /* sum_slots: 0 / 1 = l1sum, l2sum are scalars (vsx_loss_pool); VSX_LOSS_SLOTS = slotted (vsx_ssim_scale_fwd_fused) */
 
 /* K2/K4: timm LayerNorm2d / nn.LayerNorm over channels, eps 1e-6 (reached via timm ConvNeXtStage / ConvNeXtBlock at viscy_models/unet/unext2.py:79,
  * viscy_models/components/blocks.py:60-69).  gamma == NULL → no affine (the block LN's affine is folded into fc1). */

@@ -18,6 +18,7 @@ VSX_F32, VSX_BF16 = 0, 1
 A_ROWS, A_PATCH2, A_CONV3 = 0, 1, 2
 PRO_NONE, PRO_GRN = 0, 1
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_SQ, EPI_BIAS_RES, EPI_DZ, EPI_BIAS_STATS, EPI_LN_BWD = 0, 1, 2, 3, 4, 5, 6
+LOSS_SLOTS, LOSS_SLOT_STRIDE = 64, 32  # VSX_LOSS_SLOTS / VSX_LOSS_SLOT_STRIDE of include/vsx.h
 
 _I32, _F32, _P, _I64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
 
@@ -75,9 +76,11 @@ _SIGS = {
     "vsx_loss_pool": (_I32, [_P] * 7 + [_I32] * 3 + [_P]),
     "vsx_ssim_scale_fwd": (_I32, [_P] * 5 + [_I32] * 5 + [_P]),
     "vsx_ssim_scale_bwd": (_I32, [_P] * 7 + [_I32] * 5 + [_F32, _F32, _P, _I32, _P]),
-    "vsx_loss_finalize": (_I32, [_P] * 5 + [_F32, _I32, _I32, _F32, _F32, _F32, _P, _P, _P, _P, _P]),
+    "vsx_loss_finalize": (_I32, [_P] * 5 + [_F32, _I32, _I32, _I32, _F32, _F32, _F32, _P, _P, _P, _P, _P]),
     "vsx_ssim_scale_fwd_dmu": (_I32, [_P] * 6 + [_I32] * 6 + [_P]),
     "vsx_ssim_scale_bwd_in": (_I32, [_P] * 6 + [_I32] * 5 + [_F32, _F32, _P, _I32, _I32, _P]),
+    "vsx_loss_tmax": (_I32, [_P, _I64, _P, _P]),
+    "vsx_ssim_scale_fwd_fused": (_I32, [_P] * 11 + [_I32] * 6 + [_P]),
     "vsx_adamw": (_I32, [_P, _P, _P, _P, _P, _I64, _P]),
     "vsx_adamw_advance": (_I32, [_P, _P, _P, _P]),
     "vsx_fill_f32": (_I32, [_P, _I64, _F32, _P]),

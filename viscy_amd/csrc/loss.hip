@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
         for (int k = 0; k < 11; ++k) a += R[oy + k][ox];
       }
       m[i][q] = round_bf16(kb * a);
+      asm volatile("" : "+v"(m[i][q]));  // keep the sums out of the bounds-checked branch below (see ssim_tile_fused_kernel)
     }
   }
   float acc_s = 0.f, acc_c = 0.f;
@@ -253,110 +254,393 @@ __global__ __launch_bounds__(256) void ssim_tile_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------ training forward of one scale in ONE pass over the stack
+// ssim_tile_kernel<true> (sums + unscaled gradient field) that also does what loss_pool_kernel did in a pass of its own:
+// the 2x2 average pooling into the NEXT scale's stacks, that scale's data range (max of the pooled target) and, at full
+// resolution, the L1 / L2 sums.  A thread owns whole 2x2 quads of the tile's 42x42 footprint (21x21 quads, one per thread
+// of a 512-thread workgroup), so pooling is register arithmetic on values the window sums need anyway; a tile pools / sums the 32x32 pixels at
+// its origin — the last tile of a row / column everything up to the edge (at most 42: H - 10 <= 32 * tiles) — so that every
+// input pixel is counted exactly once.  
+// Same-address atomics serialise at ~10 ns each: 65 536 workgroups adding into ONE float cost more than the pass itself
+// (measured: 8.5 ms instead of 2.6).  The one-pass kernel's scalar results (data range, L1 / L2 sums) are therefore SLOTTED:
+// VSX_LOSS_SLOTS partial values, VSX_LOSS_SLOT_STRIDE floats (one 128-byte line) apart, the workgroup picks slot = id % slots;
+// readers combine the slots (64 loads + a wave reduction).
+#define LSLOTS VSX_LOSS_SLOTS
+#define LSTRIDE VSX_LOSS_SLOT_STRIDE
+// Buffer addressing for the loss kernels: a scalar plane descriptor + a 32-bit lane byte offset; the hardware range check
+// returns 0 / drops the store for lanes whose offset is VSX_BUF_OOB (outside the image), so no access needs a branch, a select
+// or a 64-bit lane pointer.
+#define VSX_BUF_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const float* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+typedef uint32_t vsx_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 buf_ld2(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+  const vsx_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0);
+  return make_float2(__uint_as_float(w.x), __uint_as_float(w.y));
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, 0, 0);
+}
+#define FT 512  // threads per workgroup of the one-pass kernel: one quad of the footprint and two outputs per thread
+__device__ __forceinline__ float block_sum_ft(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float a = 0.f;
+#pragma unroll
+  for (int w = 0; w < FT / 64; ++w) a += sh[w];
+  return a;
+}
+// VEC: even W and 8-byte aligned stacks — the two pixels of a quad row are one 8-byte load (a wave reads whole lines).
+template <bool VEC>
+__global__ __launch_bounds__(FT, 8) void ssim_tile_fused_kernel(const float* __restrict__ P, const float* __restrict__ T,
+                                                                 const float* __restrict__ tmax_p, int C, int D, int H, int W,
+                                                                 float* __restrict__ sum_ssim, float* __restrict__ sum_cs,
+                                                                 float* __restrict__ dmu, int last, float* __restrict__ Po,
+                                                                 float* __restrict__ To, float* __restrict__ tmax_next,
+                                                                 float* __restrict__ l1sum, float* __restrict__ l2sum) {
+  __shared__ float S[SI][SLD];
+  __shared__ float R[SI][ST];
+  __shared__ float sh[FT / 64];
+  const TileId tl = xcd_tile();
+  const int bc = tl.z;
+  const int b = bc / C;
+  const int oy0 = tl.y * ST, ox0 = tl.x * ST;
+  const int Ho = H - 10, Wo = W - 10;
+  const float kb = round_bf16(1.0f / (float)(D * 121));
+  const float dr = wave_max(tmax_p[(threadIdx.x & 63) * LSTRIDE]);  // slotted data range (LSLOTS == 64 == one wave)
+  const float c1 = (0.01f * dr) * (0.01f * dr), c2 = (0.03f * dr) * (0.03f * dr);
+  const bool last_y = tl.y == (int)gridDim.y - 1, last_x = tl.x == (int)gridDim.x - 1;
+
+  constexpr int QN = SI / 2;                      // quads per footprint side
+  constexpr int NQR = (QN * QN + FT - 1) / FT;      // quad rounds per thread
+  constexpr int NIN = NQR * 4;                    // footprint pixels per thread
+  constexpr int NOUT = (ST * ST + FT - 1) / FT;
+  static_assert(NOUT == 2 && FT == 16 * ST && SI * (ST / 4) <= FT, "row-pair mapping of the vertical pass");
+  float sq[NIN][5];
+  uint32_t hoff[NIN], poff[NQR];  // byte offsets into a plane (VSX_BUF_OOB outside the image / for quads this tile does not pool)
+  bool own[NQR], pool[NQR];
+  const int Hn = H / 2, Wn = W / 2;
+#pragma unroll
+  for (int r = 0; r < NQR; ++r) {
+    const int qi = threadIdx.x + r * FT;
+    const int qy = qi / QN, qx = qi - qy * QN;
+    const bool valid = qi < QN * QN;
+    own[r] = valid && (qy < ST / 2 || last_y) && (qx < ST / 2 || last_x);
+    const int py = (oy0 >> 1) + qy, px = (ox0 >> 1) + qx;
+    pool[r] = own[r] && Po != nullptr && py < Hn && px < Wn;
+    poff[r] = pool[r] ? (uint32_t)(py * Wn + px) * 4u : VSX_BUF_OOB;
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) {
+      const int gy = oy0 + 2 * qy + (ab >> 1), gx = ox0 + 2 * qx + (ab & 1);
+      hoff[r * 4 + ab] = valid && gy < H && gx < W ? (uint32_t)(gy * W + gx) * 4u : VSX_BUF_OOB;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) sq[r * 4 + ab][q] = 0.f;
+    }
+  }
+  const size_t zs = (size_t)H * W, zsn = (size_t)Hn * Wn;
+  const float* Pg = P + (size_t)bc * D * zs;
+  const float* Tg = T + (size_t)bc * D * zs;
+  float* Pog = Po ? Po + (size_t)bc * D * zsn : dmu;  // no pooling: zero-sized descriptors, every store dropped
+  float* Tog = To ? To + (size_t)bc * D * zsn : dmu;
+  const size_t pbytes = Po ? zsn * 4 : 0;
+  float mx = -INFINITY, a1 = 0.f, a2 = 0.f;
+  const bool do_l1 = l1sum != nullptr;
+  auto plane = [&](int z) {
+    float pv[NIN], tv[NIN];
+    const __amdgpu_buffer_rsrc_t rp = buf_rsrc(Pg + z * zs, zs * 4), rt = buf_rsrc(Tg + z * zs, zs * 4);
+#pragma unroll
+    for (int i = 0; i < NIN; i += 2) {
+      if constexpr (VEC) {  // even W: the two pixels of a quad row are inside or outside together
+        const float2 vp = buf_ld2(rp, hoff[i]), vt = buf_ld2(rt, hoff[i]);
+        pv[i] = vp.x; pv[i + 1] = vp.y;
+        tv[i] = vt.x; tv[i + 1] = vt.y;
+      } else {
+        pv[i] = buf_ld(rp, hoff[i]); pv[i + 1] = buf_ld(rp, hoff[i + 1]);
+        tv[i] = buf_ld(rt, hoff[i]); tv[i + 1] = buf_ld(rt, hoff[i + 1]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const float p = pv[i], t = tv[i];
+      sq[i][0] += round_bf16(p);
+      sq[i][1] += round_bf16(t);
+      sq[i][2] += round_bf16(p * p);
+      sq[i][3] += round_bf16(t * t);
+      sq[i][4] += round_bf16(p * t);
+    }
+    const __amdgpu_buffer_rsrc_t wp = buf_rsrc(Pog + z * zsn, pbytes), wt = buf_rsrc(Tog + z * zsn, pbytes);
+#pragma unroll
+    for (int r = 0; r < NQR; ++r) {
+      // same summation order as loss_pool_kernel: (0,0), (0,1), (1,0), (1,1); quads this tile does not pool: stores dropped
+      const float sp = ((pv[r * 4] + pv[r * 4 + 1]) + pv[r * 4 + 2]) + pv[r * 4 + 3];
+      const float st = ((tv[r * 4] + tv[r * 4 + 1]) + tv[r * 4 + 2]) + tv[r * 4 + 3];
+      buf_st(wp, poff[r], 0.25f * sp);
+      buf_st(wt, poff[r], 0.25f * st);
+      if (pool[r]) mx = fmaxf(mx, 0.25f * st);
+      if (do_l1 && own[r]) {  // pixels outside the image were read as p = t = 0
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+          const float d = pv[r * 4 + ab] - tv[r * 4 + ab];
+          a1 += fabsf(d);
+          a2 += d * d;
+        }
+      }
+    }
+  };
+  // a rolled depth loop: with every plane's loads in flight at once (compile-time depth) the kernel needs 94 registers and runs
+  // 2 workgroups per CU — measured 2.6 ms per forward against 2.1 ms for this loop at 3 workgroups per CU
+  for (int z = 0; z < D; ++z) plane(z);
+  float m[NOUT][5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    if (q) __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NQR; ++r) {
+      const int qi = threadIdx.x + r * FT;
+      const int qy = qi / QN, qx = qi - qy * QN;
+      if (qi < QN * QN) {
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) S[2 * qy + (ab >> 1)][2 * qx + (ab & 1)] = sq[r * 4 + ab][q];
+      }
+    }
+    __syncthreads();
+    // 11-tap sums from registers: a thread reads the 14 (12) values four (two) neighbouring outputs share once instead of
+    // 11 per output — the LDS pipe was as busy as HBM (55 -> 26 reads per thread and quantity); same summation order
+    if (threadIdx.x < SI * (ST / 4)) {
+      const int iy = threadIdx.x / (ST / 4), sg = threadIdx.x % (ST / 4);
+      float v[14];
+#pragma unroll
+      for (int k = 0; k < 14; ++k) v[k] = S[iy][sg * 4 + k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) a += v[j + k];
+        R[iy][sg * 4 + j] = a;
+      }
+    }
+    __syncthreads();
+    {
+      const int ox = threadIdx.x & (ST - 1), pr = threadIdx.x / ST;  // outputs (2 pr, ox), (2 pr + 1, ox)
+      float v[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) v[k] = R[2 * pr + k][ox];
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) a += v[i + k];
+        m[i][q] = round_bf16(kb * a);
+        // pin the mean here: hipcc otherwise sinks the 11-term sums of all five quantities into the bounds-checked pixel
+        // formula below and keeps the raw LDS values alive until then (spills at any useful occupancy)
+        asm volatile("" : "+v"(m[i][q]));
+      }
+    }
+  }
+  float acc_s = 0.f, acc_c = 0.f;
+  const float gs = last ? 1.f : 0.f, gc = last ? 0.f : 1.f;
+  const size_t plane_o = (size_t)Ho * Wo, nbc = (size_t)gridDim.z;
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const int oy = 2 * (threadIdx.x / ST) + i, ox = threadIdx.x & (ST - 1);
+    const int gy = oy0 + oy, gx = ox0 + ox;
+    if (gy >= Ho || gx >= Wo) continue;
+    SsimPix px = ssim_pixel<true>(m[i][0], m[i][1], m[i][2], m[i][3], m[i][4], c1, c2, gs, gc);
+    const uint32_t o = (uint32_t)(gy * Wo + gx) * 4u;  // unscaled field, fp32 (see ssim_tile_kernel)
+    buf_st(buf_rsrc(dmu + (size_t)bc * plane_o, plane_o * 4), o, px.dmx);
+    buf_st(buf_rsrc(dmu + (nbc + bc) * plane_o, plane_o * 4), o, px.dmxx);
+    buf_st(buf_rsrc(dmu + (2 * nbc + bc) * plane_o, plane_o * 4), o, px.dmxy);
+    acc_s += px.ssim;
+    acc_c += px.cs;
+  }
+  {
+    const float s = block_sum_ft(acc_s, sh);
+    const float c = block_sum_ft(acc_c, sh);
+    if (threadIdx.x == 0) {
+      atomicAdd(sum_ssim + b, s);
+      atomicAdd(sum_cs + b, c);
+    }
+  }
+  const unsigned slot = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % LSLOTS;
+  if (tmax_next != nullptr) {
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int w = 1; w < FT / 64; ++w) mx = fmaxf(mx, sh[w]);
+      if (mx > -INFINITY) atomic_max_float(tmax_next + slot * LSTRIDE, mx);
+    }
+  }
+  if (do_l1) {
+    const float s1 = block_sum_ft(a1, sh);
+    const float s2 = block_sum_ft(a2, sh);
+    if (threadIdx.x == 0) {
+      atomicAdd(l1sum + slot * LSTRIDE, s1);
+      atomicAdd(l2sum + slot * LSTRIDE, s2);
+    }
+  }
+}
+
+// max of a stack (the data range of scale 0 for the one-pass training forward above)
+__global__ __launch_bounds__(256) void loss_tmax_kernel(const float* __restrict__ T, long n, float* __restrict__ tmax) {
+  float mx = -INFINITY;
+  // 16-byte loads from the first aligned element on; the (at most 3) elements before it and the tail go to workgroup 0
+  const long head = (long)((16 - (reinterpret_cast<uintptr_t>(T) & 15)) & 15) >> 2;
+  const long h = head < n ? head : n;
+  const long n4 = (n - h) >> 2;
+  const float4* T4 = reinterpret_cast<const float4*>(T + h);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = T4[i];
+    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  if (blockIdx.x == 0) {
+    if ((long)threadIdx.x < h) mx = fmaxf(mx, T[threadIdx.x]);
+    const long t0 = h + (n4 << 2);
+    if (t0 + (long)threadIdx.x < n) mx = fmaxf(mx, T[t0 + threadIdx.x]);
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0 && mx > -INFINITY) atomic_max_float(tmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) % LSLOTS) * LSTRIDE, mx);
+}
+
 // ------------------------------------------------------------------ backward: transposed box filter + chain rule to the stack
 // G_q(y,x) = bf16( kb * Σ_{oy∈[y-10,y], ox∈[x-10,x]} dmu_q(oy,ox) );  dP(z,y,x) = G_x + 2 p G_xx + t G_xy
 //            + 0.25 * dPnext(z, y/2, x/2)  + l1c * sign(p - t) + l2c * 2 (p - t)
-__global__ __launch_bounds__(256) void ssim_bwd_in_kernel(const float* __restrict__ P, const float* __restrict__ T,
-                                                          const float* __restrict__ dmu, const float* __restrict__ dPn,
-                                                          float* __restrict__ dP, int D, int H, int W, float l1c_,
-                                                          float l2c_, const float* __restrict__ gout_p, int has_ssim,
-                                                          const float* __restrict__ coef, int C, int last) {
-  __shared__ float S[3][SI][SLD];
-  __shared__ float R[3][SI][ST];
+// Occupancy is what hides the latency here (measured: preloading all planes at 116 registers / 38 KB of LDS = 4 workgroups
+// per CU ran 1.28 ms at full resolution, the 64-register version with three S / R plane pairs 1.79 ms): the three gradient
+// fields go through ONE S / R pair one after the other (13 KB), the depth loop keeps one plane of loads in flight ahead of
+// the plane it is finishing, and every global access is a BUFFER access — a scalar plane descriptor + a 32-bit lane offset
+// (flat addressing kept 19 64-bit lane pointers alive: 108 registers), whose hardware range check returns 0 / drops the
+// store for the out-of-image lanes (offset VSX_BUF_OOB), so there is no branch or select around any access.
+__global__ __launch_bounds__(256, 6) void ssim_bwd_in_kernel(const float* __restrict__ P, const float* __restrict__ T,
+                                                             const float* __restrict__ dmu, const float* __restrict__ dPn,
+                                                             float* __restrict__ dP, int D, int H, int W, float l1c_,
+                                                             float l2c_, const float* __restrict__ gout_p, int has_ssim,
+                                                             const float* __restrict__ coef, int C, int last) {
+  __shared__ float S[SI][SLD];
+  __shared__ float R[SI][ST];
   const TileId tl = xcd_tile();
   const int bc = tl.z;
   const int iy0 = tl.y * ST, ix0 = tl.x * ST;
   const int Ho = H - 10, Wo = W - 10;
+  const int Hn = H / 2, Wn = W / 2;
+  constexpr int NOUT = (ST * ST + 255) / 256;
+  static_assert(NOUT == 4 && 256 / ST * NOUT == ST, "column-segment mapping of the vertical pass");
+  // thread (x = tid % 32, tid / 32) owns the NOUT consecutive rows of column x whose 11-tap column sums share their reads
+  const int tx = threadIdx.x & (ST - 1), ty0 = NOUT * (threadIdx.x / ST);
+  uint32_t off0[NOUT], offn[NOUT];  // byte offsets into a plane
+  bool live[NOUT];
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) {
+    const int gy = iy0 + ty0 + i, gx = ix0 + tx;
+    live[i] = gy < H && gx < W;
+    off0[i] = live[i] ? (uint32_t)(gy * W + gx) * 4u : VSX_BUF_OOB;
+    offn[i] = live[i] && (gy >> 1) < Hn && (gx >> 1) < Wn ? (uint32_t)((gy >> 1) * Wn + (gx >> 1)) * 4u : VSX_BUF_OOB;
+  }
+  const size_t zs = (size_t)H * W, zsn = (size_t)Hn * Wn;
+  const float* Pg = P + (size_t)bc * D * zs;
+  const float* Tg = T + (size_t)bc * D * zs;
+  float* dPg = dP + (size_t)bc * D * zs;
+  const float* Ng = dPn ? dPn + (size_t)bc * D * zsn : P;
+  const size_t nbytes = dPn ? zsn * 4 : 0;  // no next scale: every pooled load is out of range = 0
+  float pv[NOUT], tv[NOUT], nv[NOUT];
+  auto fetch = [&](int z) {
+    const __amdgpu_buffer_rsrc_t rp = buf_rsrc(Pg + z * zs, zs * 4), rt = buf_rsrc(Tg + z * zs, zs * 4),
+                                 rn = buf_rsrc(Ng + z * zsn, nbytes);
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+      pv[i] = buf_ld(rp, off0[i]);
+      tv[i] = buf_ld(rt, off0[i]);
+      nv[i] = buf_ld(rn, offn[i]);
+    }
+  };
+  fetch(0);  // in flight across the field's halo loads and the LDS passes
   const float kb = round_bf16(1.0f / (float)(D * 121));
   const float gsc = gout_p ? gout_p[0] : 1.f;
   const float l1c = l1c_ * gsc, l2c = l2c_ * gsc;
+  float G[NOUT][3];
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) G[i][0] = G[i][1] = G[i][2] = 0.f;
   if (has_ssim) {
     const size_t plane = (size_t)Ho * Wo;
     const size_t nbc = (size_t)gridDim.z;
     // dmu of an unscaled field (see ssim_tile_kernel): this sample's factor for the map the loss uses at this scale
     const float gsample = coef ? coef[2 * (bc / C) + (last ? 0 : 1)] : 1.f;
     constexpr int NIN = (SI * SI + 255) / 256;
-    float hv[NIN][3];
-#pragma unroll
-    for (int i = 0; i < NIN; ++i) {  // every halo load of the thread in flight before the first LDS store
-      const int idx = threadIdx.x + i * 256;
-      const int iy = idx / SI, ix = idx - iy * SI;
-      const int oy = iy0 - 10 + iy, ox = ix0 - 10 + ix;
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      if (idx < SI * SI && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
-        const size_t o = (size_t)bc * plane + (size_t)oy * Wo + ox;
-        v0 = dmu[o];
-        v1 = dmu[nbc * plane + o];
-        v2 = dmu[2 * nbc * plane + o];
-      }
-      hv[i][0] = v0; hv[i][1] = v1; hv[i][2] = v2;
-    }
+    float hv[NIN];
+    uint32_t ho[NIN];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       const int idx = threadIdx.x + i * 256;
-      if (idx < SI * SI) {
-        const int iy = idx / SI, ix = idx - iy * SI;
-        float v0 = hv[i][0], v1 = hv[i][1], v2 = hv[i][2];
-        if (coef) { v0 = round_bf16(v0 * gsample); v1 = round_bf16(v1 * gsample); v2 = round_bf16(v2 * gsample); }
-        S[0][iy][ix] = v0; S[1][iy][ix] = v1; S[2][iy][ix] = v2;
-      }
+      const int iy = idx / SI, ix = idx - iy * SI;
+      const int oy = iy0 - 10 + iy, ox = ix0 - 10 + ix;
+      ho[i] = idx < SI * SI && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo ? (uint32_t)(oy * Wo + ox) * 4u : VSX_BUF_OOB;
     }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < SI * ST; idx += 256) {
-      const int iy = idx / ST, x = idx - iy * ST;
+    auto halo = [&](int q) {  // one field's halo, all loads in flight together
+      const __amdgpu_buffer_rsrc_t rd = buf_rsrc(dmu + ((size_t)q * nbc + bc) * plane, plane * 4);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        float a = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; ++k) a += S[q][iy][x + k];
-        R[q][iy][x] = a;
-      }
-    }
-    __syncthreads();
-  }
-  const int Hn = H / 2, Wn = W / 2;
-  constexpr int NOUT = (ST * ST + 255) / 256;
-  float G[NOUT][3];
-  size_t off0[NOUT], offn[NOUT];
-  bool live[NOUT], pooled[NOUT];
-#pragma unroll
-  for (int i = 0; i < NOUT; ++i) {
-    const int idx = threadIdx.x + i * 256;
-    const int y = idx / ST, x = idx - y * ST;
-    const int gy = iy0 + y, gx = ix0 + x;
-    live[i] = idx < ST * ST && gy < H && gx < W;
+      for (int i = 0; i < NIN; ++i) hv[i] = buf_ld(rd, ho[i]);
+    };
+    halo(0);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      float a = 0.f;
-      if (has_ssim && live[i]) {
+      if (q) __syncthreads();  // the previous field's column sums have been read
 #pragma unroll
-        for (int k = 0; k < 11; ++k) a += R[q][y + k][x];
+      for (int i = 0; i < NIN; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < SI * SI) S[idx / SI][idx % SI] = coef ? round_bf16(hv[i] * gsample) : hv[i];
       }
-      G[i][q] = round_bf16(kb * a);
+      if (q < 2) halo(q + 1);  // the next field travels during this one's two LDS passes
+      __syncthreads();
+      // 11-tap sums from registers (see ssim_tile_fused_kernel): 14 reads per 4 outputs instead of 44, same summation order
+      for (int item = threadIdx.x; item < SI * (ST / 4); item += 256) {
+        const int iy = item / (ST / 4), sg = item % (ST / 4);
+        float v[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) v[k] = S[iy][sg * 4 + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float a = 0.f;
+#pragma unroll
+          for (int k = 0; k < 11; ++k) a += v[j + k];
+          R[iy][sg * 4 + j] = a;
+        }
+      }
+      __syncthreads();
+      float v[NOUT + 10];
+#pragma unroll
+      for (int k = 0; k < NOUT + 10; ++k) v[k] = R[ty0 + k][tx];
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) a += v[i + k];
+        G[i][q] = round_bf16(kb * (live[i] ? a : 0.f));
+      }
     }
-    pooled[i] = live[i] && dPn != nullptr && (gy >> 1) < Hn && (gx >> 1) < Wn;
-    off0[i] = ((size_t)bc * D * H + gy) * W + gx;
-    offn[i] = ((size_t)bc * D * Hn + (gy >> 1)) * Wn + (gx >> 1);
   }
-  // depth loop outside the pixel loop: the loads of a slice are issued together (see ssim_tile_kernel)
-  const size_t zs = (size_t)H * W, zsn = (size_t)Hn * Wn;
   for (int z = 0; z < D; ++z) {
-    float pv[NOUT], tv[NOUT], nv[NOUT];
+    float pc[NOUT], tc[NOUT], nc[NOUT];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) { pc[i] = pv[i]; tc[i] = tv[i]; nc[i] = nv[i]; }
+    if (z + 1 < D) fetch(z + 1);
+    const __amdgpu_buffer_rsrc_t rw = buf_rsrc(dPg + z * zs, zs * 4);
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
-      pv[i] = live[i] ? P[off0[i] + z * zs] : 0.f;
-      tv[i] = live[i] ? T[off0[i] + z * zs] : 0.f;
-      nv[i] = pooled[i] ? dPn[offn[i] + z * zsn] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < NOUT; ++i) {
-      const float p = pv[i], t = tv[i];
+      const float p = pc[i], t = tc[i];
       float g = G[i][0] + 2.f * p * G[i][1] + t * G[i][2];
-      if (pooled[i]) g += 0.25f * nv[i];
+      g += 0.25f * nc[i];  // 0 where there is no pooled pixel (out-of-range load)
       const float d = p - t;
       if (l1c != 0.f) g += d > 0.f ? l1c : (d < 0.f ? -l1c : 0.f);
       if (l2c != 0.f) g += 2.f * l2c * d;
-      if (live[i]) dP[off0[i] + z * zs] = g;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g), rw, (int)off0[i], 0, 0);  // dropped outside the image
     }
   }
 }
@@ -368,7 +652,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
                                                             const float* __restrict__ sum_cs,
                                                             const float* __restrict__ l1sum, const float* __restrict__ l2sum,
                                                             const float* __restrict__ npix, float nelem, int B, int nscale,
-                                                            float a1, float a2, float a3,
+                                                            int sum_slots, float a1, float a2, float a3,
                                                             const float* __restrict__ gout_p, float* __restrict__ loss,
                                                             float* __restrict__ coef, float* __restrict__ ms_out) {
   // one thread per batch sample (strided), block reduction of the per-sample MS-SSIM products
@@ -398,9 +682,13 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
   const float tot = block_sum_256(acc, sh);
   if (threadIdx.x == 0) {
     const float ms_mean = a3 != 0.f ? tot / (float)B : 0.f;
-    float l = 0.f;
-    if (a1 != 0.f) l += a1 * l1sum[0] / nelem;
-    if (a2 != 0.f) l += a2 * l2sum[0] / nelem;
+    float l = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < (sum_slots > 1 ? sum_slots : 1); ++i) {  // slotted partial sums of the one-pass forward (or plain scalars)
+      if (a1 != 0.f) s1 += l1sum[i * LSTRIDE];
+      if (a2 != 0.f) s2 += l2sum[i * LSTRIDE];
+    }
+    if (a1 != 0.f) l += a1 * s1 / nelem;
+    if (a2 != 0.f) l += a2 * s2 / nelem;
     if (a3 != 0.f) l += a3 * (1.f - ms_mean);
     loss[0] = l;
     if (ms_out) ms_out[0] = ms_mean;
@@ -476,6 +764,43 @@ extern "C" int32_t vsx_ssim_scale_fwd_dmu(const float* P, const float* T, const 
   return 0;
 }
 
+/* max over a stack of n floats into the SLOTTED tmax (VSX_LOSS_SLOTS x VSX_LOSS_SLOT_STRIDE floats, pre-set to -inf): metrics.py:298 data_range of scale 0 for the one-pass
+ * training forward below (the other scales' ranges come out of that pass). */
+extern "C" int32_t vsx_loss_tmax(const float* T, int64_t n, float* tmax, vsx_stream_t stream) {
+  VSX_CHECK(T && tmax && n > 0, "vsx_loss_tmax: bad arguments");
+  long nblk = vsx_cdiv((long)(n >> 2) + 1, 256L * 8);
+  if (nblk > 4096) nblk = 4096;
+  hipLaunchKernelGGL(loss_tmax_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, T, (long)n, tmax);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+/* vsx_ssim_scale_fwd_dmu + the vsx_loss_pool pass of the NEXT scale in one pass over this scale's stacks: also writes
+ * Po / To [B, C, D, H/2, W/2] (avg_pool3d (1,2,2), metrics.py:340-341; NULL for the last scale), tmax_next[0] = max(To)
+ * (pre-set to -inf; NULL with Po) and, when l1sum != NULL, adds the L1 / L2 sums of this scale (mixed_loss.py:58-63).
+ * tmax = this scale's data range, already final (vsx_loss_tmax for scale 0, the previous scale's launch otherwise).
+ * tmax, tmax_next, l1sum, l2sum are SLOTTED accumulators (VSX_LOSS_SLOTS partial values, VSX_LOSS_SLOT_STRIDE floats apart;
+ * the range is their max, the sums their sum: vsx_loss_finalize(sum_slots = VSX_LOSS_SLOTS)). */
+extern "C" int32_t vsx_ssim_scale_fwd_fused(const float* P, const float* T, const float* tmax, float* sum_ssim, float* sum_cs,
+                                            float* dmu, float* Po, float* To, float* tmax_next, float* l1sum, float* l2sum,
+                                            int32_t B, int32_t C, int32_t D, int32_t H, int32_t W, int32_t last,
+                                            vsx_stream_t stream) {
+  VSX_CHECK(P && T && tmax && sum_ssim && sum_cs && dmu, "vsx_ssim_scale_fwd_fused: null pointer");
+  VSX_CHECK(H >= 11 && W >= 11 && D >= 1, "vsx_ssim_scale_fwd_fused: plane %dx%d smaller than the 11x11 window", H, W);
+  VSX_CHECK((Po == nullptr) == (To == nullptr) && (Po == nullptr) == (tmax_next == nullptr) && (l1sum == nullptr) == (l2sum == nullptr),
+            "vsx_ssim_scale_fwd_fused: pointer groups (Po, To, tmax_next) / (l1sum, l2sum)");
+  VSX_CHECK((long)42 * W < (1l << 31), "vsx_ssim_scale_fwd_fused: row length");
+  dim3 grid(vsx_cdiv(W - 10, ST), vsx_cdiv(H - 10, ST), B * C);
+  const bool vec = (W & 1) == 0 && ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(T)) & 7) == 0;
+#define VSX_FUSED_LAUNCH(VEC_)                                                                                           \
+  hipLaunchKernelGGL((ssim_tile_fused_kernel<VEC_>), grid, dim3(FT), 0, (hipStream_t)stream, P, T, tmax, C, D, H, W,   \
+                     sum_ssim, sum_cs, dmu, last ? 1 : 0, Po, To, tmax_next, l1sum, l2sum)
+  if (vec) VSX_FUSED_LAUNCH(true); else VSX_FUSED_LAUNCH(false);
+#undef VSX_FUSED_LAUNCH
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
 /* Backward of one scale from a stored unscaled field: dP = transposed box filter of coef_b * dmu + chain to the stack +
  * 0.25 * dPnext + L1 / L2 terms (as vsx_ssim_scale_bwd).  coef [B][2] from vsx_loss_finalize for this scale. */
 extern "C" int32_t vsx_ssim_scale_bwd_in(const float* P, const float* T, const float* dmu, const float* coef,
@@ -494,12 +819,13 @@ extern "C" int32_t vsx_ssim_scale_bwd_in(const float* P, const float* T, const f
 /* ms_ssim_25d combination (metrics.py:326-349, clamp=True) + MixedLoss weights (mixed_loss.py:56-69).
  * sums: [nscale][B]; npix: [nscale] (= C*(H_s-10)*(W_s-10)); coef out: [nscale][B][2]. */
 extern "C" int32_t vsx_loss_finalize(const float* sum_ssim, const float* sum_cs, const float* l1sum, const float* l2sum,
-                                     const float* npix, float nelem, int32_t B, int32_t nscale, float a1, float a2,
-                                     float a3, const float* gout, float* loss, float* coef, float* ms_out,
+                                     const float* npix, float nelem, int32_t B, int32_t nscale, int32_t sum_slots, float a1,
+                                     float a2, float a3, const float* gout, float* loss, float* coef, float* ms_out,
                                      vsx_stream_t stream) {
   VSX_CHECK(loss && B > 0 && nscale >= 1 && nscale <= 5, "vsx_loss_finalize: bad arguments");
+  VSX_CHECK(sum_slots == 0 || sum_slots == 1 || sum_slots == LSLOTS, "vsx_loss_finalize: sum_slots must be 0 / 1 (scalars) or VSX_LOSS_SLOTS");
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sum_ssim, sum_cs, l1sum, l2sum,
-                     npix, nelem, B, nscale, a1, a2, a3, gout, loss, coef, ms_out);
+                     npix, nelem, B, nscale, sum_slots, a1, a2, a3, gout, loss, coef, ms_out);
   VSX_LAUNCH_CHECK();
   return 0;
 }

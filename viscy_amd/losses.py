@@ -45,70 +45,86 @@ class _MixedLossFn(torch.autograd.Function):
             raise ValueError(f"MS-SSIM with 5 scales needs Y, X >= 176 (got {H}x{W}): the 11x11 window must fit at 1/16 scale")
         l = lib()
         s = stream()
-        # [l1sum, l2sum, pad, pad | tmax x 5, pad x 3 | sum_ssim 5B | sum_cs 5B]: zero / -inf by vsx_fill_f32 (16-byte aligned
-        # pieces; the captured step holds no ATen fill)
-        scal = torch.empty(12 + 10 * B, dtype=torch.float32, device=dev)
+        need_grad = bool(getattr(ctx, "needs_input_grad", (True,))[0])
+        fused = bool(ns and need_grad and l.vsx_get_flag(b"loss_fused"))
+        # scalar accumulators, zero / -inf by vsx_fill_f32 (the captured step holds no ATen fill):
+        #   [l1sum | l2sum | tmax x 5 (-inf), pad | sum_ssim 5B | sum_cs 5B]; a "scalar" is one float on the two-pass path and
+        #   LOSS_SLOTS partial values LOSS_SLOT_STRIDE floats apart on the one-pass path (vsx_ssim_scale_fwd_fused)
+        w1 = L.LOSS_SLOTS * L.LOSS_SLOT_STRIDE if fused else 4
+        scal = torch.empty(8 * w1 + 10 * B, dtype=torch.float32, device=dev)
         check(l.vsx_fill_f32(ptr(scal), scal.numel(), 0.0, s), "fill")
-        l1sum, l2sum = scal[0:1], scal[1:2]
-        tmax = scal[4:9]
-        check(l.vsx_fill_f32(ptr(scal[4:12]), 8, float("-inf"), s), "fill")
-        sum_ssim = scal[12 : 12 + 5 * B]
-        sum_cs = scal[12 + 5 * B : 12 + 10 * B]
+        l1sum, l2sum = scal[0:w1], scal[w1 : 2 * w1]
+        tmax = [scal[(2 + i) * w1 : (3 + i) * w1] for i in range(5)]
+        check(l.vsx_fill_f32(ptr(scal[2 * w1 : 8 * w1]), 6 * w1, float("-inf"), s), "fill")
+        sum_ssim = scal[8 * w1 : 8 * w1 + 5 * B]
+        sum_cs = scal[8 * w1 + 5 * B : 8 * w1 + 10 * B]
         Ps, Ts, dims = [P0], [T0], [(H, W)]
         planes = B * C * D
         nlev = max(ns, 1)
-        for sc in range(nlev):
+        for sc in range(nlev - 1):
             h, w = dims[sc]
-            last = sc == nlev - 1
-            Po = To = None
-            if not last:
-                Po = torch.empty((B, C, D, h // 2, w // 2), dtype=torch.float32, device=dev)
-                To = torch.empty_like(Po)
-            check(l.vsx_loss_pool(ptr(Ps[sc]), ptr(Ts[sc]), ptr(Po), ptr(To), ptr(tmax[sc : sc + 1]),
-                                  ptr(l1sum) if sc == 0 else None, ptr(l2sum) if sc == 0 else None, planes, h, w, s),
-                  "loss_pool")
-            if not last:
-                Ps.append(Po)
-                Ts.append(To)
-                dims.append((h // 2, w // 2))
+            Ps.append(torch.empty((B, C, D, h // 2, w // 2), dtype=torch.float32, device=dev))
+            Ts.append(torch.empty_like(Ps[-1]))
+            dims.append((h // 2, w // 2))
         npix_d = _npix_cached(tuple(dims), C, dev)
-        # a forward that will be differentiated also stores each scale's unscaled gradient field in the same pass over the stack
-        # (vsx_ssim_scale_fwd_dmu): the backward is then one pass per scale instead of two
-        need_grad = bool(getattr(ctx, "needs_input_grad", (True,))[0])
         dmus = []
-        for sc in range(ns):
-            h, w = dims[sc]
-            if need_grad:
+        if fused:
+            # a forward that will be differentiated: ONE pass per scale (vsx_ssim_scale_fwd_fused) gives the scale's sums, its
+            # unscaled gradient field (the backward is then one pass per scale instead of two), the pooled stacks and data range
+            # of the next scale and, at full resolution, the L1 / L2 sums; only the first data range needs a pass of its own
+            check(l.vsx_loss_tmax(ptr(T0), T0.numel(), ptr(tmax[0]), s), "loss_tmax")
+            for sc in range(ns):
+                h, w = dims[sc]
+                last = sc == ns - 1
                 dmu = torch.empty(3 * B * C * (h - 10) * (w - 10), dtype=torch.float32, device=dev)
-                check(l.vsx_ssim_scale_fwd_dmu(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc : sc + 1]),
-                                               ptr(sum_ssim[sc * B : (sc + 1) * B]), ptr(sum_cs[sc * B : (sc + 1) * B]), ptr(dmu),
-                                               B, C, D, h, w, 1 if sc == ns - 1 else 0, s), "ssim_scale_fwd_dmu")
+                check(l.vsx_ssim_scale_fwd_fused(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc]),
+                                                 ptr(sum_ssim[sc * B : (sc + 1) * B]), ptr(sum_cs[sc * B : (sc + 1) * B]), ptr(dmu),
+                                                 None if last else ptr(Ps[sc + 1]), None if last else ptr(Ts[sc + 1]),
+                                                 None if last else ptr(tmax[sc + 1]),
+                                                 ptr(l1sum) if sc == 0 else None, ptr(l2sum) if sc == 0 else None,
+                                                 B, C, D, h, w, 1 if last else 0, s), "ssim_scale_fwd_fused")
                 dmus.append(dmu)
-            else:
-                check(l.vsx_ssim_scale_fwd(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc : sc + 1]), ptr(sum_ssim[sc * B : (sc + 1) * B]),
-                                           ptr(sum_cs[sc * B : (sc + 1) * B]), B, C, D, h, w, s), "ssim_scale_fwd")
+        else:
+            for sc in range(nlev):
+                h, w = dims[sc]
+                last = sc == nlev - 1
+                check(l.vsx_loss_pool(ptr(Ps[sc]), ptr(Ts[sc]), None if last else ptr(Ps[sc + 1]), None if last else ptr(Ts[sc + 1]),
+                                      ptr(tmax[sc]), ptr(l1sum) if sc == 0 else None, ptr(l2sum) if sc == 0 else None,
+                                      planes, h, w, s), "loss_pool")
+            for sc in range(ns):
+                h, w = dims[sc]
+                if need_grad:  # loss_fused = 0: the two-pass forward (pooling pass above, SSIM sums + gradient field here)
+                    dmu = torch.empty(3 * B * C * (h - 10) * (w - 10), dtype=torch.float32, device=dev)
+                    check(l.vsx_ssim_scale_fwd_dmu(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc]),
+                                                   ptr(sum_ssim[sc * B : (sc + 1) * B]), ptr(sum_cs[sc * B : (sc + 1) * B]), ptr(dmu),
+                                                   B, C, D, h, w, 1 if sc == ns - 1 else 0, s), "ssim_scale_fwd_dmu")
+                    dmus.append(dmu)
+                else:
+                    check(l.vsx_ssim_scale_fwd(ptr(Ps[sc]), ptr(Ts[sc]), ptr(tmax[sc]), ptr(sum_ssim[sc * B : (sc + 1) * B]),
+                                               ptr(sum_cs[sc * B : (sc + 1) * B]), B, C, D, h, w, s), "ssim_scale_fwd")
         out = torch.empty(2, dtype=torch.float32, device=dev)
         coef = torch.empty(max(ns, 1) * B * 2, dtype=torch.float32, device=dev)
         nelem = float(P0.numel())
-        check(l.vsx_loss_finalize(ptr(sum_ssim), ptr(sum_cs), ptr(l1sum), ptr(l2sum), ptr(npix_d), nelem, B, max(ns, 1),
+        nslot = L.LOSS_SLOTS if fused else 1
+        check(l.vsx_loss_finalize(ptr(sum_ssim), ptr(sum_cs), ptr(l1sum), ptr(l2sum), ptr(npix_d), nelem, B, max(ns, 1), nslot,
                                   a1, a2, a3, None, ptr(out[0:1]), ptr(coef), ptr(out[1:2]), s), "loss_finalize")
-        ctx.saved = (Ps, Ts, dims, tmax, scal, npix_d, (B, C, D), (a1, a2, a3), ns, nelem, preds.dtype)
+        ctx.saved = (Ps, Ts, dims, (w1, nslot), scal, npix_d, (B, C, D), (a1, a2, a3), ns, nelem, preds.dtype)
         ctx.dmus = dmus
         ctx.ms_ssim = out[1]
         return out[0]
 
     @staticmethod
     def backward(ctx, gout: Tensor):
-        Ps, Ts, dims, tmax, scal, npix_d, (B, C, D), (a1, a2, a3), ns, nelem, in_dtype = ctx.saved
+        Ps, Ts, dims, (w1, nslot), scal, npix_d, (B, C, D), (a1, a2, a3), ns, nelem, in_dtype = ctx.saved
         dev = Ps[0].device
         l, s = lib(), stream()
         go = gout.detach().float().reshape(1).contiguous()  # stays on the device: no host sync
-        sum_ssim = scal[12 : 12 + 5 * B]
-        sum_cs = scal[12 + 5 * B : 12 + 10 * B]
+        sum_ssim = scal[8 * w1 : 8 * w1 + 5 * B]
+        sum_cs = scal[8 * w1 + 5 * B : 8 * w1 + 10 * B]
         coef = torch.empty(max(ns, 1) * B * 2, dtype=torch.float32, device=dev)
         tmp = torch.empty(2, dtype=torch.float32, device=dev)
-        check(l.vsx_loss_finalize(ptr(sum_ssim), ptr(sum_cs), ptr(scal[0:1]), ptr(scal[1:2]), ptr(npix_d), nelem, B,
-                                  max(ns, 1), a1, a2, a3, ptr(go), ptr(tmp[0:1]), ptr(coef), ptr(tmp[1:2]), s), "loss_finalize")
+        check(l.vsx_loss_finalize(ptr(sum_ssim), ptr(sum_cs), ptr(scal[0:w1]), ptr(scal[w1 : 2 * w1]), ptr(npix_d), nelem, B,
+                                  max(ns, 1), nslot, a1, a2, a3, ptr(go), ptr(tmp[0:1]), ptr(coef), ptr(tmp[1:2]), s), "loss_finalize")
         dmus = getattr(ctx, "dmus", None) or []
         dnext = None
         for sc in range(max(ns, 1) - 1, -1, -1):
