@@ -1,1 +1,2 @@
-for i in 1 2 3; do timeout 600 python -m pytest tests/test_gpu_model.py -x -q -s -k "baseline_size" 2>&1 | grep -E "engine @256|assert|Error|passed|failed" | cut -c1-400; done > gpurun_out/r3_bs.log 2>&1; cat gpurun_out/r3_bs.log
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -k "ln or layernorm or norm" 2>&1 | tail -3
+timeout 600 python bench.py --steps 12 --warmup 3 --no-cpu-baseline > gpurun_out/r3_b9.json 2> gpurun_out/r3_b9.err; cut -c1-260 gpurun_out/r3_b9.json; grep -E "^\[ops\] (ln_|dgrad_ln)" gpurun_out/r3_b9.err

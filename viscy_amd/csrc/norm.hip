@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
 
 // ------------------------------------------------------------------ LayerNorm backward
 // xhat = mean ? (x - mean) * rstd : x ;  g = dy * gamma ;  dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)) [+ add]
-template <typename T, int G, int CPL>
+// AFF = false: no gamma and no dgamma / dbeta (the block LayerNorms, affine folded into fc1): the 3 x CPL x VN registers of the
+// affine accumulators are not allocated (98 -> 70 registers at CPL = 1: 4 -> 7 waves per SIMD)
+template <typename T, int G, int CPL, bool AFF>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* __restrict__ add,
@@ -114,19 +116,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   const int gl = threadIdx.x % G;
   const int rslot = threadIdx.x / G;
   constexpr int RPI = 256 / G;
-  if (dgamma) {
+  if (AFF && dgamma) {
     for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
     __syncthreads();
   }
-  float dg[CPL][VN], db[CPL][VN], gam[CPL][VN];
+  constexpr int CA = AFF ? CPL : 1, VA = AFF ? VN : 1;
+  float dg[CA][VA], db[CA][VA], gam[CA][VA];
+  if constexpr (AFF) {
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    int c = gl + i * G;
+    for (int i = 0; i < CPL; ++i) {
+      int c = gl + i * G;
 #pragma unroll
-    for (int j = 0; j < VN; ++j) {
-      dg[i][j] = 0.f;
-      db[i][j] = 0.f;
-      gam[i][j] = (gamma && c < nch) ? gamma[c * VN + j] : 1.f;
+      for (int j = 0; j < VN; ++j) {
+        dg[i][j] = 0.f;
+        db[i][j] = 0.f;
+        gam[i][j] = (gamma && c < nch) ? gamma[c * VN + j] : 1.f;
+      }
     }
   }
   typedef typename VT<T>::vec vec;
@@ -167,11 +172,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
           for (int j = 0; j < VN; ++j) {
             xh[i][j] = mean ? (xv[j] - mu) * rs : xv[j];
-            g[i][j] = dv[j] * gam[i][j];
+            if constexpr (AFF) {
+              g[i][j] = dv[j] * gam[i][j];
+              dg[i][j] += dv[j] * xh[i][j];
+              db[i][j] += dv[j];
+            } else {
+              g[i][j] = dv[j];
+            }
             s1 += g[i][j];
             s2 += g[i][j] * xh[i][j];
-            dg[i][j] += dv[j] * xh[i][j];
-            db[i][j] += dv[j];
           }
         } else {
 #pragma unroll
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  if (dgamma) {
+  if constexpr (AFF) if (dgamma) {
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
       int c = gl + i * G;
@@ -240,9 +249,14 @@ static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float*
     if (iters < 1) iters = 1;
     int grid = vsx_cdiv(rows, RPI * iters);
     size_t sh = dgamma ? 2 * (size_t)C * sizeof(float) : 0;
-    hipLaunchKernelGGL((ln_bwd_kernel<T, G, CPL>), dim3(grid), dim3(256), sh, s, (const T*)a0, (const T*)a1,
-                       (const float*)mean, (const float*)rstd, gamma, (const T*)add, (T*)out, dgamma, dbeta, rows, C,
-                       iters, g_vsx_ln_stream & 1);
+    if (gamma || dgamma)
+      hipLaunchKernelGGL((ln_bwd_kernel<T, G, CPL, true>), dim3(grid), dim3(256), sh, s, (const T*)a0, (const T*)a1,
+                         (const float*)mean, (const float*)rstd, gamma, (const T*)add, (T*)out, dgamma, dbeta, rows, C,
+                         iters, g_vsx_ln_stream & 1);
+    else
+      hipLaunchKernelGGL((ln_bwd_kernel<T, G, CPL, false>), dim3(grid), dim3(256), sh, s, (const T*)a0, (const T*)a1,
+                         (const float*)mean, (const float*)rstd, gamma, (const T*)add, (T*)out, dgamma, dbeta, rows, C,
+                         iters, g_vsx_ln_stream & 1);
   }
   VSX_LAUNCH_CHECK();
   return 0;
