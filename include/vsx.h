@@ -385,6 +385,26 @@ int32_t vsx_matvec_t_add(const float* W, const float* u, float* out, int32_t R, 
 int32_t vsx_transpose_f32(const float* src, float* dst, int32_t A, int32_t Bn, int32_t accumulate,
     vsx_stream_t stream);
 
+/* A list of independent weight-space jobs in one launch per VSX_WTASK_MAX tasks (the step refreshes ~200 prepared operands
+ * per weight update; as single launches each leaves the chip idle for 4 - 7 us).  kind selects which single-op entry point
+ * the task stands for; fields as documented at vsx_weight_tasks in csrc/optim.hip:
+ *   PREP: p0 src, p1 dst, p2 dstT, p3 gamma, i0 R, i1 Cs, i2 Tn, i3 tapmode, dtype;  TRANSPOSE: p0 src, p1 dst, i0 A, i1 Bn,
+ *   i2 accumulate;  MATVEC: p0 W, p3 v, p2 b, p1 out, i0 R, i1 C;  MLP_PACK: p0 W1, p3 W2, p1 img, i0 C.
+ * No task may read or accumulate into what another task of the same call writes. */
+#define VSX_WTASK_PREP 0
+#define VSX_WTASK_TRANSPOSE 1
+#define VSX_WTASK_MATVEC 2
+#define VSX_WTASK_MLP_PACK 3
+#define VSX_WTASK_MAX 60
+typedef struct VsxWTask {
+  int32_t kind, dtype, i0, i1, i2, i3;
+  const void* p0;
+  void* p1;
+  void* p2;
+  const void* p3;
+} VsxWTask;
+int32_t vsx_weight_tasks(const VsxWTask* tasks, int32_t n, vsx_stream_t stream);
+
 /* head Conv3d data-gradient weights: [Zout+2][C3][27*Cmid], zero where the depth tap falls outside [0,2]. */
 int32_t vsx_prep_head_dgrad(const float* W, void* dst, int32_t Cmid, int32_t C3, int32_t Zout, int32_t dtype,
     vsx_stream_t stream);

@@ -10,6 +10,8 @@ Used two ways, only from tests/:
 
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.nn.functional as F
 from torch import Tensor
@@ -321,6 +323,16 @@ def head_out_bwd2(U, ssum, ssq, w2, alpha, dv, S1, S2, B, H2, W2, Z, Cmid, Cout,
     dn = torch.where(nh > 0, dA, alpha * dA)
     dU = rs * (dn - (S1 / cnt).view(B, 1, 1, 1, Cmid) - nh * (S2 / cnt).view(B, 1, 1, 1, Cmid))
     return dU.reshape(-1, Z * Cmid).to(U.dtype)
+
+
+@contextlib.contextmanager
+def batch():
+    """viscy_amd.ops.batch collects the weight-space launches of the block into task lists; here every op runs at once"""
+    yield
+
+
+def flush():
+    pass
 
 
 def _tap_dst(t, tapmode):

@@ -375,10 +375,9 @@ def test_baseline_size_fp32_and_bf16_engines_vs_reference_golden():
     both GEMM generations) pinned at the BASELINE patch size.  tests/golden/unext2_tiny_256.pt holds what the REFERENCE's own
     wiring (G8b, oracle/validate_against_reference.py) computes in fp32 for tiny, B = 4, 256 x 256: forward, MixedLoss value and
     a strided sample of every parameter gradient.  fp32 engine: forward <= 1e-3 of the output maximum, loss <= 1e-3, per-stage
-    gradient direction 1 - cos < 2e-4 (PReLU kink: DESIGN §5).  bf16 engine: forward and every stage within 1.25 x the error of
-    the oracle module under ``torch.autocast(bfloat16)`` — the reference's bf16-mixed arithmetic — computed here, on the GPU,
-    against the same fp32 golden (the CPU autocast backward is not reproducible run to run, so it is not a fixture), or within
-    the absolute bars of the 128 x 128 gate where the yardstick happens to come out tighter than bf16 operand rounding."""
+    gradient direction 1 - cos < 2e-6.  bf16 engine: forward and every stage within 1.25 x the error of the oracle module under
+    ``torch.autocast(bfloat16)`` — the reference's bf16-mixed arithmetic — computed here, on the GPU, against the same fp32
+    golden (the CPU autocast backward is not reproducible run to run, so it is not a fixture)."""
     from oracle import loss_ref, unext2_ref
     from viscy_amd.losses import MixedLoss
     from viscy_amd.unext2 import UNeXt2
@@ -389,8 +388,12 @@ def test_baseline_size_fp32_and_bf16_engines_vs_reference_golden():
     ref = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=gold["seed"])
     g = torch.Generator().manual_seed(gold["x_seed"])
     x = torch.randn((B, 1, 5, S, S), generator=g)
-    smooth = torch.nn.functional.avg_pool3d(x, (1, 5, 5), stride=1, padding=(0, 2, 2))
-    tgt = (0.5 * smooth.repeat(1, 2, 1, 1, 1) + 0.1 * torch.randn((B, 2, 5, S, S), generator=g)).contiguous()
+    # the target of the fixture: the module's own fp32 output + tgt_noise standard deviations of noise (why: the generator,
+    # g8b_baseline_size — a target independent of the prediction puts ms_ssim_25d's 1e-4 clamp AT the operating point and the
+    # reference's own gradient becomes discontinuous in the bf16 noise of the prediction)
+    with torch.no_grad():
+        y0 = ref(x)
+    tgt = (y0 + gold["tgt_noise"] * y0.std() * torch.randn((B, 2, 5, S, S), generator=g)).contiguous()
     st = gold["y_stride"]
 
     def score(y, loss, grad_of):
@@ -437,21 +440,20 @@ def test_baseline_size_fp32_and_bf16_engines_vs_reference_golden():
     print("fp32 engine @256: forward", f"{fwd:.2e}", "loss", f"{lrel:.2e}", {k: f"{v[0]:.1e}/{v[1]:.1e}" for k, v in stages.items()})
     assert fwd <= 1e-3 and lrel <= 1e-3
     for gname, (omc, rel) in stages.items():
-        assert omc < 2e-4 and rel < 2e-2, (gname, omc, rel)
+        assert omc < 2e-6 and rel < 4e-3, (gname, omc, rel)  # measured: <= 3.3e-7 / 8.1e-4
     yf, yl, ys = run_autocast_yardstick()
     fwd, lrel, stages = run_engine(torch.bfloat16)
     print("bf16 engine @256: forward", f"{fwd:.2e}", "(autocast", f"{yf:.2e})", "loss", f"{lrel:.2e}", f"({yl:.2e})",
           {k: f"{v[0]:.1e} (ac {ys[k][0]:.1e})" for k, v in stages.items()})
-    # The yardstick itself moves by 100 x between runs (MIOpen / rocBLAS pick different bf16 algorithms for the oracle's
-    # convolutions: deepest-stage 1 - cos from 8e-4 to 3.3e-1 in eight runs, stem-stage from 1.4e-4 to 3.9e-2), the engine
-    # does not (deepest stages 1.6e-3 .. 2.0e-3, relative error 0.06 .. 0.083; stem-stage 3.8e-4 .. 4.8e-4): the bar is 1.25 x the
-    # yardstick OR absolute bars 1.75 x above the engine's own worst observation (forward 1.5 % as in the 128 x 128 gate above,
-    # 1 - cos 3.5e-3, relative gradient error 0.12 ~ sqrt(2 * 3.5e-3) + magnitude mismatch), whichever is larger
-    assert fwd <= max(1.25 * yf, 0.015)
-    assert lrel <= max(1.25 * yl, 2e-3)
+    # With a target the loss is differentiable at (see the fixture's generator) both sides repeat to +-5 % run to run: engine
+    # per-stage 1 - cos 1.5e-3 .. 5.7e-3 against 1.8e-3 .. 7.5e-3 for the reference arithmetic under autocast, engine below
+    # the yardstick in every stage of every run so far (ratio 0.6 .. 0.9).  (With the first fixture's independent target the
+    # SAME code gave 2e-4 .. 3e-1 on both sides: ms_ssim_25d's 1e-4 clamp sat at the operating point)
+    assert fwd <= 1.25 * yf
+    assert lrel <= max(1.25 * yl, 1e-3)
     for gname, (omc, rel) in stages.items():
-        assert omc <= max(1.25 * ys[gname][0], 3.5e-3), (gname, omc, ys[gname])
-        assert rel <= max(1.25 * ys[gname][1], 0.12), (gname, rel, ys[gname])
+        assert omc <= 1.25 * ys[gname][0], (gname, omc, ys[gname])
+        assert rel <= 1.25 * ys[gname][1], (gname, rel, ys[gname])
 
 
 @pytest.mark.parametrize("tag", ["small_z5", "vscyto3d_z15", "head_conv_z5"])

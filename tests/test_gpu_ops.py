@@ -1186,3 +1186,47 @@ def _fused_bwd_case(C, hw, B, dt, M, H4, L, ops):
     pdf = torch.exp(-0.5 * x * x) * 0.3989422804014327
     ref = ((dzf.view(B, hw, H4) * s[:, None] + (x * cdf).view(B, hw, H4) * t[:, None]).view(M, H4) * (cdf + x * pdf)).to(dt)
     close(dh, ref, dt, "dh vs fp32 statement")
+
+
+def test_weight_task_list_equals_single_launches():
+    """vsx_weight_tasks (ops.batch): prep_weight / transpose_f32 / matvec / mlp_pack collected into task lists give bit-identical
+    outputs to the single launches — more tasks than one launch holds (VSX_WTASK_MAX = 60), every kind, bf16 and fp32, tap
+    reordering, gamma fold, accumulate"""
+    O = _hip()
+
+    def jobs():
+        out = []
+        for i in range(30):
+            Rr, Cs, Tn = 32 + 8 * (i % 5), 16 + 8 * (i % 3), (1, 4, 9, 27)[i % 4]
+            src = torch.randn((Rr, Cs, Tn), generator=torch.Generator().manual_seed(100 + i)).cuda()
+            gam = torch.randn(Cs, generator=torch.Generator().manual_seed(200 + i)).cuda() if i % 2 else None
+            dt = torch.bfloat16 if i % 3 else torch.float32
+            out.append(O.prep_weight(src, Rr, Cs, Tn, dt, want=i % 4 != 1, want_t=i % 4 != 2, gamma=gam, tapmode=1 if Tn == 27 else 0))
+        for i in range(25):
+            A, Bn = 7 + 13 * i, 49 if i % 2 else 1
+            src = torch.randn((A, Bn), generator=torch.Generator().manual_seed(300 + i)).cuda()
+            dst = torch.randn((Bn, A), generator=torch.Generator().manual_seed(400 + i)).cuda()
+            O.transpose_f32(src, dst, A, Bn, bool(i % 2))
+            out.append((dst,))
+        for i in range(20):
+            Rr, Cc = 24 + 40 * i, 96 + 32 * (i % 4)
+            Wm = torch.randn((Rr, Cc), generator=torch.Generator().manual_seed(500 + i)).cuda()
+            v = torch.randn(Cc, generator=torch.Generator().manual_seed(600 + i)).cuda()
+            b = torch.randn(Rr, generator=torch.Generator().manual_seed(700 + i)).cuda() if i % 2 else None
+            out.append((O.matvec(Wm, v, b, Rr, Cc),))
+        for Cw in (96, 192, 224, 384):
+            W1 = torch.randn((4 * Cw, Cw), generator=torch.Generator().manual_seed(800 + Cw)).cuda().bfloat16()
+            W2 = torch.randn((Cw, 4 * Cw), generator=torch.Generator().manual_seed(900 + Cw)).cuda().bfloat16()
+            out.append((O.mlp_pack(W1, W2, Cw),))
+        return out
+
+    single = jobs()
+    with O.batch():
+        listed = jobs()
+    torch.cuda.synchronize()
+    assert len(single) == len(listed) == 79
+    for a, b in zip(single, listed):
+        for ta, tb in zip(a, b):
+            assert (ta is None) == (tb is None)
+            if ta is not None:
+                assert torch.equal(ta, tb)

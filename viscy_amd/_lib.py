@@ -44,8 +44,17 @@ class VsxGemm(C.Structure):
     ]
 
 
+class VsxWTask(C.Structure):
+    """one job of vsx_weight_tasks (include/vsx.h)"""
+    _fields_ = [("kind", _I32), ("dtype", _I32), ("i0", _I32), ("i1", _I32), ("i2", _I32), ("i3", _I32),
+                ("p0", _P), ("p1", _P), ("p2", _P), ("p3", _P)]
+
+
+WTASK_PREP, WTASK_TRANSPOSE, WTASK_MATVEC, WTASK_MLP_PACK = 0, 1, 2, 3
+
 _SIGS = {
     "vsx_version": (_I32, []),
+    "vsx_weight_tasks": (_I32, [_P, _I32, _P]),
     "vsx_last_error": (C.c_char_p, []),
     "vsx_set_flag": (_I32, [C.c_char_p, _I32]),
     "vsx_get_flag": (_I32, [C.c_char_p]),

@@ -40,6 +40,7 @@
 //     the residual is read in the same 16-byte fragment layout as the input rows; the result leaves through a per-wave LDS
 //     transpose as one contiguous 16-byte-vector stream.
 #include "vsx_common.h"
+#include "wtasks.h"
 #include "../../include/vsx.h"
 
 typedef float mlp_f32x4 __attribute__((ext_vector_type(4)));
@@ -597,29 +598,10 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ weight image
-// piece (hs, hf, kk) lane (p, q): W1[hs*32 + hf*16 + p][kk*32 + q*8 .. +7]
-// piece (hs, nf)     lane (p, q): W2[nf*16 + p][hs*32 + q*4 .. +3], W2[nf*16 + p][hs*32 + 16 + q*4 .. +3]
+// (layout and body: csrc/wtasks.h — shared with the task-list kernel vsx_weight_tasks)
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const bf16_t* __restrict__ W1, const bf16_t* __restrict__ W2,
                                                        char* __restrict__ img, int C) {
-  const int H4 = 4 * C, KK = C / 32, NF = C / 16, PPS = 2 * KK + NF;
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)(H4 / 32) * PPS * 64;
-  if (gid >= total) return;
-  const int lane = (int)(gid & 63);
-  const long piece = gid >> 6;
-  const int hs = (int)(piece / PPS), pp = (int)(piece % PPS);
-  const int p16 = lane & 15, kq = lane >> 4;
-  uint4 v;
-  if (pp < 2 * KK) {
-    const int hf = pp / KK, kk = pp % KK;
-    v = *reinterpret_cast<const uint4*>(W1 + (size_t)(hs * 32 + hf * 16 + p16) * C + kk * 32 + kq * 8);
-  } else {
-    const int nf = pp - 2 * KK;
-    const bf16_t* r = W2 + (size_t)(nf * 16 + p16) * H4 + hs * 32 + kq * 4;
-    const uint2 lo = *reinterpret_cast<const uint2*>(r), hi = *reinterpret_cast<const uint2*>(r + 16);
-    v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-  }
-  *reinterpret_cast<uint4*>(img + (size_t)gid * 16) = v;
+  wt_mlp_pack(blockIdx.x, W1, W2, img, C);
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch

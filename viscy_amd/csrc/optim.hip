@@ -3,6 +3,7 @@
 // K order, transposed copy for the data-gradient GEMM, LayerNorm affine folded into fc1) plus the
 // inverse mapping for gradients.  All are tiny HBM-bound passes over <=32 M parameters.
 #include "vsx_common.h"
+#include "wtasks.h"
 #include "../../include/vsx.h"
 
 // ------------------------------------------------------------------ AdamW (torch.optim.AdamW semantics)
@@ -124,32 +125,11 @@ extern "C" int32_t vsx_adamw_advance(const double* cfg, int32_t* step, float* hy
 }
 
 // ------------------------------------------------------------------ weight preparation
-// tap order of the GEMM K axis: k = t_dst * Cs + c.  tapmode 0: t_dst = t_src; tapmode 1 (head
-// Conv3d [.., kz, ky, kx] → (ky, kx, kz)): t_src = (kz*3 + ky)*3 + kx, t_dst = (ky*3 + kx)*3 + kz.
-__device__ __forceinline__ int tap_dst(int t_src, int tapmode) {
-  if (tapmode == 0) return t_src;
-  int kx = t_src % 3, ky = (t_src / 3) % 3, kz = t_src / 9;
-  return (ky * 3 + kx) * 3 + kz;
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void prep_weight_kernel(const float* __restrict__ src, T* __restrict__ dst,
                                                           T* __restrict__ dstT, const float* __restrict__ gamma, int R,
                                                           int Cs, int Tn, int tapmode) {
-  const long total = (long)R * Cs * Tn;
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const int t = (int)(gid % Tn);
-  const long rc = gid / Tn;
-  const int c = (int)(rc % Cs);
-  const int r = (int)(rc / Cs);
-  float v = src[gid];
-  if (gamma) v *= gamma[c];
-  const int K = Tn * Cs;
-  const int k = tap_dst(t, tapmode) * Cs + c;
-  const T o = from_f32<T>(v);
-  if (dst) dst[(size_t)r * K + k] = o;
-  if (dstT) dstT[(size_t)k * R + r] = o;
+  wt_prep_weight<T>(blockIdx.x, src, dst, dstT, gamma, R, Cs, Tn, tapmode);
 }
 
 /* src: fp32 parameter viewed as [R, Cs, Tn] (out, in-channels, taps) → dst [R, Tn*Cs] and/or
@@ -218,12 +198,7 @@ extern "C" int32_t vsx_unprep_grad(const float* g, float* dparam, const float* g
 __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W, const float* __restrict__ v,
                                                      const float* __restrict__ b, float* __restrict__ out, int R,
                                                      int C) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= R) return;
-  float a = 0.f;
-  for (int c = threadIdx.x & 63; c < C; c += 64) a += W[(size_t)r * C + c] * v[c];
-  a = wave_sum(a);
-  if ((threadIdx.x & 63) == 0) out[r] = a + (b ? b[r] : 0.f);
+  wt_matvec(blockIdx.x, W, v, b, out, R, C);
 }
 // out[c] += Σ_r W[r][c] * u[r]                            (gradient of the folded LN beta)
 __global__ __launch_bounds__(256) void matvec_t_kernel(const float* __restrict__ W, const float* __restrict__ u,
@@ -258,12 +233,7 @@ extern "C" int32_t vsx_matvec_t_add(const float* W, const float* u, float* out, 
 // dst[j][i] (+)= src[i][j]   (fp32; depthwise weights [C][49] <-> [49][C])
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int A,
                                                             int Bn, int accumulate) {
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long)A * Bn) return;
-  const int j = (int)(gid % Bn), i = (int)(gid / Bn);
-  const float v = src[gid];
-  float* d = dst + (size_t)j * A + i;
-  *d = accumulate ? *d + v : v;
+  wt_transpose_f32(blockIdx.x, src, dst, A, Bn, accumulate);
 }
 extern "C" int32_t vsx_transpose_f32(const float* src, float* dst, int32_t A, int32_t Bn, int32_t accumulate,
                                      vsx_stream_t stream) {
@@ -271,6 +241,88 @@ extern "C" int32_t vsx_transpose_f32(const float* src, float* dst, int32_t A, in
   hipLaunchKernelGGL(transpose_f32_kernel, dim3(vsx_cdiv((long)A * Bn, 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
                      A, Bn, accumulate);
   VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ weight-space task list
+// One launch for a list of independent weight-space jobs (vsx_prep_weight / vsx_transpose_f32 / vsx_matvec / vsx_mlp_pack
+// bodies, csrc/wtasks.h).  The list travels BY VALUE in the kernel arguments (a hipGraph node keeps it; no device-side table
+// to keep alive): <= VSX_WTASK_MAX tasks per launch, workgroup -> task by a binary search over the prefix sums.
+struct WTaskBatch {
+  int n;
+  int start[VSX_WTASK_MAX + 1];
+  VsxWTask t[VSX_WTASK_MAX];
+};
+static_assert(sizeof(WTaskBatch) <= 4096, "the task list must fit the kernel-argument segment");
+
+__global__ __launch_bounds__(256) void weight_tasks_kernel(const WTaskBatch b) {
+  int lo = 0, hi = b.n;  // largest lo with start[lo] <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (b.start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const VsxWTask& t = b.t[lo];
+  const int blk = (int)blockIdx.x - b.start[lo];
+  switch (t.kind) {
+    case VSX_WTASK_PREP:
+      if (t.dtype == VSX_BF16)
+        wt_prep_weight<bf16_t>(blk, (const float*)t.p0, (bf16_t*)t.p1, (bf16_t*)t.p2, (const float*)t.p3, t.i0, t.i1, t.i2, t.i3);
+      else
+        wt_prep_weight<float>(blk, (const float*)t.p0, (float*)t.p1, (float*)t.p2, (const float*)t.p3, t.i0, t.i1, t.i2, t.i3);
+      break;
+    case VSX_WTASK_TRANSPOSE: wt_transpose_f32(blk, (const float*)t.p0, (float*)t.p1, t.i0, t.i1, t.i2); break;
+    case VSX_WTASK_MATVEC: wt_matvec(blk, (const float*)t.p0, (const float*)t.p3, (const float*)t.p2, (float*)t.p1, t.i0, t.i1); break;
+    case VSX_WTASK_MLP_PACK: wt_mlp_pack(blk, (const bf16_t*)t.p0, (const bf16_t*)t.p3, (char*)t.p1, t.i0); break;
+    default: break;
+  }
+}
+
+/* n independent weight-space jobs in ceil(n / VSX_WTASK_MAX) launches.  Per kind (fields of VsxWTask, include/vsx.h):
+ *   VSX_WTASK_PREP      = vsx_prep_weight(p0 src, p1 dst, p2 dstT, p3 gamma, i0 R, i1 Cs, i2 Tn, i3 tapmode, dtype)
+ *   VSX_WTASK_TRANSPOSE = vsx_transpose_f32(p0 src, p1 dst, i0 A, i1 Bn, i2 accumulate)
+ *   VSX_WTASK_MATVEC    = vsx_matvec(p0 W, p3 v, p2 b, p1 out, i0 R, i1 C)
+ *   VSX_WTASK_MLP_PACK  = vsx_mlp_pack(p0 W1, p3 W2, p1 img, i0 C)
+ * No task may read or accumulate into what another task of the same call writes. */
+extern "C" int32_t vsx_weight_tasks(const VsxWTask* tasks, int32_t n, vsx_stream_t stream) {
+  VSX_CHECK(tasks && n > 0, "vsx_weight_tasks: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += VSX_WTASK_MAX) {
+    WTaskBatch b;
+    b.n = n - i0 < VSX_WTASK_MAX ? n - i0 : VSX_WTASK_MAX;
+    long total = 0;
+    for (int j = 0; j < b.n; ++j) {
+      const VsxWTask& t = tasks[i0 + j];
+      long blocks = 0;
+      switch (t.kind) {
+        case VSX_WTASK_PREP:
+          VSX_CHECK(t.p0 && (t.p1 || t.p2) && t.i0 > 0 && t.i1 > 0 && t.i2 > 0 && (t.i3 == 0 || (t.i3 == 1 && t.i2 == 27)) &&
+                        (t.dtype == VSX_BF16 || t.dtype == VSX_F32), "vsx_weight_tasks: task %d (prep_weight): bad arguments", i0 + j);
+          blocks = vsx_cdiv((long)t.i0 * t.i1 * t.i2, 256L);
+          break;
+        case VSX_WTASK_TRANSPOSE:
+          VSX_CHECK(t.p0 && t.p1 && t.i0 > 0 && t.i1 > 0, "vsx_weight_tasks: task %d (transpose_f32): bad arguments", i0 + j);
+          blocks = vsx_cdiv((long)t.i0 * t.i1, 256L);
+          break;
+        case VSX_WTASK_MATVEC:
+          VSX_CHECK(t.p0 && t.p3 && t.p1 && t.i0 > 0 && t.i1 > 0, "vsx_weight_tasks: task %d (matvec): bad arguments", i0 + j);
+          blocks = vsx_cdiv(t.i0, 4);
+          break;
+        case VSX_WTASK_MLP_PACK:
+          VSX_CHECK(t.p0 && t.p3 && t.p1 && t.i0 > 0 && t.i0 % 32 == 0, "vsx_weight_tasks: task %d (mlp_pack): C must be a multiple of 32", i0 + j);
+          blocks = vsx_cdiv(wt_mlp_pack_items(t.i0), 256L);
+          break;
+        default:
+          vsx_set_error("vsx_weight_tasks: task %d has unknown kind %d", i0 + j, t.kind);
+          return 1;
+      }
+      b.start[j] = (int)total;
+      b.t[j] = t;
+      total += blocks;
+      VSX_CHECK(total < (1l << 31), "vsx_weight_tasks: too many workgroups");
+    }
+    b.start[b.n] = (int)total;
+    hipLaunchKernelGGL(weight_tasks_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, b);
+    VSX_LAUNCH_CHECK();
+  }
   return 0;
 }
 

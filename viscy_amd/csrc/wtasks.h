@@ -1,0 +1,83 @@
+// Weight-space helpers shared by their single-op entry points (optim.hip, mlp.hip) and by the task-list kernel
+// vsx_weight_tasks (optim.hip): each body does the work of ONE 256-thread workgroup `blk` of the single-op launch.
+// The step runs ~200 of these per weight refresh, 4 - 7 us each with the chip idle behind every one: a task list turns
+// them into a handful of launches.
+#pragma once
+#include "vsx_common.h"
+
+// tap order of the GEMM K axis: k = t_dst * Cs + c.  tapmode 0: t_dst = t_src; tapmode 1 (head
+// Conv3d [.., kz, ky, kx] → (ky, kx, kz)): t_src = (kz*3 + ky)*3 + kx, t_dst = (ky*3 + kx)*3 + kz.
+__device__ __forceinline__ int tap_dst(int t_src, int tapmode) {
+  if (tapmode == 0) return t_src;
+  int kx = t_src % 3, ky = (t_src / 3) % 3, kz = t_src / 9;
+  return (ky * 3 + kx) * 3 + kz;
+}
+
+template <typename T>
+__device__ __forceinline__ void wt_prep_weight(int blk, const float* __restrict__ src, T* __restrict__ dst,
+                                               T* __restrict__ dstT, const float* __restrict__ gamma, int R, int Cs, int Tn,
+                                               int tapmode) {
+  const long total = (long)R * Cs * Tn;
+  const long gid = (long)blk * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int t = (int)(gid % Tn);
+  const long rc = gid / Tn;
+  const int c = (int)(rc % Cs);
+  const int r = (int)(rc / Cs);
+  float v = src[gid];
+  if (gamma) v *= gamma[c];
+  const int K = Tn * Cs;
+  const int k = tap_dst(t, tapmode) * Cs + c;
+  const T o = from_f32<T>(v);
+  if (dst) dst[(size_t)r * K + k] = o;
+  if (dstT) dstT[(size_t)k * R + r] = o;
+}
+
+// out[r] = (b ? b[r] : 0) + Σ_c W[r][c] * v[c]          (fold LN beta into the fc1 bias); 4 rows per workgroup
+__device__ __forceinline__ void wt_matvec(int blk, const float* __restrict__ W, const float* __restrict__ v,
+                                          const float* __restrict__ b, float* __restrict__ out, int R, int C) {
+  const int r = blk * 4 + (threadIdx.x >> 6);
+  float a = 0.f;
+  if (r < R)
+    for (int c = threadIdx.x & 63; c < C; c += 64) a += W[(size_t)r * C + c] * v[c];
+  a = wave_sum(a);
+  if (r < R && (threadIdx.x & 63) == 0) out[r] = a + (b ? b[r] : 0.f);
+}
+
+// dst[j][i] (+)= src[i][j]   (fp32; depthwise weights [C][49] <-> [49][C])
+__device__ __forceinline__ void wt_transpose_f32(int blk, const float* __restrict__ src, float* __restrict__ dst, int A, int Bn,
+                                                 int accumulate) {
+  const long gid = (long)blk * 256 + threadIdx.x;
+  if (gid >= (long)A * Bn) return;
+  const int j = (int)(gid % Bn), i = (int)(gid / Bn);
+  const float v = src[gid];
+  float* d = dst + (size_t)j * A + i;
+  *d = accumulate ? *d + v : v;
+}
+
+// fragment-major LDS image of the fused GRN-MLP kernels (csrc/mlp.hip):
+// piece (hs, hf, kk) lane (p, q): W1[hs*32 + hf*16 + p][kk*32 + q*8 .. +7]
+// piece (hs, nf)     lane (p, q): W2[nf*16 + p][hs*32 + q*4 .. +3], W2[nf*16 + p][hs*32 + 16 + q*4 .. +3]
+__device__ __forceinline__ void wt_mlp_pack(int blk, const bf16_t* __restrict__ W1, const bf16_t* __restrict__ W2,
+                                            char* __restrict__ img, int C) {
+  const int H4 = 4 * C, KK = C / 32, NF = C / 16, PPS = 2 * KK + NF;
+  const long gid = (long)blk * 256 + threadIdx.x;
+  const long total = (long)(H4 / 32) * PPS * 64;
+  if (gid >= total) return;
+  const int lane = (int)(gid & 63);
+  const long piece = gid >> 6;
+  const int hs = (int)(piece / PPS), pp = (int)(piece % PPS);
+  const int p16 = lane & 15, kq = lane >> 4;
+  uint4 v;
+  if (pp < 2 * KK) {
+    const int hf = pp / KK, kk = pp % KK;
+    v = *reinterpret_cast<const uint4*>(W1 + (size_t)(hs * 32 + hf * 16 + p16) * C + kk * 32 + kq * 8);
+  } else {
+    const int nf = pp - 2 * KK;
+    const bf16_t* r = W2 + (size_t)(nf * 16 + p16) * H4 + hs * 32 + kq * 4;
+    const uint2 lo = *reinterpret_cast<const uint2*>(r), hi = *reinterpret_cast<const uint2*>(r + 16);
+    v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+  *reinterpret_cast<uint4*>(img + (size_t)gid * 16) = v;
+}
+__host__ __device__ inline long wt_mlp_pack_items(int C) { return (long)(4 * C / 32) * (2 * (C / 32) + C / 16) * 64; }

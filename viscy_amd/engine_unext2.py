@@ -23,7 +23,7 @@ from . import _lib as L
 class _BlockW:
     """prepared operands + parameter handles of one ConvNeXt-V2 block"""
 
-    __slots__ = ("C", "p", "dw_w", "W1f", "W1fT", "b1f", "W2", "W2T", "v1", "fc2_w", "fc2_b", "grn_w", "grn_b", "dp", "img")
+    __slots__ = ("C", "p", "dw_w", "W1f", "W1fT", "b1f", "W2", "W2T", "v1", "fc2_w", "fc2_b", "grn_w", "grn_b", "dp", "img", "img2", "b2f")
 
 
 class _ProjW:
@@ -211,6 +211,9 @@ class Engine:
             w.fc2_w, w.fc2_b = blk.mlp.fc2.weight, blk.mlp.fc2.bias
             w.grn_w, w.grn_b = blk.mlp.grn.weight, blk.mlp.grn.bias
         w.W2, w.W2T = o.prep_weight(w.fc2_w, C, 4 * C, 1, dt, want=True, want_t=need_bwd)
+        # fc2 bias with the GRN beta folded in (b2 + W2 . beta): what fc2 needs when the GRN scale lives in per-sample weights
+        w.b2f = o.matvec(w.fc2_w, w.grn_b, w.fc2_b, C, 4 * C) if dt == torch.bfloat16 and C > 64 else None
+        w.img2 = None  # image of (W2^T, W2) for the block backward without a stored dz
         return w
 
     def _prep_proj(self, ln, conv, dt, need_bwd):
@@ -225,6 +228,25 @@ class Engine:
     def prepare(self, dt: torch.dtype, need_bwd: bool):
         key = (dt, need_bwd)
         m, cfg, o = self.model, self.cfg, self.ops
+        with o.batch():  # ~150 weight-space jobs -> a handful of task-list launches (ops.batch)
+            W = self._prepare_ops(dt, need_bwd)
+        if dt == torch.bfloat16 and self._mlp_flag() and hasattr(o, "mlp_pack"):
+            # fragment-major weight images of the fused GRN-MLP kernels, every block's in one task list (their inputs are the
+            # outputs of the list above); a block whose shape the fused kernels do not serve simply never reads its image
+            bwd_img = need_bwd and bool(self._mlp_flag() & 8)
+            with o.batch():
+                for _, blocks in list(W["enc"]) + list(W["dec"]):
+                    for w in blocks:
+                        if any(o.mlp_supported(w.C, 1 << 20, 1 << 20, dt, md) for md in (None, 2, 4)):  # a width the kernels serve
+                            w.img = o.mlp_pack(w.W1f, w.W2, w.C)
+                            if bwd_img:
+                                w.img2 = o.mlp_pack(w.W2T, w.W2, w.C)
+        self.W = W
+        self._prepared_for = key
+        return W
+
+    def _prepare_ops(self, dt: torch.dtype, need_bwd: bool):
+        m, cfg, o = self.model, self.cfg, self.ops
         W = {"dt": dt}
         # stem: [Cout3d, K] (block-diagonal expansion when the stem keeps D' > 1 depth slabs)
         sw = m.stem.conv.weight
@@ -233,6 +255,7 @@ class Engine:
         if Dp == 1:
             W["stem_W"], _ = o.prep_weight(sw, co3, K, 1, dt)
             if dt == torch.bfloat16 and K % 32:
+                o.flush()  # pad_cols reads what the task list has yet to write
                 # K = 80 (the 5x4x4 single-channel stem) is not a whole number of 32-deep MFMA slabs: the projection fell to
                 # the generic GEMM (2.9 ms at B = 512, 250 GB/s).  Zero-padded to 96 on both operands it runs on the lean one.
                 W["stem_W"] = o.pad_cols(W["stem_W"], (K + 31) // 32 * 32)
@@ -248,6 +271,7 @@ class Engine:
             K2 = s2.weight[0].numel()
             W["stem2d_W"], _ = o.prep_weight(s2.weight, s2.weight.shape[0], K2, 1, dt)
             if dt == torch.bfloat16 and K2 % 32:
+                o.flush()
                 W["stem2d_W"] = o.pad_cols(W["stem2d_W"], (K2 + 31) // 32 * 32)
             W["stem2d_b"] = s2.bias
         enc = []
@@ -294,10 +318,9 @@ class Engine:
             W["head_Wc"], _ = o.prep_weight(hc.weight, cmid, c3, 27, hdt, tapmode=1)
             if need_bwd:
                 if hdt == torch.bfloat16 and c3 == 8 and cmid == 32 and cfg["out_stack_depth"] == 5:
+                    o.flush()  # reads head_Wc
                     W["head_Wp"] = o.head_conv_dgrad_prep(W["head_Wc"])  # direct LDS-tiled dgrad (csrc/headconv.hip)
                 W["head_Wd"] = o.prep_head_dgrad(hc.weight, cmid, c3, cfg["out_stack_depth"], hdt)
-        self.W = W
-        self._prepared_for = key
         return W
 
     def _head_dtype(self, dt: torch.dtype) -> torch.dtype:
@@ -390,7 +413,7 @@ class Engine:
             # so fc2 is a plain GEMM (the operand prologue costs +60 % on these launches); B·C·4C extra weight bytes
             # are small next to the M·4C activation bytes when a sample spans >= 8 row tiles
             Ws = o.scale_weight_samples(w.fc2_w, s, dt)
-            b2 = o.matvec(w.fc2_w, w.grn_b, w.fc2_b, C, 4 * C)
+            b2 = w.b2f if w.b2f is not None else o.matvec(w.fc2_w, w.grn_b, w.fc2_b, C, 4 * C)
             o.gemm("nt", gact, Ws, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, hw=hw, b_bstride=C * 4 * C,
                    epi=L.EPI_BIAS_RES, bias=b2, res=xres, ldr=C, rscale=dpm)
         else:
@@ -447,7 +470,7 @@ class Engine:
             # the 4C-wide dz is never written: the statistics came from the per-sample products above; this pass recomputes
             # dz = dout·W2 tile by tile (K = C is short) and writes dh directly (csrc/mlp.hip MODE 4) — one 4C-wide write
             # where the unfused pair (dz GEMM, then GRN / GELU backward over it) has two
-            img2 = o.mlp_pack(w.W2T, w.W2, C)
+            img2 = w.img2 if w.img2 is not None else o.mlp_pack(w.W2T, w.W2, C)
             if fused_bwd == 2:  # statistics by recomputing dz tile by tile (P = Σ dz·g, S = Σ dz), nothing stored
                 o.mlp_bwd_stats(dout, img2, gact, PS[0], PS[1], M, C, hw)
             t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw, Sb=PS[1], dbeta=dgb)

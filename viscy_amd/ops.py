@@ -6,6 +6,7 @@ arithmetic happens in the HIP kernels.  Every wrapper raises if a tensor is not 
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Sequence
 
@@ -283,11 +284,54 @@ def head_out_bwd2(U, ssum, ssq, w2, alpha, dv, S1, S2, B, H2, W2, Z, Cmid, Cout,
     return dU
 
 
+# ------------------------------------------------------------------ weight-space task lists
+# prep_weight / transpose_f32 / matvec / mlp_pack are tiny (4 - 7 us, the chip idle behind each one) and the step refreshes
+# ~200 of them per weight update.  Inside ``with batch():`` they are not launched but collected and handed to
+# vsx_weight_tasks when the block ends (or at flush()): a handful of launches.  Nothing inside a batch may consume the output
+# of an op queued in the SAME batch — call flush() first.
+_BATCH: list | None = None
+_BATCH_KEEP: list = []  # the queued jobs' tensors stay alive (and their memory un-recycled) until the list is launched
+
+
+@contextlib.contextmanager
+def batch():
+    global _BATCH
+    outer = _BATCH
+    _BATCH = [] if outer is None else outer
+    try:
+        yield
+    finally:
+        if outer is None:
+            flush()
+            _BATCH = None
+
+
+def flush() -> None:
+    """launch what the current batch has collected so far (keeps collecting afterwards)"""
+    if not _BATCH:
+        return
+    arr = (L.VsxWTask * len(_BATCH))(*_BATCH)
+    del _BATCH[:]
+    check(lib().vsx_weight_tasks(C.addressof(arr), len(arr), stream()), "weight_tasks")
+    del _BATCH_KEEP[:]
+
+
+def _queue(kind: int, dtype: int, ints, p0, p1, p2, p3) -> bool:
+    if _BATCH is None:
+        return False
+    i = list(ints) + [0] * (4 - len(ints))
+    _BATCH.append(L.VsxWTask(kind, dtype, i[0], i[1], i[2], i[3], ptr(p0), ptr(p1), ptr(p2), ptr(p3)))
+    _BATCH_KEEP.append((p0, p1, p2, p3))
+    return True
+
+
 def prep_weight(src: Tensor, R: int, Cs: int, Tn: int, dtype: torch.dtype, *, want: bool = True, want_t: bool = False,
                 gamma: Tensor | None = None, tapmode: int = 0):
     K = Cs * Tn
     dst = torch.empty((R, K), dtype=dtype, device=src.device) if want else None
     dstT = torch.empty((K, R), dtype=dtype, device=src.device) if want_t else None
+    if (dst is not None or dstT is not None) and _queue(L.WTASK_PREP, dtype_code(dtype), (R, Cs, Tn, tapmode), src, dst, dstT, gamma):
+        return dst, dstT
     check(lib().vsx_prep_weight(ptr(src), ptr(dst), ptr(dstT), ptr(gamma), R, Cs, Tn, tapmode, dtype_code(dtype), stream()),
           "prep_weight")
     return dst, dstT
@@ -301,6 +345,8 @@ def unprep_grad(g: Tensor, dparam: Tensor, R: int, Cs: int, Tn: int, *, gamma=No
 
 def matvec(W: Tensor, v: Tensor, b: Tensor | None, R: int, Cc: int) -> Tensor:
     out = torch.empty(R, dtype=torch.float32, device=W.device)
+    if _queue(L.WTASK_MATVEC, 0, (R, Cc), W, out, b, v):
+        return out
     check(lib().vsx_matvec(ptr(W), ptr(v), ptr(b), ptr(out), R, Cc, stream()), "matvec")
     return out
 
@@ -310,6 +356,8 @@ def matvec_t_add(W: Tensor, u: Tensor, out: Tensor, R: int, Cc: int) -> None:
 
 
 def transpose_f32(src: Tensor, dst: Tensor, A: int, Bn: int, accumulate: bool) -> None:
+    if _queue(L.WTASK_TRANSPOSE, 0, (A, Bn, int(accumulate)), src, dst, None, None):
+        return
     check(lib().vsx_transpose_f32(ptr(src), ptr(dst), A, Bn, int(accumulate), stream()), "transpose_f32")
 
 
@@ -350,6 +398,8 @@ def mlp_supported(C: int, hw: int, M: int, dtype: torch.dtype, mode: int | None 
 def mlp_pack(W1f: Tensor, W2: Tensor, C: int) -> Tensor:
     """fragment-major LDS image of the prepared fc1 / fc2 weights (bf16 [4C, C] and [C, 4C])"""
     img = torch.empty(int(lib().vsx_mlp_image_bytes(C)), dtype=torch.uint8, device=W1f.device)
+    if _queue(L.WTASK_MLP_PACK, 0, (C,), W1f, img, None, W2):
+        return img
     check(lib().vsx_mlp_pack(ptr(W1f), ptr(W2), ptr(img), C, stream()), "mlp_pack")
     return img
 
