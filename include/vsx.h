@@ -395,13 +395,18 @@ int32_t vsx_transpose_f32(const float* src, float* dst, int32_t A, int32_t Bn, i
 #define VSX_WTASK_TRANSPOSE 1
 #define VSX_WTASK_MATVEC 2
 #define VSX_WTASK_MLP_PACK 3
-#define VSX_WTASK_MAX 60
+#define VSX_WTASK_UNPREP 4    /* vsx_unprep_grad: p0 g, p1 dparam, p3 gamma, p4 W, p2 dgamma, p5 u, p6 beta, i0 R, i1 Cs, i2 Tn, i3 tapmode */
+#define VSX_WTASK_MATVEC_T 5  /* vsx_matvec_t_add: p0 W, p3 u, p1 out, i0 R, i1 C */
+#define VSX_WTASK_MAX 48
 typedef struct VsxWTask {
   int32_t kind, dtype, i0, i1, i2, i3;
   const void* p0;
   void* p1;
   void* p2;
   const void* p3;
+  const void* p4;
+  const void* p5;
+  const void* p6;
 } VsxWTask;
 int32_t vsx_weight_tasks(const VsxWTask* tasks, int32_t n, vsx_stream_t stream);
 

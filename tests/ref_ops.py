@@ -335,6 +335,14 @@ def flush():
     pass
 
 
+def batch_open():
+    pass
+
+
+def batch_close():
+    pass
+
+
 def _tap_dst(t, tapmode):
     if tapmode == 0:
         return t

@@ -47,10 +47,10 @@ class VsxGemm(C.Structure):
 class VsxWTask(C.Structure):
     """one job of vsx_weight_tasks (include/vsx.h)"""
     _fields_ = [("kind", _I32), ("dtype", _I32), ("i0", _I32), ("i1", _I32), ("i2", _I32), ("i3", _I32),
-                ("p0", _P), ("p1", _P), ("p2", _P), ("p3", _P)]
+                ("p0", _P), ("p1", _P), ("p2", _P), ("p3", _P), ("p4", _P), ("p5", _P), ("p6", _P)]
 
 
-WTASK_PREP, WTASK_TRANSPOSE, WTASK_MATVEC, WTASK_MLP_PACK = 0, 1, 2, 3
+WTASK_PREP, WTASK_TRANSPOSE, WTASK_MATVEC, WTASK_MLP_PACK, WTASK_UNPREP, WTASK_MATVEC_T = 0, 1, 2, 3, 4, 5
 
 _SIGS = {
     "vsx_version": (_I32, []),

@@ -150,32 +150,12 @@ extern "C" int32_t vsx_prep_weight(const float* src, void* dst, void* dstT, cons
   return 0;
 }
 
-// gradient back-mapping: dparam[r][c][t] += g[r][tap_dst(t)*Cs + c] * (gamma ? gamma[c] : 1) + (u ? u[r]*beta[c] : 0);
-// dgamma[c] += Σ_{r,t} g[r][k] * W[r][c][t]
-// (u, beta): the folded bias b' = b + W·beta also depends on W  →  dW += u ⊗ beta with u = db'
+// gradient back-mapping (body and grid shape: csrc/wtasks.h)
 __global__ __launch_bounds__(256) void unprep_grad_kernel(const float* __restrict__ g, float* __restrict__ dparam,
                                                           const float* __restrict__ gamma, const float* __restrict__ W,
                                                           float* __restrict__ dgamma, const float* __restrict__ u,
-                                                          const float* __restrict__ beta, int R, int Cs, int Tn,
-                                                          int tapmode, int rows_per_block) {
-  // thread = one (c, t) column; loops a chunk of rows so dgamma needs one atomic per thread
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= Cs * Tn) return;
-  const int t = col % Tn, c = col / Tn;
-  const int K = Tn * Cs;
-  const int k = tap_dst(t, tapmode) * Cs + c;
-  const float gm = gamma ? gamma[c] : 1.f;
-  const float bt = u ? beta[c] : 0.f;
-  const int r0 = blockIdx.y * rows_per_block;
-  const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-  float dg = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const float gv = g[(size_t)r * K + k];
-    const size_t pi = ((size_t)r * Cs + c) * Tn + t;
-    dparam[pi] += gv * gm + (u ? u[r] * bt : 0.f);
-    if (dgamma) dg += gv * W[pi];
-  }
-  if (dgamma) atomicAdd(dgamma + c, dg);
+                                                          const float* __restrict__ beta, int R, int Cs, int Tn, int tapmode) {
+  wt_unprep_grad(blockIdx.x, g, dparam, gamma, W, dgamma, u, beta, R, Cs, Tn, tapmode);
 }
 
 extern "C" int32_t vsx_unprep_grad(const float* g, float* dparam, const float* gamma, const float* W, float* dgamma,
@@ -185,11 +165,9 @@ extern "C" int32_t vsx_unprep_grad(const float* g, float* dparam, const float* g
   VSX_CHECK((gamma == nullptr) == (dgamma == nullptr) && (gamma == nullptr || W != nullptr),
             "vsx_unprep_grad: gamma / dgamma / W must come together");
   VSX_CHECK((u == nullptr) == (beta == nullptr) && (u == nullptr || Tn == 1), "vsx_unprep_grad: u / beta need Tn == 1");
-  int rpb = vsx_cdiv(R, 64);
-  if (rpb < 8) rpb = 8;
-  dim3 grid(vsx_cdiv(Cs * Tn, 256), vsx_cdiv(R, rpb));
+  dim3 grid(wt_unprep_bx(Cs, Tn) * vsx_cdiv(R, wt_unprep_rpb(R)));
   hipLaunchKernelGGL(unprep_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, dparam, gamma, W, dgamma, u, beta, R,
-                     Cs, Tn, tapmode, rpb);
+                     Cs, Tn, tapmode);
   VSX_LAUNCH_CHECK();
   return 0;
 }
@@ -200,16 +178,10 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W
                                                      int C) {
   wt_matvec(blockIdx.x, W, v, b, out, R, C);
 }
-// out[c] += Σ_r W[r][c] * u[r]                            (gradient of the folded LN beta)
+// out[c] += Σ_r W[r][c] * u[r]                            (gradient of the folded LN beta; body: csrc/wtasks.h)
 __global__ __launch_bounds__(256) void matvec_t_kernel(const float* __restrict__ W, const float* __restrict__ u,
-                                                       float* __restrict__ out, int R, int C, int rows_per_block) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const int r0 = blockIdx.y * rows_per_block;
-  const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-  float a = 0.f;
-  for (int r = r0; r < r1; ++r) a += W[(size_t)r * C + c] * u[r];
-  atomicAdd(out + c, a);
+                                                       float* __restrict__ out, int R, int C) {
+  wt_matvec_t(blockIdx.x, W, u, out, R, C);
 }
 
 extern "C" int32_t vsx_matvec(const float* W, const float* v, const float* b, float* out, int32_t R, int32_t C,
@@ -222,10 +194,8 @@ extern "C" int32_t vsx_matvec(const float* W, const float* v, const float* b, fl
 extern "C" int32_t vsx_matvec_t_add(const float* W, const float* u, float* out, int32_t R, int32_t C,
                                     vsx_stream_t stream) {
   VSX_CHECK(W && u && out && R > 0 && C > 0, "vsx_matvec_t_add: bad arguments");
-  int rpb = vsx_cdiv(R, 32);
-  if (rpb < 16) rpb = 16;
-  dim3 grid(vsx_cdiv(C, 256), vsx_cdiv(R, rpb));
-  hipLaunchKernelGGL(matvec_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, u, out, R, C, rpb);
+  dim3 grid(vsx_cdiv(C, 256) * vsx_cdiv(R, wt_matvec_t_rpb(R)));
+  hipLaunchKernelGGL(matvec_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, u, out, R, C);
   VSX_LAUNCH_CHECK();
   return 0;
 }
@@ -273,6 +243,11 @@ __global__ __launch_bounds__(256) void weight_tasks_kernel(const WTaskBatch b) {
     case VSX_WTASK_TRANSPOSE: wt_transpose_f32(blk, (const float*)t.p0, (float*)t.p1, t.i0, t.i1, t.i2); break;
     case VSX_WTASK_MATVEC: wt_matvec(blk, (const float*)t.p0, (const float*)t.p3, (const float*)t.p2, (float*)t.p1, t.i0, t.i1); break;
     case VSX_WTASK_MLP_PACK: wt_mlp_pack(blk, (const bf16_t*)t.p0, (const bf16_t*)t.p3, (char*)t.p1, t.i0); break;
+    case VSX_WTASK_UNPREP:
+      wt_unprep_grad(blk, (const float*)t.p0, (float*)t.p1, (const float*)t.p3, (const float*)t.p4, (float*)t.p2,
+                     (const float*)t.p5, (const float*)t.p6, t.i0, t.i1, t.i2, t.i3);
+      break;
+    case VSX_WTASK_MATVEC_T: wt_matvec_t(blk, (const float*)t.p0, (const float*)t.p3, (float*)t.p1, t.i0, t.i1); break;
     default: break;
   }
 }
@@ -282,6 +257,8 @@ __global__ __launch_bounds__(256) void weight_tasks_kernel(const WTaskBatch b) {
  *   VSX_WTASK_TRANSPOSE = vsx_transpose_f32(p0 src, p1 dst, i0 A, i1 Bn, i2 accumulate)
  *   VSX_WTASK_MATVEC    = vsx_matvec(p0 W, p3 v, p2 b, p1 out, i0 R, i1 C)
  *   VSX_WTASK_MLP_PACK  = vsx_mlp_pack(p0 W1, p3 W2, p1 img, i0 C)
+ *   VSX_WTASK_UNPREP    = vsx_unprep_grad(p0 g, p1 dparam, p3 gamma, p4 W, p2 dgamma, p5 u, p6 beta, i0 R, i1 Cs, i2 Tn, i3 tapmode)
+ *   VSX_WTASK_MATVEC_T  = vsx_matvec_t_add(p0 W, p3 u, p1 out, i0 R, i1 C)
  * No task may read or accumulate into what another task of the same call writes. */
 extern "C" int32_t vsx_weight_tasks(const VsxWTask* tasks, int32_t n, vsx_stream_t stream) {
   VSX_CHECK(tasks && n > 0, "vsx_weight_tasks: bad arguments");
@@ -309,6 +286,16 @@ extern "C" int32_t vsx_weight_tasks(const VsxWTask* tasks, int32_t n, vsx_stream
         case VSX_WTASK_MLP_PACK:
           VSX_CHECK(t.p0 && t.p3 && t.p1 && t.i0 > 0 && t.i0 % 32 == 0, "vsx_weight_tasks: task %d (mlp_pack): C must be a multiple of 32", i0 + j);
           blocks = vsx_cdiv(wt_mlp_pack_items(t.i0), 256L);
+          break;
+        case VSX_WTASK_UNPREP:
+          VSX_CHECK(t.p0 && t.p1 && t.i0 > 0 && t.i1 > 0 && t.i2 > 0 && (t.p3 == nullptr) == (t.p2 == nullptr) &&
+                        (t.p3 == nullptr || t.p4 != nullptr) && (t.p5 == nullptr) == (t.p6 == nullptr) && (t.p5 == nullptr || t.i2 == 1),
+                    "vsx_weight_tasks: task %d (unprep_grad): bad arguments", i0 + j);
+          blocks = (long)wt_unprep_bx(t.i1, t.i2) * vsx_cdiv(t.i0, wt_unprep_rpb(t.i0));
+          break;
+        case VSX_WTASK_MATVEC_T:
+          VSX_CHECK(t.p0 && t.p3 && t.p1 && t.i0 > 0 && t.i1 > 0, "vsx_weight_tasks: task %d (matvec_t_add): bad arguments", i0 + j);
+          blocks = (long)vsx_cdiv(t.i1, 256) * vsx_cdiv(t.i0, wt_matvec_t_rpb(t.i0));
           break;
         default:
           vsx_set_error("vsx_weight_tasks: task %d has unknown kind %d", i0 + j, t.kind);

@@ -81,3 +81,48 @@ __device__ __forceinline__ void wt_mlp_pack(int blk, const bf16_t* __restrict__ 
   *reinterpret_cast<uint4*>(img + (size_t)gid * 16) = v;
 }
 __host__ __device__ inline long wt_mlp_pack_items(int C) { return (long)(4 * C / 32) * (2 * (C / 32) + C / 16) * 64; }
+
+// gradient back-mapping: dparam[r][c][t] += g[r][tap_dst(t)*Cs + c] * (gamma ? gamma[c] : 1) + (u ? u[r]*beta[c] : 0);
+// dgamma[c] += Σ_{r,t} g[r][k] * W[r][c][t]
+// (u, beta): the folded bias b' = b + W·beta also depends on W  →  dW += u ⊗ beta with u = db'
+// thread = one (c, t) column; a workgroup loops a chunk of rows so dgamma needs one atomic per thread.
+// Grid: wt_unprep_bx(Cs, Tn) column blocks x cdiv(R, wt_unprep_rpb(R)) row chunks, flattened (x fastest).
+__host__ __device__ inline int wt_unprep_rpb(int R) { const int r = (R + 63) / 64; return r < 8 ? 8 : r; }
+__host__ __device__ inline int wt_unprep_bx(int Cs, int Tn) { return (Cs * Tn + 255) / 256; }
+__device__ __forceinline__ void wt_unprep_grad(int blk, const float* __restrict__ g, float* __restrict__ dparam,
+                                               const float* __restrict__ gamma, const float* __restrict__ W,
+                                               float* __restrict__ dgamma, const float* __restrict__ u,
+                                               const float* __restrict__ beta, int R, int Cs, int Tn, int tapmode) {
+  const int nbx = wt_unprep_bx(Cs, Tn), rows_per_block = wt_unprep_rpb(R);
+  const int col = (blk % nbx) * 256 + threadIdx.x;
+  if (col >= Cs * Tn) return;
+  const int t = col % Tn, c = col / Tn;
+  const int K = Tn * Cs;
+  const int k = tap_dst(t, tapmode) * Cs + c;
+  const float gm = gamma ? gamma[c] : 1.f;
+  const float bt = u ? beta[c] : 0.f;
+  const int r0 = (blk / nbx) * rows_per_block;
+  const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  float dg = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float gv = g[(size_t)r * K + k];
+    const size_t pi = ((size_t)r * Cs + c) * Tn + t;
+    dparam[pi] += gv * gm + (u ? u[r] * bt : 0.f);
+    if (dgamma) dg += gv * W[pi];
+  }
+  if (dgamma) atomicAdd(dgamma + c, dg);
+}
+
+// out[c] += Σ_r W[r][c] * u[r]                            (gradient of the folded LN beta)
+__host__ __device__ inline int wt_matvec_t_rpb(int R) { const int r = (R + 31) / 32; return r < 16 ? 16 : r; }
+__device__ __forceinline__ void wt_matvec_t(int blk, const float* __restrict__ W, const float* __restrict__ u,
+                                            float* __restrict__ out, int R, int C) {
+  const int nbx = (C + 255) / 256, rows_per_block = wt_matvec_t_rpb(R);
+  const int c = (blk % nbx) * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = (blk / nbx) * rows_per_block;
+  const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  float a = 0.f;
+  for (int r = r0; r < r1; ++r) a += W[(size_t)r * C + c] * u[r];
+  atomicAdd(out + c, a);
+}

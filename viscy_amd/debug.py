@@ -59,23 +59,39 @@ class FiniteGuard:
     def __init__(self, *modules, raise_on_first: bool = True, skip=("gemm_z",)):
         self.modules, self.raise_on_first, self.skip = modules, raise_on_first, set(skip)
         self._orig = []
+        self._pending = []
         self.first = None
         self.calls = 0
+
+    def _check(self, call, name, items):
+        if self.first is not None:
+            return
+        for path, t in items:
+            if t.is_cuda and t.is_floating_point() and t.numel():
+                bad = (~torch.isfinite(t)).sum().item()
+                if bad:
+                    self.first = (call, name, path, int(bad), tuple(t.shape))
+                    if self.raise_on_first:
+                        raise NonFinite(f"first non-finite values after launch #{call} {name}: {path} "
+                                        f"{tuple(t.shape)} has {bad} non-finite elements")
+                    break
 
     def _wrap(self, name, fn):
         def wrapped(*a, **k):
             out = fn(*a, **k)
             self.calls += 1
             if self.first is None:
-                for path, t in list(_tensors(a, "arg")) + list(_tensors(k, "kw")) + list(_tensors(out, "out")):
-                    if t.is_cuda and t.is_floating_point() and t.numel():
-                        bad = (~torch.isfinite(t)).sum().item()
-                        if bad:
-                            self.first = (self.calls, name, path, int(bad), tuple(t.shape))
-                            if self.raise_on_first:
-                                raise NonFinite(f"first non-finite values after launch #{self.calls} {name}: {path} "
-                                                f"{tuple(t.shape)} has {bad} non-finite elements")
-                            break
+                items = list(_tensors(a, "arg")) + list(_tensors(k, "kw")) + list(_tensors(out, "out"))
+                # while ops.batch is collecting, the weight-space ops are queued, not launched: their outputs are written at
+                # the flush — everything seen since then is checked there, in call order
+                collecting = any(getattr(m, "_BATCH", None) is not None for m in self.modules)
+                if collecting and name not in ("flush", "batch_close"):
+                    self._pending.append((self.calls, name, items))
+                    return out
+                pending, self._pending = self._pending, []
+                for c, n, it in pending:
+                    self._check(c, n, it)
+                self._check(self.calls, name, items)
             return out
 
         return wrapped
@@ -94,6 +110,10 @@ class FiniteGuard:
         for mod, name, fn in self._orig:
             setattr(mod, name, fn)
         self._orig.clear()
+        if exc[0] is None:
+            pending, self._pending = self._pending, []
+            for c, n, it in pending:
+                self._check(c, n, it)
 
 
 def soak(step_fn, n_steps: int, state_tensors, check_tensors=None, on_fail=None):

@@ -780,108 +780,120 @@ class Engine:
         2 = stages 1-0 + stem) right after the last launch that writes into that bucket of the flat gradient buffer.
         ``viscy_amd.step.TrainStep`` captures the stretch between two yields as one hipGraph segment and issues the
         bucket's RCCL all-reduce between the segments."""
-        o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, sv["W"]
-        dt = sv["dt"]
-        B, H, Wd = sv["shape"]
-        dev = self.device
-        za_key = ("bwd", B, H, Wd, sv["masked"])
-        self._za = za = _ZeroArena(dev, self._za_need.get(za_key, 0), self.ops)
-        if cfg.get("head") == "embed":
-            d = self._embed_tail_bwd(sv, dout[0], dout[1], dt, B)
-        elif cfg.get("head", "conv") == "shuffle":
-            fh, fw = sv["head"]
-            d = o.voxel_shuffle_bwd(dout.contiguous().float(), B, fh, fw, cfg["out_channels"], cfg["out_stack_depth"],
-                                    cfg["stem_kernel"][-1], True, dt)
-        else:
-            hdt = self._head_dtype(dt)
-            d = self._head_conv_bwd(sv, dout, hdt, B, dev)
-            if hdt != dt:
-                d = d.to(dt)
-        # ---- decoder (reverse)
-        dskips = {}
-        for k in (2, 1, 0) if cfg.get("head") != "embed" else ():
-            proj, blocks = W["dec"][k]
-            st_sv = sv["dec"][k]
-            cat, xn, mean, rstd, c_up, sc = st_sv["proj"]
-            _, sh, sw_, _ = (None, *sv["feat_dims"][2 - k])
-            Mk, ccat = B * sh * sw_, c_up + sc
-            for bw, bsv in zip(reversed(blocks), reversed(st_sv["blocks"])):
-                d = self._block_bwd(d, bw, bsv, B, sh, sw_, dt)
-            o.gemm("tn", xn, d, g(proj.conv.weight), Mk, proj.cout, ccat, ccat, proj.cout, ccat, dtype=dt,
-                   colsum=g(proj.conv.bias))
-            dxn = torch.empty((Mk, ccat), dtype=dt, device=dev)
-            o.gemm("nt", d, proj.WT, dxn, Mk, ccat, proj.cout, proj.cout, proj.cout, ccat, dtype=dt)
-            dcat = o.ln_bwd(dxn, cat, mean, rstd, proj.ln.weight, None, g(proj.ln.weight), g(proj.ln.bias), Mk, ccat)
-            del dxn
-            d, dskips[2 - k] = o.pixel_shuffle_cat_bwd(dcat, B, sh // 2, sw_ // 2, c_up, sc)
-            del dcat
-            pre = W["dec_pre"][k]
-            if pre is not None:  # pre-convolution: weight gradient from the re-gathered patch matrix, data gradient through its transpose
-                pc, _, WpT = pre
-                lh, lw, cpc = sh // 2, sw_ // 2, 4 * c_up
-                Ml = B * lh * lw
-                col = o.im2col3x3(st_sv["pre_in"], B, lh, lw, cpc)
-                dWp = self._za.take(cpc, 9 * cpc)
-                o.gemm("tn", col, d, dWp, Ml, cpc, 9 * cpc, 9 * cpc, cpc, 9 * cpc, dtype=dt, colsum=g(pc.bias))
-                o.unprep_grad(dWp, g(pc.weight), cpc, cpc, 9)
-                del col
-                dcol = torch.empty((Ml, 9 * cpc), dtype=dt, device=dev)
-                o.gemm("nt", d, WpT, dcol, Ml, 9 * cpc, cpc, cpc, cpc, 9 * cpc, dtype=dt)
-                d = o.col2im3x3(dcol, B, lh, lw, cpc)
-                del dcol
-        yield 0
-        if self.encoder_frozen():  # nothing below the decoder needs a gradient: skip ~40 % of the backward
-            self._za_need[za_key] = za.used
-            yield 1
-            yield 2
-            return
-        # ---- encoder (reverse); d = gradient w.r.t. feats[3]
-        for i in (3, 2, 1, 0):
-            proj, blocks = W["enc"][i]
-            st_sv = sv["enc"][i]
-            ch, cw, cc = sv["feat_dims"][i]
-            for bw, bsv in zip(reversed(blocks), reversed(st_sv["blocks"])):
-                d = self._block_bwd(d, bw, bsv, B, ch, cw, dt)
-            if proj is not None:
-                prev, xn, mean, rstd = st_sv["proj"]
-                cin = proj.cin
-                Mo = B * ch * cw
-                dWg = self._za.take(proj.cout, 4 * cin)
-                o.gemm("tn", xn, d, dWg, Mo, proj.cout, 4 * cin, cin, proj.cout, 4 * cin, dtype=dt, a_mode=L.A_PATCH2,
-                       gh=ch, gw=cw, cs=cin, colsum=g(proj.conv.bias))
-                o.unprep_grad(dWg, g(proj.conv.weight), proj.cout, cin, 4)
-                dxn = torch.empty((B * 4 * ch * cw, cin), dtype=dt, device=dev)
-                o.gemm("nt", d, proj.WT, dxn, Mo, 4 * cin, proj.cout, proj.cout, proj.cout, cin, dtype=dt,
-                       c_mode=L.A_PATCH2, c_cs=cin, gh=ch, gw=cw)
-                d = o.ln_bwd(dxn, prev, mean, rstd, proj.ln.weight, dskips.get(i - 1), g(proj.ln.weight), g(proj.ln.bias),
-                             B * 4 * ch * cw, cin)
+        # the gradient finalisers of a segment (unprep_grad / matvec_t_add / accumulating transposes: ~100 launches of 5 - 20 us
+        # that only touch weight-sized data) are collected and launched as task lists when the segment ends (ops.batch_open)
+        self.ops.batch_open()
+        try:
+            o, cfg, m, g, W = self.ops, self.cfg, self.model, self.g, sv["W"]
+            dt = sv["dt"]
+            B, H, Wd = sv["shape"]
+            dev = self.device
+            za_key = ("bwd", B, H, Wd, sv["masked"])
+            self._za = za = _ZeroArena(dev, self._za_need.get(za_key, 0), self.ops)
+            if cfg.get("head") == "embed":
+                d = self._embed_tail_bwd(sv, dout[0], dout[1], dt, B)
+            elif cfg.get("head", "conv") == "shuffle":
+                fh, fw = sv["head"]
+                d = o.voxel_shuffle_bwd(dout.contiguous().float(), B, fh, fw, cfg["out_channels"], cfg["out_stack_depth"],
+                                        cfg["stem_kernel"][-1], True, dt)
+            else:
+                hdt = self._head_dtype(dt)
+                d = self._head_conv_bwd(sv, dout, hdt, B, dev)
+                if hdt != dt:
+                    d = d.to(dt)
+            # ---- decoder (reverse)
+            dskips = {}
+            for k in (2, 1, 0) if cfg.get("head") != "embed" else ():
+                proj, blocks = W["dec"][k]
+                st_sv = sv["dec"][k]
+                cat, xn, mean, rstd, c_up, sc = st_sv["proj"]
+                _, sh, sw_, _ = (None, *sv["feat_dims"][2 - k])
+                Mk, ccat = B * sh * sw_, c_up + sc
+                for bw, bsv in zip(reversed(blocks), reversed(st_sv["blocks"])):
+                    d = self._block_bwd(d, bw, bsv, B, sh, sw_, dt)
+                o.gemm("tn", xn, d, g(proj.conv.weight), Mk, proj.cout, ccat, ccat, proj.cout, ccat, dtype=dt,
+                       colsum=g(proj.conv.bias))
+                dxn = torch.empty((Mk, ccat), dtype=dt, device=dev)
+                o.gemm("nt", d, proj.WT, dxn, Mk, ccat, proj.cout, proj.cout, proj.cout, ccat, dtype=dt)
+                dcat = o.ln_bwd(dxn, cat, mean, rstd, proj.ln.weight, None, g(proj.ln.weight), g(proj.ln.bias), Mk, ccat)
                 del dxn
-            if i == 2:
-                yield 1
-        # ---- stem_1 LayerNorm + stem projection
-        P, f, mean, rstd = sv["stem"]
-        ln1 = m.encoder_stages.stem_1
-        M0, C0, K0 = f.shape[0], f.shape[1], P.shape[1]
-        df = o.ln_bwd(d, f, mean, rstd, ln1.weight, None, g(ln1.weight), g(ln1.bias), M0, C0)
-        Dp = cfg["ratio"]
-        if sv.get("flat_stem"):
-            Kw = m.stem2d.weight[0].numel()
-            o.gemm("tn", P, df, g(m.stem2d.weight), M0, C0, Kw, K0, C0, Kw, dtype=dt, colsum=g(m.stem2d.bias))
-        elif Dp == 1:
-            Kw = m.stem.conv.weight[0].numel()  # the patch matrix may carry zero-padded tail columns (lda = K0 >= Kw)
-            o.gemm("tn", P, df, g(m.stem.conv.weight), M0, C0, Kw, K0, C0, Kw, dtype=dt, colsum=g(m.stem.conv.bias))
-        else:
-            co3 = C0 // Dp
-            K = K0 // Dp
-            dWe = self._za.take(C0, K0)
-            dbe = self._za.take(C0)
-            o.gemm("tn", P, df, dWe, M0, C0, K0, K0, C0, K0, dtype=dt, colsum=dbe)
-            dWe = dWe.view(co3, Dp, Dp, K)
-            g(m.stem.conv.weight).add_(torch.stack([dWe[:, dd, dd] for dd in range(Dp)], 0).sum(0).view_as(m.stem.conv.weight))
-            g(m.stem.conv.bias).add_(dbe.view(co3, Dp).sum(1))
-        self._za_need[za_key] = za.used
-        yield 2
+                d, dskips[2 - k] = o.pixel_shuffle_cat_bwd(dcat, B, sh // 2, sw_ // 2, c_up, sc)
+                del dcat
+                pre = W["dec_pre"][k]
+                if pre is not None:  # pre-convolution: weight gradient from the re-gathered patch matrix, data gradient through its transpose
+                    pc, _, WpT = pre
+                    lh, lw, cpc = sh // 2, sw_ // 2, 4 * c_up
+                    Ml = B * lh * lw
+                    col = o.im2col3x3(st_sv["pre_in"], B, lh, lw, cpc)
+                    dWp = self._za.take(cpc, 9 * cpc)
+                    o.gemm("tn", col, d, dWp, Ml, cpc, 9 * cpc, 9 * cpc, cpc, 9 * cpc, dtype=dt, colsum=g(pc.bias))
+                    o.unprep_grad(dWp, g(pc.weight), cpc, cpc, 9)
+                    del col
+                    dcol = torch.empty((Ml, 9 * cpc), dtype=dt, device=dev)
+                    o.gemm("nt", d, WpT, dcol, Ml, 9 * cpc, cpc, cpc, cpc, 9 * cpc, dtype=dt)
+                    d = o.col2im3x3(dcol, B, lh, lw, cpc)
+                    del dcol
+            yield from self._segment_end(0)
+            if self.encoder_frozen():  # nothing below the decoder needs a gradient: skip ~40 % of the backward
+                self._za_need[za_key] = za.used
+                yield from self._segment_end(1)
+                yield from self._segment_end(2)
+                return
+            # ---- encoder (reverse); d = gradient w.r.t. feats[3]
+            for i in (3, 2, 1, 0):
+                proj, blocks = W["enc"][i]
+                st_sv = sv["enc"][i]
+                ch, cw, cc = sv["feat_dims"][i]
+                for bw, bsv in zip(reversed(blocks), reversed(st_sv["blocks"])):
+                    d = self._block_bwd(d, bw, bsv, B, ch, cw, dt)
+                if proj is not None:
+                    prev, xn, mean, rstd = st_sv["proj"]
+                    cin = proj.cin
+                    Mo = B * ch * cw
+                    dWg = self._za.take(proj.cout, 4 * cin)
+                    o.gemm("tn", xn, d, dWg, Mo, proj.cout, 4 * cin, cin, proj.cout, 4 * cin, dtype=dt, a_mode=L.A_PATCH2,
+                           gh=ch, gw=cw, cs=cin, colsum=g(proj.conv.bias))
+                    o.unprep_grad(dWg, g(proj.conv.weight), proj.cout, cin, 4)
+                    dxn = torch.empty((B * 4 * ch * cw, cin), dtype=dt, device=dev)
+                    o.gemm("nt", d, proj.WT, dxn, Mo, 4 * cin, proj.cout, proj.cout, proj.cout, cin, dtype=dt,
+                           c_mode=L.A_PATCH2, c_cs=cin, gh=ch, gw=cw)
+                    d = o.ln_bwd(dxn, prev, mean, rstd, proj.ln.weight, dskips.get(i - 1), g(proj.ln.weight), g(proj.ln.bias),
+                                 B * 4 * ch * cw, cin)
+                    del dxn
+                if i == 2:
+                    yield from self._segment_end(1)
+            # ---- stem_1 LayerNorm + stem projection
+            P, f, mean, rstd = sv["stem"]
+            ln1 = m.encoder_stages.stem_1
+            M0, C0, K0 = f.shape[0], f.shape[1], P.shape[1]
+            df = o.ln_bwd(d, f, mean, rstd, ln1.weight, None, g(ln1.weight), g(ln1.bias), M0, C0)
+            Dp = cfg["ratio"]
+            if sv.get("flat_stem"):
+                Kw = m.stem2d.weight[0].numel()
+                o.gemm("tn", P, df, g(m.stem2d.weight), M0, C0, Kw, K0, C0, Kw, dtype=dt, colsum=g(m.stem2d.bias))
+            elif Dp == 1:
+                Kw = m.stem.conv.weight[0].numel()  # the patch matrix may carry zero-padded tail columns (lda = K0 >= Kw)
+                o.gemm("tn", P, df, g(m.stem.conv.weight), M0, C0, Kw, K0, C0, Kw, dtype=dt, colsum=g(m.stem.conv.bias))
+            else:
+                co3 = C0 // Dp
+                K = K0 // Dp
+                dWe = self._za.take(C0, K0)
+                dbe = self._za.take(C0)
+                o.gemm("tn", P, df, dWe, M0, C0, K0, K0, C0, K0, dtype=dt, colsum=dbe)
+                dWe = dWe.view(co3, Dp, Dp, K)
+                g(m.stem.conv.weight).add_(torch.stack([dWe[:, dd, dd] for dd in range(Dp)], 0).sum(0).view_as(m.stem.conv.weight))
+                g(m.stem.conv.bias).add_(dbe.view(co3, Dp).sum(1))
+            self._za_need[za_key] = za.used
+            yield from self._segment_end(2)
 
+
+        finally:
+            self.ops.batch_close()
+
+    def _segment_end(self, k: int):
+        self.ops.batch_close()
+        yield k
+        self.ops.batch_open()
 
 # ------------------------------------------------------------------------------------------------
 class _UNeXt2Fn(torch.autograd.Function):

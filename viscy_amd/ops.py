@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 from typing import Sequence
 
 import torch
@@ -290,6 +291,7 @@ def head_out_bwd2(U, ssum, ssq, w2, alpha, dv, S1, S2, B, H2, W2, Z, Cmid, Cout,
 # vsx_weight_tasks when the block ends (or at flush()): a handful of launches.  Nothing inside a batch may consume the output
 # of an op queued in the SAME batch — call flush() first.
 _BATCH: list | None = None
+_BATCH_ON = os.environ.get("VSX_WBATCH", "1") != "0"  # VSX_WBATCH=0: every job its own launch (A/B measurements)
 _BATCH_KEEP: list = []  # the queued jobs' tensors stay alive (and their memory un-recycled) until the list is launched
 
 
@@ -297,13 +299,29 @@ _BATCH_KEEP: list = []  # the queued jobs' tensors stay alive (and their memory 
 def batch():
     global _BATCH
     outer = _BATCH
-    _BATCH = [] if outer is None else outer
+    if _BATCH_ON:
+        _BATCH = [] if outer is None else outer
     try:
         yield
     finally:
         if outer is None:
             flush()
             _BATCH = None
+
+
+def batch_open() -> None:
+    """generator-friendly form of ``batch()`` (a context manager must not be held across a yield): start collecting ..."""
+    global _BATCH
+    if _BATCH is None and _BATCH_ON:
+        _BATCH = []
+
+
+def batch_close() -> None:
+    """... launch what was collected and stop collecting"""
+    global _BATCH
+    if _BATCH is not None:
+        flush()
+        _BATCH = None
 
 
 def flush() -> None:
@@ -316,12 +334,12 @@ def flush() -> None:
     del _BATCH_KEEP[:]
 
 
-def _queue(kind: int, dtype: int, ints, p0, p1, p2, p3) -> bool:
+def _queue(kind: int, dtype: int, ints, p0, p1, p2, p3, p4=None, p5=None, p6=None) -> bool:
     if _BATCH is None:
         return False
     i = list(ints) + [0] * (4 - len(ints))
-    _BATCH.append(L.VsxWTask(kind, dtype, i[0], i[1], i[2], i[3], ptr(p0), ptr(p1), ptr(p2), ptr(p3)))
-    _BATCH_KEEP.append((p0, p1, p2, p3))
+    _BATCH.append(L.VsxWTask(kind, dtype, i[0], i[1], i[2], i[3], ptr(p0), ptr(p1), ptr(p2), ptr(p3), ptr(p4), ptr(p5), ptr(p6)))
+    _BATCH_KEEP.append((p0, p1, p2, p3, p4, p5, p6))
     return True
 
 
@@ -339,6 +357,8 @@ def prep_weight(src: Tensor, R: int, Cs: int, Tn: int, dtype: torch.dtype, *, wa
 
 def unprep_grad(g: Tensor, dparam: Tensor, R: int, Cs: int, Tn: int, *, gamma=None, W=None, dgamma=None, u=None,
                 beta=None, tapmode=0):
+    if _queue(L.WTASK_UNPREP, 0, (R, Cs, Tn, tapmode), g, dparam, dgamma, gamma, W, u, beta):
+        return
     check(lib().vsx_unprep_grad(ptr(g), ptr(dparam), ptr(gamma), ptr(W), ptr(dgamma), ptr(u), ptr(beta), R, Cs, Tn,
                                 tapmode, stream()), "unprep_grad")
 
@@ -352,6 +372,8 @@ def matvec(W: Tensor, v: Tensor, b: Tensor | None, R: int, Cc: int) -> Tensor:
 
 
 def matvec_t_add(W: Tensor, u: Tensor, out: Tensor, R: int, Cc: int) -> None:
+    if _queue(L.WTASK_MATVEC_T, 0, (R, Cc), W, out, None, u):
+        return
     check(lib().vsx_matvec_t_add(ptr(W), ptr(u), ptr(out), R, Cc, stream()), "matvec_t_add")
 
 
