@@ -292,7 +292,9 @@ int32_t vsx_grn_scale(const float* colsq, const float* gamma, float* s, int32_t 
     vsx_stream_t stream);
 
 /* backward of the GRN statistics path: P[b,n] = Σ_hw dz*g, Sb[b,n] = Σ_hw dz → t[b,n] (factor of g in dG), dgamma, dbeta
- * (both ADDED to).  rowst: nb*N floats of scratch (per-sample dgamma contributions, column-reduced by a second launch). */
+ * (both ADDED to).  rowst: nb*N floats of scratch (per-sample dgamma contributions, column-reduced by a second launch).
+ * dgamma == NULL (then Sb, dbeta NULL too): only t and rowst are produced, the caller reduces rowst / its Sb over the samples
+ * itself (VSX_WTASK_REDUCE_ROWS jobs of vsx_weight_tasks). */
 int32_t vsx_grn_bwd_stats(const float* colsq, const float* P, const float* Sb, const float* gamma, float* t,
     float* dgamma, float* dbeta, float* rowst, int32_t nb, int32_t N, float eps, vsx_stream_t stream);
 
@@ -397,6 +399,7 @@ int32_t vsx_transpose_f32(const float* src, float* dst, int32_t A, int32_t Bn, i
 #define VSX_WTASK_MLP_PACK 3
 #define VSX_WTASK_UNPREP 4    /* vsx_unprep_grad: p0 g, p1 dparam, p3 gamma, p4 W, p2 dgamma, p5 u, p6 beta, i0 R, i1 Cs, i2 Tn, i3 tapmode */
 #define VSX_WTASK_MATVEC_T 5  /* vsx_matvec_t_add: p0 W, p3 u, p1 out, i0 R, i1 C */
+#define VSX_WTASK_REDUCE_ROWS 6  /* p1 out[n] += sum_r p0 ws[r][n], i0 rows, i1 columns */
 #define VSX_WTASK_MAX 48
 typedef struct VsxWTask {
   int32_t kind, dtype, i0, i1, i2, i3;

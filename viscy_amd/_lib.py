@@ -50,7 +50,7 @@ class VsxWTask(C.Structure):
                 ("p0", _P), ("p1", _P), ("p2", _P), ("p3", _P), ("p4", _P), ("p5", _P), ("p6", _P)]
 
 
-WTASK_PREP, WTASK_TRANSPOSE, WTASK_MATVEC, WTASK_MLP_PACK, WTASK_UNPREP, WTASK_MATVEC_T = 0, 1, 2, 3, 4, 5
+WTASK_PREP, WTASK_TRANSPOSE, WTASK_MATVEC, WTASK_MLP_PACK, WTASK_UNPREP, WTASK_MATVEC_T, WTASK_REDUCE_ROWS = 0, 1, 2, 3, 4, 5, 6
 
 _SIGS = {
     "vsx_version": (_I32, []),

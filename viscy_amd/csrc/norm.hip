@@ -3,6 +3,7 @@
 // reduced by an aligned group of G lanes of one wave64 with shuffle reductions (no LDS, no
 // barriers); loads/stores are 16-byte vectors.
 #include "vsx_common.h"
+#include "wtasks.h"
 #include "../../include/vsx.h"
 extern int g_vsx_grn_stream;
 extern int g_vsx_ggb_contig;
@@ -370,10 +371,15 @@ extern "C" int32_t vsx_grn_scale(const float* colsq, const float* gamma, float* 
 extern "C" int32_t vsx_grn_bwd_stats(const float* colsq, const float* P, const float* Sb, const float* gamma, float* t,
                                      float* dgamma, float* dbeta, float* rowst, int32_t nb, int32_t N, float eps,
                                      vsx_stream_t stream) {
-  VSX_CHECK(colsq && P && gamma && t && dgamma && rowst && nb > 0 && N > 0, "vsx_grn_bwd_stats: bad arguments");
+  VSX_CHECK(colsq && P && gamma && t && rowst && nb > 0 && N > 0, "vsx_grn_bwd_stats: bad arguments");
   VSX_CHECK((Sb == nullptr) == (dbeta == nullptr), "vsx_grn_bwd_stats: Sb and dbeta come together");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(grn_bwd_stats_kernel, dim3(nb), dim3(256), 0, st, colsq, P, gamma, t, rowst, N, eps);
+  if (dgamma == nullptr) {  // the caller folds rowst (and its Sb) into the gradients itself: VSX_WTASK_REDUCE_ROWS jobs
+    VSX_CHECK(dbeta == nullptr, "vsx_grn_bwd_stats: dgamma == NULL (reductions left to the caller) needs dbeta == NULL");
+    VSX_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 rg(vsx_cdiv(N, 64), vsx_cdiv(nb, 64));
   hipLaunchKernelGGL(reduce_rows_kernel, rg, dim3(256), 0, st, (const float*)rowst, dgamma, nb, N);
   if (Sb) hipLaunchKernelGGL(reduce_rows_kernel, rg, dim3(256), 0, st, Sb, dbeta, nb, N);  // GRN beta gradient = sum_b sum_hw dz
@@ -471,19 +477,7 @@ __global__ __launch_bounds__(256) void grn_gelu_bwd_kernel(T* __restrict__ dz, c
 // combined in LDS, slabs with <= R/64 atomics per address.
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ ws, float* __restrict__ out, int R,
                                                           int N) {
-  __shared__ float red[4][64];
-  const int nl = threadIdx.x & 63, slot = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + nl;
-  const int r0 = blockIdx.y * 64;
-  const int r1 = r0 + 64 < R ? r0 + 64 : R;
-  float a = 0.f;
-  if (n < N) {
-#pragma unroll 4
-    for (int r = r0 + slot; r < r1; r += 4) a += ws[(size_t)r * N + n];
-  }
-  red[slot][nl] = a;
-  __syncthreads();
-  if (slot == 0 && n < N) atomicAdd(out + n, red[0][nl] + red[1][nl] + red[2][nl] + red[3][nl]);
+  wt_reduce_rows(blockIdx.x + gridDim.x * blockIdx.y, ws, out, R, N);  // body: csrc/wtasks.h
 }
 
 extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, const float* t, float* colsum, float* ws,

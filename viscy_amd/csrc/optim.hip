@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void weight_tasks_kernel(const WTaskBatch b) {
                      (const float*)t.p5, (const float*)t.p6, t.i0, t.i1, t.i2, t.i3);
       break;
     case VSX_WTASK_MATVEC_T: wt_matvec_t(blk, (const float*)t.p0, (const float*)t.p3, (float*)t.p1, t.i0, t.i1); break;
+    case VSX_WTASK_REDUCE_ROWS: wt_reduce_rows(blk, (const float*)t.p0, (float*)t.p1, t.i0, t.i1); break;
     default: break;
   }
 }
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256) void weight_tasks_kernel(const WTaskBatch b) {
  *   VSX_WTASK_MLP_PACK  = vsx_mlp_pack(p0 W1, p3 W2, p1 img, i0 C)
  *   VSX_WTASK_UNPREP    = vsx_unprep_grad(p0 g, p1 dparam, p3 gamma, p4 W, p2 dgamma, p5 u, p6 beta, i0 R, i1 Cs, i2 Tn, i3 tapmode)
  *   VSX_WTASK_MATVEC_T  = vsx_matvec_t_add(p0 W, p3 u, p1 out, i0 R, i1 C)
+ *   VSX_WTASK_REDUCE_ROWS: p1 out[n] += sum over the i0 rows of p0 ws [i0, i1]   (column sums of a workspace of partials)
  * No task may read or accumulate into what another task of the same call writes. */
 extern "C" int32_t vsx_weight_tasks(const VsxWTask* tasks, int32_t n, vsx_stream_t stream) {
   VSX_CHECK(tasks && n > 0, "vsx_weight_tasks: bad arguments");
@@ -296,6 +298,10 @@ extern "C" int32_t vsx_weight_tasks(const VsxWTask* tasks, int32_t n, vsx_stream
         case VSX_WTASK_MATVEC_T:
           VSX_CHECK(t.p0 && t.p3 && t.p1 && t.i0 > 0 && t.i1 > 0, "vsx_weight_tasks: task %d (matvec_t_add): bad arguments", i0 + j);
           blocks = (long)vsx_cdiv(t.i1, 256) * vsx_cdiv(t.i0, wt_matvec_t_rpb(t.i0));
+          break;
+        case VSX_WTASK_REDUCE_ROWS:
+          VSX_CHECK(t.p0 && t.p1 && t.i0 > 0 && t.i1 > 0, "vsx_weight_tasks: task %d (reduce_rows): bad arguments", i0 + j);
+          blocks = (long)vsx_cdiv(t.i1, 64) * vsx_cdiv(t.i0, 64);
           break;
         default:
           vsx_set_error("vsx_weight_tasks: task %d has unknown kind %d", i0 + j, t.kind);

@@ -126,3 +126,22 @@ __device__ __forceinline__ void wt_matvec_t(int blk, const float* __restrict__ W
   for (int r = r0; r < r1; ++r) a += W[(size_t)r * C + c] * u[r];
   atomicAdd(out + c, a);
 }
+
+// out[n] += Σ_r ws[r][n].  Workgroup = 64 columns x 4 row slots over a 64-row slab; slots are combined in LDS, slabs with
+// <= R/64 atomics per address.  Grid: cdiv(N, 64) column blocks x cdiv(R, 64) slabs, flattened (x fastest).
+__device__ __forceinline__ void wt_reduce_rows(int blk, const float* __restrict__ ws, float* __restrict__ out, int R, int N) {
+  __shared__ float red[4][64];
+  const int nbx = (N + 63) / 64;
+  const int nl = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int n = (blk % nbx) * 64 + nl;
+  const int r0 = (blk / nbx) * 64;
+  const int r1 = r0 + 64 < R ? r0 + 64 : R;
+  float a = 0.f;
+  if (n < N) {
+#pragma unroll 4
+    for (int r = r0 + slot; r < r1; r += 4) a += ws[(size_t)r * N + n];
+  }
+  red[slot][nl] = a;
+  __syncthreads();
+  if (slot == 0 && n < N) atomicAdd(out + n, red[0][nl] + red[1][nl] + red[2][nl] + red[3][nl]);
+}

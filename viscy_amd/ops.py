@@ -151,6 +151,14 @@ def grn_bwd_stats(colsq: Tensor, P: Tensor, gamma: Tensor, dgamma: Tensor, eps: 
     """Sb [nb, N] = per-sample Σ_hw dz (EPI_DZ red1); dbeta[N] += Σ_b Sb."""
     t = torch.empty_like(colsq)
     rowst = torch.empty_like(colsq)
+    if _BATCH is not None:  # the two column reductions into the parameter gradients join the segment's task list
+        nb, N = colsq.shape
+        check(lib().vsx_grn_bwd_stats(ptr(colsq), ptr(P), None, ptr(gamma), ptr(t), None, None, ptr(rowst), nb, N, eps, stream()),
+              "grn_bwd_stats")
+        _queue(L.WTASK_REDUCE_ROWS, 0, (nb, N), rowst, dgamma, None, None)
+        if Sb is not None:
+            _queue(L.WTASK_REDUCE_ROWS, 0, (nb, N), Sb, dbeta, None, None)
+        return t
     check(lib().vsx_grn_bwd_stats(ptr(colsq), ptr(P), ptr(Sb), ptr(gamma), ptr(t), ptr(dgamma), ptr(dbeta), ptr(rowst), colsq.shape[0],
                                   colsq.shape[1], eps, stream()), "grn_bwd_stats")
     return t
