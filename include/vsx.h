@@ -318,6 +318,14 @@ int32_t vsx_mlp_supported(int32_t C, int32_t hw, int64_t M, int32_t dtype);   /*
 int32_t vsx_mlp_mode_supported(int32_t C, int32_t hw, int64_t M, int32_t mode, int32_t dtype);  /* one pass (mode 0..4) */
 int64_t vsx_mlp_image_bytes(int32_t C);
 int32_t vsx_mlp_pack(const void* W1, const void* W2, void* img, int32_t C, vsx_stream_t stream);
+/* vsx_mlp_fwd / vsx_mlp_fc1 with the block LayerNorm (eps, no affine) applied in the kernel's prologue: y = the UN-normalised
+ * rows (output of the depthwise convolution).  Modes 0 / 1: the normalised rows never exist in memory; vsx_mlp_fc1_ln also
+ * writes them (xh_out [M, C]) and rstd_out [M] for the backward.  Replaces vsx_ln_fwd + vsx_mlp_fwd / vsx_mlp_fc1. */
+int32_t vsx_mlp_fwd_ln(const void* y, float eps, const void* wimg, const float* b1, const float* grn_s, const float* grn_b,
+    const float* b2, const void* res, const float* rscale, void* out, float* colsq, const float* gtab, int64_t M, int32_t C,
+    int32_t hw, int32_t mode, int32_t dtype, vsx_stream_t stream);
+int32_t vsx_mlp_fc1_ln(const void* y, float eps, void* xh_out, float* rstd_out, const void* wimg, const float* b1, float* colsq,
+    const float* gtab, void* h, void* g, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
 int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1, const float* grn_s, const float* grn_b, const float* b2,
     const void* res, const float* rscale, void* out, float* colsq, const float* gelu_table, int64_t M, int32_t C, int32_t hw,
     int32_t mode, int32_t dtype, vsx_stream_t stream);

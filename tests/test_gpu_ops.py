@@ -1112,6 +1112,54 @@ def _fused_mlp_case(C, hw, B, drop_path, dt, M, H4, L, ops):
         assert torch.equal(out[:hw], res[:hw])
 
 
+@pytest.mark.parametrize("C,hw,B", [(96, 256, 3), (192, 1024, 2), (224, 512, 2), (384, 256, 2)])
+def test_fused_grn_mlp_with_layernorm_in_the_prologue(C, hw, B):
+    """vsx_mlp_fc1_ln / vsx_mlp_fwd_ln (the block LayerNorm applied to the un-normalised rows inside the fused passes) against
+    vsx_ln_fwd followed by the plain passes: the normalised rows and rstd the training pass writes are what the LayerNorm
+    kernel writes (same arithmetic, another summation order: at most a bf16 ulp on rare elements), h / g / colsq / out follow"""
+    if SELF_CHECK:
+        pytest.skip("HIP-only kernel")
+    from viscy_amd import _lib as L
+    from viscy_amd import ops
+
+    dt = torch.bfloat16
+    M, H4 = B * hw, 4 * C
+    saved = L.lib().vsx_get_flag(b"mlp_fused")
+    L.lib().vsx_set_flag(b"mlp_fused", 63)
+    try:
+        y = (rnd(M, C, dt=torch.float32, seed=11) * 1.7 + 0.4 + rnd(M, 1, dt=torch.float32, seed=12)).to(dt).cuda()  # row offsets: a real mean
+        res = rnd(M, C, dt=dt, seed=2).cuda()
+        W1 = rnd(H4, C, dt=dt, seed=3, scale=C ** -0.5).cuda()
+        W2 = rnd(C, H4, dt=dt, seed=4, scale=H4 ** -0.5).cuda()
+        b1, b2 = rnd(H4, seed=5, scale=0.1).cuda(), rnd(C, seed=6, scale=0.1).cuda()
+        gamma, beta = rnd(H4, seed=7, scale=0.3).cuda(), rnd(H4, seed=8, scale=0.1).cuda()
+        img = ops.mlp_pack(W1, W2, C)
+        xh_ref, _, rstd_ref = ops.ln_fwd(y, None, None, M, C, 1e-6, need_mean=False)
+        # training pass
+        cs_a, cs_b = torch.zeros((B, H4), device="cuda"), torch.zeros((B, H4), device="cuda")
+        h_ref, g_ref = ops.mlp_fc1(xh_ref, img, b1, cs_a, M, C, hw)
+        xh, rstd, h, g = ops.mlp_fc1_ln(y, img, b1, cs_b, M, C, hw, 1e-6)
+        torch.testing.assert_close(rstd, rstd_ref, rtol=1e-5, atol=0)  # fp32 sums in another order
+        dx = (xh.float() - xh_ref.float()).abs()
+        assert dx.max().item() <= 0.008 * xh_ref.float().abs().max().item() and (dx > 0).float().mean().item() < 1e-3
+        same = (xh == xh_ref).all(dim=1)  # rows whose normalised values agree bit for bit give bit-identical h / g
+        assert same.float().mean().item() > 0.9
+        assert torch.equal(h[same], h_ref[same]) and torch.equal(g[same], g_ref[same])
+        close(cs_b, cs_a, torch.float32, "colsq (LayerNorm in the prologue)", scale=cs_a.abs().max().item() * 5)
+        # inference pair
+        cs_c = torch.zeros_like(cs_a)
+        ops.mlp_stats(y, img, b1, cs_c, M, C, hw, ln_eps=1e-6)
+        close(cs_c, cs_a, torch.float32, "colsq (inference, LayerNorm in the prologue)", scale=cs_a.abs().max().item() * 5)
+        s = ops.grn_scale(cs_a, gamma)
+        out_ref = ops.mlp_out(xh_ref, img, b1, s, beta, b2, res, None, M, C, hw)
+        out = ops.mlp_out(y, img, b1, s, beta, b2, res, None, M, C, hw, ln_eps=1e-6)
+        assert torch.equal(out[same], out_ref[same])
+        err = (out.float() - out_ref.float()).abs().max().item() / out_ref.float().abs().max().item()
+        assert err <= 1e-2, err
+    finally:
+        L.lib().vsx_set_flag(b"mlp_fused", saved)
+
+
 @pytest.mark.parametrize("C,hw,B", [(96, 256, 3), (96, 1024, 2), (192, 256, 2), (224, 512, 2), (96, 4096, 2), (224, 8192, 1),
                                     (384, 256, 3)])
 def test_fused_block_backward_without_stored_dz(C, hw, B):

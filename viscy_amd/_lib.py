@@ -99,6 +99,8 @@ _SIGS = {
     "vsx_mlp_pack": (_I32, [_P, _P, _P, _I32, _P]),
     "vsx_mlp_fwd": (_I32, [_P] * 11 + [_I64, _I32, _I32, _I32, _I32, _P]),
     "vsx_mlp_fc1": (_I32, [_P] * 7 + [_I64, _I32, _I32, _I32, _P]),
+    "vsx_mlp_fwd_ln": (_I32, [_P, _F32] + [_P] * 10 + [_I64, _I32, _I32, _I32, _I32, _P]),
+    "vsx_mlp_fc1_ln": (_I32, [_P, _F32] + [_P] * 8 + [_I64, _I32, _I32, _I32, _P]),
     "vsx_grn_q_reduce": (_I32, [_P] * 10 + [_I64, _I32, _I32, _I32, _P]),
     "vsx_grn_q_reduce_ws_floats": (_I64, [_I32, _I32]),
     "vsx_mlp_bwd_stats": (_I32, [_P] * 5 + [_I64, _I32, _I32, _I32, _P]),

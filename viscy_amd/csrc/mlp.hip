@@ -59,6 +59,9 @@ struct MlpArgs {
   float* colsq;         // [B, 4C] += sum_hw gelu(h)^2           (MODE 0, 2)
   bf16_t* hout;         // [M, 4C] pre-activation                (MODE 2)
   bf16_t* gout;         // [M, 4C] activation                    (MODE 2)
+  float ln_eps;         // > 0: `xh` holds the UN-normalised rows y; the kernel applies the block LayerNorm (no affine) itself (MODE 0, 1, 2)
+  bf16_t* xh_out;       // [M, C]  the normalised rows, for the backward   (MODE 2 with ln_eps > 0)
+  float* rstd_out;      // [M]     1 / sqrt(var + eps) of every row        (MODE 2 with ln_eps > 0)
   const bf16_t* tin;    // [M, 4C] stored activation g (MODE 3) / stored pre-activation h (MODE 4)
   float* red0;          // [B, 4C] += sum_hw dz * g  (MODE 3)
   float* red1;          // [B, 4C] += sum_hw dz      (MODE 3)
@@ -149,6 +152,58 @@ __global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
       xf[mf][kk] = *reinterpret_cast<const mlp_bf16x8*>(a.xh + (size_t)(row0 + mf * 16 + p16) * C + kk * 32 + kq * 8);
+
+  if constexpr (!BWD) {
+    if (a.ln_eps > 0.f) {
+      // The block LayerNorm in the prologue (timm ConvNeXtBlock.norm: no affine here, it is folded into W1' / b1): a row's C
+      // values sit in the 4 lanes (p, q = 0..3) x KK fragments this wave already holds, so its statistics are a register sum
+      // and two cross-lane steps — same arithmetic as ln_fwd_kernel (norm.hip: sums shifted by the row's first element).  The
+      // separate LayerNorm pass (read y, write x^) and, in inference, x^ itself disappear; MODE 2 writes x^ / rstd for the
+      // backward from here.
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        float v[KK][8];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          union { mlp_bf16x8 b; uint4 u; } cv;
+          cv.b = xf[mf][kk];
+          unpack<bf16_t>(cv.u, v[kk]);
+        }
+        const float x0 = __shfl(v[0][0], p16, 64);  // lane (p, q = 0) holds k = 0 of row p
+        float sm = 0.f, sq2 = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = v[kk][j] - x0;
+            sm += d;
+            sq2 = fmaf(d, d, sq2);
+          }
+        sm += __shfl_xor(sm, 16, 64);
+        sq2 += __shfl_xor(sq2, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        sq2 += __shfl_xor(sq2, 32, 64);
+        sm /= (float)C;
+        sq2 /= (float)C;
+        const float mean = x0 + sm;
+        const float rstd = rsqrtf(fmaxf(sq2 - sm * sm, 0.f) + a.ln_eps);
+        const size_t rowi = (size_t)(row0 + mf * 16 + p16);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (v[kk][j] - mean) * rstd;
+          union { mlp_bf16x8 b; uint4 u; } cv;
+          cv.u = pack<bf16_t>(o);
+          xf[mf][kk] = cv.b;
+          if constexpr (MODE == 2) *reinterpret_cast<uint4*>(a.xh_out + rowi * C + kk * 32 + kq * 8) = cv.u;
+        }
+        if constexpr (MODE == 2) {
+          if (kq == 0) a.rstd_out[rowi] = rstd;
+        }
+      }
+    }
+  }
 
   mlp_f32x4 oacc[MODE == 1 ? MF : 1][MODE == 1 ? NF : 1];
   if constexpr (MODE == 1) {
@@ -684,6 +739,11 @@ extern "C" int32_t vsx_mlp_gelu_table(float* tab, vsx_stream_t stream) {
   return 0;
 }
 
+// LayerNorm-in-prologue variants (vsx_mlp_fwd_ln / vsx_mlp_fc1_ln) reuse the argument marshalling of the plain entry points
+static thread_local float g_mlp_ln_eps = 0.f;
+static thread_local bf16_t* g_mlp_xh_out = nullptr;
+static thread_local float* g_mlp_rstd_out = nullptr;
+
 extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1, const float* grn_s, const float* grn_b,
                                const float* b2, const void* res, const float* rscale, void* out, float* colsq,
                                const float* gtab, int64_t M, int32_t C, int32_t hw, int32_t mode, int32_t dtype,
@@ -697,6 +757,7 @@ extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1
   a.xh = (const bf16_t*)xh; a.wimg = (const char*)wimg; a.b1 = b1; a.grn_s = grn_s; a.grn_b = grn_b; a.b2 = b2;
   a.res = (const bf16_t*)res; a.rscale = rscale; a.out = (bf16_t*)out; a.colsq = colsq; a.gtab = gtab; a.M = (int)M; a.hw = hw;
   a.hout = nullptr; a.gout = nullptr; a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.nt = 0;
+  a.ln_eps = g_mlp_ln_eps; a.xh_out = nullptr; a.rstd_out = nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) {
     VSX_CHECK(colsq != nullptr, "vsx_mlp_fwd: mode 0 needs colsq");
@@ -720,7 +781,32 @@ extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1
   a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = colsq; a.gtab = gtab; a.hout = (bf16_t*)h; a.gout = (bf16_t*)g;
   a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.nt = mlp_nt();
   a.M = (int)M; a.hw = hw;
+  a.ln_eps = g_mlp_ln_eps; a.xh_out = g_mlp_xh_out; a.rstd_out = g_mlp_rstd_out;
   return mlp_dispatch<2>(c, a, (hipStream_t)stream);
+}
+
+/* The same passes with the block LayerNorm (eps, no affine: folded into W1' / b1) applied in the kernel's prologue: `y` holds
+ * the UN-normalised rows (the depthwise convolution's output).  vsx_mlp_fwd_ln: modes 0 / 1 as vsx_mlp_fwd — the normalised
+ * rows never exist in memory.  vsx_mlp_fc1_ln additionally writes them (xh_out [M, C]) and rstd_out [M] for the backward.
+ * Replaces vsx_ln_fwd + vsx_mlp_* (timm ConvNeXtBlock.norm -> .mlp, reached from viscy_models/unet/unext2.py:79). */
+extern "C" int32_t vsx_mlp_fwd_ln(const void* y, float eps, const void* wimg, const float* b1, const float* grn_s,
+                                  const float* grn_b, const float* b2, const void* res, const float* rscale, void* out,
+                                  float* colsq, const float* gtab, int64_t M, int32_t C, int32_t hw, int32_t mode, int32_t dtype,
+                                  vsx_stream_t stream) {
+  VSX_CHECK(eps > 0.f, "vsx_mlp_fwd_ln: eps must be positive");
+  g_mlp_ln_eps = eps;
+  const int32_t rc = vsx_mlp_fwd(y, wimg, b1, grn_s, grn_b, b2, res, rscale, out, colsq, gtab, M, C, hw, mode, dtype, stream);
+  g_mlp_ln_eps = 0.f;
+  return rc;
+}
+extern "C" int32_t vsx_mlp_fc1_ln(const void* y, float eps, void* xh_out, float* rstd_out, const void* wimg, const float* b1,
+                                  float* colsq, const float* gtab, void* h, void* g, int64_t M, int32_t C, int32_t hw,
+                                  int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(eps > 0.f && xh_out && rstd_out, "vsx_mlp_fc1_ln: eps must be positive, xh_out / rstd_out non-null");
+  g_mlp_ln_eps = eps; g_mlp_xh_out = (bf16_t*)xh_out; g_mlp_rstd_out = rstd_out;
+  const int32_t rc = vsx_mlp_fc1(y, wimg, b1, colsq, gtab, h, g, M, C, hw, dtype, stream);
+  g_mlp_ln_eps = 0.f; g_mlp_xh_out = nullptr; g_mlp_rstd_out = nullptr;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ backward passes
@@ -730,6 +816,7 @@ static void mlp_bwd_args(MlpArgs& a, const void* dout, const void* wimg, const v
   a.xh = (const bf16_t*)dout; a.wimg = (const char*)wimg; a.b1 = nullptr; a.grn_s = nullptr; a.grn_b = nullptr; a.b2 = nullptr;
   a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = nullptr; a.gtab = nullptr; a.hout = nullptr; a.gout = nullptr;
   a.tin = (const bf16_t*)tin; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.M = (int)M; a.hw = hw; a.nt = mlp_nt();
+  a.ln_eps = 0.f; a.xh_out = nullptr; a.rstd_out = nullptr;
 }
 
 /* MODE 3: the GRN statistics path of the block backward without a stored dz: dz = dout . W2 recomputed tile by tile

@@ -371,8 +371,15 @@ class Engine:
             M, hw = B * Lr, Lr
             y = o.rows_select(y, idx, M, C)      # masked_patchify
             xres = o.rows_select(x, idx, M, C)   # the shortcut of the kept tokens
-        xh, _, rstd = o.ln_fwd(y, None, None, M, C, 1e-6, need_mean=False)
-        del y
+        fused = self._mlp_mode(C, hw, M, dt, save is not None)
+        # mlp_fused bit 5: the block LayerNorm rides in the prologue of the fused GRN-MLP passes (csrc/mlp.hip) — no LayerNorm
+        # pass over y, and in inference no normalised rows in memory at all
+        ln_in = fused and bool(self._mlp_flag() & 32) and hasattr(o, "mlp_fc1_ln")
+        if ln_in:
+            xh, rstd = y, None
+        else:
+            xh, _, rstd = o.ln_fwd(y, None, None, M, C, 1e-6, need_mean=False)
+            del y
         colsq = self._za.take(B, 4 * C)
         # stochastic depth (timm DropPath, scale_by_keep): the whole branch of a sample is dropped with probability dp and
         # the survivors are scaled by 1 / (1 - dp); training mode only.  One device-side draw per block (graph-capturable).
@@ -380,15 +387,20 @@ class Engine:
         if w.dp > 0.0 and self.model.training:
             inj = self._dp_inject
             dpm = inj.pop(0) if inj else (torch.rand(B, device=x.device) < (1.0 - w.dp)).float() / (1.0 - w.dp)
-        fused = self._mlp_mode(C, hw, M, dt, save is not None)
+        lne = 1e-6 if ln_in else 0.0
         if fused and save is None:
             # inference: the 4C-wide hidden never leaves the CU (csrc/mlp.hip) — pass 1 = GRN statistics, pass 2 = fc1
             # recomputed, GELU, GRN, fc2, bias, shortcut
             if w.img is None:
                 w.img = o.mlp_pack(w.W1f, w.W2, C)
-            o.mlp_stats(xh, w.img, w.b1f, colsq, M, C, hw)
-            s = o.grn_scale(colsq, w.grn_w)
-            out = o.mlp_out(xh, w.img, w.b1f, s, w.grn_b, w.fc2_b, xres, dpm, M, C, hw)
+            if ln_in:
+                o.mlp_stats(xh, w.img, w.b1f, colsq, M, C, hw, ln_eps=lne)
+                s = o.grn_scale(colsq, w.grn_w)
+                out = o.mlp_out(xh, w.img, w.b1f, s, w.grn_b, w.fc2_b, xres, dpm, M, C, hw, ln_eps=lne)
+            else:
+                o.mlp_stats(xh, w.img, w.b1f, colsq, M, C, hw)
+                s = o.grn_scale(colsq, w.grn_w)
+                out = o.mlp_out(xh, w.img, w.b1f, s, w.grn_b, w.fc2_b, xres, dpm, M, C, hw)
             if rows is not None:
                 out = o.rows_select(out, rows[1], B * H * Wd, C)
             return out
@@ -399,7 +411,10 @@ class Engine:
             # training fc1 on the fused kernel's statistics pass, which also stores h and g (csrc/mlp.hip MODE 2)
             if w.img is None:
                 w.img = o.mlp_pack(w.W1f, w.W2, C)
-            h, gact = o.mlp_fc1(xh, w.img, w.b1f, colsq, M, C, hw)
+            if ln_in:
+                xh, rstd, h, gact = o.mlp_fc1_ln(xh, w.img, w.b1f, colsq, M, C, hw, 1e-6)
+            else:
+                h, gact = o.mlp_fc1(xh, w.img, w.b1f, colsq, M, C, hw)
         else:
             h = torch.empty((M, 4 * C), dtype=dt, device=x.device) if save is not None else None
             gact = torch.empty((M, 4 * C), dtype=dt, device=x.device)

@@ -447,8 +447,13 @@ def _gelu_table(dev) -> Tensor:
     return t
 
 
-def mlp_stats(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int) -> None:
-    """colsq[b, 4C] += per-sample column sums of gelu(fc1(xh))^2 — nothing 4C-wide is written"""
+def mlp_stats(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int, ln_eps: float = 0.0) -> None:
+    """colsq[b, 4C] += per-sample column sums of gelu(fc1(xh))^2 — nothing 4C-wide is written.  ``ln_eps`` > 0: ``xh`` holds the
+    UN-normalised rows and the kernel applies the block LayerNorm (no affine) in its prologue"""
+    if ln_eps > 0.0:
+        check(lib().vsx_mlp_fwd_ln(ptr(xh), ln_eps, ptr(img), ptr(b1), None, None, None, None, None, None, ptr(colsq),
+                                   ptr(_gelu_table(xh.device)), M, C, hw, 0, dtype_code(xh.dtype), stream()), "mlp_stats")
+        return
     check(lib().vsx_mlp_fwd(ptr(xh), ptr(img), ptr(b1), None, None, None, None, None, None, ptr(colsq), ptr(_gelu_table(xh.device)),
                             M, C, hw, 0, dtype_code(xh.dtype), stream()), "mlp_stats")
 
@@ -460,6 +465,18 @@ def mlp_fc1(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, 
     check(lib().vsx_mlp_fc1(ptr(xh), ptr(img), ptr(b1), ptr(colsq), ptr(_gelu_table(xh.device)), ptr(h), ptr(g), M, C, hw,
                             dtype_code(xh.dtype), stream()), "mlp_fc1")
     return h, g
+
+
+def mlp_fc1_ln(y: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int, eps: float = 1e-6):
+    """the block LayerNorm (no affine) + training fc1 in one pass over the depthwise convolution's output ``y``: returns
+    (xh, rstd, h, g) — what ln_fwd + mlp_fc1 return, without the LayerNorm pass"""
+    xh = torch.empty_like(y)
+    rstd = torch.empty(M, dtype=torch.float32, device=y.device)
+    h = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device)
+    g = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device)
+    check(lib().vsx_mlp_fc1_ln(ptr(y), eps, ptr(xh), ptr(rstd), ptr(img), ptr(b1), ptr(colsq), ptr(_gelu_table(y.device)), ptr(h),
+                               ptr(g), M, C, hw, dtype_code(y.dtype), stream()), "mlp_fc1_ln")
+    return xh, rstd, h, g
 
 
 def grn_q_reduce(Q: Tensor, cs: Tensor, W2: Tensor, s: Tensor, beta: Tensor, P: Tensor, S: Tensor, dW2: Tensor, db2: Tensor) -> None:
@@ -489,9 +506,13 @@ def mlp_bwd_dh(dout: Tensor, img2: Tensor, h: Tensor, s: Tensor, t: Tensor, cols
 
 
 def mlp_out(xh: Tensor, img: Tensor, b1: Tensor, s: Tensor, beta: Tensor, b2: Tensor, res: Tensor, rscale: Tensor | None,
-            M: int, C: int, hw: int) -> Tensor:
-    """out = res + rscale * (fc2(gelu(fc1(xh)) * s + beta) + b2), hidden activation kept on chip"""
+            M: int, C: int, hw: int, ln_eps: float = 0.0) -> Tensor:
+    """out = res + rscale * (fc2(gelu(fc1(xh)) * s + beta) + b2), hidden activation kept on chip (``ln_eps``: see mlp_stats)"""
     out = torch.empty((M, C), dtype=xh.dtype, device=xh.device)
+    if ln_eps > 0.0:
+        check(lib().vsx_mlp_fwd_ln(ptr(xh), ln_eps, ptr(img), ptr(b1), ptr(s), ptr(beta), ptr(b2), ptr(res), ptr(rscale), ptr(out),
+                                   None, ptr(_gelu_table(xh.device)), M, C, hw, 1, dtype_code(xh.dtype), stream()), "mlp_out")
+        return out
     check(lib().vsx_mlp_fwd(ptr(xh), ptr(img), ptr(b1), ptr(s), ptr(beta), ptr(b2), ptr(res), ptr(rscale), ptr(out), None,
                             ptr(_gelu_table(xh.device)), M, C, hw, 1, dtype_code(xh.dtype), stream()), "mlp_out")
     return out
