@@ -109,6 +109,10 @@ class _MixedLossFn(torch.autograd.Function):
         check(l.vsx_loss_finalize(ptr(sum_ssim), ptr(sum_cs), ptr(l1sum), ptr(l2sum), ptr(npix_d), nelem, B, max(ns, 1), nslot,
                                   a1, a2, a3, None, ptr(out[0:1]), ptr(coef), ptr(out[1:2]), s), "loss_finalize")
         ctx.saved = (Ps, Ts, dims, (w1, nslot), scal, npix_d, (B, C, D), (a1, a2, a3), ns, nelem, preds.dtype)
+        # The unscaled gradient fields live from the forward to the backward: 3 * B * C * (h - 10) * (w - 10) fp32 per scale,
+        # 4/3 of the full-resolution one in total = 0.99 GB at B = 512, C = 2, 256 x 256 (0.6 % of the step's 164 GB peak) — the
+        # price of one pass over the stacks less per scale.  They are scratch this Function alone writes and reads (detached,
+        # never exposed): plain attributes, not autograd-saved tensors, so that no version counter is involved.
         ctx.dmus = dmus
         ctx.ms_ssim = out[1]
         return out[0]
