@@ -723,7 +723,7 @@ def test_stem_im2col_and_normalize_fusion(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("c,cs", [(48, 96), (20, 40), (96, 0)])
+@pytest.mark.parametrize("c,cs", [(48, 96), (20, 40), (96, 0), (12, 52), (10, 54), (224, 96)])  # vector form (c, cs whole vectors) and the element-wise fallback
 def test_pixel_shuffle_cat(dt, c, cs):
     H = _hip()
     if (c + cs) % (8 if dt == torch.bfloat16 else 4) and not SELF_CHECK:

@@ -287,6 +287,61 @@ __global__ __launch_bounds__(256) void ps_cat_bwd_kernel(const T* __restrict__ d
   }
 }
 
+// Vector form of the two kernels above for c % VN == 0 and cs % VN == 0 (every configuration of the path): the 4 sub-pixels of a
+// low-resolution pixel take their VN channels j0 .. j0 + VN - 1 from the 4 * VN CONTIGUOUS low channels 4 j0 .. 4 j0 + 4 VN - 1, so
+// one thread moves four whole vectors in and four out and (de)interleaves them in registers — the element-wise kernels issue
+// VN two-byte accesses per vector (1.3 ms per step at 3.2 – 4.9 TB/s of 16-byte traffic's worth).
+// items: [0, na) = (low pixel, channel group) of the shuffled part, [na, na + nb) = (output pixel, vector) of the skip part
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void ps_cat_vec_kernel(const T* __restrict__ a0, const T* __restrict__ a1, T* __restrict__ o0,
+                                                         T* __restrict__ o1, int B, int h, int w, int c, int cs) {
+  // forward:  a0 = low, a1 = skip, o0 = out (o1 unused);  backward: a0 = dcat, o0 = dlow, o1 = dskip (a1 unused)
+  constexpr int VN = VT<T>::N;
+  typedef typename VT<T>::vec vec;
+  const int ct = c + cs, ng = c / VN, nsv = cs / VN;
+  const int H2 = 2 * h, W2 = 2 * w;
+  const long na = (long)B * h * w * ng, nb = (long)B * H2 * W2 * nsv;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= na + nb) return;
+  if (gid >= na) {  // skip channels: a vector copy between the concatenated tensor and the skip tensor
+    const long i = gid - na;
+    const int k = (int)(i % nsv);
+    const long pix = i / nsv;
+    if (BWD) stvec<T>(o1 + (size_t)pix * cs + k * VN, ldvec<T>(a0 + (size_t)pix * ct + c + k * VN));
+    else stvec<T>(o0 + (size_t)pix * ct + c + k * VN, ldvec<T>(a1 + (size_t)pix * cs + k * VN));
+    return;
+  }
+  const int jg = (int)(gid % ng);
+  const long lp = gid / ng;
+  const int x = (int)(lp % w);
+  const long r = lp / w;
+  const int y = (int)(r % h);
+  const int b = (int)(r / h);
+  const size_t lowoff = (size_t)lp * (4 * c) + (size_t)jg * 4 * VN;
+  const size_t pix00 = ((size_t)b * H2 + 2 * y) * W2 + 2 * x;  // sub-pixel s sits at pix00 + (s >> 1) * W2 + (s & 1)
+  T lo[4 * VN], hi[4][VN];
+  if (!BWD) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) *reinterpret_cast<vec*>(lo + v * VN) = ldvec<T>(a0 + lowoff + v * VN);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+      for (int j = 0; j < VN; ++j) hi[s4][j] = lo[4 * j + s4];
+      stvec<T>(o0 + (pix00 + (s4 >> 1) * W2 + (s4 & 1)) * ct + jg * VN, *reinterpret_cast<const vec*>(hi[s4]));
+    }
+  } else {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+      *reinterpret_cast<vec*>(hi[s4]) = ldvec<T>(a0 + (pix00 + (s4 >> 1) * W2 + (s4 & 1)) * ct + jg * VN);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int j = 0; j < VN; ++j) lo[4 * j + s4] = hi[s4][j];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) stvec<T>(o0 + lowoff + v * VN, *reinterpret_cast<const vec*>(lo + v * VN));
+  }
+}
+
 /* K10: MONAI UpSample(mode="pixelshuffle", pre_conv=None) + torch.cat([up, skip], 1)
  * (viscy_models/components/blocks.py:138-146,170-171).  skip may be NULL (cs = 0). */
 extern "C" int32_t vsx_pixel_shuffle_cat_fwd(const void* low, const void* skip, void* out, int32_t B, int32_t h,
@@ -295,6 +350,18 @@ extern "C" int32_t vsx_pixel_shuffle_cat_fwd(const void* low, const void* skip, 
   VSX_CHECK(low && out && B > 0 && h > 0 && w > 0 && c > 0 && cs >= 0, "vsx_pixel_shuffle_cat_fwd: bad arguments");
   VSX_CHECK((cs == 0) == (skip == nullptr), "vsx_pixel_shuffle_cat_fwd: skip pointer / cs mismatch");
   VSX_CHECK((c + cs) % vn == 0, "vsx_pixel_shuffle_cat_fwd: c+cs=%d must be a multiple of %d", c + cs, vn);
+  if (c % vn == 0 && cs % vn == 0) {  // whole vectors on both sides: the register-(de)interleaving form
+    const long items = (long)B * h * w * (c / vn) + (long)B * 4 * h * w * (cs / vn);
+    dim3 g(vsx_cdiv(items, 256));
+    if (dtype == VSX_BF16)
+      hipLaunchKernelGGL((ps_cat_vec_kernel<bf16_t, false>), g, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)low,
+                         (const bf16_t*)skip, (bf16_t*)out, (bf16_t*)nullptr, B, h, w, c, cs);
+    else
+      hipLaunchKernelGGL((ps_cat_vec_kernel<float, false>), g, dim3(256), 0, (hipStream_t)stream, (const float*)low,
+                         (const float*)skip, (float*)out, (float*)nullptr, B, h, w, c, cs);
+    VSX_LAUNCH_CHECK();
+    return 0;
+  }
   long total = (long)B * 4 * h * w * ((c + cs) / vn);
   dim3 grid(vsx_cdiv(total, 256));
   if (dtype == VSX_BF16)
@@ -312,6 +379,18 @@ extern "C" int32_t vsx_pixel_shuffle_cat_bwd(const void* dcat, void* dlow, void*
   VSX_CHECK(dcat && dlow && B > 0 && h > 0 && w > 0 && c > 0 && cs >= 0, "vsx_pixel_shuffle_cat_bwd: bad arguments");
   VSX_CHECK((cs == 0) == (dskip == nullptr), "vsx_pixel_shuffle_cat_bwd: dskip pointer / cs mismatch");
   VSX_CHECK((c + cs) % vn == 0, "vsx_pixel_shuffle_cat_bwd: c+cs=%d must be a multiple of %d", c + cs, vn);
+  if (c % vn == 0 && cs % vn == 0) {
+    const long items = (long)B * h * w * (c / vn) + (long)B * 4 * h * w * (cs / vn);
+    dim3 g(vsx_cdiv(items, 256));
+    if (dtype == VSX_BF16)
+      hipLaunchKernelGGL((ps_cat_vec_kernel<bf16_t, true>), g, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dcat,
+                         (const bf16_t*)nullptr, (bf16_t*)dlow, (bf16_t*)dskip, B, h, w, c, cs);
+    else
+      hipLaunchKernelGGL((ps_cat_vec_kernel<float, true>), g, dim3(256), 0, (hipStream_t)stream, (const float*)dcat,
+                         (const float*)nullptr, (float*)dlow, (float*)dskip, B, h, w, c, cs);
+    VSX_LAUNCH_CHECK();
+    return 0;
+  }
   long total = (long)B * 4 * h * w * ((c + cs) / vn);
   dim3 grid(vsx_cdiv(total, 256));
   if (dtype == VSX_BF16)
