@@ -36,8 +36,14 @@ class TrainStep:
     Capturing runs two warm-up steps (allocator / workspace sizing); parameters, Adam moments, the step counter and the
     module buffers are restored afterwards, so N calls are exactly N optimisation steps in every mode."""
 
-    def __init__(self, model, criterion, optimizer, ddp=None, use_graph: bool = True, loss_fn=None, segments: bool | None = None):
+    def __init__(self, model, criterion, optimizer, ddp=None, use_graph: bool = True, loss_fn=None, segments: bool | None = None,
+                 static_inputs: bool = False):
+        """``static_inputs``: the caller hands the SAME two device tensors to every call and refills them in place (a loader
+        that writes its host->device copies straight into them; the bench, whose batch is resident): the captured graph reads
+        them directly.  Otherwise the step owns static copies and every call pays a device-to-device copy of the batch into them
+        (2 GB read + 2 GB written at B = 512: 0.6 - 0.8 ms of a 105 ms step)."""
         self.model, self.crit, self.opt, self.ddp = model, criterion, optimizer, ddp
+        self.static_inputs = static_inputs
         self.loss_fn = loss_fn
         self.use_graph = use_graph
         self.graphs = None
@@ -187,7 +193,10 @@ class TrainStep:
             self.opt.device_step()
             return self.loss
         if self.graphs is None:
-            self.x, self.t = x.clone(), t.clone()
+            if self.static_inputs and x.is_contiguous() and t.is_contiguous():
+                self.x, self.t = x, t  # the graph is captured on the caller's own buffers
+            else:
+                self.x, self.t = x.clone(), t.clone()
             self._capture()
         if x.data_ptr() != self.x.data_ptr():
             self.x.copy_(x, non_blocking=True)
