@@ -53,6 +53,7 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
                                                                    int B, int H, int W, int C, int nslab, int tiles_total,
                                                                    int tiles_per_wg) {
   typedef DwmGeom<NXT> G;
+  constexpr int THREADS = DWM_THREADS, CPW = DWM_CB / (DWM_THREADS / 64);  // channels per wave (2)
   __shared__ __attribute__((aligned(16))) unsigned short lds[2][G::BUF];
 
   // XCD-aware order (workgroups are dealt round-robin to the 8 XCDs): one XCD gets a contiguous range of logical ids, so
@@ -72,12 +73,21 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
   const int p16 = lane & 15, kq = lane >> 4;
 
   // ---- Toeplitz fragments of this wave's two channels: A[i = p16][k = kq*8 + e] = w[ky][k - i]
-  dwm_bf16x8 afrag[2][7];
-  float bias_v[2];
+  // The slab's 49 x 32 taps go through LDS first (one coalesced load per thread): built straight from global memory the 112
+  // predicated scalar loads of a lane compiled to 112 branch + load + s_waitcnt vmcnt(0) round trips in a row (950 lines of
+  // ISA) with the results parked in scratch.
+  __shared__ float wsm[49 * DWM_CB];
+  for (int i = tid; i < 49 * DWM_CB; i += THREADS) {
+    const int tap = i / DWM_CB, cl = i - tap * DWM_CB;
+    wsm[i] = c_base + cl < C ? w[(size_t)tap * C + c_base + cl] : 0.f;
+  }
+  __syncthreads();
+  dwm_bf16x8 afrag[CPW][7];
+  float bias_v[CPW];
 #pragma unroll
-  for (int cc = 0; cc < 2; ++cc) {
-    const int ch = c_base + wave * 2 + cc;
-    bias_v[cc] = (bias && ch < C) ? bias[ch] : 0.f;
+  for (int cc = 0; cc < CPW; ++cc) {
+    const int cl = wave * CPW + cc;
+    bias_v[cc] = (bias && c_base + cl < C) ? bias[c_base + cl] : 0.f;
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
       uint32_t pk[4];
@@ -87,8 +97,11 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int t = kq * 8 + e2 * 2 + h - p16;
-          const int tap = FLIP ? 48 - (ky * 7 + t) : ky * 7 + t;
-          v[h] = (t >= 0 && t < 7 && ch < C) ? w[(size_t)tap * C + ch] : 0.f;
+          const bool in = t >= 0 && t < 7;
+          const int tt = in ? t : 0;
+          const int tap = FLIP ? 48 - (ky * 7 + tt) : ky * 7 + tt;
+          const float wv = wsm[tap * DWM_CB + cl];
+          v[h] = in ? wv : 0.f;
         }
         pk[e2] = f32x2_to_bf16x2_bits(v[0], v[1]);
       }
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
   // ---- zero the pad columns of both buffers once (never written afterwards)
   {
     constexpr int PADW = G::PITCH - G::IW;
-    for (int i = tid; i < 2 * DWM_CB * DWM_ROWS * PADW; i += DWM_THREADS) {
+    for (int i = tid; i < 2 * DWM_CB * DWM_ROWS * PADW; i += THREADS) {
       const int col = G::IW + i % PADW;
       int r = i / PADW;
       const int row = r % DWM_ROWS; r /= DWM_ROWS;
@@ -112,23 +125,35 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
 
   // staging items: (pixel of the 22 x IW halo tile, 8-channel vector): consecutive lanes = the 4 vectors of a pixel
   constexpr int ITEMS = DWM_ROWS * G::IW * 4;
-  constexpr int NIT = (ITEMS + DWM_THREADS - 1) / DWM_THREADS;
+  constexpr int NIT = (ITEMS + THREADS - 1) / THREADS;
   uint4 stage[NIT];
 
-  auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
+  // tile coordinates advance incrementally (x fastest): two runtime integer divisions per tile and use were a measurable part
+  // of the 0.9 us an empty pass through the tile loop cost
+  struct TileAt { int b, y0, x0; };
+  auto tile_first = [&](int t) {
+    TileAt a;
     const int tx = t % tiles_x;
     t /= tiles_x;
-    const int ty = t % tiles_y;
-    b = t / tiles_y;
-    y0 = ty * 16;
-    x0 = tx * G::TW;
+    a.b = t / tiles_y;
+    a.y0 = (t % tiles_y) * 16;
+    a.x0 = tx * G::TW;
+    return a;
   };
-  auto load_tile = [&](int t) {
-    int b, y0, x0;
-    tile_origin(t, b, y0, x0);
+  auto tile_next = [&](TileAt a) {
+    a.x0 += G::TW;
+    if (a.x0 >= tiles_x * G::TW) {
+      a.x0 = 0;
+      a.y0 += 16;
+      if (a.y0 >= tiles_y * 16) { a.y0 = 0; a.b += 1; }
+    }
+    return a;
+  };
+  auto load_tile = [&](const TileAt& at, int tv) {
+    const int b = at.b, y0 = at.y0, x0 = at.x0;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int i = tid + it * DWM_THREADS;
+      const int i = tv + it * THREADS;
       const int cv = i & 3, p = i >> 2;
       const int col = p % G::IW, row = p / G::IW;
       const int gy = y0 + row - 3, gx = x0 + col - 3;
@@ -138,10 +163,10 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
       stage[it] = v;
     }
   };
-  auto store_tile_lds = [&](int buf) {
+  auto store_tile_lds = [&](int buf, int tv) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int i = tid + it * DWM_THREADS;
+      const int i = tv + it * THREADS;
       if (i < ITEMS) {
         const int cv = i & 3, p = i >> 2;
         const int col = p % G::IW, row = p / G::IW;
@@ -156,20 +181,25 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
     }
   };
 
-  load_tile(t_begin);
+  TileAt at_cur = tile_first(t_begin), at_nxt = tile_next(at_cur);
+  load_tile(at_cur, tid);
   __syncthreads();  // pad zeroing done
-  store_tile_lds(0);
+  store_tile_lds(0, tid);
   __syncthreads();
 
   for (int t = t_begin; t < t_end; ++t) {
     const int cur = (t - t_begin) & 1;
     const bool more = t + 1 < t_end;
-    if (more) load_tile(t + 1);  // in flight under the MFMAs
+    // the per-thread index arithmetic of the staging / gather loops is cheap; kept loop-invariant (hipcc hoists it out of the tile
+    // loop) it occupies ~40 registers for the whole launch — an opaque copy of the thread index per tile makes it local again
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+    if (more) load_tile(at_nxt, tv);  // in flight under the MFMAs
 
     // ---- compute: this wave's two channels, NXT x tiles of 16 columns, 16 rows
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-      const int chl = wave * 2 + cc;
+    for (int cc = 0; cc < CPW; ++cc) {
+      const int chl = wave * CPW + cc;
       const unsigned short* plane = &lds[cur][dwm_plane_base(chl, G::PLANE)];
       dwm_f32x4 acc[NXT];
 #pragma unroll
@@ -191,17 +221,16 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
         *reinterpret_cast<uint2*>(const_cast<unsigned short*>(plane) + p16 * G::PITCH + xt * 16 + kq * 4) = o;
       }
     }
-    if (more) store_tile_lds(cur ^ 1);
+    if (more) store_tile_lds(cur ^ 1, tv);
     __syncthreads();
 
     // ---- gather channel vectors back and store
     {
-      int b, y0, x0;
-      tile_origin(t, b, y0, x0);
+      const int b = at_cur.b, y0 = at_cur.y0, x0 = at_cur.x0;
       constexpr int OITEMS = 16 * G::TW * 4;
 #pragma unroll
-      for (int it = 0; it < (OITEMS + DWM_THREADS - 1) / DWM_THREADS; ++it) {
-        const int i = tid + it * DWM_THREADS;
+      for (int it = 0; it < (OITEMS + THREADS - 1) / THREADS; ++it) {
+        const int i = tv + it * THREADS;
         const int cv = i & 3, p = i >> 2;
         const int col = p % G::TW, row = p / G::TW;
         const int gy = y0 + row, gx = x0 + col;
@@ -226,6 +255,8 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
       }
     }
     __syncthreads();  // the planes of `cur` are overwritten by the staging of tile t + 2
+    at_cur = at_nxt;
+    at_nxt = tile_next(at_nxt);
   }
 }
 
