@@ -102,8 +102,11 @@ struct MlpGeom {
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES + OUT_BYTES + (VEC_FLOATS + RED_FLOATS) * 4;
 };
 
+// The dh pass of the C = 96 blocks needs 143 registers and 54 KB of LDS: capped at 128 registers (52 bytes of spill per lane)
+// two workgroups share a CU and the pass runs 4 % faster (1018 -> ~975 us at B = 512).  The same cap on C = 192 / 224 (132 / 160
+// bytes of spill) makes the pass 30 % slower: measured, not applied.
 template <int C, int MF, int NW, int MODE>
-__global__ __launch_bounds__(NW * 64) void mlp_fused_kernel(const MlpArgs a) {
+__global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1)) void mlp_fused_kernel(const MlpArgs a) {
   typedef MlpGeom<C, MF, NW, MODE> G;
   constexpr int H4 = G::H4, NHS = G::NHS, KK = G::KK, NF = G::NF, WM = G::WM;
   constexpr bool STATS = MODE == 0 || MODE == 2, STORE = MODE == 2, BWD = MODE >= 3;
