@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 FWD_GFLOP_PER_PATCH = 22.56  # SURVEY §8d / BASELINE.md §2 (256x256, Z=5, tiny)
 FWD_MB_PER_PATCH = 75.5  # forward "two-pass floor" 
 ALGO_MB_PER_PATCH = 226.5    # fwd+bwd two-pass-GRN floor, bf16 activations
+PROFILE_ROUND = "r04"        # prefix of this round's files under profiles/
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
@@ -82,58 +83,108 @@ def nonzero_grn_(model, seed=1):
                 p.copy_((torch.randn(p.shape, generator=g) * 0.1).to(p.device))
 
 
-# ------------------------------------------------------------------ per-op event timing
+# ------------------------------------------------------------------ per-family event timing
+# Kernel FAMILIES (one per kernel template / kernel group), named the same way from both sides: the launch wrappers of
+# viscy_amd.ops that bench.py times live with HIP events (OP_FAMILY; the GEMM entry points report the template they dispatched
+# through vsx_last_kernel()), and the kernel names of a rocprofv3 trace (KERNEL_FAMILY, used by tools/roofline_table.py and
+# tools/pmc_traffic.py) — so that the live table, the kernel-stats CSV and the PMC traffic file can be laid side by side.
+OP_FAMILY = {
+    "mlp_stats": "mlp_fused", "mlp_out": "mlp_fused", "mlp_fc1": "mlp_fused", "mlp_fc1_ln": "mlp_fused", "mlp_bwd_stats": "mlp_fused",
+    "mlp_bwd_dh": "mlp_fused", "mlp_bwd_dh_re": "mlp_fused",
+    "dwconv7_fwd": "dwconv7", "dwconv7_bwd_data": "dwconv7", "dwconv7_bwd_weight": "dwconv7", "dwconv7_bwd": "dwconv7",
+    "head_shuffle_fwd": "head", "head_shuffle_bwd": "head", "head_out_fwd": "head", "head_out_bwd1": "head", "head_out_bwd1_wgrad": "head",
+    "head_out_bwd2": "head", "head_conv_fwd": "head", "head_conv_wgrad": "head", "head_conv_dgrad": "head", "head_conv_dgrad_prep": "head",
+    "prep_head_dgrad": "head",
+    "ln_fwd": "layernorm", "ln_bwd": "layernorm",
+    "grn_scale": "grn_small", "grn_bwd_stats": "grn_small", "grn_q_reduce": "grn_small", "grn_gelu_bwd": "grn_gelu_bwd",
+    "scale_weight_samples": "grn_small",
+    "pixel_shuffle_cat_fwd": "ps_cat", "pixel_shuffle_cat_bwd": "ps_cat", "stem_im2col": "stem_im2col",
+    "flush": "weight_tasks", "adamw": "adamw",
+}
+# wrappers that only delegate to other wrappers (timing them would count their launches twice) or launch nothing
+OP_SKIP = {"gemm_z", "dgrad_ln_bwd", "zeros", "batch", "batch_open", "batch_close", "mlp_supported", "head_conv_supported"}
+KERNEL_FAMILY = [
+    (r"mlp_fused_kernel", "mlp_fused"), (r"gemm_nt2_(lnbwd_)?kernel", "gemm_nt2"), (r"gemm_nt_fast_kernel", "gemm_nt_fast"),
+    (r"gemm_nt_kernel", "gemm_nt_generic"), (r"gemm_tn_fast_kernel", "gemm_tn_fast"), (r"gemm_tn_kernel|tn_zero_kernel", "gemm_tn_generic"),
+    (r"dwconv7|dw_reduce_rows", "dwconv7"), (r"head_", "head"), (r"ssim_|loss_", "loss"), (r"ln_(fwd|bwd)_kernel", "layernorm"),
+    (r"grn_gelu_bwd", "grn_gelu_bwd"), (r"grn_|scale_weight_samples", "grn_small"), (r"ps_cat", "ps_cat"), (r"stem_im2col", "stem_im2col"),
+    (r"weight_tasks", "weight_tasks"), (r"adamw", "adamw"),
+]
+
+
+def kernel_family(kernel_name: str) -> str:
+    import re
+
+    for pat, fam in KERNEL_FAMILY:
+        if re.search(pat, kernel_name):
+            return fam
+    return "other"
+
+
 class OpTimer:
     """Wraps viscy_amd.ops launch wrappers with torch.cuda events (recorded on the current stream,
-    which is the stream every kernel is launched on)."""
-
-    GEMM_EPI = {0: "none", 1: "bias", 2: "bias_gelu_sq", 3: "bias_res", 4: "dz", 5: "bias_stats"}
+    which is the stream every kernel is launched on) and groups the launches by kernel family."""
 
     def __init__(self, ops, only: str | None = None, by_shape: bool = False):
         self.ops, self.only, self.by_shape = ops, only, by_shape
-        self.records = {}  # name -> list of (start, end, flops, bytes)
+        self.records = {}  # family -> list of (start, end, flops, bytes, strict bytes, floor bytes)
         self._orig = {}
 
     @staticmethod
-    def _bytes(args, out):
-        n = 0
-        seen = set()
+    def _tensors(args, out):
+        seen, ts = set(), []
         stack = list(args) + (list(out) if isinstance(out, (tuple, list)) else [out])
         for t in stack:
             if torch.is_tensor(t) and t.data_ptr() not in seen:
                 seen.add(t.data_ptr())
-                n += t.numel() * t.element_size()
-        return n
+                ts.append(t)
+        return ts
 
     def _wrap(self, name, fn):
+        import inspect
+
+        sig = inspect.signature(fn)
+
         def wrapped(*a, **k):
-            cls, flops, nbytes, strict = name, 0.0, None, None
-            if name == "gemm":
+            cls, flops, nbytes, strict, floor = OP_FAMILY.get(name, name), 0.0, None, None, None
+            is_gemm = name == "gemm"
+            if is_gemm:
                 kind, M, N, K = a[0], a[4], a[5], a[6]
                 nz = k.get("nz", 1)
                 es = 2 if k.get("dtype") == torch.bfloat16 else 4
-                cls = f"gemm_{kind}" if not self.by_shape else f"gemm_{kind} M{M} N{N} K{K} z{nz} e{k.get('epi', 0)} p{k.get('pro', 0)} a{k.get('a_mode', 0)}"
                 flops = 2.0 * M * N * K * nz
                 nbytes = (M * K + M * N) * es * nz + N * K * (es if kind == "nt" else 4)
                 strict = nbytes
                 if kind == "nt":
                     # operands of the fused epilogues are part of the launch's algorithmic traffic: the second output of
                     # fc1 (g = gelu(h)), the activation the dZ epilogue reads for the GRN statistics, the residual of fc2
-                    extra = sum(k.get(name) is not None for name in ("C2", "aux", "res")) - (a[3] is None)
+                    extra = sum(k.get(nm) is not None for nm in ("C2", "aux", "res")) - (a[3] is None)
                     nbytes += extra * M * N * es * nz
-            elif name in ("mlp_stats", "mlp_out"):  # fused GRN-MLP: M = a[-3], C = a[-2]
-                Mm, Cc = a[-3], a[-2]
-                flops = 2.0 * Mm * 4 * Cc * Cc * (2 if name == "mlp_out" else 1)
-                nbytes = Mm * Cc * 2 * (3 if name == "mlp_out" else 1) + 16 * Cc * Cc
-            if self.only is not None and cls != self.only:
+            elif cls == "mlp_fused":  # fused GRN-MLP passes: one (two for the output pass) M x 4C x C contraction(s)
+                ba = sig.bind(*a, **k).arguments
+                Mm, Cc = ba["M"], ba["C"]
+                flops = 2.0 * Mm * 4 * Cc * Cc * (2 if name in ("mlp_out", "mlp_bwd_dh_re") else 1)
+            if self.only is not None and not is_gemm and cls != self.only:
                 return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(*a, **k)
             e1.record()
+            if is_gemm:
+                cls = lib_last_kernel() or f"gemm_{a[0]}"
+                if self.by_shape:
+                    cls += f" M{M} N{N} K{K} z{nz} e{k.get('epi', 0)} p{k.get('pro', 0)} a{k.get('a_mode', 0)}"
+                if self.only is not None and cls != self.only:
+                    return out
             if nbytes is None:
-                nbytes = self._bytes(list(a) + list(k.values()), out)
-            self.records.setdefault(cls, []).append((e0, e1, flops, nbytes, strict if strict is not None else nbytes))
+                ts = self._tensors(list(a) + list(k.values()), out)
+                nbytes = sum(t.numel() * t.element_size() for t in ts)
+                if cls == "mlp_fused":
+                    # SURVEY §8(d)'s floor counts a block as "read x, write y (+ the GRN second read)": the 4C-wide h / g / dh
+                    # this kernel family moves are design bytes, not floor bytes
+                    floor = sum(t.numel() * t.element_size() for t in ts if t.numel() != Mm * 4 * Cc)
+            self.records.setdefault(cls, []).append((e0, e1, flops, nbytes, strict if strict is not None else nbytes,
+                                                     floor if floor is not None else nbytes))
             return out
 
         return wrapped
@@ -141,7 +192,7 @@ class OpTimer:
     def __enter__(self):
         for name in dir(self.ops):
             fn = getattr(self.ops, name)
-            if callable(fn) and not name.startswith("_") and getattr(fn, "__module__", "") == self.ops.__name__ and name not in ("gemm_z",):
+            if callable(fn) and not name.startswith("_") and getattr(fn, "__module__", "") == self.ops.__name__ and name not in OP_SKIP:
                 self._orig[name] = fn
                 setattr(self.ops, name, self._wrap(name, fn))
         return self
@@ -156,8 +207,14 @@ class OpTimer:
         for cls, recs in self.records.items():
             ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             out[cls] = {"launches": len(recs), "ms": ms, "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs),
-                        "strict_bytes": sum(r[4] for r in recs)}
+                        "strict_bytes": sum(r[4] for r in recs), "floor_bytes": sum(r[5] for r in recs)}
         return out
+
+
+def lib_last_kernel() -> str:
+    from viscy_amd import _lib
+
+    return _lib.lib().vsx_last_kernel().decode()
 
 
 def gate_shape_record(dev, steps: int = 5, B: int = 8, size: int = 2048) -> dict:
@@ -240,12 +297,47 @@ def cpu_baseline(budget_s: float = 75.0):
     return json.loads(lines[-1])
 
 
+def launch_command(n: int, argv: list[str], port: int | None = None) -> list[str]:
+    """the command `bench.py --gpus N` re-executes itself under when it is started as ONE process (the driver's form for
+    N = 1; for N > 1 the driver starts torch.distributed.run itself and WORLD_SIZE is set): one rank per GPU of one node,
+    rendezvous on 127.0.0.1 (the reference's topology: recipes/topology/ddp_4gpu.yml:2-6 — `strategy: ddp`, `devices: 4`)"""
+    if port is None:
+        port = 29500 + os.getpid() % 2000
+    rest = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + rest
+
+
+def resolve_world(gpus: int, env: dict, visible_devices: int) -> tuple[str, int]:
+    """What a `bench.py --gpus N` process has to do, from N, the launcher environment and the number of visible GPUs:
+    ("run", world) — this process is a rank (or the only one); ("spawn", N) — started alone with N > 1: re-execute under
+    torch.distributed.run; raises SystemExit (non-zero) when the request cannot be honoured — a line with n_gpus != N is never
+    printed."""
+    if gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {gpus} is not a GPU count")
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to "
+                             f"print a line whose n_gpus is not what was asked for")
+        if visible_devices < world:
+            raise SystemExit(f"bench.py: {world} ranks but only {visible_devices} GPU(s) visible on this node")
+        return "run", world
+    if gpus == 1:
+        return "run", 1
+    if visible_devices < gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} needs {gpus} visible GPUs on this node, found {visible_devices}")
+    return "spawn", gpus
+
+
 def main():
     if "--cpu-baseline-child" in sys.argv:
         _cpu_baseline_child()
         return
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node to run on: one rank per GPU.  Started as a single process "
+                    "with N > 1, bench.py re-executes itself under torch.distributed.run with N ranks")
+    ap.add_argument("--dry-launch", action="store_true", help="print the N-rank launch command as JSON and exit (no GPU needed)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("VSX_BENCH_BATCH", 512)), help="patches per GPU per step")
@@ -259,6 +351,17 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel collective path even with one rank (RCCL smoke test on a single GPU)")
     args = ap.parse_args()
 
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "n_gpus": args.gpus,
+                          "command": launch_command(args.gpus, sys.argv[1:]) if args.gpus > 1 else [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--dry-launch"]}))
+        return
+    action, world = resolve_world(args.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    if action == "spawn":
+        import subprocess
+
+        # rank 0 of the child job prints the one JSON line on the inherited stdout; this process only forwards the exit code
+        raise SystemExit(subprocess.call(launch_command(world, sys.argv[1:])))
+
     # stdout carries exactly ONE line, the JSON result: everything any library writes to file descriptor 1 during the run
     # (RCCL prints a version banner through C stdio at communicator init and flushes it at exit, i.e. AFTER a Python print)
     # is routed to stderr, and the result is written to the saved descriptor at the very end.
@@ -266,7 +369,6 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -333,7 +435,6 @@ def main():
     table = tm.summary()
     for _ in range(max(args.warmup, 1)):
         step()
-    dominant = max(table, key=lambda c: table[c]["ms"]) if table else None
     if args.profile_ops and rank == 0:
         tot = sum(v["ms"] for v in table.values())
         for c, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
@@ -350,8 +451,9 @@ def main():
     elapsed = t1 - t0
     # dominant kernel class: average launch duration measured live with HIP events on the launch stream, over
     # eager replays of the same step right behind the timed region (events cannot be recorded inside a graph replay)
-    with OpTimer(ops, only=dominant) as tm:
-        for _ in range(3):
+    REPLAYS = 3
+    with OpTimer(ops) as tm:
+        for _ in range(REPLAYS):
             eager(x, tgt)
     # the metric's second half, "fwd HBM GB/s": forward-only passes (inference schedule, one hipGraph replay each) priced at
     # SURVEY §8(d)'s algorithmic two-pass floor of 75.5 MB per patch
@@ -372,7 +474,9 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = tt.item()
-    dom = tm.summary().get(dominant) if dominant else None
+    fam_table = tm.summary()
+    dominant = max(fam_table, key=lambda c: fam_table[c]["ms"]) if fam_table else None  # largest summed launch time, by kernel family
+    dom = fam_table.get(dominant) if dominant else None
 
     binfo = build_info()
     gate, peak_main = None, None
@@ -395,12 +499,53 @@ def main():
         patches = world * B * args.steps
         value = patches / elapsed
         scale = (args.size / 256.0) ** 2
-        roof = None
+        roof, roof_classes = None, []
+        # HBM traffic per kernel family: PMC counters cannot be read from inside this process, so the figures come from the
+        # committed rocprofv3 --pmc passes of the SAME configuration (scripts/pmc_traffic.sh -> profiles/r04_pmc_traffic_b<batch>.json:
+        # FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a launch with a known byte count as MI355X_MICROARCH.md
+        # prescribes).  The file records the kernel-source hash and the flag set it was measured with; a file from other
+        # sources / flags is refused (traffic stays null).
+        tfam, trefused, tf_path = {}, None, os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_traffic_b{B}.json")
+        if args.size == 256 and args.dtype == "bf16" and os.path.exists(tf_path):
+            try:
+                tfj = json.load(open(tf_path))
+                if tfj.get("source_hash") == binfo["source_hash"] and tfj.get("flags") == binfo["flags"]:
+                    tfam = tfj.get("families", {})
+                else:
+                    trefused = "profiles file was measured on other kernel sources / flags"
+            except (OSError, ValueError, KeyError):
+                pass
+
+        def family_record(fam, d):
+            """one kernel family over the REPLAYS instrumented eager steps behind the timed region"""
+            ms_step = d["ms"] / REPLAYS
+            gb = d["bytes"] / REPLAYS / 1e9
+            rec = {"family": fam, "ms_per_step": round(ms_step, 3), "launches_per_step": round(d["launches"] / REPLAYS, 1),
+                   "algorithmic_GB_per_step": round(gb, 3),
+                   "hbm_frac": round(gb / (ms_step * 1e-3) / HBM_PEAK_GBS, 4),
+                   "tflops": round(d["flops"] / REPLAYS / (ms_step * 1e-3) / 1e12, 1),
+                   "mfma_frac": round(d["flops"] / REPLAYS / (ms_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+            if fam == "mlp_fused":
+                # priced both ways: design bytes (what the passes are built to move, incl. the 4C-wide h / g / dh) and the bytes
+                # SURVEY §8(d)'s floor contains for them (C-wide tensors only)
+                fgb = d["floor_bytes"] / REPLAYS / 1e9
+                rec["floor_GB_per_step"] = round(fgb, 3)
+                rec["hbm_frac_floor_bytes"] = round(fgb / (ms_step * 1e-3) / HBM_PEAK_GBS, 4)
+            t = tfam.get(fam)
+            if t:
+                rec["traffic_GB_per_step"] = round(t["read_GB_per_step"] + t["write_GB_per_step"], 3)
+                rec["traffic_over_algorithmic"] = round(rec["traffic_GB_per_step"] / max(gb, 1e-9), 3)
+            else:
+                rec["traffic_GB_per_step"] = None
+            return rec
+
+        for fam, d in sorted(fam_table.items(), key=lambda kv: -kv[1]["ms"])[:6]:
+            roof_classes.append(family_record(fam, d))
         if dom:
             ms = dom["ms"] / dom["launches"]
             tf = dom["flops"] / dom["launches"] / (ms * 1e-3) / 1e12
             gbs = dom["bytes"] / dom["launches"] / (ms * 1e-3) / 1e9
-            if dominant.startswith("gemm") and tf / MFMA_BF16_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS:
+            if tf / MFMA_BF16_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS:
                 roof = {"kernel": dominant, "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                         "avg_launch_ms": round(ms, 5), "launches": dom["launches"],
@@ -408,28 +553,18 @@ def main():
             else:
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 5),
-                        "launches": dom["launches"]}
-        if roof is not None and dom:
+                        "launches": dom["launches"], "mfma_frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
+            roof["ms_per_step"] = round(dom["ms"] / REPLAYS, 3)
             roof["strict_frac"] = round(dom["strict_bytes"] / dom["launches"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)  # operands + ONE output only
-            # HBM traffic of the dominant kernel class: PMC counters cannot be read from inside this process, so the
-            # figure comes from the committed rocprofv3 --pmc passes of the SAME configuration (scripts/pmc_traffic.sh ->
-            # profiles/r03_pmc_traffic_b<batch>.json: FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a launch with
-            # a known byte count as MI355X_MICROARCH.md prescribes).  The file records the kernel-source hash and the flag
-            # set it was measured with; a file from other sources / flags is refused (traffic stays null).
-            tf_path = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_b{B}.json")
-            if args.size == 256 and args.dtype == "bf16" and os.path.exists(tf_path):
-                try:
-                    tfj = json.load(open(tf_path))
-                    same = tfj.get("source_hash") == binfo["source_hash"] and tfj.get("flags") == binfo["flags"]
-                    cls = tfj.get("classes", {}).get(dominant)
-                    if cls and same:
-                        roof["traffic"] = round(cls["traffic_bytes_per_launch"])
-                        roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / dom["launches"])
-                        roof["traffic_source"] = os.path.relpath(tf_path, ROOT)
-                    elif cls:
-                        roof["traffic_refused"] = "profiles file was measured on other kernel sources / flags"
-                except (OSError, ValueError, KeyError):
-                    pass
+            roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / dom["launches"])
+            if dominant == "mlp_fused":
+                roof["frac_floor_bytes"] = round(dom["floor_bytes"] / dom["launches"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            t = tfam.get(dominant)
+            if t:
+                roof["traffic"] = round((t["read_GB_per_step"] + t["write_GB_per_step"]) * 1e9 / max(t["launches_per_step"], 1e-9))
+                roof["traffic_source"] = os.path.relpath(tf_path, ROOT)
+            elif trefused:
+                roof["traffic_refused"] = trefused
         res = {
             "metric": "training patches/sec (Z=5, 256x256, 1->2ch UNeXt2)",
             "value": round(value, 2),
@@ -453,6 +588,7 @@ def main():
                 "peak_hbm_gb": round((peak_main if peak_main is not None else torch.cuda.max_memory_reserved()) / 1e9, 1),
             },
             "roofline": roof,
+            "roofline_classes": roof_classes,
             "gate_shape": gate,
             "build": binfo,
             "fwd": {"ms_per_pass": round(fwd_s * 1e3, 3), "patches_per_s_per_gpu": round(B / fwd_s, 1),

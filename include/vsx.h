@@ -34,6 +34,10 @@ typedef void* vsx_stream_t; /* hipStream_t */
 
 int32_t vsx_version(void);
 const char* vsx_last_error(void);
+/* kernel template the last vsx_gemm_nt / vsx_gemm_tn call on this thread dispatched to: "gemm_nt_fast", "gemm_nt_generic",
+ * "gemm_nt2" (both kernels of gemm_nt2.hip), "gemm_tn_fast", "gemm_tn_generic" ("" before the first call).  Measurement aid:
+ * bench.py groups its live launch timings by kernel family with it. */
+const char* vsx_last_kernel(void);
 /* debug / A-B knobs: "tn_tr" (1 = ds_read_b64_tr_b16 fragments in the wgrad GEMM, default 1) */
 int32_t vsx_set_flag(const char* name, int32_t value);
 int32_t vsx_get_flag(const char* name);

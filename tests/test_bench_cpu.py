@@ -1,0 +1,87 @@
+"""bench.py host logic that needs no GPU: the N-rank launcher (`--gpus N` must either run N ranks or fail — VERDICT r3 item 2)
+and the kernel-family naming shared by the live timing table, tools/roofline_table.py and tools/pmc_traffic.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_resolve_world_single_process():
+    assert bench.resolve_world(1, {}, 0) == ("run", 1)
+    assert bench.resolve_world(1, {}, 8) == ("run", 1)
+    assert bench.resolve_world(8, {}, 8) == ("spawn", 8)
+    assert bench.resolve_world(2, {}, 8) == ("spawn", 2)
+
+
+def test_resolve_world_refuses_what_it_cannot_honour():
+    with pytest.raises(SystemExit) as e:
+        bench.resolve_world(2, {}, 1)  # one visible GPU: never an n_gpus = 1 line for a --gpus 2 request
+    assert e.value.code not in (0, None)
+    with pytest.raises(SystemExit):
+        bench.resolve_world(8, {"WORLD_SIZE": "4"}, 8)  # launcher and flag disagree
+    with pytest.raises(SystemExit):
+        bench.resolve_world(4, {"WORLD_SIZE": "4"}, 2)  # more ranks than devices
+    with pytest.raises(SystemExit):
+        bench.resolve_world(0, {}, 8)
+
+
+def test_resolve_world_under_the_driver_launcher():
+    # the driver's N > 1 form: torch.distributed.run sets WORLD_SIZE, every rank gets the same --gpus N
+    assert bench.resolve_world(8, {"WORLD_SIZE": "8"}, 8) == ("run", 8)
+    assert bench.resolve_world(1, {"WORLD_SIZE": "1"}, 1) == ("run", 1)
+
+
+def test_launch_command_is_the_documented_form():
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "7", "--dry-launch", "--warmup", "2"], port=29601)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29601"
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "7", "--warmup", "2"]  # own flags forwarded, --dry-launch dropped
+
+
+def test_cli_fails_loudly_without_enough_gpus_and_dry_launch_prints_the_command():
+    # this container has no GPU: `--gpus 2` must exit non-zero and print NO result line
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    import torch
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the request can be honoured here")
+    assert p.returncode != 0 and p.stdout.strip() == "" and "--gpus 2 needs 2 visible GPUs" in p.stderr
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch", "--steps", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0
+    j = json.loads(p.stdout)
+    assert j["dry_launch"] and j["n_gpus"] == 8 and "--nproc-per-node=8" in j["command"] and "--dry-launch" not in j["command"]
+
+
+def test_kernel_families_cover_the_step_kernels():
+    names = {
+        "void mlp_fused_kernel<224, 2, 8, 4>(MlpArgs)": "mlp_fused",
+        "_Z19gemm_tn_fast_kernelIDF16bLi256ELb1ELb0ELi64ELi1ELi128EEv7VsxGemm": "gemm_tn_fast",
+        "_Z14gemm_tn_kernelIDF16bLi128ELb1EEv7VsxGemmi": "gemm_tn_generic",
+        "void (anonymous namespace)::gemm_nt2_lnbwd_kernel<256>(VsxGemm)": "gemm_nt2",
+        "void (anonymous namespace)::gemm_nt2_kernel<3, 256, false>(VsxGemm)": "gemm_nt2",
+        "_Z19gemm_nt_fast_kernelIDF16bLi3ELb0ELi64ELi1ELi128EEv7VsxGemm": "gemm_nt_fast",
+        "_Z14gemm_nt_kernelIDF16bLi128ELi128ELi2ELi2ELi32ELi2EEv7VsxGemm": "gemm_nt_generic",
+        "_Z19dwconv7_mfma_kernelILi2ELb1EEvPKDF16bPKfS3_S1_PDF16biiiiiii": "dwconv7",
+        "void dwconv7_wgrad_mfma_kernel<1>(...)": "dwconv7",
+        "_Z20head_conv_fwd_kernelPKDF16bS0_PKfPDF16bPfS4_ii": "head",
+        "_Z26head_out_bwd1_wgrad_kernelILi32ELi8EEv": "head",
+        "void ssim_tile_fused_kernel<true>(float const*)": "loss",
+        "_Z13ln_bwd_kernelIDF16bLi32ELi1ELb1EEv": "layernorm",
+        "_Z19grn_q_reduce_kernelIDF16bEv": "grn_small",
+        "__amd_rocclr_copyBuffer": "other",
+    }
+    for k, fam in names.items():
+        assert bench.kernel_family(k) == fam, k
+    # every family the live timer can emit for a wrapper is one the trace side knows
+    trace_side = {f for _, f in bench.KERNEL_FAMILY}
+    assert set(bench.OP_FAMILY.values()) <= trace_side

@@ -69,6 +69,17 @@ def main(fetch_csv, write_csv, steps, batch, out):
     for c in cls.values():
         c["traffic_bytes_per_launch"] = (c["read_GB_per_step"] + c["write_GB_per_step"]) * 1e9 / max(c["launches_per_step"], 1e-9)
     res["classes"] = dict(cls)
+    # kernel FAMILIES as bench.py's roofline_classes names them (bench.KERNEL_FAMILY: one per kernel template / kernel group)
+    fam = collections.defaultdict(lambda: {"launches_per_step": 0.0, "read_GB_per_step": 0.0, "write_GB_per_step": 0.0})
+    try:
+        from bench import kernel_family
+    except Exception:  # noqa: BLE001
+        kernel_family = None
+    if kernel_family is not None:
+        for k, v in res["kernels"].items():
+            for f in ("launches_per_step", "read_GB_per_step", "write_GB_per_step"):
+                fam[kernel_family(k)][f] += v[f]
+    res["families"] = dict(fam)
     tot = sum(v["read_GB_per_step"] + v["write_GB_per_step"] for v in res["kernels"].values())
     res["total_GB_per_step"] = tot
     res["total_MB_per_patch"] = tot * 1e3 / batch
@@ -77,6 +88,8 @@ def main(fetch_csv, write_csv, steps, batch, out):
     print(f"total {tot:.2f} GB/step = {tot * 1e3 / batch:.1f} MB/patch")
     for k, v in sorted(res["classes"].items(), key=lambda kv: -(kv[1]["read_GB_per_step"] + kv[1]["write_GB_per_step"])):
         print(f"[class] {k:28s} {v['launches_per_step']:6.1f}/step  R {v['read_GB_per_step']:7.3f} GB  W {v['write_GB_per_step']:7.3f} GB  {v['traffic_bytes_per_launch'] / 1e6:9.2f} MB/launch")
+    for k, v in sorted(res["families"].items(), key=lambda kv: -(kv[1]["read_GB_per_step"] + kv[1]["write_GB_per_step"])):
+        print(f"[family] {k:27s} {v['launches_per_step']:6.1f}/step  R {v['read_GB_per_step']:7.3f} GB  W {v['write_GB_per_step']:7.3f} GB")
     for k, v in list(res["kernels"].items())[:25]:
         print(f"{k:40s} {v['launches_per_step']:6.1f}/step  R {v['read_GB_per_step']:7.3f} GB  W {v['write_GB_per_step']:7.3f} GB  {v['traffic_bytes_per_launch'] / 1e6:9.2f} MB/launch")
 

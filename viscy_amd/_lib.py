@@ -56,6 +56,7 @@ _SIGS = {
     "vsx_version": (_I32, []),
     "vsx_weight_tasks": (_I32, [_P, _I32, _P]),
     "vsx_last_error": (C.c_char_p, []),
+    "vsx_last_kernel": (C.c_char_p, []),
     "vsx_set_flag": (_I32, [C.c_char_p, _I32]),
     "vsx_get_flag": (_I32, [C.c_char_p]),
     "vsx_gemm_nt": (_I32, [C.POINTER(VsxGemm), _I32, _P]),

@@ -6,6 +6,7 @@
 #include "../../include/vsx.h"
 
 static thread_local char g_err[512] = "";
+thread_local const char* g_vsx_last_kernel = "";  // kernel template the last GEMM entry point on this thread dispatched (vsx_last_kernel)
 int g_vsx_tn_tr = 1;
 int g_vsx_nt_wide = 1;
 int g_vsx_nt_fast = 1;
@@ -37,6 +38,7 @@ void vsx_set_error(const char* fmt, ...) {
 
 extern "C" int32_t vsx_version(void) { return 1; }
 extern "C" const char* vsx_last_error(void) { return g_err; }
+extern "C" const char* vsx_last_kernel(void) { return g_vsx_last_kernel; }
 extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "tn_tr")) { g_vsx_tn_tr = value; return 0; }
   if (name && !strcmp(name, "nt_wide")) { g_vsx_nt_wide = value; return 0; }

@@ -772,6 +772,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
 
 template <typename T, int EPI, bool PRO>
 static int launch_nt_fast(const VsxGemm* pin, hipStream_t s) {
+  g_vsx_last_kernel = "gemm_nt_fast";
   VsxGemm pq = *pin;
   if (g_vsx_nt_stream & 1) pq.pro |= 256;
   if (g_vsx_nt_stream & 2) pq.pro |= 512;  // kernel-side flag bit (the prologue kind itself is a template parameter there)
@@ -842,6 +843,7 @@ static int dispatch_nt_fast(const VsxGemm* p, hipStream_t s) {
 
 template <typename T, int BM, int BN, int WM_, int WN_, int BK, int NBUF = 2>
 static int launch_nt(const VsxGemm* p, hipStream_t s) {
+  g_vsx_last_kernel = "gemm_nt_generic";
   int tiles = vsx_cdiv(p->M, BM) * vsx_cdiv(p->N, BN);
   dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
   hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN, WM_, WN_, BK, NBUF>), grid, dim3(256), 0, s, *p);
@@ -1339,6 +1341,7 @@ __global__ __launch_bounds__(256) void tn_zero_kernel(float* __restrict__ p, lon
 
 template <typename T, int BT, bool TR>
 static int launch_tn(const VsxGemm* p, hipStream_t s) {
+  g_vsx_last_kernel = "gemm_tn_fast";  // (the generic kernel overrides this at its launch below)
   int tiles = vsx_cdiv(p->N, BT) * vsx_cdiv(p->K, BT);
   int nz = p->nz > 0 ? p->nz : 1;
   // split the pixel (contraction) axis so that the launch fills 256 CUs, but keep the number of
@@ -1448,6 +1451,7 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
     VSX_LAUNCH_CHECK();
     return 0;
   }
+  g_vsx_last_kernel = "gemm_tn_generic";
   hipLaunchKernelGGL((gemm_tn_kernel<T, BT, TR>), grid, dim3(256), 0, s, *p, rpb);
   VSX_LAUNCH_CHECK();
   return 0;

@@ -558,6 +558,7 @@ bool vsx_gemm_nt2_ok(const VsxGemm* p) {
 }
 
 int vsx_gemm_nt2(const VsxGemm* p, hipStream_t s) {
+  g_vsx_last_kernel = "gemm_nt2";
   if (p->epi == VSX_EPI_LN_BWD) {
     const int tiles = p->M / BM;
     if (p->N <= 128) hipLaunchKernelGGL((gemm_nt2_lnbwd_kernel<128>), dim3(tiles), dim3(512), 0, s, *p);

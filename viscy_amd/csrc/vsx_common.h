@@ -12,6 +12,7 @@ typedef __bf16 bf16_t;
 
 // ------------------------------------------------------------------ error plumbing (host)
 void vsx_set_error(const char* fmt, ...);
+extern thread_local const char* g_vsx_last_kernel;  // api.hip: set by the GEMM dispatchers, read by vsx_last_kernel()
 #define VSX_CHECK(cond, ...)            \
   do {                                  \
     if (!(cond)) {                      \

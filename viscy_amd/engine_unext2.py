@@ -56,7 +56,7 @@ class _ZeroArena:
     def _zeros(self, *shape) -> Tensor:
         if self.ops is not None and hasattr(self.ops, "zeros"):
             return self.ops.zeros(*shape, device=self.dev)  # vsx_fill_f32: the captured step holds no ATen fill
-        return self._zeros(*shape)
+        return torch.zeros(shape, dtype=torch.float32, device=self.dev)
 
     def take(self, *shape) -> Tensor:
         n = 1
@@ -68,7 +68,7 @@ class _ZeroArena:
             v = self.buf[self.off:self.off + n].view(*shape)
             self.off += n_al
             return v
-        return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+        return self._zeros(*shape)
 
 
 class Engine:
@@ -393,6 +393,7 @@ class Engine:
             # recomputed, GELU, GRN, fc2, bias, shortcut
             if w.img is None:
                 w.img = o.mlp_pack(w.W1f, w.W2, C)
+                o.flush()  # inside an open task-list batch the pack is only queued; its reader is the next launch
             if ln_in:
                 o.mlp_stats(xh, w.img, w.b1f, colsq, M, C, hw, ln_eps=lne)
                 s = o.grn_scale(colsq, w.grn_w)
@@ -411,6 +412,7 @@ class Engine:
             # training fc1 on the fused kernel's statistics pass, which also stores h and g (csrc/mlp.hip MODE 2)
             if w.img is None:
                 w.img = o.mlp_pack(w.W1f, w.W2, C)
+                o.flush()
             if ln_in:
                 xh, rstd, h, gact = o.mlp_fc1_ln(xh, w.img, w.b1f, colsq, M, C, hw, 1e-6)
             else:
@@ -428,7 +430,10 @@ class Engine:
             # so fc2 is a plain GEMM (the operand prologue costs +60 % on these launches); B·C·4C extra weight bytes
             # are small next to the M·4C activation bytes when a sample spans >= 8 row tiles
             Ws = o.scale_weight_samples(w.fc2_w, s, dt)
-            b2 = w.b2f if w.b2f is not None else o.matvec(w.fc2_w, w.grn_b, w.fc2_b, C, 4 * C)
+            b2 = w.b2f
+            if b2 is None:
+                b2 = o.matvec(w.fc2_w, w.grn_b, w.fc2_b, C, 4 * C)
+                o.flush()
             o.gemm("nt", gact, Ws, out, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, hw=hw, b_bstride=C * 4 * C,
                    epi=L.EPI_BIAS_RES, bias=b2, res=xres, ldr=C, rscale=dpm)
         else:
@@ -485,7 +490,13 @@ class Engine:
             # the 4C-wide dz is never written: the statistics came from the per-sample products above; this pass recomputes
             # dz = dout·W2 tile by tile (K = C is short) and writes dh directly (csrc/mlp.hip MODE 4) — one 4C-wide write
             # where the unfused pair (dz GEMM, then GRN / GELU backward over it) has two
-            img2 = w.img2 if w.img2 is not None else o.mlp_pack(w.W2T, w.W2, C)
+            img2 = w.img2
+            if img2 is None:
+                # not packed by prepare() (mlp_fused bit 3 switched on between a forward and its backward): _block_bwd runs
+                # inside the backward segment's open task-list batch, where the pack would only be QUEUED while the passes below
+                # read the image right away — launch the list before going on
+                img2 = w.img2 = o.mlp_pack(w.W2T, w.W2, C)
+                o.flush()
             if fused_bwd == 2:  # statistics by recomputing dz tile by tile (P = Σ dz·g, S = Σ dz), nothing stored
                 o.mlp_bwd_stats(dout, img2, gact, PS[0], PS[1], M, C, hw)
             t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw, Sb=PS[1], dbeta=dgb)

@@ -301,6 +301,7 @@ def head_out_bwd2(U, ssum, ssq, w2, alpha, dv, S1, S2, B, H2, W2, Z, Cmid, Cout,
 _BATCH: list | None = None
 _BATCH_ON = os.environ.get("VSX_WBATCH", "1") != "0"  # VSX_WBATCH=0: every job its own launch (A/B measurements)
 _BATCH_KEEP: list = []  # the queued jobs' tensors stay alive (and their memory un-recycled) until the list is launched
+_BATCH_WRITTEN: set = set()  # start addresses the queued jobs write: a later job touching one of them flushes first (see _queue)
 
 
 @contextlib.contextmanager
@@ -340,11 +341,22 @@ def flush() -> None:
     del _BATCH[:]
     check(lib().vsx_weight_tasks(C.addressof(arr), len(arr), stream()), "weight_tasks")
     del _BATCH_KEEP[:]
+    _BATCH_WRITTEN.clear()
 
 
 def _queue(kind: int, dtype: int, ints, p0, p1, p2, p3, p4=None, p5=None, p6=None) -> bool:
     if _BATCH is None:
         return False
+    # The jobs of one list run CONCURRENTLY (one launch): a job must not read, write or accumulate into what another job of the
+    # same list writes (UNPREP and the accumulating TRANSPOSE / MATVEC_T / REDUCE_ROWS are non-atomic read-modify-writes).
+    # Outputs are p1 (+ p2 for PREP / UNPREP); a job that touches a tensor an already queued job writes — a tied parameter, two
+    # finalisers on one gradient — launches the list collected so far first (same-tensor hazards, by start address).
+    tens = [t for t in (p0, p1, p2, p3, p4, p5, p6) if torch.is_tensor(t)]
+    if _BATCH_WRITTEN and any(t.data_ptr() in _BATCH_WRITTEN for t in tens):
+        flush()
+    for t in (p1, p2) if kind in (L.WTASK_PREP, L.WTASK_UNPREP) else (p1,):
+        if torch.is_tensor(t):
+            _BATCH_WRITTEN.add(t.data_ptr())
     i = list(ints) + [0] * (4 - len(ints))
     _BATCH.append(L.VsxWTask(kind, dtype, i[0], i[1], i[2], i[3], ptr(p0), ptr(p1), ptr(p2), ptr(p3), ptr(p4), ptr(p5), ptr(p6)))
     _BATCH_KEEP.append((p0, p1, p2, p3, p4, p5, p6))
