@@ -319,7 +319,7 @@ int32_t vsx_adamw(float* p, const float* g, float* m, float* v, const float* hyp
  *   vsx_mlp_fwd mode 0: colsq[b, 4C] += sum_hw gelu(fc1(xh))^2   (GRN statistics; nothing else is stored)
  *               mode 1: out = res + rscale[b] * (fc2(gelu(fc1(xh)) * s[b] + beta) + b2) */
 int32_t vsx_mlp_supported(int32_t C, int32_t hw, int64_t M, int32_t dtype);   /* the inference pair (modes 0 and 1) */
-int32_t vsx_mlp_mode_supported(int32_t C, int32_t hw, int64_t M, int32_t mode, int32_t dtype);  /* one pass (mode 0..4) */
+int32_t vsx_mlp_mode_supported(int32_t C, int32_t hw, int64_t M, int32_t mode, int32_t dtype);  /* one pass (mode 0..6) */
 int64_t vsx_mlp_image_bytes(int32_t C);
 int32_t vsx_mlp_pack(const void* W1, const void* W2, void* img, int32_t C, vsx_stream_t stream);
 /* vsx_mlp_fwd / vsx_mlp_fc1 with the block LayerNorm (eps, no affine) applied in the kernel's prologue: y = the UN-normalised
@@ -355,10 +355,22 @@ int64_t vsx_grn_q_reduce_ws_floats(int32_t nb, int32_t C);
 int32_t vsx_mlp_bwd_stats(const void* dout, const void* wimg, const void* g, float* P, float* S, int64_t M, int32_t C, int32_t hw,
     int32_t dtype, vsx_stream_t stream);
 int32_t vsx_mlp_bwd_dh(const void* dout, const void* wimg, const void* h, const float* s, const float* t, void* dh, float* ws,
-    int64_t ws_rows, float* colsum, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
+                       int64_t ws_rows, float* colsum, const float* gelu_table, int64_t M, int32_t C, int32_t hw, int32_t dtype,
+                       vsx_stream_t stream);
 int32_t vsx_mlp_rows_per_workgroup(int32_t C, int32_t hw, int64_t M);
-/* GELU of a bf16 value through a table (csrc/mlp.hip): vsx_mlp_gelu_table fills `tab` (vsx_mlp_gelu_table_len() floats) with
- * a * Phi(-a) for every bf16 magnitude a in [2^-24, 16); gelu(h) = max(h, 0) - tab[bits(|h|)]. */
+/* vsx_mlp_bwd_dh WITHOUT a stored pre-activation (csrc/mlp.hip MODE 5; round 4): h = bf16(xh . W1'^T + b1) is recomputed on chip
+ * from the normalised rows xh [M, C] — wimg_fwd = vsx_mlp_pack(W1', W2) and b1 are the operands vsx_mlp_fc1 ran with, so the
+ * recomputed h is bit-identical to the one it would have stored — beside dz = dout . W2 (wimg_bwd as for vsx_mlp_bwd_dh).  With
+ * vsx_mlp_fc1 / vsx_mlp_fc1_ln called with h = NULL (MODE 6: only g is stored) the 4C-wide h never exists in memory: one 4C-wide
+ * write less in the forward, one 4C-wide read less in the backward, per block.  Available where
+ * vsx_mlp_mode_supported(.., 5, ..) / (.., 6, ..) (C <= 224, `mlp_fused` bit 6).  Reference math: timm GlobalResponseNormMlp as
+ * restated in viscy_models/unet/fcmae.py:174-221. */
+int32_t vsx_mlp_bwd_dh_re(const void* dout, const void* xh, const void* wimg_bwd, const void* wimg_fwd, const float* b1, const float* s,
+                          const float* t, void* dh, float* ws, int64_t ws_rows, float* colsum, const float* gelu_table, int64_t M,
+                          int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
+/* GELU of a bf16 value through a table (csrc/mlp.hip): vsx_mlp_gelu_table fills `tab` (vsx_mlp_gelu_table_len() = 2 N floats)
+ * with r(a) = a * Phi(-a) (first N) and d(a) = Phi(a) + a * phi(a) - 1/2 (second N) for every bf16 magnitude a in [2^-24, 16):
+ * gelu(h) = max(h, 0) - r(|h|), gelu'(h) = 1/2 + sign(h) * d(|h|).  The forward passes read the first half, the dh passes both. */
 int32_t vsx_mlp_gelu_table_len(void);
 int32_t vsx_mlp_gelu_table(float* tab, vsx_stream_t stream);
 

@@ -1236,6 +1236,67 @@ def _fused_bwd_case(C, hw, B, dt, M, H4, L, ops):
     close(dh, ref, dt, "dh vs fp32 statement")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,hw,B", [(96, 4096, 3), (192, 1024, 5), (224, 4096, 2), (96, 256, 8)])
+@pytest.mark.parametrize("ln_in", [False, True])
+def test_fused_block_without_a_stored_preactivation(C, hw, B, ln_in):
+    """csrc/mlp.hip MODE 6 (training fc1 that stores g only) and MODE 5 (dh pass that recomputes h = x^ . W1'^T + b1 on chip):
+    g, x^, rstd and the GRN sums BIT-IDENTICAL to MODE 2's, dh and its column sums bit-identical to MODE 4 run on MODE 2's stored
+    h — and dh against an fp32 statement of the block backward (timm GlobalResponseNormMlp as restated in
+    viscy_models/unet/fcmae.py:174-221), so the pair is not only compared with itself"""
+    if SELF_CHECK:
+        pytest.skip("HIP-only kernel")
+    from viscy_amd import _lib as L
+    from viscy_amd import ops
+
+    dt = torch.bfloat16
+    M, H4 = B * hw, 4 * C
+    saved = L.lib().vsx_get_flag(b"mlp_fused")
+    L.lib().vsx_set_flag(b"mlp_fused", 127)
+    try:
+        assert ops.mlp_supported(C, hw, M, dt, 5) and ops.mlp_supported(C, hw, M, dt, 6)
+        y = rnd(M, C, dt=dt, seed=11, scale=2.0).cuda()
+        W1 = rnd(H4, C, dt=dt, seed=12, scale=C ** -0.5).cuda()
+        W2 = rnd(C, H4, dt=dt, seed=13, scale=H4 ** -0.5).cuda()
+        W2T = W2.t().contiguous()
+        b1 = (0.1 * rnd(H4, seed=14)).cuda()
+        dout = rnd(M, C, dt=dt, seed=15).cuda()
+        s = (1 + 0.2 * rnd(B, H4, seed=16)).cuda()
+        t = (0.05 * rnd(B, H4, seed=17)).cuda()
+        img, img2 = ops.mlp_pack(W1, W2, C), ops.mlp_pack(W2T, W2, C)
+        q2, q6 = torch.zeros((B, H4), device="cuda"), torch.zeros((B, H4), device="cuda")
+        if ln_in:
+            xh2, r2, h2, g2 = ops.mlp_fc1_ln(y, img, b1, q2, M, C, hw, 1e-6)
+            xh6, r6, h6, g6 = ops.mlp_fc1_ln(y, img, b1, q6, M, C, hw, 1e-6, store_h=False)
+            assert torch.equal(xh2, xh6) and torch.equal(r2, r6)
+        else:
+            xh2 = xh6 = y
+            h2, g2 = ops.mlp_fc1(y, img, b1, q2, M, C, hw)
+            h6, g6 = ops.mlp_fc1(y, img, b1, q6, M, C, hw, store_h=False)
+        assert h6 is None and torch.equal(g2, g6)
+        close(q6, q2, torch.float32, "GRN sums")  # (atomics: order only)
+        db4, db5 = torch.zeros(H4, device="cuda"), torch.zeros(H4, device="cuda")
+        dh4 = ops.mlp_bwd_dh(dout, img2, h2, s, t, db4, M, C, hw)
+        dh5 = torch.full((M, H4), float("nan"), dtype=dt, device="cuda")
+        dh5 = ops.mlp_bwd_dh_re(dout, xh6, img2, img, b1, s, t, db5, M, C, hw)
+        assert torch.isfinite(dh5.float()).all()
+        assert torch.equal(dh4, dh5), (dh4.float() - dh5.float()).abs().max().item()
+        assert torch.equal(db4, db5)
+        # fp32 statement: h from the bf16 operands with fp32 accumulation, rounded as the forward stores it
+        hf = (xh6.float() @ W1.float().t() + b1).to(dt).float()
+        close(h2, hf.to(dt), dt, "stored h vs fp32 statement")
+        dzf = (dout.float() @ W2.float()).to(dt).float()
+        cdf = 0.5 * (1 + torch.erf(hf * 0.7071067811865476))
+        pdf = torch.exp(-0.5 * hf * hf) * 0.3989422804014327
+        ref = ((dzf.view(B, hw, H4) * s[:, None] + (hf * cdf).view(B, hw, H4) * t[:, None]).view(M, H4) * (cdf + hf * pdf)).to(dt)
+        # (a bf16 ulp of h here and there — another accumulation order than the MFMA's — moves gelu'(h) by its slope)
+        err = (dh5.float() - ref.float()).abs()
+        assert (err > 2e-2 * ref.float().abs().max()).float().mean().item() < 1e-4, err.max().item()
+        close(db5, ref.float().sum(0), torch.float32, "colsum dh", scale=ref.float().sum(0).abs().max().item() * 5 + float(M) ** 0.5 * 0.05)
+    finally:
+        L.lib().vsx_set_flag(b"mlp_fused", saved)
+
+
 def test_weight_task_list_equals_single_launches():
     """vsx_weight_tasks (ops.batch): prep_weight / transpose_f32 / matvec / mlp_pack / unprep_grad / matvec_t_add collected into task lists give identical
     outputs to the single launches — more tasks than one launch holds (VSX_WTASK_MAX = 48), every kind, bf16 and fp32, tap

@@ -105,8 +105,9 @@ _SIGS = {
     "vsx_grn_q_reduce": (_I32, [_P] * 10 + [_I64, _I32, _I32, _I32, _P]),
     "vsx_grn_q_reduce_ws_floats": (_I64, [_I32, _I32]),
     "vsx_mlp_bwd_stats": (_I32, [_P] * 5 + [_I64, _I32, _I32, _I32, _P]),
-    "vsx_mlp_bwd_dh": (_I32, [_P] * 7 + [_I64, _P, _I64, _I32, _I32, _I32, _P]),
+    "vsx_mlp_bwd_dh": (_I32, [_P] * 7 + [_I64, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "vsx_mlp_rows_per_workgroup": (_I32, [_I32, _I32, _I64]),
+    "vsx_mlp_bwd_dh_re": (_I32, [_P] * 9 + [_I64, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "vsx_mlp_gelu_table_len": (_I32, []),
     "vsx_mlp_gelu_table": (_I32, [_P, _P]),
     "vsx_prep_weight": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),

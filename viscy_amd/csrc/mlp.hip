@@ -18,6 +18,11 @@
 //                        write-dominated launches of THIS kernel family land at 3.5 - 3.9 TB/s; linear and tile-shaped store
 //                        probes reach 5.5 - 6.9 TB/s on the part, tools/micro/write_rate.hip — the limit is the kernels'
 //                        structure, DESIGN.md §3 item 10, not the memory.)
+//   MODE 5 (backward dh, h RECOMPUTED): MODE 4 without a stored pre-activation — h = x^ . W1'^T + b1 is recomputed from the
+//                        C-wide normalised rows (the same MFMA sequence as the forward: bit-identical h) beside dz = dout . W2;
+//   MODE 6 (training fc1, g only): MODE 2 that stores the activation g but NOT h.  Together they take the 4C-wide h out of HBM
+//                        (one 4C-wide write in the forward, one 4C-wide read in the backward, per block): K = C is short and the
+//                        matrix cores were idle 85 % of these passes (round 4).
 // (SURVEY §7 step 4 / VERDICT r1 "what's missing" 1.  The unfused schedule moved 8 of its 15 C-units per pixel as 4C-wide
 // h / g tensors through HBM in inference; this one moves 1 + 3.)
 //
@@ -66,7 +71,9 @@ struct MlpArgs {
   float* red0;          // [B, 4C] += sum_hw dz * g  (MODE 3)
   float* red1;          // [B, 4C] += sum_hw dz      (MODE 3)
   float* ws;            // [M / BM, 4C] per-workgroup column sums of dh (MODE 4)
-  const float* gtab;    // [MLP_GT_N] r(a) = a * Phi(-a) for every bf16 a in [2^-24, 16)  (vsx_mlp_gelu_table)
+  const float* gtab;    // [2 * MLP_GT_N] r(a) = a * Phi(-a), then d(a) = Phi(a) + a * phi(a) - 1/2, for every bf16 a in [2^-24, 16)  (vsx_mlp_gelu_table)
+  const bf16_t* xh2;    // [M, C]  normalised rows x^ (MODE 5: `xh` holds dout, as in MODE 3 / 4)
+  const char* wimg2;    // forward image (W1', W2) (MODE 5: `wimg` holds the backward image (W2^T, W2), as in MODE 3 / 4)
   int M, hw;
   int nt;               // bit 0: non-temporal stores of h / g / dh (read by a later launch only), bit 1: non-temporal load of the stored
                         // activation (MODE 3: g, MODE 4: h — this pass is its last reader)
@@ -82,6 +89,13 @@ struct MlpArgs {
 #define MLP_GT_LIM (131 << 7)             /* ... of 16 */
 #define MLP_GT_N (MLP_GT_LIM - MLP_GT_BASE)
 
+// max(h, 0) on the bit pattern: a negative float is a negative integer.  (fmaxf costs two instructions here: kernels run in IEEE
+// mode, where the compiler has to canonicalise the operand first.)
+__device__ __forceinline__ float mlp_relu(float h) {
+  const int b = __float_as_int(h);
+  return __int_as_float(b > 0 ? b : 0);
+}
+
 __device__ __forceinline__ mlp_f32x4 mlp_mfma(const mlp_bf16x8& a, const mlp_bf16x8& b, const mlp_f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -91,14 +105,15 @@ struct MlpGeom {
   static constexpr int H4 = 4 * C, NHS = H4 / 32, KK = C / 32, NF = C / 16;
   static constexpr int WM = 16 * MF, BM = NW * WM;
   static constexpr int W1_PIECES = 2 * KK, IMG_PIECES = 2 * KK + NF;   // KiB per hidden sub-chunk in the image
-  static constexpr int NP = MODE != 1 ? W1_PIECES : IMG_PIECES;        // pieces staged per sub-chunk
+  static constexpr int NP = MODE == 5 ? 2 * W1_PIECES : (MODE != 1 ? W1_PIECES : IMG_PIECES);  // pieces staged per sub-chunk
   static constexpr int STAGE_BYTES = NP * 1024;
-  static constexpr int OB_COLS = 64;                                   // output leaves in blocks of 64 columns
+  static constexpr int OB_COLS = MODE == 0 ? 32 : 64;                  // output leaves in blocks of 64 columns (MODE 0: the
+                                                                       // wave-private g tile of ONE sub-chunk, for the statistics)
   static constexpr int OB_RS = OB_COLS * 2 + 16;                       // staging row stride (bytes)
-  static constexpr int OUT_BYTES = MODE == 2 ? NW * 2 * WM * OB_RS : (MODE == 0 ? 16 : NW * WM * OB_RS);
-  static constexpr int VEC_FLOATS = MODE == 1 ? 3 * H4 + C : (MODE == 4 ? 2 * H4 : (MODE == 3 ? 4 : H4));
+  static constexpr int OUT_BYTES = MODE == 2 ? NW * 2 * WM * OB_RS : NW * WM * OB_RS;  // MODE 6: g only
+  static constexpr int VEC_FLOATS = MODE == 1 ? 3 * H4 + C : (MODE == 4 ? 2 * H4 : (MODE == 5 ? 3 * H4 : (MODE == 3 ? 4 : H4)));
   static constexpr int RED_FLOATS = MODE == 1 ? 4 : (MODE == 3 ? 4 * NW * 32 : 2 * NW * 32);
-  static constexpr int GT_FLOATS = MODE <= 2 ? MLP_GT_N : 4;
+  static constexpr int GT_FLOATS = (MODE <= 2 || MODE == 6) ? MLP_GT_N : ((MODE == 4 || MODE == 5) ? 2 * MLP_GT_N : 4);
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES + OUT_BYTES + (VEC_FLOATS + RED_FLOATS) * 4;
 };
 
@@ -109,7 +124,8 @@ template <int C, int MF, int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1)) void mlp_fused_kernel(const MlpArgs a) {
   typedef MlpGeom<C, MF, NW, MODE> G;
   constexpr int H4 = G::H4, NHS = G::NHS, KK = G::KK, NF = G::NF, WM = G::WM;
-  constexpr bool STATS = MODE == 0 || MODE == 2, STORE = MODE == 2, BWD = MODE >= 3;
+  constexpr bool STATS = MODE == 0 || MODE == 2 || MODE == 6, STORE = MODE == 2 || MODE == 6, STORE_H = MODE == 2;
+  constexpr bool BWD = MODE >= 3 && MODE <= 5, DH = MODE == 4 || MODE == 5, RE = MODE == 5;
   // SEPARATE LDS objects, on purpose: the two weight stages, the per-channel vectors and the output staging are distinct
   // variables, so the compiler's alias scopes let fragment / vector reads proceed while the LDS-DMA prefetch of the OTHER
   // stage is in flight (through one array every ds_read behind a global_load_lds costs an s_waitcnt vmcnt(0): no overlap)
@@ -129,6 +145,11 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
 
   if constexpr (!BWD) {
     for (int i = tid; i < MLP_GT_N; i += NW * 64) gt[i] = a.gtab[i];
+  } else if constexpr (DH) {  // {r(a), d(a)} pairs: one 8-byte gather per element yields gelu AND its derivative
+    for (int i = tid; i < MLP_GT_N; i += NW * 64) {
+      gt[2 * i] = a.gtab[i];
+      gt[2 * i + 1] = a.gtab[MLP_GT_N + i];
+    }
   }
   // ---- per-channel vectors -> LDS (once)
   if constexpr (!BWD) {
@@ -139,10 +160,11 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
         vec[2 * H4 + i] = a.grn_b[i];
       }
     }
-  } else if constexpr (MODE == 4) {
+  } else if constexpr (DH) {
     for (int i = tid; i < H4; i += NW * 64) {  // this sample's GRN scale s and statistics-path factor t
       vec[i] = a.grn_s[(size_t)b * H4 + i];
       vec[H4 + i] = a.grn_b[(size_t)b * H4 + i];
+      if constexpr (RE) vec[2 * H4 + i] = a.b1[i];
     }
   }
   if constexpr (MODE == 1) {
@@ -155,6 +177,16 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk)
       xf[mf][kk] = *reinterpret_cast<const mlp_bf16x8*>(a.xh + (size_t)(row0 + mf * 16 + p16) * C + kk * 32 + kq * 8);
+
+  // MODE 5: the normalised rows x^ as a second fragment set (operand of the recomputed fc1)
+  mlp_bf16x8 xg[RE ? MF : 1][RE ? KK : 1];
+  if constexpr (RE) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+        xg[mf][kk] = *reinterpret_cast<const mlp_bf16x8*>(a.xh2 + (size_t)(row0 + mf * 16 + p16) * C + kk * 32 + kq * 8);
+  }
 
   if constexpr (!BWD) {
     if (a.ln_eps > 0.f) {
@@ -199,9 +231,9 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
           union { mlp_bf16x8 b; uint4 u; } cv;
           cv.u = pack<bf16_t>(o);
           xf[mf][kk] = cv.b;
-          if constexpr (MODE == 2) *reinterpret_cast<uint4*>(a.xh_out + rowi * C + kk * 32 + kq * 8) = cv.u;
+          if constexpr (STORE) *reinterpret_cast<uint4*>(a.xh_out + rowi * C + kk * 32 + kq * 8) = cv.u;
         }
-        if constexpr (MODE == 2) {
+        if constexpr (STORE) {
           if (kq == 0) a.rstd_out[rowi] = rstd;
         }
       }
@@ -218,7 +250,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
 
   // fc1 of one hidden sub-chunk (roles swapped): acc[hf][mf][r] = H[pixel mf*16 + p][hidden 32*hs + hf*16 + q*4 + r];
   // `W` = the W1 fragments of that sub-chunk in a stage buffer (+ lane * 16)
-  auto gemm1 = [&](const char* W, mlp_f32x4 (&acc)[2][MF]) {
+  auto gemm1 = [&](const char* W, const auto& xfr, mlp_f32x4 (&acc)[2][MF]) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -229,7 +261,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
       for (int kk = 0; kk < KK; ++kk) {
         const mlp_bf16x8 wa = *reinterpret_cast<const mlp_bf16x8*>(W + (hf * KK + kk) * 1024);
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) acc[hf][mf] = mlp_mfma(wa, xf[mf][kk], acc[hf][mf]);
+        for (int mf = 0; mf < MF; ++mf) acc[hf][mf] = mlp_mfma(wa, xfr[mf][kk], acc[hf][mf]);
       }
   };
   // bias, GELU, GRN in registers (same rounding points as the unfused kernels: h and g are bf16 values); MODE 0 adds g^2
@@ -237,8 +269,8 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
   // MODE 2: h / g of two consecutive sub-chunks are parked in a wave-private LDS tile [2 outputs][WM rows][64 hidden] and
   // leave as 16-byte vectors, 128-byte row segments (8-byte stores straight from the accumulator layout — 32-byte segments —
   // ran at 2.4-2.8 TB/s and made this pass slower than the unfused GEMM)
-  char* sb = obuf + wave * ((MODE == 2 ? 2 : 1) * WM * G::OB_RS);
-  auto activate = [&](int hs, const mlp_f32x4 (&acc)[2][MF], mlp_bf16x8 (&zf)[MF], float (&sq)[2][4]) {
+  char* sb = obuf + wave * ((STORE_H ? 2 : 1) * WM * G::OB_RS);
+  auto activate = [&](int hs, const mlp_f32x4 (&acc)[2][MF], mlp_bf16x8 (&zf)[MF]) {
     const float* vb = vec + hs * 32 + kq * 4;
     float b1v[2][4], sv[2][4], bv[2][4];
 #pragma unroll
@@ -252,10 +284,6 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
         bv[hf][0] = t3.x; bv[hf][1] = t3.y; bv[hf][2] = t3.z; bv[hf][3] = t3.w;
       }
     }
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sq[hf][r] = 0.f;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       // all 8 table reads of this pixel fragment are issued before the first is consumed (one LDS latency, not eight)
@@ -281,17 +309,19 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
         for (int r = 0; r < 4; r += 2) {
           const uint32_t Pq = P[hf * 2 + r / 2];
           const float h0 = __uint_as_float(Pq << 16), h1 = __uint_as_float(Pq & 0xFFFF0000u);
-          const uint32_t Gq = f32x2_to_bf16x2_bits(fmaxf(h0, 0.f) - rr[hf * 4 + r], fmaxf(h1, 0.f) - rr[hf * 4 + r + 1]);
-          const float g0 = __uint_as_float(Gq << 16), g1 = __uint_as_float(Gq & 0xFFFF0000u);
-          if constexpr (STORE) {
-            char* d = sb + (mf * 16 + p16) * G::OB_RS + ((hs & 1) * 32 + hf * 16 + kq * 4 + r) * 2;
-            *reinterpret_cast<uint32_t*>(d) = Pq;
-            *reinterpret_cast<uint32_t*>(d + WM * G::OB_RS) = Gq;
-          }
+          const uint32_t Gq = f32x2_to_bf16x2_bits(mlp_relu(h0) - rr[hf * 4 + r], mlp_relu(h1) - rr[hf * 4 + r + 1]);
           if constexpr (STATS) {
-            sq[hf][r] = fmaf(g0, g0, sq[hf][r]);
-            sq[hf][r + 1] = fmaf(g1, g1, sq[hf][r + 1]);
+            // g (and h) are parked in the wave-private tile [WM pixels][hidden]: the stores leave from there, and the GRN
+            // statistics are taken from the parked g by the matrix cores (stats_mfma below) — no per-lane squares, no DPP sums
+            char* d = sb + (mf * 16 + p16) * G::OB_RS + ((STORE ? (hs & 1) * 32 : 0) + hf * 16 + kq * 4 + r) * 2;
+            if constexpr (STORE_H) {
+              *reinterpret_cast<uint32_t*>(d) = Pq;
+              *reinterpret_cast<uint32_t*>(d + WM * G::OB_RS) = Gq;
+            } else {
+              *reinterpret_cast<uint32_t*>(d) = Gq;
+            }
           } else {
+            const float g0 = __uint_as_float(Gq << 16), g1 = __uint_as_float(Gq & 0xFFFF0000u);
             z[hf * 4 + r] = fmaf(g0, sv[hf][r], bv[hf][r]);
             z[hf * 4 + r + 1] = fmaf(g1, sv[hf][r + 1], bv[hf][r + 1]);
           }
@@ -304,12 +334,53 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
     }
   };
 
+  // Column sums over this wave's WM = 32 pixels by the matrix cores, from a bf16 tile parked row-major [pixel][hidden] in LDS:
+  // the transposing read (ds_read_b64_tr_b16) hands lane (j, kq) 8 pixels of hidden column j — an MFMA operand whose
+  // contraction index is the pixel.  X . X^T has the sums of squares on its diagonal (products of bf16 values are exact in
+  // fp32: the arithmetic of fmaf(g, g, acc), in another order); X . 1 has the plain sums in every column.  Replaces 8 squares +
+  // 32 DPP steps per lane and sub-chunk (a quarter of the VALU instructions of these passes: round 4).
+  auto tile_frag = [&](const char* tile, int col0) -> mlp_bf16x8 {
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    const char* a0 = tile + (kq * 4 + (p16 >> 2)) * G::OB_RS + (col0 + (p16 & 3) * 4) * 2;
+    union { struct { s16x4_t lo, hi; } s; mlp_bf16x8 v; } u;
+    u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+    u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 16 * G::OB_RS));
+    return u.v;
+  };
+  auto stats_mfma = [&](int hs, float* rw) {  // rw[32] = sum over the wave's pixels of g^2, this sub-chunk's 32 columns
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const char* gt_ = sb + (STORE_H ? WM * G::OB_RS : 0);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const mlp_bf16x8 X = tile_frag(gt_, (STORE ? (hs & 1) * 32 : 0) + ct * 16);
+      const mlp_f32x4 D = mlp_mfma(X, X, (mlp_f32x4){0.f, 0.f, 0.f, 0.f});
+      // lane (n, q) holds D[4q + i][n]: the diagonal element of column n sits in lane (n, n / 4), register n % 4
+      const int i = p16 & 3;
+      const float dsel = i == 0 ? D[0] : (i == 1 ? D[1] : (i == 2 ? D[2] : D[3]));
+      if (kq == (p16 >> 2)) rw[ct * 16 + p16] = dsel;
+    }
+  };
+  auto colsum_mfma = [&](int hs, float* rw) {  // rw[32] = sum over the wave's pixels of the parked tile (dh), 32 columns
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    union { unsigned short h[8]; mlp_bf16x8 v; } one;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) one.h[j] = 0x3F80;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const mlp_bf16x8 X = tile_frag(sb, (hs & 1) * 32 + ct * 16);
+      const mlp_f32x4 D = mlp_mfma(X, one.v, (mlp_f32x4){0.f, 0.f, 0.f, 0.f});
+      if (p16 == 0) *reinterpret_cast<float4*>(rw + ct * 16 + kq * 4) = make_float4(D[0], D[1], D[2], D[3]);
+    }
+  };
+
   // ---- MODE 3 / 4: the stored activation (MODE 3: g, MODE 4: h) of a PAIR of sub-chunks travels HBM -> registers (16-byte
   // vectors, 128-byte row segments, issued two sub-chunks ahead) -> a wave-private LDS tile [WM rows][64 hidden], from where
   // the accumulator layout reads 8 bytes per lane; MODE 4 writes dh over h in that tile and flushes it like MODE 2
-  uint4 tq[BWD ? (WM * 8) / 64 : 1];
+  uint4 tq[BWD && !RE ? (WM * 8) / 64 : 1];
   auto tile_load = [&](int hs) {   // hs even: the pair (hs, hs + 1)
-    if constexpr (BWD) {
+    if constexpr (BWD && !RE) {
 #pragma unroll
       for (int i = 0; i < (WM * 8) / 64; ++i) {
         const int idx = lane + 64 * i, row = idx >> 3, ch = idx & 7;
@@ -318,7 +389,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
     }
   };
   auto tile_write = [&]() {
-    if constexpr (BWD) {
+    if constexpr (BWD && !RE) {
 #pragma unroll
       for (int i = 0; i < (WM * 8) / 64; ++i) {
         const int idx = lane + 64 * i, row = idx >> 3, ch = idx & 7;
@@ -329,8 +400,8 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
       __builtin_amdgcn_wave_barrier();
     }
   };
-  auto tile_flush = [&](int hs) {  // MODE 4: dh of the pair (hs - 1, hs), hs odd
-    if constexpr (MODE == 4) {
+  auto tile_flush = [&](int hs) {  // MODE 4 / 5: dh of the pair (hs - 1, hs), hs odd
+    if constexpr (DH) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -344,14 +415,14 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
     }
   };
   // backward activation of one sub-chunk: acc = dz (fp32) of [WM pixels] x [32 hidden] in the accumulator layout
-  auto bwd_act = [&](int hs, const mlp_f32x4 (&acc)[2][MF], float (&r0)[2][4], float (&r1)[2][4]) {
+  auto bwd_act = [&](int hs, const mlp_f32x4 (&acc)[2][MF], const mlp_f32x4 (&hacc)[2][MF], float (&r0)[2][4], float (&r1)[2][4]) {
     if constexpr (BWD) {
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { r0[hf][r] = 0.f; r1[hf][r] = 0.f; }
-      float sv[2][4], tv[2][4];
-      if constexpr (MODE == 4) {
+      float sv[2][4], tv[2][4], b1v[2][4];
+      if constexpr (DH) {
         const float* vb = vec + hs * 32 + kq * 4;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -359,6 +430,10 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
           const float4 t3 = *reinterpret_cast<const float4*>(vb + H4 + hf * 16);
           sv[hf][0] = t2.x; sv[hf][1] = t2.y; sv[hf][2] = t2.z; sv[hf][3] = t2.w;
           tv[hf][0] = t3.x; tv[hf][1] = t3.y; tv[hf][2] = t3.z; tv[hf][3] = t3.w;
+          if constexpr (RE) {
+            const float4 t4 = *reinterpret_cast<const float4*>(vb + 2 * H4 + hf * 16);
+            b1v[hf][0] = t4.x; b1v[hf][1] = t4.y; b1v[hf][2] = t4.z; b1v[hf][3] = t4.w;
+          }
         }
       }
 #pragma unroll
@@ -366,10 +441,16 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           char* tp = sb + (mf * 16 + p16) * G::OB_RS + ((hs & 1) * 32 + hf * 16 + kq * 4) * 2;
-          const uint2 tw = *reinterpret_cast<const uint2*>(tp);   // 4 bf16: g (MODE 3) or h (MODE 4)
-          const float e[4] = {__uint_as_float(tw.x << 16), __uint_as_float(tw.x & 0xFFFF0000u), __uint_as_float(tw.y << 16),
-                              __uint_as_float(tw.y & 0xFFFF0000u)};
+          uint2 tw;  // the pre-activation h (MODE 4 / 5) or the activation g (MODE 3) as two bf16 pairs
+          if constexpr (RE) {  // recomputed: the forward's accumulator + bias, rounded to bf16 as the stored h was
+            tw.x = f32x2_to_bf16x2_bits(hacc[hf][mf][0] + b1v[hf][0], hacc[hf][mf][1] + b1v[hf][1]);
+            tw.y = f32x2_to_bf16x2_bits(hacc[hf][mf][2] + b1v[hf][2], hacc[hf][mf][3] + b1v[hf][3]);
+          } else {
+            tw = *reinterpret_cast<const uint2*>(tp);
+          }
           if constexpr (MODE == 3) {
+            const float e[4] = {__uint_as_float(tw.x << 16), __uint_as_float(tw.x & 0xFFFF0000u), __uint_as_float(tw.y << 16),
+                                __uint_as_float(tw.y & 0xFFFF0000u)};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float dz = round_bf16(acc[hf][mf][r]);
@@ -377,22 +458,31 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
               r1[hf][r] += dz;
             }
           } else {
-            float o[4];
+            // gelu(h) = max(h, 0) - r(|h|) and gelu'(h) = 1/2 + sign(h) * d(|h|), d(a) = Phi(a) + a * phi(a) - 1/2, BOTH from one
+            // 8-byte gather of the {r, d} table indexed by the magnitude bits of the bf16 value h (the forward's table, computed
+            // in double): 2 VALU operations per element where the erf / exp evaluation (gelu_parts2) took 11 (round 4)
+            float2 tb[4];
 #pragma unroll
-            for (int r = 0; r < 4; r += 2) {  // packed fp32 pairs, same arithmetic as grn_gelu_bwd_kernel (norm.hip)
-              const vsx_v2f x = {e[r], e[r + 1]};
-              const vsx_v2f d2 = {round_bf16(acc[hf][mf][r]), round_bf16(acc[hf][mf][r + 1])};
-              const vsx_v2f s2 = {sv[hf][r], sv[hf][r + 1]}, t2 = {tv[hf][r], tv[hf][r + 1]};
-              vsx_v2f cdf, pdf;
-              gelu_parts2(x, cdf, pdf);
-              const vsx_v2f gv = x * cdf, dgv = cdf + x * pdf;
-              const vsx_v2f rr = (d2 * s2 + gv * t2) * dgv;
-              o[r] = round_bf16(rr.x);
-              o[r + 1] = round_bf16(rr.y);
-              r0[hf][r] += o[r];
-              r0[hf][r + 1] += o[r + 1];
+            for (int r = 0; r < 4; ++r) {
+              const uint32_t w = r < 2 ? tw.x : tw.y;
+              int a0 = (int)((r & 1) ? (w >> 16) & 0x7FFFu : w & 0x7FFFu);
+              a0 = a0 < MLP_GT_BASE ? MLP_GT_BASE : (a0 > MLP_GT_LIM - 1 ? MLP_GT_LIM - 1 : a0);
+              tb[r] = *reinterpret_cast<const float2*>(gt + 2 * (a0 - MLP_GT_BASE));
             }
-            *reinterpret_cast<uint2*>(tp) = make_uint2(f32x2_to_bf16x2_bits(o[0], o[1]), f32x2_to_bf16x2_bits(o[2], o[3]));
+            uint32_t ob[2];
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              const uint32_t w = r < 2 ? tw.x : tw.y;
+              const float h0 = __uint_as_float(w << 16), h1 = __uint_as_float(w & 0xFFFF0000u);
+              const uint32_t Dq = f32x2_to_bf16x2_bits(acc[hf][mf][r], acc[hf][mf][r + 1]);  // dz as the unfused GEMM stores it
+              const vsx_v2f d2 = {__uint_as_float(Dq << 16), __uint_as_float(Dq & 0xFFFF0000u)};
+              const vsx_v2f s2 = {sv[hf][r], sv[hf][r + 1]}, t2 = {tv[hf][r], tv[hf][r + 1]};
+              const vsx_v2f gv = {mlp_relu(h0) - tb[r].x, mlp_relu(h1) - tb[r + 1].x};
+              const vsx_v2f dgv = {0.5f + copysignf(tb[r].y, h0), 0.5f + copysignf(tb[r + 1].y, h1)};
+              const vsx_v2f rr = (d2 * s2 + gv * t2) * dgv;
+              ob[r / 2] = f32x2_to_bf16x2_bits(rr.x, rr.y);
+            }
+            *reinterpret_cast<uint2*>(tp) = make_uint2(ob[0], ob[1]);  // dh parked: colsum_mfma and tile_flush read it
           }
         }
     }
@@ -406,9 +496,12 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
   auto stage_load2 = [&](int s, char* dst) {
     // W1 pieces of sub-chunk s + 1 (absent for the last stage), W2 pieces of sub-chunk s
     const char* src1 = a.wimg + (size_t)(s + 1) * (G::IMG_PIECES * 1024) + lane * 16;
-    const char* src2 = a.wimg + (size_t)s * (G::IMG_PIECES * 1024) + lane * 16;
+    // MODE 5: the second half of a stage = the W1' pieces of sub-chunk s + 1 out of the FORWARD image (both halves feed the
+    // next sub-chunk's two accumulator sets)
+    const char* src2 = RE ? a.wimg2 + (size_t)(s + 1) * (G::IMG_PIECES * 1024) - G::W1_PIECES * 1024 + lane * 16
+                          : a.wimg + (size_t)s * (G::IMG_PIECES * 1024) + lane * 16;
     for (int p = wave; p < G::NP; p += NW) {
-      if (p < G::W1_PIECES && s + 1 >= NHS) continue;
+      if ((RE || p < G::W1_PIECES) && s + 1 >= NHS) continue;
       const char* src = p < G::W1_PIECES ? src1 : src2;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
                                        (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
@@ -420,11 +513,11 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
     if constexpr (STORE) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      for (int idx = lane; idx < 2 * WM * 8; idx += 64) {
+      for (int idx = lane; idx < (STORE_H ? 2 : 1) * WM * 8; idx += 64) {
         const int o = idx / (WM * 8), rem = idx - o * (WM * 8);
         const int row = rem >> 3, ch = rem & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(sb + (o * WM + row) * G::OB_RS + ch * 16);
-        bf16_t* dst = (o ? a.gout : a.hout) + (size_t)(row0 + row) * H4 + (hs - 1) * 32 + ch * 8;
+        bf16_t* dst = (o || !STORE_H ? a.gout : a.hout) + (size_t)(row0 + row) * H4 + (hs - 1) * 32 + ch * 8;
         stvec_stream(dst, v, (a.nt & 1) != 0);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -432,18 +525,26 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
     }
   };
   mlp_f32x4 hcur[2][MF], hnxt[2][MF];
+  mlp_f32x4 gcur[RE ? 2 : 1][RE ? MF : 1], gnxt[RE ? 2 : 1][RE ? MF : 1];  // MODE 5: the recomputed fc1 accumulators
   // prologue: W1 of sub-chunk 0 goes where "stage -1" would sit (buffer 1)
   {
     const char* src = a.wimg + lane * 16;
     for (int p = wave; p < G::W1_PIECES; p += NW)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
                                        (__attribute__((address_space(3))) void*)(buf1 + p * 1024), 16, 0, 0);
+    if constexpr (RE) {
+      const char* srcf = a.wimg2 + lane * 16;
+      for (int p = wave; p < G::W1_PIECES; p += NW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcf + p * 1024),
+                                         (__attribute__((address_space(3))) void*)(buf1 + (G::W1_PIECES + p) * 1024), 16, 0, 0);
+    }
   }
   stage_load2(0, buf0);
   tile_load(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  gemm1(buf1 + lane * 16, hcur);
+  gemm1(buf1 + lane * 16, xf, hcur);
+  if constexpr (RE) gemm1(buf1 + G::W1_PIECES * 1024 + lane * 16, xg, gcur);
 
   auto step = [&](int hs, const char* Sb, char* other) {
     // stage hs has landed for everyone (waited + barrier by the caller); every wave is done with stage hs - 1 in `other`
@@ -469,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
         atomicAdd((lane < 32 ? a.red0 : a.red1) + (size_t)b * H4 + (hs - 1) * 32 + (lane & 31), t);
       }
     }
-    if constexpr (MODE == 4) {
+    if constexpr (DH) {
       if (hs > 0 && wave == (hs - 1) % NW && lane < 32) {  // column sums of dh: one workspace row per workgroup, no atomics
         const float* r = red + ((hs - 1) & 1) * NW * 32 + lane;
         float t = 0.f;
@@ -488,47 +589,40 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
       }
     }
     mlp_bf16x8 zf[MF];
-    float sq[2][4];
     // three scheduling regions.  Inside the GEMM regions the fragment reads run three ahead of the MFMAs that consume them
     // (left alone, hipcc sinks every ds_read_b128 to just before its two MFMAs: read - wait - MFMA - MFMA chains with every
     // LDS latency exposed — 31 waits per sub-chunk at C = 224); the activation region in between is left to the compiler
     // (it batches the eight table reads of a fragment by itself)
     __builtin_amdgcn_sched_barrier(0);
-    gemm1(S, hnxt);  // fc1 of the NEXT sub-chunk (the last step multiplies stale fragments, result unused)
+    gemm1(S, xf, hnxt);  // fc1 of the NEXT sub-chunk (the last step multiplies stale fragments, result unused)
+    if constexpr (RE) gemm1(S + G::W1_PIECES * 1024, xg, gnxt);
     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-    for (int i = 0; i < 2 * KK; ++i) {
+    for (int i = 0; i < (RE ? 4 : 2) * KK; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     float q0[2][4], q1[2][4];
-    if constexpr (BWD) bwd_act(hs, hcur, q0, q1);
-    else activate(hs, hcur, zf, sq);
+    if constexpr (RE) bwd_act(hs, hcur, gcur, q0, q1);
+    else if constexpr (BWD) bwd_act(hs, hcur, hcur, q0, q1);
+    else activate(hs, hcur, zf);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (BWD) {
-      float* rw = red + (hs & 1) * (MODE == 3 ? 2 : 1) * NW * 32 + wave * 32;
+    if constexpr (DH) {
+      colsum_mfma(hs, red + (hs & 1) * NW * 32 + wave * 32);  // column sums of the parked dh (the fc1 bias gradient)
+    } else if constexpr (BWD) {
+      float* rw = red + (hs & 1) * 2 * NW * 32 + wave * 32;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float t0 = group_sum<16>(q0[hf][r]);
           if (p16 == 0) rw[hf * 16 + kq * 4 + r] = t0;
-          if constexpr (MODE == 3) {
-            const float t1 = group_sum<16>(q1[hf][r]);
-            if (p16 == 0) rw[NW * 32 + hf * 16 + kq * 4 + r] = t1;
-          }
+          const float t1 = group_sum<16>(q1[hf][r]);
+          if (p16 == 0) rw[NW * 32 + hf * 16 + kq * 4 + r] = t1;
         }
     } else if constexpr (STATS) {
-      // sum over this wave's pixels: the 16 lanes of a DPP row share q, i.e. the same 8 hidden columns
-      float* rw = red + (hs & 1) * NW * 32 + wave * 32;
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = group_sum<16>(sq[hf][r]);
-          if (p16 == 0) rw[hf * 16 + kq * 4 + r] = t;
-        }
+      stats_mfma(hs, red + (hs & 1) * NW * 32 + wave * 32);  // sum over this wave's pixels of g^2 (the GRN statistics)
     } else {
       // fc2: out[pixel][n] += Z[pixel][32 hidden] . W2[n][same 32 hidden, permuted alike in the image]
 #pragma unroll
@@ -548,7 +642,10 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) hcur[hf][mf] = hnxt[hf][mf];
+      for (int mf = 0; mf < MF; ++mf) {
+        hcur[hf][mf] = hnxt[hf][mf];
+        if constexpr (RE) gcur[hf][mf] = gnxt[hf][mf];
+      }
   };
 
   static_assert(NHS % 2 == 0, "the hidden axis is walked two sub-chunks (one per stage buffer) per loop trip");
@@ -674,13 +771,14 @@ struct MlpCfg { int C, MF, NW, modes; };  // modes: bit m set = this geometry se
 extern int g_vsx_mlp_fused;
 extern int g_vsx_nt_stream;
 static inline int mlp_nt() { return (g_vsx_nt_stream >> 2) & 3; }  // bits 2 / 3 of nt_stream: the fused passes' stores / last-reader loads
-static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 31}, {192, 2, 8, 31}, {224, 2, 8, 31}, {384, 2, 8, 1 | 4 | 8 | 16}, {384, 2, 4, 2}};
+static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 127}, {192, 2, 8, 127}, {224, 2, 8, 127}, {384, 2, 8, 1 | 4 | 8 | 16}, {384, 2, 4, 2}};
 
 static const MlpCfg* mlp_cfg(int C, int hw, long M, int mode) {
   for (const MlpCfg& c : kMlpCfgs) {
     const int bm = c.NW * 16 * c.MF;
     if (!(c.modes & (1 << mode))) continue;
     if (c.C == 384 && !(g_vsx_mlp_fused & (mode <= 1 ? 16 : 4))) continue;  // bit 2: training passes, bit 4: inference pair
+    if ((mode == 5 || mode == 6) && !(g_vsx_mlp_fused & 64)) continue;          // bit 6: the pre-activation h is recomputed, not stored
     if (c.C == C && hw % bm == 0 && M % bm == 0) return &c;
   }
   return nullptr;
@@ -690,9 +788,10 @@ static const MlpCfg* mlp_cfg(int C, int hw, long M, int mode) {
 extern "C" int32_t vsx_mlp_supported(int32_t C, int32_t hw, int64_t M, int32_t dtype) {
   return dtype == VSX_BF16 && mlp_cfg(C, hw, M, 0) != nullptr && mlp_cfg(C, hw, M, 1) != nullptr;
 }
-/* one pass: mode 0 statistics, 1 output, 2 training fc1, 3 backward statistics, 4 backward dh */
+/* one pass: mode 0 statistics, 1 output, 2 training fc1, 3 backward statistics, 4 backward dh, 5 backward dh with the
+ * pre-activation recomputed (vsx_mlp_bwd_dh_re), 6 training fc1 that stores g only (vsx_mlp_fc1 / _ln with h = NULL) */
 extern "C" int32_t vsx_mlp_mode_supported(int32_t C, int32_t hw, int64_t M, int32_t mode, int32_t dtype) {
-  return dtype == VSX_BF16 && mode >= 0 && mode <= 4 && mlp_cfg(C, hw, M, mode) != nullptr;
+  return dtype == VSX_BF16 && mode >= 0 && mode <= 6 && mlp_cfg(C, hw, M, mode) != nullptr;
 }
 
 extern "C" int64_t vsx_mlp_image_bytes(int32_t C) { return (int64_t)(4 * C / 32) * (2 * (C / 32) + C / 16) * 1024; }
@@ -720,19 +819,24 @@ static int mlp_dispatch(const MlpCfg* c, const MlpArgs& a, hipStream_t s) {
   if (c->C == 192) return mlp_launch<192, 2, 8, MODE>(a, s);
   if (c->C == 224) return mlp_launch<224, 2, 8, MODE>(a, s);
   if constexpr (MODE == 1) return mlp_launch<384, 2, 4, MODE>(a, s);
+  else if constexpr (MODE >= 5) { vsx_set_error("vsx_mlp: mode %d is built for C <= 224", MODE); return 1; }
   else return mlp_launch<384, 2, 8, MODE>(a, s);
 }
 
 /* mode 0: colsq[b, 4C] += sum over the sample's pixels of gelu(fc1(xh))^2 (bf16-rounded g, as the unfused fc1 epilogue);
  * mode 1: out = res + rscale[b] * (fc2(gelu(fc1(xh)) * s[b] + beta) + b2). */
-extern "C" int32_t vsx_mlp_gelu_table_len(void) { return MLP_GT_N; }
+extern "C" int32_t vsx_mlp_gelu_table_len(void) { return 2 * MLP_GT_N; }
 
-// tab[i] = a * Phi(-a) for the bf16 value a whose magnitude bits are MLP_GT_BASE + i (double precision, once per process)
+// For the bf16 value a whose magnitude bits are MLP_GT_BASE + i (double precision, once per process):
+//   tab[i]            = r(a) = a * Phi(-a)                  gelu(h)  = max(h, 0) - r(|h|)
+//   tab[MLP_GT_N + i] = d(a) = Phi(a) + a * phi(a) - 1/2    gelu'(h) = 1/2 + sign(h) * d(|h|)   (d >= 0; gelu'(-a) = 1 - gelu'(a))
 __global__ void mlp_gelu_table_kernel(float* __restrict__ tab) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= MLP_GT_N) return;
   const double a = (double)__uint_as_float((uint32_t)(MLP_GT_BASE + i) << 16);
   tab[i] = (float)(a * 0.5 * erfc(a * 0.70710678118654752440));
+  const double Phi = 0.5 * erfc(-a * 0.70710678118654752440), phi = exp(-0.5 * a * a) * 0.39894228040143267794;
+  tab[MLP_GT_N + i] = (float)(Phi + a * phi - 0.5);
 }
 
 extern "C" int32_t vsx_mlp_gelu_table(float* tab, vsx_stream_t stream) {
@@ -760,7 +864,7 @@ extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1
   a.xh = (const bf16_t*)xh; a.wimg = (const char*)wimg; a.b1 = b1; a.grn_s = grn_s; a.grn_b = grn_b; a.b2 = b2;
   a.res = (const bf16_t*)res; a.rscale = rscale; a.out = (bf16_t*)out; a.colsq = colsq; a.gtab = gtab; a.M = (int)M; a.hw = hw;
   a.hout = nullptr; a.gout = nullptr; a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.nt = 0;
-  a.ln_eps = g_mlp_ln_eps; a.xh_out = nullptr; a.rstd_out = nullptr;
+  a.ln_eps = g_mlp_ln_eps; a.xh_out = nullptr; a.rstd_out = nullptr; a.xh2 = nullptr; a.wimg2 = nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) {
     VSX_CHECK(colsq != nullptr, "vsx_mlp_fwd: mode 0 needs colsq");
@@ -771,12 +875,13 @@ extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1
 }
 
 /* training fc1 (MODE 2): h = bf16(xh . W1'^T + b1), g = bf16(gelu(h)) stored for the backward, colsq[b, 4C] += sum_hw g^2 —
- * the outputs of vsx_gemm_nt with VSX_EPI_BIAS_GELU_SQ, from the kernel that keeps its activation rows in registers */
+ * the outputs of vsx_gemm_nt with VSX_EPI_BIAS_GELU_SQ, from the kernel that keeps its activation rows in registers.
+ * h = NULL (MODE 6, where vsx_mlp_mode_supported(.., 6, ..)): only g is stored — the backward recomputes h (vsx_mlp_bwd_dh_re) */
 extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1, float* colsq, const float* gtab, void* h,
                                void* g, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream) {
   VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_fc1: bf16 only");
-  VSX_CHECK(xh && wimg && b1 && colsq && gtab && h && g && M > 0 && hw > 0, "vsx_mlp_fc1: bad arguments");
-  const MlpCfg* c = mlp_cfg(C, hw, M, 2);
+  VSX_CHECK(xh && wimg && b1 && colsq && gtab && g && M > 0 && hw > 0, "vsx_mlp_fc1: bad arguments");
+  const MlpCfg* c = mlp_cfg(C, hw, M, h ? 2 : 6);
   VSX_CHECK(c != nullptr, "vsx_mlp_fc1: unsupported shape C=%d hw=%d M=%ld (query vsx_mlp_supported first)", C, hw, (long)M);
   VSX_CHECK(M < (1ll << 31), "vsx_mlp_fc1: M too large");
   MlpArgs a;
@@ -784,8 +889,8 @@ extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1
   a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = colsq; a.gtab = gtab; a.hout = (bf16_t*)h; a.gout = (bf16_t*)g;
   a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.nt = mlp_nt();
   a.M = (int)M; a.hw = hw;
-  a.ln_eps = g_mlp_ln_eps; a.xh_out = g_mlp_xh_out; a.rstd_out = g_mlp_rstd_out;
-  return mlp_dispatch<2>(c, a, (hipStream_t)stream);
+  a.ln_eps = g_mlp_ln_eps; a.xh_out = g_mlp_xh_out; a.rstd_out = g_mlp_rstd_out; a.xh2 = nullptr; a.wimg2 = nullptr;
+  return h ? mlp_dispatch<2>(c, a, (hipStream_t)stream) : mlp_dispatch<6>(c, a, (hipStream_t)stream);
 }
 
 /* The same passes with the block LayerNorm (eps, no affine: folded into W1' / b1) applied in the kernel's prologue: `y` holds
@@ -815,11 +920,11 @@ extern "C" int32_t vsx_mlp_fc1_ln(const void* y, float eps, void* xh_out, float*
 // ------------------------------------------------------------------------------------------------ backward passes
 __global__ void reduce_rows_kernel(const float* __restrict__ ws, float* __restrict__ out, int R, int N);  // norm.hip
 
-static void mlp_bwd_args(MlpArgs& a, const void* dout, const void* wimg, const void* tin, int64_t M, int32_t hw) {
+static void mlp_bwd_args(MlpArgs& a, const void* dout, const void* wimg, const void* tin, int64_t M, int32_t hw, const float* gtab = nullptr) {
   a.xh = (const bf16_t*)dout; a.wimg = (const char*)wimg; a.b1 = nullptr; a.grn_s = nullptr; a.grn_b = nullptr; a.b2 = nullptr;
-  a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = nullptr; a.gtab = nullptr; a.hout = nullptr; a.gout = nullptr;
+  a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = nullptr; a.gtab = gtab; a.hout = nullptr; a.gout = nullptr;
   a.tin = (const bf16_t*)tin; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.M = (int)M; a.hw = hw; a.nt = mlp_nt();
-  a.ln_eps = 0.f; a.xh_out = nullptr; a.rstd_out = nullptr;
+  a.ln_eps = 0.f; a.xh_out = nullptr; a.rstd_out = nullptr; a.xh2 = nullptr; a.wimg2 = nullptr;
 }
 
 /* MODE 3: the GRN statistics path of the block backward without a stored dz: dz = dout . W2 recomputed tile by tile
@@ -841,18 +946,42 @@ extern "C" int32_t vsx_mlp_bwd_stats(const void* dout, const void* wimg, const v
  * of dh through ws ([M / rows-per-workgroup, 4C] floats, caller-owned) — vsx_gemm_nt(VSX_EPI_DZ) + vsx_grn_gelu_bwd in one
  * pass that writes the 4C-wide tensor once */
 extern "C" int32_t vsx_mlp_bwd_dh(const void* dout, const void* wimg, const void* h, const float* s, const float* t, void* dh,
-                                  float* ws, int64_t ws_rows, float* colsum, int64_t M, int32_t C, int32_t hw, int32_t dtype,
-                                  vsx_stream_t stream) {
+                                  float* ws, int64_t ws_rows, float* colsum, const float* gtab, int64_t M, int32_t C, int32_t hw,
+                                  int32_t dtype, vsx_stream_t stream) {
   VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_bwd_dh: bf16 only");
-  VSX_CHECK(dout && wimg && h && s && t && dh && ws && colsum && M > 0 && hw > 0, "vsx_mlp_bwd_dh: bad arguments");
+  VSX_CHECK(dout && wimg && h && s && t && dh && ws && colsum && gtab && M > 0 && hw > 0, "vsx_mlp_bwd_dh: bad arguments");
   const MlpCfg* c = mlp_cfg(C, hw, M, 4);
   VSX_CHECK(c != nullptr && M < (1ll << 31), "vsx_mlp_bwd_dh: unsupported shape C=%d hw=%d M=%ld", C, hw, (long)M);
   const int bm = c->NW * 16 * c->MF;
   VSX_CHECK(ws_rows >= M / bm, "vsx_mlp_bwd_dh: workspace needs %ld rows of %d floats", (long)(M / bm), 4 * C);
   MlpArgs a;
-  mlp_bwd_args(a, dout, wimg, h, M, hw);
+  mlp_bwd_args(a, dout, wimg, h, M, hw, gtab);
   a.grn_s = s; a.grn_b = t; a.hout = (bf16_t*)dh; a.ws = ws;
   if (int e = mlp_dispatch<4>(c, a, (hipStream_t)stream)) return e;
+  const int R = (int)(M / bm), N = 4 * C;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv(N, 64), vsx_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)ws, colsum, R, N);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+/* MODE 5: vsx_mlp_bwd_dh WITHOUT a stored pre-activation: h = bf16(xh . W1'^T + b1) is recomputed on chip from the normalised
+ * rows xh [M, C] (wimg_fwd = the forward image vsx_mlp_pack(W1', W2), b1 = the folded fc1 bias — the operands of vsx_mlp_fc1, so
+ * the recomputed h is bit-identical to the one MODE 2 would have stored); everything else as vsx_mlp_bwd_dh.  Block math:
+ * viscy_models/unet/fcmae.py:174-221 (backward of GRN-MLP as timm's GlobalResponseNormMlp computes it). */
+extern "C" int32_t vsx_mlp_bwd_dh_re(const void* dout, const void* xh, const void* wimg_bwd, const void* wimg_fwd, const float* b1,
+                                     const float* s, const float* t, void* dh, float* ws, int64_t ws_rows, float* colsum,
+                                     const float* gtab, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_bwd_dh_re: bf16 only");
+  VSX_CHECK(dout && xh && wimg_bwd && wimg_fwd && b1 && s && t && dh && ws && colsum && gtab && M > 0 && hw > 0, "vsx_mlp_bwd_dh_re: bad arguments");
+  const MlpCfg* c = mlp_cfg(C, hw, M, 5);
+  VSX_CHECK(c != nullptr && M < (1ll << 31), "vsx_mlp_bwd_dh_re: unsupported shape C=%d hw=%d M=%ld", C, hw, (long)M);
+  const int bm = c->NW * 16 * c->MF;
+  VSX_CHECK(ws_rows >= M / bm, "vsx_mlp_bwd_dh_re: workspace needs %ld rows of %d floats", (long)(M / bm), 4 * C);
+  MlpArgs a;
+  mlp_bwd_args(a, dout, wimg_bwd, nullptr, M, hw, gtab);
+  a.grn_s = s; a.grn_b = t; a.hout = (bf16_t*)dh; a.ws = ws; a.xh2 = (const bf16_t*)xh; a.wimg2 = (const char*)wimg_fwd; a.b1 = b1;
+  if (int e = mlp_dispatch<5>(c, a, (hipStream_t)stream)) return e;
   const int R = (int)(M / bm), N = 4 * C;
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv(N, 64), vsx_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)ws, colsum, R, N);

@@ -355,6 +355,11 @@ class Engine:
             return 1
         return 2 if self.ops.mlp_supported(C, hw, M, dt, 3) else 0
 
+    def _mlp_recompute_h(self, C, hw, M, dt, B) -> bool:
+        """``mlp_fused`` bit 6: the training fc1 stores g only and the dh pass recomputes h (needs the fused backward)"""
+        return bool(self._mlp_flag() & 64) and self._mlp_bwd_fused(C, hw, M, dt, B) != 0 and self.ops.mlp_supported(C, hw, M, dt, 5) \
+            and self.ops.mlp_supported(C, hw, M, dt, 6)
+
     def _block_fwd(self, x, w, B, H, Wd, dt, save, rows=None):
         """One ConvNeXt-V2 block on a dense channels-last map [B*H*W, C].  ``rows = (idx, inv, keep, L)`` selects the FCMAE
         masked path (fcmae.py:196-230): ``x`` arrives already multiplied by the mask, the depthwise convolution runs dense,
@@ -413,10 +418,13 @@ class Engine:
             if w.img is None:
                 w.img = o.mlp_pack(w.W1f, w.W2, C)
                 o.flush()
+            # mlp_fused bit 6: the pre-activation h is NOT stored — the backward's dh pass recomputes it from the C-wide
+            # normalised rows (csrc/mlp.hip MODE 6 here, MODE 5 there): one 4C-wide write and one 4C-wide read less per block
+            keep_h = not self._mlp_recompute_h(C, hw, M, dt, B)
             if ln_in:
-                xh, rstd, h, gact = o.mlp_fc1_ln(xh, w.img, w.b1f, colsq, M, C, hw, 1e-6)
+                xh, rstd, h, gact = o.mlp_fc1_ln(xh, w.img, w.b1f, colsq, M, C, hw, 1e-6, store_h=keep_h)
             else:
-                h, gact = o.mlp_fc1(xh, w.img, w.b1f, colsq, M, C, hw)
+                h, gact = o.mlp_fc1(xh, w.img, w.b1f, colsq, M, C, hw, store_h=keep_h)
         else:
             h = torch.empty((M, 4 * C), dtype=dt, device=x.device) if save is not None else None
             gact = torch.empty((M, 4 * C), dtype=dt, device=x.device)
@@ -466,6 +474,9 @@ class Engine:
             dW2, db2 = g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias)
             dgw, dgb = g(blk.mlp.grn.weight), g(blk.mlp.grn.bias)
         fused_bwd = self._mlp_bwd_fused(C, hw, M, dt, B)
+        if h is None and not fused_bwd:
+            raise RuntimeError("this block's forward did not store the pre-activation h (mlp_fused bit 6) and the fused backward "
+                               "that recomputes it is switched off now: do not change `mlp_fused` between a forward and its backward")
         PS = self._za.take(2, B, 4 * C)
         if fused_bwd == 1:
             # dz = dout·W2 is LINEAR in dout, so everything the backward needs from "Σ over the sample of dz·(something)" comes
@@ -500,7 +511,10 @@ class Engine:
             if fused_bwd == 2:  # statistics by recomputing dz tile by tile (P = Σ dz·g, S = Σ dz), nothing stored
                 o.mlp_bwd_stats(dout, img2, gact, PS[0], PS[1], M, C, hw)
             t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw, Sb=PS[1], dbeta=dgb)
-            dz = o.mlp_bwd_dh(dout, img2, h, s, t, db1f, M, C, hw)  # (named dz below: it holds dH)
+            if h is None:  # h recomputed on chip from the normalised rows (MODE 5)
+                dz = o.mlp_bwd_dh_re(dout, xh, img2, w.img, w.b1f, s, t, db1f, M, C, hw)
+            else:
+                dz = o.mlp_bwd_dh(dout, img2, h, s, t, db1f, M, C, hw)  # (named dz below: it holds dH)
         else:
             # fc2 data gradient dZ, with Σ dZ·gelu(h) (GRN statistics path) and Σ dZ (GRN beta gradient)
             dz = torch.empty((M, 4 * C), dtype=dt, device=dev)

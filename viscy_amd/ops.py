@@ -470,21 +470,22 @@ def mlp_stats(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int
                             M, C, hw, 0, dtype_code(xh.dtype), stream()), "mlp_stats")
 
 
-def mlp_fc1(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int):
-    """training fc1 on the fused kernel: returns (h, g) [M, 4C] and accumulates the GRN statistics into colsq"""
-    h = torch.empty((M, 4 * C), dtype=xh.dtype, device=xh.device)
+def mlp_fc1(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int, store_h: bool = True):
+    """training fc1 on the fused kernel: returns (h, g) [M, 4C] and accumulates the GRN statistics into colsq.  ``store_h=False``
+    (where ``mlp_supported(.., 6)``): h is None — the backward recomputes it (mlp_bwd_dh_re)"""
+    h = torch.empty((M, 4 * C), dtype=xh.dtype, device=xh.device) if store_h else None
     g = torch.empty((M, 4 * C), dtype=xh.dtype, device=xh.device)
     check(lib().vsx_mlp_fc1(ptr(xh), ptr(img), ptr(b1), ptr(colsq), ptr(_gelu_table(xh.device)), ptr(h), ptr(g), M, C, hw,
                             dtype_code(xh.dtype), stream()), "mlp_fc1")
     return h, g
 
 
-def mlp_fc1_ln(y: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int, eps: float = 1e-6):
+def mlp_fc1_ln(y: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int, eps: float = 1e-6, store_h: bool = True):
     """the block LayerNorm (no affine) + training fc1 in one pass over the depthwise convolution's output ``y``: returns
-    (xh, rstd, h, g) — what ln_fwd + mlp_fc1 return, without the LayerNorm pass"""
+    (xh, rstd, h, g) — what ln_fwd + mlp_fc1 return, without the LayerNorm pass (``store_h=False``: h is None, see mlp_fc1)"""
     xh = torch.empty_like(y)
     rstd = torch.empty(M, dtype=torch.float32, device=y.device)
-    h = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device)
+    h = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device) if store_h else None
     g = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device)
     check(lib().vsx_mlp_fc1_ln(ptr(y), eps, ptr(xh), ptr(rstd), ptr(img), ptr(b1), ptr(colsq), ptr(_gelu_table(y.device)), ptr(h),
                                ptr(g), M, C, hw, dtype_code(y.dtype), stream()), "mlp_fc1_ln")
@@ -512,8 +513,20 @@ def mlp_bwd_dh(dout: Tensor, img2: Tensor, h: Tensor, s: Tensor, t: Tensor, cols
     dh = torch.empty((M, 4 * C), dtype=dout.dtype, device=dout.device)
     rows = M // int(lib().vsx_mlp_rows_per_workgroup(C, hw, M))
     ws = _workspace(dout.device, rows * 4 * C)
-    check(lib().vsx_mlp_bwd_dh(ptr(dout), ptr(img2), ptr(h), ptr(s), ptr(t), ptr(dh), ptr(ws), rows, ptr(colsum), M, C, hw,
-                               dtype_code(dout.dtype), stream()), "mlp_bwd_dh")
+    check(lib().vsx_mlp_bwd_dh(ptr(dout), ptr(img2), ptr(h), ptr(s), ptr(t), ptr(dh), ptr(ws), rows, ptr(colsum),
+                               ptr(_gelu_table(dout.device)), M, C, hw, dtype_code(dout.dtype), stream()), "mlp_bwd_dh")
+    return dh
+
+
+def mlp_bwd_dh_re(dout: Tensor, xh: Tensor, img2: Tensor, img: Tensor, b1: Tensor, s: Tensor, t: Tensor, colsum: Tensor, M: int, C: int,
+                  hw: int) -> Tensor:
+    """mlp_bwd_dh without a stored pre-activation: h = xh . W1'^T + b1 is recomputed on chip from the normalised rows (img = the
+    forward image mlp_pack(W1f, W2), b1 = the folded fc1 bias: bit-identical to what mlp_fc1 would have stored)"""
+    dh = torch.empty((M, 4 * C), dtype=dout.dtype, device=dout.device)
+    rows = M // int(lib().vsx_mlp_rows_per_workgroup(C, hw, M))
+    ws = _workspace(dout.device, rows * 4 * C)
+    check(lib().vsx_mlp_bwd_dh_re(ptr(dout), ptr(xh), ptr(img2), ptr(img), ptr(b1), ptr(s), ptr(t), ptr(dh), ptr(ws), rows, ptr(colsum),
+                                  ptr(_gelu_table(dout.device)), M, C, hw, dtype_code(dout.dtype), stream()), "mlp_bwd_dh_re")
     return dh
 
 
