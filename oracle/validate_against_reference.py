@@ -536,6 +536,48 @@ def g8b_baseline_size():
     print(f"G8b baseline size: reference tiny B=4 256x256 fp32 forward / loss {l32:.6f} / gradient samples written ({time.time() - t0:.0f} s)")
 
 
+def g8c_gate_size():
+    """tests/golden/unext2_tiny_2048.pt — the north star's gate shape pinned on the REFERENCE: the reference's
+    own wiring (g8_wiring must have run), tiny, B = 1, Z = 5, 2048 x 2048, fp32 forward on the CPU: a strided sample of the
+    output and the per-sample GRN statistics ||h||_2 over (H, W) of one encoder block (stage 0, block 1: 512 x 512 x 384) and
+    one decoder block (last stage, block 0: 512 x 512 x 896) — the statistics every tile of a 2048 x 2048 forward contributes
+    to.  tests/test_gpu_model.py holds the fp32 engine to 1e-3 and the bf16 engine to 1.25 x the autocast yardstick on them."""
+    import time
+
+    R = unext2_ref
+    ref = sys.modules["viscy_models.unet.unext2"]
+    kw = dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True, head_expansion_ratio=4,
+              decoder_conv_blocks=2)
+    r = ref.UNeXt2(**kw)
+    o = R.UNeXt2(**kw)
+    R.randomize_(o, seed=17)
+    r.load_state_dict(o.state_dict(), strict=True)
+    r.eval()
+    g = torch.Generator().manual_seed(4096)
+    S = 2048
+    x = torch.randn((1, 1, 5, S, S), generator=g)
+    grn = {}
+
+    def hook(tag):
+        def fn(mod, inp, out):
+            grn[tag] = inp[0].norm(p=2, dim=mod.spatial_dim).reshape(1, -1).clone()  # timm GlobalResponseNorm: x_g
+        return fn
+
+    enc_grn = r.encoder_stages.stages_0.blocks[1].mlp.grn
+    dec_grn = r.decoder.decoder_stages[2].conv.blocks[0].mlp.grn
+    h1, h2 = enc_grn.register_forward_hook(hook("enc_s0_b1")), dec_grn.register_forward_hook(hook("dec_s2_b0"))
+    t0 = time.time()
+    with torch.no_grad():
+        y = r(x)
+    h1.remove(), h2.remove()
+    st = 16
+    gold = {"kwargs": kw, "seed": 17, "x_seed": 4096, "shape": (1, S), "y_stride": st, "y": y[..., ::st, ::st].clone(),
+            "y_absmax": y.abs().max().item(), "grn": grn, "grn_paths": {"enc_s0_b1": ("enc", 0, 1), "dec_s2_b0": ("dec", 2, 0)}}
+    assert grn["enc_s0_b1"].shape == (1, 384) and grn["dec_s2_b0"].shape == (1, 896)
+    torch.save(gold, os.path.join(GOLD, "unext2_tiny_2048.pt"))
+    print(f"G8c gate shape: reference tiny B=1 2048x2048 fp32 forward sample + GRN statistics written ({time.time() - t0:.0f} s)")
+
+
 def g9_fcmae():
     """Run the reference's own fcmae.py (dense path) on stubbed timm / monai modules == oracle/fcmae_ref.py."""
     from oracle import fcmae_ref as F
@@ -924,6 +966,7 @@ if __name__ == "__main__":
     g5_unet2d()
     g8_wiring()
     g8b_baseline_size()
+    g8c_gate_size()
     g9_fcmae()
     g10_contrastive()
     g11_hcs_sampling()
