@@ -63,8 +63,8 @@ def build_info() -> dict:
     return info
 
 
-FLAG_NAMES = ["tn_tr", "nt_wide", "nt_fast", "tn_wide", "nt_tall", "nt2", "nt_stream", "grn_stream", "ggb_contig", "tn_want", "tn_contig",
-              "ln_stream", "ggb_blocks", "tn_rect", "dw_rows2", "dw_wg16", "dw_mfma", "ln_fblk", "ln_bblk", "mlp_fused", "loss_fused"]
+FLAG_NAMES = ["tn_tr", "nt_wide", "nt_fast", "tn_wide", "nt2", "nt_stream", "grn_stream", "ggb_contig", "tn_want", "tn_contig",
+              "ln_stream", "ggb_blocks", "tn_rect", "dw_mfma", "ln_fblk", "ln_bblk", "mlp_fused", "loss_fused"]
 
 
 def make_batch(B, H, W, device, seed=42):

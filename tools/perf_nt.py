@@ -11,7 +11,6 @@ from viscy_amd import ops  # noqa: E402
 dt, dev = torch.bfloat16, "cuda"
 from viscy_amd._lib import lib  # noqa: E402
 lib().vsx_set_flag(b"nt_wide", int(os.environ.get("NTW", 1)))
-lib().vsx_set_flag(b"nt_tall", int(os.environ.get("NTT", 1)))
 lib().vsx_set_flag(b"tn_rect", int(os.environ.get("TNR", 1)))
 B = int(os.environ.get("B", 128))
 

@@ -171,7 +171,7 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = l
-        # VSX_FLAGS="nt_tall=1,tn_rect=0": tuning knobs of vsx_set_flag for A/B runs of unmodified programs (bench.py, tests)
+        # VSX_FLAGS="nt2=0,tn_rect=0": tuning knobs of vsx_set_flag for A/B runs of unmodified programs (bench.py, tests)
         for kv in filter(None, os.environ.get("VSX_FLAGS", "").split(",")):
             name, _, val = kv.partition("=")
             if l.vsx_set_flag(name.strip().encode(), int(val)) != 0:

@@ -111,130 +111,6 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const T* __restrict__ x, c
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// two output rows per thread (bf16 production shapes).  The one-row kernel above is co-limited by VALU — half of it
-// bf16 -> fp32 unpacking — and by LDS reads (per 7-tap row: 10 input vectors + 14 weight vectors for 4 outputs).  A thread
-// that owns the SAME strip of two ADJACENT output rows walks the 8 input rows they touch once: every input vector is read
-// and unpacked once and feeds both rows (tap row r for the upper, r - 1 for the lower output row), and the weight row
-// loaded for the upper row is kept in registers for the lower row of the next step: 8 x (10 + 14) LDS reads and 8 x 10
-// unpacks for 8 outputs instead of 14 x 24 and 14 x 10.
-// MEASURED (tools/perf_ops.py dw, B = 512; VSX_FLAGS=dw_rows2=1): 3-8 % slower forward, 18 % slower data gradient than the
-// one-row kernel — 240 registers and a 73 KB tile leave 2 workgroups per CU instead of 3, which costs more than the saved
-// LDS reads and unpacks bring.  Kept behind the flag (default off) as the record of the experiment.
-// ---------------------------------------------------------------------------------------------------
-template <typename T, int NCV, int TH, int TW, int K, bool FLIP>
-__global__ __launch_bounds__(256, 2) void dwconv7_rows2_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                                const float* __restrict__ bias, const T* __restrict__ add,
-                                                                T* __restrict__ y, int B, int H, int W, int C) {
-  constexpr int VN = VT<T>::N;
-  constexpr int CB = NCV * VN;
-  constexpr int PITCH = CB * (int)sizeof(T) + 16;
-  constexpr int IH = TH + 6, IW = TW + 6;
-  constexpr int SPR = TW / K;
-  static_assert(NCV * (TH / 2) * SPR == 256, "thread mapping");
-  typedef typename VT<T>::vec vec;
-  __shared__ __attribute__((aligned(16))) char tile[IH * IW * PITCH];
-  __shared__ __attribute__((aligned(16))) float wl[49 * CB];
-
-  const int ncb = (C + CB - 1) / CB;
-  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-  int bid = blockIdx.x;
-  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);  // XCD-aware (see dwconv7_kernel)
-  const int cb = bid % ncb; bid /= ncb;
-  const int tx = bid % tiles_x; bid /= tiles_x;
-  const int ty = bid % tiles_y;
-  const int b = bid / tiles_y;
-  const int c_base = cb * CB;
-  const int y0 = ty * TH, x0 = tx * TW;
-
-  for (int i = threadIdx.x; i < 49 * CB; i += 256) {
-    const int t = i / CB, c = i - t * CB;
-    const int tap = FLIP ? 48 - t : t;
-    wl[i] = (c_base + c < C) ? w[(size_t)tap * C + c_base + c] : 0.f;
-  }
-  for (int i = threadIdx.x; i < IH * IW * NCV; i += 256) {
-    const int cv = i % NCV;
-    const int p = i / NCV;
-    const int ix = p % IW, iy = p / IW;
-    const int gy = y0 + iy - 3, gx = x0 + ix - 3;
-    vec v = vzero<T>();
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W && c_base + cv * VN < C)
-      v = ldvec<T>(x + (((size_t)b * H + gy) * W + gx) * C + c_base + cv * VN);
-    *reinterpret_cast<vec*>(tile + p * PITCH + cv * 16) = v;
-  }
-  __syncthreads();
-
-  const int cv = threadIdx.x % NCV;
-  const int pt = threadIdx.x / NCV;
-  const int sx = pt % SPR, sp = pt / SPR;  // strip sx of the row pair sp
-  const int sy = 2 * sp;
-  const int c0 = c_base + cv * VN;
-  float acc0[K][VN], acc1[K][VN];
-#pragma unroll
-  for (int o = 0; o < K; ++o)
-#pragma unroll
-    for (int j = 0; j < VN; ++j) acc0[o][j] = acc1[o][j] = (bias && c0 + j < C) ? bias[c0 + j] : 0.f;
-
-  float wcur[7][VN], wprev[7][VN];
-#pragma unroll
-  for (int kx = 0; kx < 7; ++kx)
-#pragma unroll
-    for (int j = 0; j < VN; ++j) wprev[kx][j] = 0.f;
-#pragma unroll 1
-  for (int r = 0; r < 8; ++r) {  // input row sy + r of the halo tile: tap row r of output row sy, r - 1 of row sy + 1
-    const int rw = r < 7 ? r : 6;
-    const float m0 = r < 7 ? 1.f : 0.f;  // uniform: input row 7 belongs to the lower output row only -> zero upper taps
-#pragma unroll
-    for (int kx = 0; kx < 7; ++kx)
-#pragma unroll
-      for (int j = 0; j < VN; j += 4) {
-        float4 t = *reinterpret_cast<const float4*>(wl + (rw * 7 + kx) * CB + cv * VN + j);
-        wcur[kx][j] = t.x * m0; wcur[kx][j + 1] = t.y * m0; wcur[kx][j + 2] = t.z * m0; wcur[kx][j + 3] = t.w * m0;
-      }
-    const char* rowp = tile + ((sy + r) * IW + sx * K) * PITCH + cv * 16;
-#pragma unroll
-    for (int i = 0; i < K + 6; ++i) {
-      float v[VN];
-      unpack<T>(*reinterpret_cast<const vec*>(rowp + i * PITCH), v);
-#pragma unroll
-      for (int kx = 0; kx < 7; ++kx) {
-        const int o = i - kx;
-        if (o >= 0 && o < K) {
-#pragma unroll
-          for (int j = 0; j < VN; ++j) {
-            acc0[o][j] = fmaf(v[j], wcur[kx][j], acc0[o][j]);
-            acc1[o][j] = fmaf(v[j], wprev[kx][j], acc1[o][j]);  // wprev = 0 at r = 0
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int kx = 0; kx < 7; ++kx)
-#pragma unroll
-      for (int j = 0; j < VN; ++j) wprev[kx][j] = wcur[kx][j];
-  }
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int gy = y0 + sy + rr;
-    if (gy < H && c0 < C) {
-#pragma unroll
-      for (int o = 0; o < K; ++o) {
-        const int gx = x0 + sx * K + o;
-        if (gx < W) {
-          const size_t off = (((size_t)b * H + gy) * W + gx) * C + c0;
-          float* a_ = rr ? acc1[o] : acc0[o];
-          if (add) {
-            float a[VN];
-            unpack<T>(ldvec<T>(add + off), a);
-#pragma unroll
-            for (int j = 0; j < VN; ++j) a_[j] += a[j];
-          }
-          stvec<T>(y + off, pack<T>(a_));
-        }
-      }
-    }
-  }
-}
 
 // weight gradient: dw[ky*7+kx][c] += sum_{b,y,x} dy[b,y,x,c] * x[b,y+ky-3,x+kx-3,c];  db[c] += sum dy
 // LDS-tiled like the forward: a block stages the (TH+6)x(TW+6) input halo tile and the TH x TW dy tile of
@@ -425,8 +301,6 @@ static int dw_launch_cfg(const void* x, const float* w, const float* bias, const
 template <typename T>
 static int dw_launch(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W,
                      int C, bool flip, hipStream_t s);
-extern int g_vsx_dw_rows2;
-extern int g_vsx_dw_wg16;
 int vsx_dwconv7_mfma_try(const void* x, const float* w, const float* bias, const void* add, void* y, int B, int H, int W, int C,
                          bool flip, hipStream_t s, int* taken);  // dwconv_mfma.hip
 int vsx_dwconv7_wgrad_mfma_try(const void* dy, const void* x, float* ws, int ws_rows, int B, int H, int W, int C,
@@ -437,21 +311,9 @@ int dw_launch<bf16_t>(const void* x, const float* w, const float* bias, const vo
   int taken = 0;  // matrix-core Toeplitz path (flag dw_mfma, images >= 16 x 16): memory-bound instead of VALU-bound
   if (int rc = vsx_dwconv7_mfma_try(x, w, bias, add, y, B, H, W, C, flip, s, &taken)) return rc;
   if (taken) return 0;
-  if (g_vsx_dw_rows2 && W >= 24 && H >= 16) {  // 32 ch x 16x32 px, two output rows per thread
-    constexpr int CB = 4 * VT<bf16_t>::N;
-    long blocks = (long)B * vsx_cdiv(H, 16) * vsx_cdiv(W, 32) * vsx_cdiv(C, CB);
-    dim3 grid((unsigned)blocks);
-    if (flip)
-      hipLaunchKernelGGL((dwconv7_rows2_kernel<bf16_t, 4, 16, 32, 4, true>), grid, dim3(256), 0, s, (const bf16_t*)x, w, bias,
-                         (const bf16_t*)add, (bf16_t*)y, B, H, W, C);
-    else
-      hipLaunchKernelGGL((dwconv7_rows2_kernel<bf16_t, 4, 16, 32, 4, false>), grid, dim3(256), 0, s, (const bf16_t*)x, w, bias,
-                         (const bf16_t*)add, (bf16_t*)y, B, H, W, C);
-    VSX_LAUNCH_CHECK();
-    return 0;
-  }
   // measured alternatives (B = 512, tools/perf_ops.py dw): 8x16 px x 2 outputs / thread (occupancy 4) is 5-9 % slower,
-  // 16x16 px x 4 outputs / thread within 2 % -> the kernel is VALU-bound (49 FMAs + bf16 unpacks per output), not LDS-bound
+  // 16x16 px x 4 outputs / thread within 2 %, two output rows per thread 3-18 % slower (240 registers, 2 workgroups per CU
+  // instead of 3; removed in round 4) -> the kernel is VALU-bound (49 FMAs + bf16 unpacks per output), not LDS-bound
   if (W >= 24) return dw_launch_cfg<bf16_t, 4, 8, 32, 4>(x, w, bias, add, y, B, H, W, C, flip, s);   // 32 ch x 8x32 px
   return dw_launch_cfg<bf16_t, 8, 8, 8, 2>(x, w, bias, add, y, B, H, W, C, flip, s);                 // 64 ch x 8x8 px
 }
@@ -515,8 +377,8 @@ extern "C" int32_t vsx_dwconv7_bwd_weight(const void* dy, const void* x, float* 
       VSX_LAUNCH_CHECK();
       return 0;
     }
-    if (W >= 24 && g_vsx_dw_wg16) return dw_wgrad_cfg<bf16_t, 4, 8, 16>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
-    if (W >= 24) return dw_wgrad_cfg<bf16_t, 4, 8, 32>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
+    // 8 x 16-pixel tiles: 35 KB of LDS, 4 workgroups per CU (8 x 32: 63 KB, 2 workgroups, 13-22 % slower; removed in round 4)
+    if (W >= 24) return dw_wgrad_cfg<bf16_t, 4, 8, 16>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
     return dw_wgrad_cfg<bf16_t, 4, 8, 8>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);
   }
   if (W >= 24) return dw_wgrad_cfg<float, 4, 8, 32>(dy, x, dw, db, ws, ws_rows, B, H, W, C, st);

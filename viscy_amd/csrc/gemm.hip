@@ -22,7 +22,6 @@ extern int g_vsx_tn_rect;
 extern int g_vsx_nt_wide;
 extern int g_vsx_nt_fast;
 extern int g_vsx_tn_wide;
-extern int g_vsx_nt_tall;
 extern int g_vsx_nt_stream;
 extern int g_vsx_tn_want;
 extern int g_vsx_tn_contig;
@@ -475,9 +474,8 @@ __device__ __forceinline__ typename VT<T>::vec grn_apply(typename VT<T>::vec v, 
 // ------------------------------------------------------------------------------------------------
 template <typename T, int EPI, bool PRO, int BK = 32, int NBUF = 2, int BM = 128>
 __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 : 1)) void gemm_nt_fast_kernel(const VsxGemm p) {
-  // BM = 256: each wave owns a 128x64 sub-tile (8x4 fragments, 128 accumulator registers): 12 fragment reads per 32
-  // MFMAs instead of 8 per 16, half the weight (B) traffic and half the per-tile fixed cost (launch, first-slab
-  // latency, store drain) per output — used for the M >= 65536 launches
+  // (BM = 256 — 128x64 wave tiles — measured -5..-9 % on isolated wide-output launches and nothing on the whole step; its
+  // dispatch (`nt_tall`) was removed in round 4: the launches it served run on the 256 x BN kernel of gemm_nt2.hip)
   constexpr int BN = 128, WN_ = 2, FM = BM / 32, FN = 4;
   constexpr int ES = sizeof(T);
   constexpr int RS = BK * ES + (ES == 2 ? 32 : 16);
@@ -780,18 +778,6 @@ static int launch_nt_fast(const VsxGemm* pin, hipStream_t s) {
   int tiles = vsx_cdiv(p->M, 128) * vsx_cdiv(p->N, 128);
   dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
   if constexpr (sizeof(T) == 2) {
-    // measured (tools/perf_nt.py): -5..-9 % on the wide-output launches (N >= 384: fc1, fc2 data gradient), +5..+10 % on
-    // the GRN-prologue / two-N-tile launches -> only the former
-    const bool tall = g_vsx_nt_tall && !PRO && p->N >= 384 && p->M >= 65536 && p->M % 256 == 0 && (p->hw <= 0 || p->hw % 256 == 0);
-    if (tall) {
-      dim3 g2(vsx_cdiv(p->M, 256) * vsx_cdiv(p->N, 128), 1, p->nz > 0 ? p->nz : 1);
-      if (p->K % 64 == 0 && p->K >= 128)
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 64, 1, 256>), g2, dim3(256), 0, s, *p);
-      else
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 32, 2, 256>), g2, dim3(256), 0, s, *p);
-      VSX_LAUNCH_CHECK();
-      return 0;
-    }
     if (g_vsx_nt_wide == 1 && p->K % 64 == 0 && p->K >= 256) {
       hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 64, 1>), grid, dim3(256), 0, s, *p);
       VSX_LAUNCH_CHECK();

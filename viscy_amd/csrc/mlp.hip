@@ -762,22 +762,20 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const bf16_t* __restrict_
 // ------------------------------------------------------------------------------------------------ dispatch
 struct MlpCfg { int C, MF, NW, modes; };  // modes: bit m set = this geometry serves MODE m
 // rows per workgroup must divide the pixels of a sample; the large maps take 256-row workgroups (8 waves x 32 rows: weight
-// traffic L2 -> LDS per flop is 1 / rows).  C = 384 lives on 16 x 16 maps (256 rows = one sample): the passes without fc2
-// accumulators (MODE 0, 2, 3, 4) fit 8 waves at <= 256 registers, the output pass (MODE 1, 192 accumulator registers) only
-// 4 waves x 32 rows (one wave per SIMD: measured 875 us against 614 us for the unfused pair at B = 512).  The C = 384
-// training passes (MODE 2 / 3 / 4) sit behind bit 2 of the mlp_fused flag — on since round 3: the step time is unchanged
-// (fc1 -12 %, backward -4 %), the block's backward no longer writes dz and reads it back (-0.7 GB per block and step at
-// B = 512) — the inference pair behind bit 4 (slower than the unfused GEMMs: off).
+// traffic L2 -> LDS per flop is 1 / rows).  C = 384 lives on 16 x 16 maps (256 rows = one sample): its TRAINING passes (MODE 2 / 3 /
+// 4, no fc2 accumulators) fit 8 waves at <= 256 registers and sit behind bit 2 of the mlp_fused flag (fc1 -12 %, backward -4 %,
+// -0.7 GB per block and step at B = 512).  The C = 384 inference pair (the output pass needs 192 accumulator registers: 4 waves x
+// 32 rows at one wave per SIMD, 875 us against 614 us for the unfused GEMMs at B = 512) was removed in round 4 (flag bit 4).
 extern int g_vsx_mlp_fused;
 extern int g_vsx_nt_stream;
 static inline int mlp_nt() { return (g_vsx_nt_stream >> 2) & 3; }  // bits 2 / 3 of nt_stream: the fused passes' stores / last-reader loads
-static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 127}, {192, 2, 8, 127}, {224, 2, 8, 127}, {384, 2, 8, 1 | 4 | 8 | 16}, {384, 2, 4, 2}};
+static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 127}, {192, 2, 8, 127}, {224, 2, 8, 127}, {384, 2, 8, 4 | 8 | 16}};
 
 static const MlpCfg* mlp_cfg(int C, int hw, long M, int mode) {
   for (const MlpCfg& c : kMlpCfgs) {
     const int bm = c.NW * 16 * c.MF;
     if (!(c.modes & (1 << mode))) continue;
-    if (c.C == 384 && !(g_vsx_mlp_fused & (mode <= 1 ? 16 : 4))) continue;  // bit 2: training passes, bit 4: inference pair
+    if (c.C == 384 && !(g_vsx_mlp_fused & 4)) continue;  // bit 2: the training passes (MODE 2 / 3 / 4) on the C = 384 blocks
     if ((mode == 5 || mode == 6) && !(g_vsx_mlp_fused & 64)) continue;          // bit 6: the pre-activation h is recomputed, not stored
     if (c.C == C && hw % bm == 0 && M % bm == 0) return &c;
   }
@@ -818,8 +816,7 @@ static int mlp_dispatch(const MlpCfg* c, const MlpArgs& a, hipStream_t s) {
   if (c->C == 96) return mlp_launch<96, 2, 8, MODE>(a, s);
   if (c->C == 192) return mlp_launch<192, 2, 8, MODE>(a, s);
   if (c->C == 224) return mlp_launch<224, 2, 8, MODE>(a, s);
-  if constexpr (MODE == 1) return mlp_launch<384, 2, 4, MODE>(a, s);
-  else if constexpr (MODE >= 5) { vsx_set_error("vsx_mlp: mode %d is built for C <= 224", MODE); return 1; }
+  if constexpr (MODE <= 1 || MODE >= 5) { vsx_set_error("vsx_mlp: mode %d is built for C <= 224", MODE); return 1; }
   else return mlp_launch<384, 2, 8, MODE>(a, s);
 }
 
