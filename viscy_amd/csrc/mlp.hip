@@ -111,7 +111,11 @@ struct MlpGeom {
                                                                        // wave-private g tile of ONE sub-chunk, for the statistics)
   static constexpr int OB_RS = OB_COLS * 2 + 16;                       // staging row stride (bytes)
   static constexpr int OUT_BYTES = MODE == 2 ? NW * 2 * WM * OB_RS : NW * WM * OB_RS;  // MODE 6: g only
-  static constexpr int VEC_FLOATS = MODE == 1 ? 3 * H4 + C : (MODE == 4 ? 2 * H4 : (MODE == 5 ? 3 * H4 : (MODE == 3 ? 4 : H4)));
+  // MODE 6: the bias vector b1 lives in the 16 pad bytes behind every row of the staging tile (256 rows x 4 floats >= 4C for
+  // C <= 256) instead of an array of its own: at C = 224 that is exactly what two workgroups per CU need (2 x 81 920 B = 160 KiB;
+  // measured 1803 -> ~1600 us for that pass at B = 512, tools/perf_mlp_train.py)
+  static constexpr bool B1_IN_PADS = MODE == 6;
+  static constexpr int VEC_FLOATS = MODE == 1 ? 3 * H4 + C : (MODE == 4 ? 2 * H4 : (MODE == 5 ? 3 * H4 : (MODE == 3 || B1_IN_PADS ? 4 : H4)));
   static constexpr int RED_FLOATS = MODE == 1 ? 4 : (MODE == 3 ? 4 * NW * 32 : 2 * NW * 32);
   static constexpr int GT_FLOATS = (MODE <= 2 || MODE == 6) ? MLP_GT_N : ((MODE == 4 || MODE == 5) ? 2 * MLP_GT_N : 4);
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES + OUT_BYTES + (VEC_FLOATS + RED_FLOATS) * 4;
@@ -152,7 +156,10 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
     }
   }
   // ---- per-channel vectors -> LDS (once)
-  if constexpr (!BWD) {
+  if constexpr (G::B1_IN_PADS) {
+    static_assert(!G::B1_IN_PADS || (NW * WM * 4 >= H4 && G::OB_RS == 144), "b1 rides in the pad bytes of the staging rows");
+    for (int i = tid; i < H4; i += NW * 64) *reinterpret_cast<float*>(obuf + (i >> 2) * G::OB_RS + 128 + (i & 3) * 4) = a.b1[i];
+  } else if constexpr (!BWD) {
     for (int i = tid; i < H4; i += NW * 64) {
       vec[i] = a.b1[i];
       if constexpr (MODE == 1) {
@@ -275,7 +282,8 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
     float b1v[2][4], sv[2][4], bv[2][4];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      const float4 t1 = *reinterpret_cast<const float4*>(vb + hf * 16);
+      const float4 t1 = G::B1_IN_PADS ? *reinterpret_cast<const float4*>(obuf + (hs * 8 + hf * 4 + kq) * G::OB_RS + 128)
+                                      : *reinterpret_cast<const float4*>(vb + hf * 16);
       b1v[hf][0] = t1.x; b1v[hf][1] = t1.y; b1v[hf][2] = t1.z; b1v[hf][3] = t1.w;
       if constexpr (MODE == 1) {
         const float4 t2 = *reinterpret_cast<const float4*>(vb + H4 + hf * 16);
