@@ -16,11 +16,12 @@ int g_vsx_tn_rect = 3;  // rectangular TN tiles: bit 0 = when N or K is 224..256
 int g_vsx_dw_mfma = 7;   // depthwise conv on the matrix cores (dwconv_mfma.hip): bit 0 forward / data gradient (banded Toeplitz tiles), bit 1 weight gradient (row contraction, transpose reads), bit 2 16-column weight-gradient tiles at every width (the 32-column variant spills: 471 vs 285 us at 64x64x96, B = 512); 0: VALU stencils
 int g_vsx_ln_fblk = 32768;  // LayerNorm forward: cap on workgroups per launch (each sweeps rows / cap windows).  Measured at B = 512 (64x64x96 / x224): 2048 -> 209 / 438 us, 8192 -> 172 / 351, 32768 -> 162 / 331 (a grid-stride sweep by few workgroups streams at 5.0 TB/s where one vector per thread reaches 6.8: tools/micro/write_rate.hip)
 int g_vsx_ln_bblk = 8192;   // LayerNorm backward WITHOUT affine gradients (the block LayerNorms): cap on workgroups (with dgamma: 512, same-address atomics).  512 -> 319 / 651 us, 2048 -> 254 / 586, 8192 -> 240 / 541 (16x16x384: 83 -> 61), 32768 -> 225 / 516 but 78 at 16x16x384
-int g_vsx_nt_stream = 3;  // lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B).  ON since round 3: the streaming stores are compiler builtins now (round 1 used inline asm, see vsx_common.h stvec_stream), soak / determinism / poison tests run with them
+int g_vsx_nt_stream = 3;  // (round 4: a non-temporal LDS-DMA of the A panel in the second-generation NT kernel measured 14.9 -> 17.1 ms for the class: not kept) lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B).  ON since round 3: the streaming stores are compiler builtins now (round 1 used inline asm, see vsx_common.h stvec_stream), soak / determinism / poison tests run with them
 int g_vsx_grn_stream = 2;  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
 int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup instead of grid-strided rows
 int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x splits)
 int g_vsx_ln_stream = 3;  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
+int g_vsx_tn_stream = 3;  // lean TN kernel: non-temporal loads of an operand that the launch reads exactly once (its dimension fits one tile): bit 0 = X [M, N], bit 1 = Y [M, K] (round 4)
 int g_vsx_tn_contig = 1;  // lean TN kernel: contiguous step range per split
 int g_vsx_mlp_fused = 111;  // fused GRN-MLP kernels (csrc/mlp.hip): bit 0 = inference forward (statistics + output passes, hidden activation on chip), bit 1 = training fc1 (statistics pass that also stores h and g), bit 3 = block backward without a stored dz (statistics from the per-sample weight-gradient products or MODE 3, then MODE 4 writes dh once) — on the C = 96 / 192 / 224 blocks; bit 2 = the training passes also on the C = 384 blocks (same step time, 7.7 GB less traffic per step); (bit 4 was the inference pair on the C = 384 blocks, slower than the unfused GEMMs there: removed in round 4); bit 5 = the block LayerNorm in the prologue of the fused passes (vsx_mlp_fwd_ln / vsx_mlp_fc1_ln: no separate LayerNorm pass); bit 6 = the pre-activation h is never stored on the C <= 224 blocks: the training fc1 writes g only (MODE 6) and the dh pass recomputes h from the C-wide normalised rows (MODE 5, vsx_mlp_bwd_dh_re)
 int g_vsx_nt2 = 1;  // second-generation NT kernel (gemm_nt2.hip: 256 x 128 tiles, LDS-DMA operand path, wave-private epilogue): bit 0 = on for the launches it supports, bit 1 = also below 512 tiles
@@ -47,6 +48,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "ggb_contig")) { g_vsx_ggb_contig = value; return 0; }
   if (name && !strcmp(name, "tn_want")) { g_vsx_tn_want = value; return 0; }
   if (name && !strcmp(name, "tn_contig")) { g_vsx_tn_contig = value; return 0; }
+  if (name && !strcmp(name, "tn_stream")) { g_vsx_tn_stream = value; return 0; }
   if (name && !strcmp(name, "ln_stream")) { g_vsx_ln_stream = value; return 0; }
   if (name && !strcmp(name, "ggb_blocks")) { g_vsx_ggb_blocks = value; return 0; }
   if (name && !strcmp(name, "tn_rect")) { g_vsx_tn_rect = value; return 0; }
@@ -69,6 +71,7 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "ggb_contig")) return g_vsx_ggb_contig;
   if (name && !strcmp(name, "tn_want")) return g_vsx_tn_want;
   if (name && !strcmp(name, "tn_contig")) return g_vsx_tn_contig;
+  if (name && !strcmp(name, "tn_stream")) return g_vsx_tn_stream;
   if (name && !strcmp(name, "ln_stream")) return g_vsx_ln_stream;
   if (name && !strcmp(name, "ggb_blocks")) return g_vsx_ggb_blocks;
   if (name && !strcmp(name, "tn_rect")) return g_vsx_tn_rect;

@@ -25,6 +25,7 @@ extern int g_vsx_tn_wide;
 extern int g_vsx_nt_stream;
 extern int g_vsx_tn_want;
 extern int g_vsx_tn_contig;
+extern int g_vsx_tn_stream;
 bool vsx_gemm_nt2_ok(const VsxGemm* p);           // gemm_nt2.hip
 bool vsx_gemm_nt2_lnbwd_ok(const VsxGemm* p);
 int vsx_gemm_nt2(const VsxGemm* p, hipStream_t s);
@@ -1180,15 +1181,20 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
   }
 
   vec xreg[NCHX], yreg[NCHY];
+  // An operand that ONE tile column / row covers completely is read exactly once by the launch: its loads are non-temporal, so
+  // that the stream does not evict the other operand — which the other tiles of the split re-read — from the XCD's L2 (the TN
+  // class hit the L2 in 50 % of its requests, profiles/r04_tcc_gemm.txt).  `tn_stream` flag (bits 13 / 14 of p.pro, set by the launcher): bit 0 = X, bit 1 = Y.
+  const int tiles_n_ = (p.N + BTN - 1) / BTN;
+  const bool x_once = (p.pro & 8192) && tiles_k == 1, y_once = (p.pro & 16384) && tiles_n_ == 1;
   auto load_tiles = [&](int step, vec* xr, vec* yr) {
     const char* Xs = Xb + (size_t)step * xstep;
     const char* Ys = Yb + (size_t)step * ystep;
 #pragma unroll
     for (int i = 0; i < NCHX; ++i)
-      if (livex[i]) xr[i] = *reinterpret_cast<const vec*>(Xs + xoff[i]);
+      if (livex[i]) xr[i] = ldvec_stream<T>(reinterpret_cast<const T*>(Xs + xoff[i]), x_once);
 #pragma unroll
     for (int i = 0; i < NCHY; ++i)
-      if (livey[i]) yr[i] = *reinterpret_cast<const vec*>(Ys + yoff[i]);
+      if (livey[i]) yr[i] = ldvec_stream<T>(reinterpret_cast<const T*>(Ys + yoff[i]), y_once);
   };
   // GRN prologue operands: every chunk of this thread covers the SAME 8 (4) columns (256 % CPRY == 0), and the sample
   // index changes only every hw / BMS steps -> s[b, k..] and beta[k..] live in registers, reloaded on a sample change
@@ -1352,6 +1358,7 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
                 "vsx_gemm_tn: per-sample outputs (b_bstride) need plain bf16 row operands, no prologue, hw %% 64 == 0");
       VsxGemm pq = *p;
       pq.pro |= 1024;  // contiguous step range per split: a whole sample, or 1 / ks of one
+      pq.pro |= (g_vsx_tn_stream & 3) << 13;
       const int nb = p->M / p->hw;
       const bool n_full = p->N >= 224 && p->N <= 256 && p->K >= 128;
       const int t2 = n_full ? vsx_cdiv(p->N, 256) * vsx_cdiv(p->K, 128) : tiles;
@@ -1387,6 +1394,7 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
   if (fast) {
     VsxGemm pq = *p;
     if (g_vsx_tn_contig) pq.pro |= 1024;  // kernel-side flag bit (the prologue kind is a template parameter there)
+    pq.pro |= (g_vsx_tn_stream & 3) << 13;
     if constexpr (sizeof(T) == 2 && BT == 128) {
       if (g_vsx_tn_wide && p->M % 64 == 0 && (p->pro == VSX_PRO_NONE || p->hw % 64 == 0) && p->M / 64 >= 2 * splits) {
         if constexpr (TR) {
