@@ -1307,6 +1307,52 @@ def test_fused_block_without_a_stored_preactivation(C, hw, B, ln_in):
         L.lib().vsx_set_flag(b"mlp_fused", saved)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,hw,B", [(192, 1024, 128), (224, 4096, 64)])
+def test_fused_passes_with_two_workgroups_per_cu(C, hw, B):
+    """Regression test of a race that only large launches show (round 4): the fused GRN-MLP kernels refilled stage buffer 1 by
+    LDS-DMA at the top of their first step while slower waves of the workgroup were still multiplying sub-chunk 0's fragments out
+    of it (no barrier behind the prologue GEMM).  One workgroup per CU hid it behind the DMA latency; MODE 6 fits two per CU at
+    C = 192 / 224 and then wrote wrong hidden columns 16..31 of the first sub-chunk for whole 32-row groups — only when the launch
+    has more workgroups than CUs (the unit tests above never do).  Here: >= 512 workgroups, MODE 6 against MODE 2 bit for bit,
+    MODE 5 against MODE 4 bit for bit, three repetitions each."""
+    if SELF_CHECK:
+        pytest.skip("HIP-only kernel")
+    from viscy_amd import _lib as L
+    from viscy_amd import ops
+
+    dt = torch.bfloat16
+    M, H4 = B * hw, 4 * C
+    saved = L.lib().vsx_get_flag(b"mlp_fused")
+    L.lib().vsx_set_flag(b"mlp_fused", 127)
+    try:
+        y = rnd(M, C, dt=dt, seed=1, scale=2.0).cuda()
+        W1 = rnd(H4, C, dt=dt, seed=2, scale=C ** -0.5).cuda()
+        W2 = rnd(C, H4, dt=dt, seed=3, scale=H4 ** -0.5).cuda()
+        b1 = (0.1 * rnd(H4, seed=4)).cuda()
+        dout = rnd(M, C, dt=dt, seed=5).cuda()
+        s = (1 + 0.2 * rnd(B, H4, seed=6)).cuda()
+        t = (0.05 * rnd(B, H4, seed=7)).cuda()
+        img, img2 = ops.mlp_pack(W1, W2, C), ops.mlp_pack(W2.t().contiguous(), W2, C)
+        q2 = torch.zeros((B, H4), device="cuda")
+        xh2, r2, h2, g2 = ops.mlp_fc1_ln(y, img, b1, q2, M, C, hw, 1e-6)
+        db4 = torch.zeros(H4, device="cuda")
+        dh4 = ops.mlp_bwd_dh(dout, img2, h2, s, t, db4, M, C, hw)
+        for it in range(3):
+            q6 = torch.zeros((B, H4), device="cuda")
+            xh6, r6, h6, g6 = ops.mlp_fc1_ln(y, img, b1, q6, M, C, hw, 1e-6, store_h=False)
+            bad = (g2 != g6).any(1).nonzero().flatten()
+            assert bad.numel() == 0, (it, bad.numel(), bad[:8].tolist())
+            assert torch.equal(xh2, xh6)
+            close(q6, q2, torch.float32, "GRN sums")
+            db5 = torch.zeros(H4, device="cuda")
+            dh5 = ops.mlp_bwd_dh_re(dout, xh6, img2, img, b1, s, t, db5, M, C, hw)
+            assert torch.equal(dh4, dh5), (it, (dh4 != dh5).any(1).sum().item())
+            del g6, xh6, dh5
+    finally:
+        L.lib().vsx_set_flag(b"mlp_fused", saved)
+
+
 def test_weight_task_list_equals_single_launches():
     """vsx_weight_tasks (ops.batch): prep_weight / transpose_f32 / matvec / mlp_pack / unprep_grad / matvec_t_add collected into task lists give identical
     outputs to the single launches — more tasks than one launch holds (VSX_WTASK_MAX = 48), every kind, bf16 and fp32, tap

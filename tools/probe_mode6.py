@@ -1,0 +1,48 @@
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from viscy_amd import _lib as L, ops
+L.lib().vsx_set_flag(b"mlp_fused", 127)
+dt = torch.bfloat16
+for C, hw, B in [(96, 4096, 64), (192, 1024, 128), (224, 4096, 64), (96, 262144, 1)]:
+    M, H4 = B * hw, 4 * C
+    g = torch.Generator().manual_seed(1)
+    y = (torch.randn(M, C, generator=g) * 2).to(dt).cuda()
+    W1 = (torch.randn(H4, C, generator=g) * C ** -0.5).to(dt).cuda()
+    W2 = (torch.randn(C, H4, generator=g) * H4 ** -0.5).to(dt).cuda()
+    b1 = (torch.randn(H4, generator=g) * 0.1).cuda()
+    img = ops.mlp_pack(W1, W2, C)
+    q2 = torch.zeros((B, H4), device="cuda")
+    xh2, r2, h2, g2 = ops.mlp_fc1_ln(y, img, b1, q2, M, C, hw, 1e-6)
+    for it in range(3):
+        q6 = torch.zeros((B, H4), device="cuda")
+        xh6, r6, h6, g6 = ops.mlp_fc1_ln(y, img, b1, q6, M, C, hw, 1e-6, store_h=False)
+        torch.cuda.synchronize()
+        ng = int((g2 != g6).sum()); nx = int((xh2 != xh6).sum())
+        rows = (g2 != g6).any(1).nonzero().flatten()
+        qe = ((q6 - q2).abs().max() / q2.abs().max()).item()
+        print(f"C={C} hw={hw} B={B} it={it}: g mismatches {ng} (rows {rows.numel()}, first {rows[:6].tolist()}), xh mismatches {nx}, colsq rel diff {qe:.2e}", flush=True)
+
+# ---- detail of the mismatches of the last failing shape
+C, hw, B = 224, 4096, 64
+M, H4 = B * hw, 4 * C
+g = torch.Generator().manual_seed(1)
+y = (torch.randn(M, C, generator=g) * 2).to(dt).cuda()
+W1 = (torch.randn(H4, C, generator=g) * C ** -0.5).to(dt).cuda()
+W2 = (torch.randn(C, H4, generator=g) * H4 ** -0.5).to(dt).cuda()
+b1 = (torch.randn(H4, generator=g) * 0.1).cuda()
+img = ops.mlp_pack(W1, W2, C)
+q2 = torch.zeros((B, H4), device="cuda")
+xh2, r2, h2, g2 = ops.mlp_fc1_ln(y, img, b1, q2, M, C, hw, 1e-6)
+q6 = torch.zeros((B, H4), device="cuda")
+xh6, r6, h6, g6 = ops.mlp_fc1_ln(y, img, b1, q6, M, C, hw, 1e-6, store_h=False)
+bad = (g2 != g6)
+rows = bad.any(1).nonzero().flatten()
+print("bad rows", rows.numel(), "distinct 256-row workgroups", (rows // 256).unique().numel(), "waves", ((rows % 256) // 32).unique().tolist())
+cols = bad.any(0).nonzero().flatten()
+print("bad cols", cols.numel(), cols[:40].tolist(), "sub-chunks", (cols // 32).unique().tolist())
+r = int(rows[0]); cs = bad[r].nonzero().flatten()
+print("row", r, "bad cols in row", cs.numel(), cs[:12].tolist())
+c0 = int(cs[0])
+print("g2", g2[r, c0:c0 + 8].float().tolist()); print("g6", g6[r, c0:c0 + 8].float().tolist()); print("h2", h2[r, c0:c0 + 8].float().tolist())
+gm = torch.nn.functional.gelu(h2[r].float())
+print("g6 - gelu(h2) at bad cols", (g6[r, cs].float() - gm[cs]).abs().max().item(), " g6 - gelu(h2 - b1):", (g6[r, cs].float() - torch.nn.functional.gelu(h2[r, cs].float() - b1[cs])).abs().max().item())

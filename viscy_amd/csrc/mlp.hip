@@ -553,6 +553,11 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
   __syncthreads();
   gemm1(buf1 + lane * 16, xf, hcur);
   if constexpr (RE) gemm1(buf1 + G::W1_PIECES * 1024 + lane * 16, xg, gcur);
+  // every wave must be done reading sub-chunk 0's fragments out of buffer 1 before step 0 refills that buffer by LDS-DMA.  (This
+  // barrier was missing until round 4: a fast wave's prefetch could overwrite the fragments a slow wave was still multiplying —
+  // hidden by the DMA latency while one workgroup owned the CU, exposed as wrong hidden columns 16..31 of the first sub-chunk in
+  // whole 32-row groups once two workgroups shared a CU at C = 192 / 224: tools/probe_mode6.py, tools/det_fwd.py.)
+  __syncthreads();
 
   auto step = [&](int hs, const char* Sb, char* other) {
     // stage hs has landed for everyone (waited + barrier by the caller); every wave is done with stage hs - 1 in `other`

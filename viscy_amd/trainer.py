@@ -51,6 +51,8 @@ class Trainer:
 
     _MAX_CAPTURED_SHAPES = 2  # each captured step owns a memory pool the size of the step's activations
 
+    GRAPH_BELOW_PIXELS = 256 * 256 * 256  # per-rank batch pixels (B x Y x X) below which the captured step is replayed as a hipGraph
+
     def _graphed_step(self, module, opt, ddp, batch):
         """the captured ``TrainStep`` serving this batch, or None (eager path): see the module docstring"""
         from .vsunet import VSUNet
@@ -58,6 +60,8 @@ class Trainer:
         if not (self.graph_step and self.device.type == "cuda" and getattr(module, "_native", False)):
             return None
         if type(module).training_step is not VSUNet.training_step or type(module)._compute_loss is not VSUNet._compute_loss:
+            return None
+        if "training_step" in vars(module) or "_compute_loss" in vars(module):  # instance-level overrides count too
             return None
         if not isinstance(batch, dict) or "fg_mask" in batch:
             return None
@@ -68,10 +72,26 @@ class Trainer:
         step = self._train_steps.get(key)
         if step is None:
             if len(self._train_steps) >= self._MAX_CAPTURED_SHAPES:
-                return None
+                # every captured shape holds a private graph memory pool of about the step's activation footprint: release the
+                # least recently used one instead of growing (a second shape at a large batch could run out of memory where the
+                # eager loop would not)
+                old_key = next(iter(self._train_steps))
+                del self._train_steps[old_key]
+                torch.cuda.empty_cache()
             from .step import TrainStep
 
-            step = self._train_steps[key] = TrainStep(module.model, module.loss_function, opt, ddp, use_graph=True)
+            # hipGraph replay or eager launches of the SAME direct engine step: measured on the bench workload, the replay pays
+            # below ~128 patches of 256 x 256 per rank (launch gaps were 23 % of the step at B = 32) and costs 0.5 - 0.7 ms per step
+            # at B = 512, where every launch is long (profiles/r03_fit_throughput.json)
+            voxels = src.shape[0] * src.shape[-1] * src.shape[-2]
+            use_graph = voxels < self.GRAPH_BELOW_PIXELS
+            step = self._train_steps[key] = TrainStep(module.model, module.loss_function, opt, ddp, use_graph=use_graph)
+            import logging
+
+            logging.getLogger("viscy_amd").info("Trainer.fit: direct engine step for batch %s (%s)", tuple(src.shape),
+                                                "hipGraph replay" if use_graph else "eager launches")
+        else:
+            self._train_steps[key] = self._train_steps.pop(key)  # most recently used last
         return step
 
     def fit(self, module, datamodule) -> None:
