@@ -537,14 +537,11 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
   const bool split_tile = BM == 128 && p.hw > 0 && (p.hw % 128) != 0;
 
   vec ar[NA], br[NB];
-  const bool a_once = (p.pro & 2048) != 0 && tiles_n == 1;
   auto gload = [&](int kt, vec* ar, vec* br) {
     const char* Ak = Abase + (size_t)kt * (BK * ES);
     const char* Bk = Bbase + (size_t)kt * (BK * ES);
-    // an A panel that ONE column tile reads (N <= 128) is read exactly once by the launch: non-temporal, so that the stream does
-    // not push the weight slabs every row tile re-reads out of the XCD's L2 (nt_stream bit 4; measured on the TN kernels first)
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ar[i] = ldvec_stream<T>(reinterpret_cast<const T*>(Ak + offA[i]), a_once);
+    for (int i = 0; i < NA; ++i) ar[i] = *reinterpret_cast<const vec*>(Ak + offA[i]);  // (non-temporal loads of a read-once A panel: +-0, round 4)
 #pragma unroll
     for (int i = 0; i < NB; ++i) br[i] = *reinterpret_cast<const vec*>(Bk + offB[i]);
   };
@@ -778,7 +775,6 @@ static int launch_nt_fast(const VsxGemm* pin, hipStream_t s) {
   VsxGemm pq = *pin;
   if (g_vsx_nt_stream & 1) pq.pro |= 256;
   if (g_vsx_nt_stream & 2) pq.pro |= 512;  // kernel-side flag bit (the prologue kind itself is a template parameter there)
-  if (g_vsx_nt_stream & 16) pq.pro |= 2048;
   const VsxGemm* p = &pq;
   int tiles = vsx_cdiv(p->M, 128) * vsx_cdiv(p->N, 128);
   dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
