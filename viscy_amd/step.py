@@ -16,8 +16,26 @@ stay outside the captures).
 
 from __future__ import annotations
 
+import contextlib
+import gc
+
 import torch
 
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a stream is capturing: a collection that runs INSIDE a capture can finalise objects whose
+    destructors call APIs a capturing stream forbids (a pinned host buffer of an earlier DataLoader batch -> hipHostFree), which
+    aborts the process — seen once in ~3 full `-m gpu` runs, always in the first capture behind a DataLoader test (round 4).
+    torch.cuda.graph collects BEFORE it starts capturing; this keeps the collector off until the capture has ended."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 class TrainStep:
     """``step(x, t) -> loss`` = zero-grad, forward, loss, backward, gradient all-reduce (if data parallel), AdamW.
@@ -155,7 +173,7 @@ class TrainStep:
         def capture(body):
             nonlocal pool
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with _no_gc(), torch.cuda.graph(g, pool=pool):
                 body()
             pool = g.pool()
             graphs.append(g)
@@ -174,7 +192,7 @@ class TrainStep:
 
             capture(body)
         gopt = torch.cuda.CUDAGraph()  # its own graph: with data parallelism it runs after the last bucket's all-reduce
-        with torch.cuda.graph(gopt, pool=pool):
+        with _no_gc(), torch.cuda.graph(gopt, pool=pool):
             self.opt.device_step()
         self.gopt = gopt
         # the warm-up steps (and nothing else: a capture records, it does not execute) changed the training state
@@ -240,7 +258,7 @@ class InferStep:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _no_gc(), torch.cuda.graph(g):
                 self.y = self.model(self.x)
             self.graph = g
         self.x.copy_(x, non_blocking=True)
