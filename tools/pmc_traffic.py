@@ -49,8 +49,8 @@ def main(fetch_csv, write_csv, steps, batch, out):
     except Exception as e:  # noqa: BLE001
         res["identity_error"] = repr(e)
     for k, d in sorted(agg.items(), key=lambda kv: -(kv[1]["read"] + kv[1]["write"])):
-        if k == "normalize_kernel":
-            continue
+        if k == "normalize_kernel" or "distribution_elementwise" in k:
+            continue  # the calibration launches and the torch.rand that fills their 256 MiB / 1 GiB inputs: not part of a step
         n = d["launches"]
         res["kernels"][k] = {"launches_per_step": n / steps, "read_GB_per_step": d["read"] / steps / 1e9, "write_GB_per_step": d["write"] / steps / 1e9,
                              "traffic_bytes_per_launch": (d["read"] + d["write"]) / n}
