@@ -490,8 +490,13 @@ int32_t vsx_sample_minmax(const float* x, float* mn, float* mx, int32_t B, int64
 /* K19-K21 fused: BatchedRandAdjustContrast (_adjust_contrast.py:54-86) -> BatchedRandScaleIntensity
  * (_scale_intensity.py:59-77) -> BatchedRandGaussianNoise (_noise.py:158-204) with injected per-sample parameters. */
 int32_t vsx_intensity_aug(const float* x, float* y, const float* mn, const float* mx, const float* gamma,
-    const float* factor, const float* noise, const float* nstd, float nmean, int32_t B, int64_t per_sample,
+    const float* factor, const float* noise, const float* nstd, float nmean, int32_t invert, int32_t B, int64_t per_sample,
     vsx_stream_t stream);
+/* invert: bit 0 = the gamma curve runs on -x (MONAI AdjustContrast(invert_image=True), called at _adjust_contrast.py:76-80),
+ * bit 1 = the result is negated back; 0 or 3 in normal use, 1 when the retain_stats affine follows on the host side.
+ * vsx_sample_moments: per-sample sum and sum of squares in double (sums[B][2], pre-set to 0) — the mean / std that
+ * AdjustContrast(retain_stats=True) measures before and restores after the curve. */
+int32_t vsx_sample_moments(const float* x, double* sums, int32_t B, int64_t per_sample, vsx_stream_t stream);
 
 /* K25 _blend_in (viscy_utils/callbacks/prediction_writer.py:74-111): Z-feathered running average, fz[Z] = factors. */
 int32_t vsx_blend_in(const float* oldp, const float* newp, float* out, const float* fz, int32_t Z, int64_t plane,
@@ -508,13 +513,15 @@ int32_t vsx_crop3d(const float* x, float* y, const int32_t* starts, int32_t B, i
     int32_t cz, int32_t cy, int32_t cx, vsx_stream_t stream);
 
 /* K18 kornia warp_affine3d as used by BatchedRandAffined (viscy_transforms/_affine.py:33-47,358-393): trilinear (or
- * nearest) resampling, zero padding; Minv[B][3][4] maps output-voxel to input-voxel coordinates (x, y, z order). */
+ * nearest) resampling; Minv[B][3][4] maps output-voxel to input-voxel coordinates (x, y, z order).
+ * mode: bit 0 = nearest-neighbour; bits 1-2 = padding_mode of _affine.py:102-108 as torch's grid_sample(align_corners=True)
+ * treats it: 0 "zeros", 1 "border" (coordinates clamped to the volume), 2 "reflection" (mirrored about 0 and n-1). */
 int32_t vsx_warp_affine3d(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,
-    int32_t W, int32_t nearest, vsx_stream_t stream);
+    int32_t W, int32_t mode, vsx_stream_t stream);
 /* the same warp restricted to the output window [z0,z0+Do) x [y0,y0+Ho) x [x0,x0+Wo) of the (D,H,W) frame: fuses the
  * BatchedCenterSpatialCrop that follows the affine in the recipes (_crop.py:164-187); y: (B,C,Do,Ho,Wo). */
 int32_t vsx_warp_affine3d_roi(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,
-    int32_t W, int32_t z0, int32_t y0, int32_t x0, int32_t Do, int32_t Ho, int32_t Wo, int32_t nearest, vsx_stream_t stream);
+    int32_t W, int32_t z0, int32_t y0, int32_t x0, int32_t Do, int32_t Ho, int32_t Wo, int32_t mode, vsx_stream_t stream);
 
 /* K22 one pass of the separable Gaussian of BatchedRandGaussianSmooth (viscy_transforms/_gaussian_smooth.py:141-167):
  * per-sample 1-D taps along the axis with element stride `stride` and length L, zero border. */

@@ -35,19 +35,28 @@ def scale_intensity(x: Tensor, factors: Tensor) -> Tensor:
     return x * f.view(*f.shape, *([1] * (x.ndim - f.ndim)))
 
 
-def adjust_contrast(x: Tensor, gamma: Tensor, apply: Tensor, invert_image: bool = False) -> Tensor:
+def adjust_contrast(x: Tensor, gamma: Tensor, apply: Tensor, invert_image: bool = False, retain_stats: bool = False) -> Tensor:
     """BatchedRandAdjustContrast.__call__, _adjust_contrast.py:54-86, which loops MONAI
-    ``AdjustContrast(gamma)`` (monai 1.5.2 transforms/intensity/array.py) per sample:
-    eps=1e-7; m=x.min(); r=x.max()-m; ((x-m)/(r+eps))**gamma * r + m  (retain_stats=False)."""
+    ``AdjustContrast(gamma, invert_image, retain_stats)`` (monai 1.5.2 transforms/intensity/array.py — not installed here,
+    restated from its published source) per sample:
+    [invert: x = -x] → [retain_stats: mn = x.mean(); sd = x.std()] → eps=1e-7; m=x.min(); r=x.max()-m;
+    ret = ((x-m)/(r+eps))**gamma * r + m → [retain_stats: ret -= ret.mean(); ret /= ret.std() + 1e-8; ret = sd*ret + mn]
+    → [invert: ret = -ret].  ``std`` is torch's unbiased one."""
     out = torch.empty_like(x)
     for i in range(x.shape[0]):
         s = x[i]
         if bool(apply[i]):
             if invert_image:
                 s = -s
+            if retain_stats:
+                mn, sd = s.mean(), s.std()
             m = s.min()
             r = s.max() - m
             s = ((s - m) / (r + 1e-7)) ** float(gamma[i]) * r + m
+            if retain_stats:
+                s = s - s.mean()
+                s = s / (s.std() + 1e-8)
+                s = sd * s + mn
             if invert_image:
                 s = -s
         out[i] = s
@@ -111,8 +120,8 @@ def gaussian_smooth(x: Tensor, sigma: Tensor, apply: Tensor, truncated: float = 
     return out
 
 
-def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear") -> Tensor:
-    """What kornia ``warp_affine3d(..., padding_mode="zeros", align_corners=True)`` (called at _affine.py:33-47)
+def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear", padding_mode: str = "zeros") -> Tensor:
+    """What kornia ``warp_affine3d(..., padding_mode=..., align_corners=True)`` (called at _affine.py:33-47)
     computes, stated with torch's own ``affine_grid`` / ``grid_sample``: output voxel (x, y, z) samples the input at
     ``Minv · (x, y, z, 1)`` (voxel coordinates)."""
     import torch.nn.functional as F
@@ -127,7 +136,7 @@ def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear") -> Tensor:
     M4 = torch.cat([Minv.float(), torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(B, 1, 4)], dim=1)
     theta = (N @ M4 @ torch.linalg.inv(N))[:, :3]
     grid = F.affine_grid(theta, (B, C, D, H, W), align_corners=True)
-    return F.grid_sample(x.float(), grid, mode=mode, padding_mode="zeros", align_corners=True)
+    return F.grid_sample(x.float(), grid, mode=mode, padding_mode=padding_mode, align_corners=True)
 
 
 def affine_matrix_zyx(angle_z_deg: Tensor, scale_xyz: Tensor, shape_dhw, shear_xy: Tensor | None = None) -> Tensor:

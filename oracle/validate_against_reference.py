@@ -174,8 +174,16 @@ def g3_normalize():
     y = t(x.clone())
     factors = t._broadcast_factors.reshape(6) - 1.0
     assert torch.equal(y, transforms_ref.scale_intensity(x, factors)) and (factors == 0).any() and (factors != 0).any()
-    g4 = {"scale": {"x": x, "factors": factors, "y": y}}
-    print("G4 scale intensity: exact (BatchedRandGaussianNoise / flip / weighted crop: see G4b)")
+    g4 = {"scale": {"x": x, "factors": factors, "y": y, "seed": 11}}
+    # channel_wise=True (_scale_intensity.py:46-55): one factor per (sample, channel); the dict form draws from the FIRST key
+    # and broadcasts over the others (a 1-channel first key scales every channel of a 2-channel second key alike)
+    tc = rs.BatchedRandScaleIntensity(factors=(-0.3, 0.6), prob=0.5, channel_wise=True)
+    torch.manual_seed(12)
+    yc = tc(x.clone())
+    fc = tc._broadcast_factors.reshape(6, 2) - 1.0
+    assert torch.equal(yc, transforms_ref.scale_intensity(x, fc)) and (fc[:, 0] != fc[:, 1]).any() and (fc == 0).all(1).any()
+    g4["scale_channel_wise"] = {"x": x, "factors": fc, "y": yc, "seed": 12, "range": (-0.3, 0.6), "prob": 0.5}
+    print("G4 scale intensity (per sample and channel_wise): exact (BatchedRandGaussianNoise / flip / weighted crop: see G4b)")
     torch.save(g4, os.path.join(GOLD, "intensity.pt"))
 
 

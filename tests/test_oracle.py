@@ -209,6 +209,35 @@ def test_scale_intensity_golden():
     assert torch.equal(transforms_ref.scale_intensity(g["x"], g["factors"]), g["y"])
 
 
+def test_scale_intensity_channel_wise_golden_and_draw_order():
+    """G4 channel_wise=True: oracle == reference output; and the product class draws what the reference drew (selection first,
+    then one uniform per (sample, channel) — _scale_intensity.py:42-50) from the same seed of the global generator"""
+    from viscy_amd.transforms import BatchedRandScaleIntensityd
+
+    all_g = load_golden("intensity.pt")
+    g = all_g["scale_channel_wise"]
+    assert g["factors"].shape == (6, 2) and torch.equal(transforms_ref.scale_intensity(g["x"], g["factors"]), g["y"])
+    t = BatchedRandScaleIntensityd(["a"], factors=g["range"], prob=g["prob"], channel_wise=True)
+    torch.manual_seed(g["seed"])
+    torch.testing.assert_close(t.randomize(6, 2), g["factors"], rtol=0, atol=1e-6)  # the golden holds (1 + f) - 1
+    g1 = all_g["scale"]
+    t1 = BatchedRandScaleIntensityd(["a"], factors=0.5, prob=0.5)
+    torch.manual_seed(g1["seed"])
+    torch.testing.assert_close(t1.randomize(6, 2), g1["factors"], rtol=0, atol=1e-6)
+
+
+def test_oracle_adjust_contrast_options():
+    """restated MONAI AdjustContrast options: retain_stats restores mean / std of the sample, invert_image mirrors the curve"""
+    x = torch.rand((3, 2, 4, 8, 8), generator=torch.Generator().manual_seed(5)) * 4 - 1
+    gamma, sel = torch.tensor([0.6, 1.0, 2.2]), torch.tensor([True, False, True])
+    r = transforms_ref.adjust_contrast(x, gamma, sel, retain_stats=True)
+    for i in (0, 2):
+        assert abs(r[i].mean() - x[i].mean()) < 1e-5 and abs(r[i].std() - x[i].std()) < 1e-5 and not torch.allclose(r[i], x[i])
+    assert torch.equal(r[1], x[1])
+    inv = transforms_ref.adjust_contrast(x, gamma, sel, invert_image=True)
+    torch.testing.assert_close(inv, -transforms_ref.adjust_contrast(-x, gamma, sel), rtol=0, atol=0)
+
+
 def test_oracle_transforms_match_the_reference_pins():
     """G4b (oracle/validate_against_reference.py): outputs of the reference's own _noise.py / _flip.py / _crop.py (run on a
     stub of their MONAI base classes) with the draws the reference made; the oracle reproduces them from those draws."""

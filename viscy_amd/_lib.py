@@ -119,7 +119,8 @@ _SIGS = {
     "vsx_normalize": (_I32, [_P, _P, _P, _P, _I32, _I64, _P]),
     "vsx_minmax_norm": (_I32, [_P, _P, _P, _P, _I32, _I64, _P]),
     "vsx_sample_minmax": (_I32, [_P, _P, _P, _I32, _I64, _P]),
-    "vsx_intensity_aug": (_I32, [_P] * 8 + [_F32, _I32, _I64, _P]),
+    "vsx_intensity_aug": (_I32, [_P] * 8 + [_F32, _I32, _I32, _I64, _P]),
+    "vsx_sample_moments": (_I32, [_P, _P, _I32, _I64, _P]),
     "vsx_blend_in": (_I32, [_P, _P, _P, _P, _I32, _I64, _I64, _P]),
     "vsx_scale_weight_samples": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_voxel_shuffle_fwd": (_I32, [_P, _P] + [_I32] * 8 + [_P]),

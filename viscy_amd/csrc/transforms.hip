@@ -57,15 +57,39 @@ __global__ __launch_bounds__(256) void sample_minmax_kernel(const float* __restr
   if ((threadIdx.x & 63) == 0 && hi >= lo) atomic_minmax(mn + b, mx + b, lo, hi);
 }
 
+// per-sample sum and sum of squares in double (MONAI AdjustContrast(retain_stats=True) wants mean / unbiased std of a sample
+// before and after the gamma curve); sums[2b], sums[2b + 1] pre-set to 0; gridDim.y = B
+__global__ __launch_bounds__(256) void sample_moments_kernel(const float* __restrict__ x, double* __restrict__ sums, long per_sample) {
+  const int b = blockIdx.y;
+  const float* xs = x + (size_t)b * per_sample;
+  double s1 = 0.0, s2 = 0.0;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * 256 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(xs + i);
+    s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+    s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(sums + 2 * b, s1);
+    atomicAdd(sums + 2 * b + 1, s2);
+  }
+}
+
 // fused intensity augmentation (BatchedRandAdjustContrast → BatchedRandScaleIntensity → BatchedRandGaussianNoise):
 //   gamma[b] > 0 : x = ((x - m)/(r + 1e-7))^gamma * r + m     (MONAI AdjustContrast, m = min, r = max - min)
+//                  invert bit 0 (invert_image=True): the curve runs on v = -x (m = -max, same r); bit 1: ... and the result is
+//                  negated back (bit 0 alone hands the un-negated curve to the retain_stats pass of the host)
 //   x *= (1 + factor[b])
 //   nstd[b] >= 0 (applied): x += nmean + noise[i mod per_sample] * nstd[b]   (one field shared by the batch)
 __global__ __launch_bounds__(256) void intensity_aug_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             const float* __restrict__ mn, const float* __restrict__ mx,
                                                             const float* __restrict__ gamma, const float* __restrict__ factor,
                                                             const float* __restrict__ noise, const float* __restrict__ nstd,
-                                                            float nmean, long per_sample, long total) {
+                                                            float nmean, int invert, long per_sample, long total) {
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (long)gridDim.x * 256 * 4) {
     const int b = (int)(i / per_sample);
     const long off = i - (long)b * per_sample;
@@ -73,10 +97,11 @@ __global__ __launch_bounds__(256) void intensity_aug_kernel(const float* __restr
     float* p = &v.x;
     const float g = gamma ? gamma[b] : 0.f;
     if (g > 0.f) {
-      const float m = mn[b], r = mx[b] - m;
+      const float sg = (invert & 1) ? -1.f : 1.f, so = (invert & 2) ? -1.f : 1.f;
+      const float m = (invert & 1) ? -mx[b] : mn[b], r = mx[b] - mn[b];
       const float inv = 1.f / (r + 1e-7f);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) p[j] = __powf((p[j] - m) * inv, g) * r + m;
+      for (int j = 0; j < 4; ++j) p[j] = so * (__powf((sg * p[j] - m) * inv, g) * r + m);
     }
     if (factor) {
       const float f = 1.f + factor[b];
@@ -138,18 +163,29 @@ extern "C" int32_t vsx_sample_minmax(const float* x, float* mn, float* mx, int32
   VSX_LAUNCH_CHECK();
   return 0;
 }
+/* per-sample sum / sum of squares (double; sums[B][2] pre-set to 0): the statistics AdjustContrast(retain_stats=True) restores. */
+extern "C" int32_t vsx_sample_moments(const float* x, double* sums, int32_t B, int64_t per_sample, vsx_stream_t stream) {
+  VSX_CHECK(x && sums && B > 0 && per_sample > 0 && per_sample % 4 == 0, "vsx_sample_moments: bad arguments");
+  int gx = vsx_cdiv(per_sample, 256L * 4 * 8);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(sample_moments_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, x, sums, (long)per_sample);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
 /* K19-K21 fused: BatchedRandAdjustContrast (_adjust_contrast.py:54-86) → BatchedRandScaleIntensity
  * (_scale_intensity.py:59-77) → BatchedRandGaussianNoise (_noise.py:158-204) with injected per-sample parameters;
- * any of gamma / factor / noise may be NULL (stage skipped); gamma[b] <= 0 or nstd[b] < 0 = sample not selected. */
+ * any of gamma / factor / noise may be NULL (stage skipped); gamma[b] <= 0 or nstd[b] < 0 = sample not selected;
+ * invert: 0, or 3 = AdjustContrast(invert_image=True) (1 = the curve of -x without negating back: retain_stats path). */
 extern "C" int32_t vsx_intensity_aug(const float* x, float* y, const float* mn, const float* mx, const float* gamma,
-                                     const float* factor, const float* noise, const float* nstd, float nmean, int32_t B,
-                                     int64_t per_sample, vsx_stream_t stream) {
+                                     const float* factor, const float* noise, const float* nstd, float nmean, int32_t invert,
+                                     int32_t B, int64_t per_sample, vsx_stream_t stream) {
   VSX_CHECK(x && y && B > 0 && per_sample > 0 && per_sample % 4 == 0, "vsx_intensity_aug: bad arguments");
+  VSX_CHECK(invert >= 0 && invert <= 3, "vsx_intensity_aug: invert is a 2-bit mask");
   VSX_CHECK(!gamma || (mn && mx), "vsx_intensity_aug: gamma needs per-sample min/max");
   VSX_CHECK((noise == nullptr) == (nstd == nullptr), "vsx_intensity_aug: noise and nstd come together");
   long total = (long)B * per_sample;
   hipLaunchKernelGGL(intensity_aug_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, mn, mx, gamma, factor,
-                     noise, nstd, nmean, (long)per_sample, total);
+                     noise, nstd, nmean, (int)invert, (long)per_sample, total);
   VSX_LAUNCH_CHECK();
   return 0;
 }
@@ -171,18 +207,38 @@ extern "C" int32_t vsx_blend_in(const float* oldp, const float* newp, float* out
 // A workgroup owns a 32 x 8 output tile of one z-slice: under an in-plane rotation its input footprint is a compact
 // ~30 x 30 patch per tap plane, so the 8 gathers per voxel hit L1 lines shared by the whole tile (a 256 x 1 row of outputs
 // would sweep up to 180 input rows).  The matrix is wave-uniform (scalar registers).
+// out-of-volume source coordinates as torch's grid_sample treats them with align_corners=True (kornia warp_affine3d hands
+// padding_mode through, _affine.py:33-47): 1 "border" = clamp to [0, n-1]; 2 "reflection" = mirror about 0 and n-1, then clamp
+__device__ __forceinline__ float warp_pad_coord(float v, int n, int pad) {
+  if (pad == 2) {
+    const float span = (float)(n - 1);
+    if (span <= 0.f) return 0.f;
+    v = fabsf(v);
+    const float extra = fmodf(v, span);
+    const int flips = (int)floorf(v / span);
+    v = (flips & 1) ? span - extra : extra;
+  }
+  return fminf(fmaxf(v, 0.f), (float)(n - 1));
+}
+
 __global__ __launch_bounds__(256) void warp_affine3d_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                             const float* __restrict__ Minv, int C, int D, int H, int W, int z0,
-                                                            int y0, int x0, int Do, int Ho, int Wo, int tiles_x, int nearest) {
+                                                            int y0, int x0, int Do, int Ho, int Wo, int tiles_x, int mode) {
+  const int nearest = mode & 1, pad = mode >> 1;
   const int b = blockIdx.z, oz = blockIdx.y;
   const int ty_ = blockIdx.x / tiles_x, tx_ = blockIdx.x - ty_ * tiles_x;
   const int ox = tx_ * 32 + (threadIdx.x & 31), oy = ty_ * 8 + (threadIdx.x >> 5);
   if (ox >= Wo || oy >= Ho) return;
   const float* m = Minv + (size_t)b * 12;
   const float fx_ = (float)(ox + x0), fy_ = (float)(oy + y0), fz_ = (float)(oz + z0);
-  const float sx = m[0] * fx_ + m[1] * fy_ + m[2] * fz_ + m[3];
-  const float sy = m[4] * fx_ + m[5] * fy_ + m[6] * fz_ + m[7];
-  const float sz = m[8] * fx_ + m[9] * fy_ + m[10] * fz_ + m[11];
+  float sx = m[0] * fx_ + m[1] * fy_ + m[2] * fz_ + m[3];
+  float sy = m[4] * fx_ + m[5] * fy_ + m[6] * fz_ + m[7];
+  float sz = m[8] * fx_ + m[9] * fy_ + m[10] * fz_ + m[11];
+  if (pad) {
+    sx = warp_pad_coord(sx, W, pad);
+    sy = warp_pad_coord(sy, H, pad);
+    sz = warp_pad_coord(sz, D, pad);
+  }
   const size_t vol = (size_t)D * H * W, ovol = (size_t)Do * Ho * Wo;
   const float* xb = x + (size_t)b * C * vol;
   float* yb = y + (size_t)b * C * ovol + ((size_t)oz * Ho + oy) * Wo + ox;
@@ -246,25 +302,26 @@ __global__ __launch_bounds__(256) void conv1d_axis_kernel(const float* __restric
 }
 
 /* K18 kornia warp_affine3d as used by BatchedRandAffined (viscy_transforms/_affine.py:33-47,358-393): trilinear (or
- * nearest) resampling with zero padding; Minv[B][3][4] = output-voxel → input-voxel coordinates (x, y, z order).
+ * nearest) resampling; Minv[B][3][4] = output-voxel → input-voxel coordinates (x, y, z order).
+ * mode: bit 0 = nearest; bits 1-2 = padding_mode (0 "zeros", 1 "border", 2 "reflection", _affine.py:102-108).
  * vsx_warp_affine3d_roi produces only the output window [z0,z0+Do) x [y0,y0+Ho) x [x0,x0+Wo) of the full (D,H,W) frame:
  * the warp fused with the BatchedCenterSpatialCrop that follows it in the recipes (_crop.py:164-187). */
 extern "C" int32_t vsx_warp_affine3d_roi(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D,
                                          int32_t H, int32_t W, int32_t z0, int32_t y0, int32_t x0, int32_t Do, int32_t Ho,
-                                         int32_t Wo, int32_t nearest, vsx_stream_t stream) {
-  VSX_CHECK(x && y && Minv && B > 0 && C > 0 && D > 0 && H > 0 && W > 0, "vsx_warp_affine3d: bad arguments");
+                                         int32_t Wo, int32_t mode, vsx_stream_t stream) {
+  VSX_CHECK(x && y && Minv && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 5, "vsx_warp_affine3d: bad arguments");
   VSX_CHECK(Do > 0 && Ho > 0 && Wo > 0 && z0 >= 0 && y0 >= 0 && x0 >= 0 && z0 + Do <= D && y0 + Ho <= H && x0 + Wo <= W,
             "vsx_warp_affine3d: output window (%d,%d,%d)+(%d,%d,%d) outside the (%d,%d,%d) frame", z0, y0, x0, Do, Ho, Wo, D, H, W);
   VSX_CHECK(B <= 65535 && Do <= 65535, "vsx_warp_affine3d: B and the output depth must be <= 65535");
   const int tiles_x = vsx_cdiv(Wo, 32), tiles_y = vsx_cdiv(Ho, 8);
   hipLaunchKernelGGL(warp_affine3d_kernel, dim3(tiles_x * tiles_y, Do, B), dim3(256), 0, (hipStream_t)stream, x, y, Minv, C, D, H, W,
-                     z0, y0, x0, Do, Ho, Wo, tiles_x, nearest);
+                     z0, y0, x0, Do, Ho, Wo, tiles_x, mode);
   VSX_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int32_t vsx_warp_affine3d(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,
-                                     int32_t W, int32_t nearest, vsx_stream_t stream) {
-  return vsx_warp_affine3d_roi(x, y, Minv, B, C, D, H, W, 0, 0, 0, D, H, W, nearest, stream);
+                                     int32_t W, int32_t mode, vsx_stream_t stream) {
+  return vsx_warp_affine3d_roi(x, y, Minv, B, C, D, H, W, 0, 0, 0, D, H, W, mode, stream);
 }
 /* K22 one pass of kornia filter3d's separable form as used by BatchedRandGaussianSmooth
  * (viscy_transforms/_gaussian_smooth.py:141-167): per-sample 1-D taps along the axis with element stride `stride`

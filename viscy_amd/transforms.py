@@ -120,14 +120,57 @@ class MinMaxSampled:
         return sample
 
 
+def _sample_mean_std(x: Tensor) -> tuple[Tensor, Tensor]:
+    """per-sample mean and unbiased std (``Tensor.mean()`` / ``Tensor.std()`` of MONAI's AdjustContrast) from one pass of
+    double sums (csrc/transforms.hip::sample_moments_kernel); (B,) float64 on the device."""
+    B, per = x.shape[0], x[0].numel()
+    sums = torch.zeros((B, 2), dtype=torch.float64, device=x.device)
+    check(lib().vsx_sample_moments(ptr(x), ptr(sums), B, per, stream()), "sample_moments")
+    mean = sums[:, 0] / per
+    var = (sums[:, 1] - per * mean * mean).clamp_min(0.0) / max(per - 1, 1)
+    return mean, var.sqrt()
+
+
 def intensity_augment(x: Tensor, *, gamma: Tensor | None = None, factor: Tensor | None = None,
-                      noise: Tensor | None = None, noise_std: Tensor | None = None, noise_mean: float = 0.0) -> Tensor:
+                      noise: Tensor | None = None, noise_std: Tensor | None = None, noise_mean: float = 0.0,
+                      invert_image: bool = False, retain_stats: bool = False, _invert: int | None = None) -> Tensor:
     """Fused contrast → scale → noise pass on a (B, ...) fp32 GPU batch (csrc/transforms.hip).
-    gamma[b] <= 0: no contrast change; factor[b] = 0: no scaling; noise_std[b] < 0: no noise."""
+    gamma[b] <= 0: no contrast change; factor[b] = 0: no scaling; noise_std[b] < 0: no noise.
+    ``factor`` may be (B,) or (B, C) (``channel_wise=True``: one factor per channel, _scale_intensity.py:46-55).
+    ``invert_image`` / ``retain_stats``: the options of MONAI's ``AdjustContrast`` (forwarded at _adjust_contrast.py:76-80):
+    the curve runs on -x and is negated back; mean and std of the (inverted) sample are restored after the curve."""
     if not _gpu_ok(x):
         raise RuntimeError("viscy_amd GPU augmentations need a contiguous float32 batch on the HIP device (no CPU fallback)")
     B, per = x.shape[0], x[0].numel()
     dev = x.device
+    if factor is not None and factor.ndim == 2:
+        # per-channel factors: the same pass over a (B*C, ...) view (contrast and noise are per sample: not combined with it)
+        if gamma is not None or noise is not None:
+            raise ValueError("per-channel factors go in a pass of their own")
+        if x.ndim < 3 or factor.shape not in ((B, x.shape[1]), (B, 1)):
+            raise RuntimeError(f"factors of shape {tuple(factor.shape)} do not broadcast over a batch of shape {tuple(x.shape)}")
+        f = factor.expand(B, x.shape[1]).reshape(-1)
+        return intensity_augment(x.view(B * x.shape[1], *x.shape[2:]), factor=f).view(x.shape)
+    if retain_stats and gamma is not None:
+        if factor is not None or noise is not None:
+            raise ValueError("retain_stats is an option of the contrast stage alone")
+        # MONAI: [invert] → mean / std → curve → (ret - mean(ret)) / (std(ret) + 1e-8) * std + mean → [invert back]
+        sel = gamma.to(dev) > 0
+        m0, s0 = _sample_mean_std(x)
+        if invert_image:
+            m0 = -m0
+        ret = intensity_augment(x, gamma=gamma, _invert=1 if invert_image else 0)
+        m1, s1 = _sample_mean_std(ret)
+        div = (s1 + 1e-8) / s0
+        sub = m1 - m0 * div
+        if invert_image:
+            div = -div
+        one, zero = torch.ones_like(div), torch.zeros_like(sub)
+        div_f = (torch.where(sel, div, one) - 1e-8).float()  # vsx_normalize divides by (div + 1e-8), NormalizeSampled's form
+        sub_f = torch.where(sel, sub, zero).float()
+        y = torch.empty_like(x)
+        check(lib().vsx_normalize(ptr(ret), ptr(y), ptr(sub_f), ptr(div_f), B, per, stream()), "normalize")
+        return y
     mn = mx = None
     if gamma is not None:
         mm = torch.empty(2, B, dtype=torch.float32, device=dev)
@@ -139,7 +182,8 @@ def intensity_augment(x: Tensor, *, gamma: Tensor | None = None, factor: Tensor 
     f32 = lambda t: None if t is None else t.to(dev, torch.float32).contiguous()  # noqa: E731
     g_d, f_d, n_d, s_d = f32(gamma), f32(factor), f32(noise), f32(noise_std)  # named: ptr() does not keep a tensor alive
     check(lib().vsx_intensity_aug(ptr(x), ptr(y), ptr(mn), ptr(mx), ptr(g_d), ptr(f_d), ptr(n_d), ptr(s_d),
-                                  float(noise_mean), B, per, stream()), "intensity_aug")
+                                  float(noise_mean), _invert if _invert is not None else (3 if invert_image else 0), B, per,
+                                  stream()), "intensity_aug")
     return y
 
 
@@ -159,17 +203,21 @@ class BatchedRandScaleIntensityd(_BatchedRand):
 
     def __init__(self, keys, factors=0.1, prob: float = 0.1, channel_wise: bool = False, allow_missing_keys: bool = False):
         super().__init__(keys, prob)
-        if channel_wise:
-            raise NotImplementedError("channel_wise scaling is not built")
+        self.channel_wise = channel_wise
         self.range = (-abs(factors), abs(factors)) if isinstance(factors, (int, float)) else (min(factors), max(factors))
 
-    def randomize(self, B: int) -> Tensor:
-        f = torch.empty(B).uniform_(*self.range, generator=self.generator)
-        f[~(self._rand(B) < self.prob)] = 0.0
+    def randomize(self, B: int, C: int | None = None) -> Tensor:
+        """the reference's draw order (_scale_intensity.py:42-50): selection first, then one factor per sample — or, with
+        ``channel_wise``, per (sample, channel) of the FIRST key; unselected samples get 0"""
+        do = self._rand(B) < self.prob
+        shape = (B, C) if self.channel_wise and C is not None else (B,)
+        f = torch.empty(shape).uniform_(*self.range, generator=self.generator)
+        f[~do] = 0.0
         return f
 
     def __call__(self, sample: dict, params: Tensor | None = None) -> dict:
-        f = params if params is not None else self.randomize(sample[self.keys[0]].shape[0])
+        first = sample[self.keys[0]]
+        f = params if params is not None else self.randomize(first.shape[0], first.shape[1] if first.ndim > 2 else None)
         for k in self.keys:
             sample[k] = intensity_augment(sample[k], factor=f)
         return sample
@@ -181,8 +229,7 @@ class BatchedRandAdjustContrastd(_BatchedRand):
     def __init__(self, keys, gamma=(0.5, 4.5), prob: float = 0.1, invert_image: bool = False, retain_stats: bool = False,
                  allow_missing_keys: bool = False):
         super().__init__(keys, prob)
-        if invert_image or retain_stats:
-            raise NotImplementedError("invert_image / retain_stats are not built")
+        self.invert_image, self.retain_stats = invert_image, retain_stats
         self.gamma_range = (gamma, gamma) if isinstance(gamma, (int, float)) else (min(gamma), max(gamma))
         if self.gamma_range[0] <= 0.0:
             raise ValueError("Gamma must be a positive value.")
@@ -195,7 +242,7 @@ class BatchedRandAdjustContrastd(_BatchedRand):
     def __call__(self, sample: dict, params: Tensor | None = None) -> dict:
         g = params if params is not None else self.randomize(sample[self.keys[0]].shape[0])
         for k in self.keys:
-            sample[k] = intensity_augment(sample[k], gamma=g)
+            sample[k] = intensity_augment(sample[k], gamma=g, invert_image=self.invert_image, retain_stats=self.retain_stats)
         return sample
 
 
@@ -349,17 +396,23 @@ def _center_window(shape, roi_size):
     return tuple((d - s) // 2 for d, s in zip(dims, size)) + tuple(size)
 
 
-def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear", window=None) -> Tensor:
-    """resample (B,C,D,H,W) with the output→input voxel matrices Minv (B,3,4), zero padding (csrc/transforms.hip).
+_PADDING_MODES = {"zeros": 0, "border": 1, "reflection": 2}
+
+
+def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear", window=None, padding_mode: str = "zeros") -> Tensor:
+    """resample (B,C,D,H,W) with the output→input voxel matrices Minv (B,3,4) (csrc/transforms.hip); ``padding_mode`` as in
+    the reference (_affine.py:102-108): "zeros", "border" (edge voxels replicated) or "reflection".
     ``window = (z0, y0, x0, Do, Ho, Wo)`` produces only that region of the output frame (warp + crop in one pass)."""
+    if padding_mode not in _PADDING_MODES:
+        raise ValueError(f"padding_mode must be one of {sorted(_PADDING_MODES)}, got {padding_mode!r}")
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 5):
         raise RuntimeError("viscy_amd GPU augmentations need a contiguous float32 (B,C,Z,Y,X) batch on the HIP device (no CPU fallback)")
     B, C, D, H, W = x.shape
     m = Minv.to(x.device, torch.float32).contiguous()
     z0, y0, x0, Do, Ho, Wo = window if window is not None else (0, 0, 0, D, H, W)
     y = torch.empty((B, C, Do, Ho, Wo), dtype=torch.float32, device=x.device)
-    check(lib().vsx_warp_affine3d_roi(ptr(x), ptr(y), ptr(m), B, C, D, H, W, z0, y0, x0, Do, Ho, Wo, int(mode == "nearest"),
-                                      stream()), "warp_affine3d")
+    check(lib().vsx_warp_affine3d_roi(ptr(x), ptr(y), ptr(m), B, C, D, H, W, z0, y0, x0, Do, Ho, Wo,
+                                      int(mode == "nearest") | (_PADDING_MODES[padding_mode] << 1), stream()), "warp_affine3d")
     return y
 
 
@@ -411,7 +464,7 @@ def kornia_affine_matrix3d(angles_xyz_deg: Tensor, scale_xyz: Tensor, shears_deg
 
 class BatchedRandAffined(_BatchedRand):
     """``viscy_transforms.BatchedRandAffined`` (_affine.py:107-393): one random 3-D affine per sample, the same matrix for
-    every key, trilinear resampling with zero padding (``vsx_warp_affine3d``).  Arguments as in the reference:
+    every key, trilinear resampling with zero / border / reflection padding (``vsx_warp_affine3d``).  Arguments as in the reference:
 
     * ``rotate_range`` — radians per axis in (Z, Y, X) order, a value ``v`` meaning ``(-v, v)`` (or explicit ``(lo, hi)``);
     * ``shear_range`` — degrees: ``(min, max)`` for all six facets, six ``(min, max)`` pairs, or MONAI's three-value
@@ -431,9 +484,9 @@ class BatchedRandAffined(_BatchedRand):
                  isotropic_scale: bool = False, scale_z_shear: bool = True, mode: str = "bilinear", padding_mode: str = "zeros",
                  safe_crop_size=None, safe_crop_coverage: float = 1.0, allow_missing_keys: bool = False):
         super().__init__(keys, prob)
-        if padding_mode != "zeros":
-            raise NotImplementedError("only zero padding is built")
-        self.mode = mode
+        if padding_mode not in _PADDING_MODES:
+            raise ValueError(f"padding_mode must be one of {sorted(_PADDING_MODES)}, got {padding_mode!r}")
+        self.mode, self.padding_mode = mode, padding_mode
 
         def pairs(v, n):  # per-axis (Z, Y, X) values -> kornia (X, Y, Z) list of (lo, hi)
             if v is None:
@@ -528,7 +581,7 @@ class BatchedRandAffined(_BatchedRand):
         for k in self.keys:
             if k in sample:
                 win = _center_window(sample[k].shape, crop_roi_size) if crop_roi_size is not None else None
-                sample[k] = warp_affine3d(sample[k], Minv, self.mode, win)
+                sample[k] = warp_affine3d(sample[k], Minv, self.mode, win, self.padding_mode)
         return sample
 
 
