@@ -90,7 +90,7 @@ def nonzero_grn_(model, seed=1):
 # tools/pmc_traffic.py) — so that the live table, the kernel-stats CSV and the PMC traffic file can be laid side by side.
 OP_FAMILY = {
     "mlp_stats": "mlp_fused", "mlp_out": "mlp_fused", "mlp_fc1": "mlp_fused", "mlp_fc1_ln": "mlp_fused", "mlp_bwd_stats": "mlp_fused",
-    "mlp_bwd_dh": "mlp_fused", "mlp_bwd_dh_re": "mlp_fused",
+    "mlp_bwd_dh": "mlp_fused", "mlp_bwd_dh_re": "mlp_fused", "mlp_bwd_dh_ln": "mlp_fused",
     "dwconv7_fwd": "dwconv7", "dwconv7_bwd_data": "dwconv7", "dwconv7_bwd_weight": "dwconv7", "dwconv7_bwd": "dwconv7",
     "head_shuffle_fwd": "head", "head_shuffle_bwd": "head", "head_out_fwd": "head", "head_out_bwd1": "head", "head_out_bwd1_wgrad": "head",
     "head_out_bwd2": "head", "head_conv_fwd": "head", "head_conv_wgrad": "head", "head_conv_dgrad": "head", "head_conv_dgrad_prep": "head",
@@ -163,7 +163,7 @@ class OpTimer:
             elif cls == "mlp_fused":  # fused GRN-MLP passes: one (two for the output pass) M x 4C x C contraction(s)
                 ba = sig.bind(*a, **k).arguments
                 Mm, Cc = ba["M"], ba["C"]
-                flops = 2.0 * Mm * 4 * Cc * Cc * (2 if name in ("mlp_out", "mlp_bwd_dh_re") else 1)
+                flops = 2.0 * Mm * 4 * Cc * Cc * (2 if name in ("mlp_out", "mlp_bwd_dh_re", "mlp_bwd_dh_ln") else 1)
             if self.only is not None and not is_gemm and cls != self.only:
                 return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

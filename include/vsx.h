@@ -67,7 +67,9 @@ int32_t vsx_get_flag(const char* name);
                                 * the backward of an affine-free LayerNorm over the N columns applied to the GEMM result (fc1 data
                                 * gradient + block LayerNorm backward in one launch).  aux = xh [M, ldx] (the normalised rows),
                                 * grn_s = rstd [M] (fp32).  bf16, plain row operands, N <= 256, M % 256 == 0, K % 32 == 0 only
-                                * (vsx_gemm_nt_ln_bwd_supported). */
+                                * (vsx_gemm_nt_ln_bwd_supported).  With grn_b = mean [M] non-NULL: aux holds the UN-normalised rows y
+                                * (xh = bf16((y - mean) * rstd) is re-formed in the epilogue) and A is expected row-scaled by rstd
+                                * (vsx_mlp_bwd_dh_ln), so c = d - mean_n(d) - xh * mean_n(d * xh) without the leading factor. */
 
 typedef struct VsxGemm {
   /* C[M, N] = pro(A)[M, K] * B[N, K]^T  (vsx_gemm_nt)   |   W[N, K] += X[M, N]^T * pro(A)[M, K]  (vsx_gemm_tn) */
@@ -319,17 +321,18 @@ int32_t vsx_adamw(float* p, const float* g, float* m, float* v, const float* hyp
  *   vsx_mlp_fwd mode 0: colsq[b, 4C] += sum_hw gelu(fc1(xh))^2   (GRN statistics; nothing else is stored)
  *               mode 1: out = res + rscale[b] * (fc2(gelu(fc1(xh)) * s[b] + beta) + b2) */
 int32_t vsx_mlp_supported(int32_t C, int32_t hw, int64_t M, int32_t dtype);   /* the inference pair (modes 0 and 1) */
-int32_t vsx_mlp_mode_supported(int32_t C, int32_t hw, int64_t M, int32_t mode, int32_t dtype);  /* one pass (mode 0..6) */
+int32_t vsx_mlp_mode_supported(int32_t C, int32_t hw, int64_t M, int32_t mode, int32_t dtype);  /* one pass (mode 0..7) */
 int64_t vsx_mlp_image_bytes(int32_t C);
 int32_t vsx_mlp_pack(const void* W1, const void* W2, void* img, int32_t C, vsx_stream_t stream);
 /* vsx_mlp_fwd / vsx_mlp_fc1 with the block LayerNorm (eps, no affine) applied in the kernel's prologue: y = the UN-normalised
  * rows (output of the depthwise convolution).  Modes 0 / 1: the normalised rows never exist in memory; vsx_mlp_fc1_ln also
- * writes them (xh_out [M, C]) and rstd_out [M] for the backward.  Replaces vsx_ln_fwd + vsx_mlp_fwd / vsx_mlp_fc1. */
+ * writes them (xh_out [M, C]) and rstd_out [M] for the backward — or, with xh_out = NULL and mean_out [M] non-NULL, only the
+ * two row statistics (the backward then re-normalises y: vsx_mlp_bwd_dh_ln).  Replaces vsx_ln_fwd + vsx_mlp_fwd / vsx_mlp_fc1. */
 int32_t vsx_mlp_fwd_ln(const void* y, float eps, const void* wimg, const float* b1, const float* grn_s, const float* grn_b,
     const float* b2, const void* res, const float* rscale, void* out, float* colsq, const float* gtab, int64_t M, int32_t C,
     int32_t hw, int32_t mode, int32_t dtype, vsx_stream_t stream);
-int32_t vsx_mlp_fc1_ln(const void* y, float eps, void* xh_out, float* rstd_out, const void* wimg, const float* b1, float* colsq,
-    const float* gtab, void* h, void* g, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
+int32_t vsx_mlp_fc1_ln(const void* y, float eps, void* xh_out, float* rstd_out, float* mean_out, const void* wimg, const float* b1,
+    float* colsq, const float* gtab, void* h, void* g, int64_t M, int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
 int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1, const float* grn_s, const float* grn_b, const float* b2,
     const void* res, const float* rscale, void* out, float* colsq, const float* gelu_table, int64_t M, int32_t C, int32_t hw,
     int32_t mode, int32_t dtype, vsx_stream_t stream);
@@ -368,6 +371,20 @@ int32_t vsx_mlp_rows_per_workgroup(int32_t C, int32_t hw, int64_t M);
 int32_t vsx_mlp_bwd_dh_re(const void* dout, const void* xh, const void* wimg_bwd, const void* wimg_fwd, const float* b1, const float* s,
                           const float* t, void* dh, float* ws, int64_t ws_rows, float* colsum, const float* gelu_table, int64_t M,
                           int32_t C, int32_t hw, int32_t dtype, vsx_stream_t stream);
+/* vsx_mlp_bwd_dh_re for a block whose forward stored NO normalised rows (csrc/mlp.hip MODE 7; vsx_mlp_fc1_ln with xh_out = NULL):
+ * y [M, C] = the LayerNorm input (depthwise output), mean / rstd [M] = its row statistics; x^ = bf16((y - mean) * rstd) is re-formed
+ * on chip as the forward formed it.  The pass writes dh' = dh * rstd (row-scaled) — what the consumers want once they read y, too:
+ *   fc1 weight gradient  dh^T . x^ = dh'^T . y - u (x) 1  with u[j] = sum_r dh'[r, j] * mean[r]   (plain vsx_gemm_tn on y; then
+ *                        vsx_unprep_grad(.., rowsub = u))
+ *   LayerNorm backward   dy = dx' - mean_c(dx') - x^ * mean_c(dx' * x^), dx' = dh' . W1'   (vsx_gemm_nt VSX_EPI_LN_BWD with
+ *                        aux = y, grn_s = rstd, grn_b = mean: the trailing "* rstd" is already in dx')
+ * colsum2 [2, 4C] += { sum_r dh[r, j] (the fc1 bias gradient), u[j] }; ws [ws_rows >= M / vsx_mlp_rows_per_workgroup, 2 * 4C].
+ * Available where vsx_mlp_mode_supported(.., 7, ..) (C <= 224, `mlp_fused` bits 5, 6 and 7).  Reference math: the LayerNorm
+ * -> Linear pair of timm's ConvNeXtBlock (norm, mlp.fc1) as restated in viscy_models/unet/fcmae.py:174-221. */
+int32_t vsx_mlp_bwd_dh_ln(const void* dout, const void* y, const float* mean, const float* rstd, const void* wimg_bwd,
+                          const void* wimg_fwd, const float* b1, const float* s, const float* t, void* dh, float* ws, int64_t ws_rows,
+                          float* colsum2, const float* gelu_table, int64_t M, int32_t C, int32_t hw, int32_t dtype,
+                          vsx_stream_t stream);
 /* GELU of a bf16 value through a table (csrc/mlp.hip): vsx_mlp_gelu_table fills `tab` (vsx_mlp_gelu_table_len() = 2 N floats)
  * with r(a) = a * Phi(-a) (first N) and d(a) = Phi(a) + a * phi(a) - 1/2 (second N) for every bf16 magnitude a in [2^-24, 16):
  * gelu(h) = max(h, 0) - r(|h|), gelu'(h) = 1/2 + sign(h) * d(|h|).  The forward passes read the first half, the dh passes both. */
@@ -390,9 +407,12 @@ int32_t vsx_fill_f32(float* p, int64_t n, float value, vsx_stream_t stream);
 int32_t vsx_prep_weight(const float* src, void* dst, void* dstT, const float* gamma, int32_t R, int32_t Cs,
     int32_t Tn, int32_t tapmode, int32_t dtype, vsx_stream_t stream);
 
-/* inverse of vsx_prep_weight for gradients: dparam[r][c][t] += g[r][k]*gamma[c] + u[r]*beta[c]; dgamma[c] += Σ g*W. */
+/* inverse of vsx_prep_weight for gradients: dparam[r][c][t] += g'[r][k]*gamma[c] + u[r]*beta[c]; dgamma[c] += Σ g'*W, with
+ * g'[r][k] = g[r][k] - rowsub[r] (rowsub may be NULL: the rank-1 term of a weight gradient that was contracted with un-centred
+ * rows, see vsx_mlp_bwd_dh_ln). */
 int32_t vsx_unprep_grad(const float* g, float* dparam, const float* gamma, const float* W, float* dgamma,
-    const float* u, const float* beta, int32_t R, int32_t Cs, int32_t Tn, int32_t tapmode, vsx_stream_t stream);
+    const float* u, const float* beta, const float* rowsub, int32_t R, int32_t Cs, int32_t Tn, int32_t tapmode,
+    vsx_stream_t stream);
 
 /* fold of the GRN affine into the fc2 weights (timm GlobalResponseNorm inside GlobalResponseNormMlp, between act and fc2):
  * out[b][r][k] = dtype(W[r][k] * s[b][k]) for b < B; W fp32 [R][K], s fp32 [B][K].  Pairs with VsxGemm.b_bstride = R*K. */
@@ -421,10 +441,10 @@ int32_t vsx_transpose_f32(const float* src, float* dst, int32_t A, int32_t Bn, i
 #define VSX_WTASK_TRANSPOSE 1
 #define VSX_WTASK_MATVEC 2
 #define VSX_WTASK_MLP_PACK 3
-#define VSX_WTASK_UNPREP 4    /* vsx_unprep_grad: p0 g, p1 dparam, p3 gamma, p4 W, p2 dgamma, p5 u, p6 beta, i0 R, i1 Cs, i2 Tn, i3 tapmode */
+#define VSX_WTASK_UNPREP 4    /* vsx_unprep_grad: p0 g, p1 dparam, p3 gamma, p4 W, p2 dgamma, p5 u, p6 beta, p7 rowsub, i0 R, i1 Cs, i2 Tn, i3 tapmode */
 #define VSX_WTASK_MATVEC_T 5  /* vsx_matvec_t_add: p0 W, p3 u, p1 out, i0 R, i1 C */
 #define VSX_WTASK_REDUCE_ROWS 6  /* p1 out[n] += sum_r p0 ws[r][n], i0 rows, i1 columns */
-#define VSX_WTASK_MAX 48
+#define VSX_WTASK_MAX 40
 typedef struct VsxWTask {
   int32_t kind, dtype, i0, i1, i2, i3;
   const void* p0;
@@ -434,6 +454,7 @@ typedef struct VsxWTask {
   const void* p4;
   const void* p5;
   const void* p6;
+  const void* p7;
 } VsxWTask;
 int32_t vsx_weight_tasks(const VsxWTask* tasks, int32_t n, vsx_stream_t stream);
 

@@ -361,8 +361,10 @@ def prep_weight(src, R, Cs, Tn, dtype, *, want=True, want_t=False, gamma=None, t
     return (dst if want else None), (dst.t().contiguous() if want_t else None)
 
 
-def unprep_grad(g, dparam, R, Cs, Tn, *, gamma=None, W=None, dgamma=None, u=None, beta=None, tapmode=0):
+def unprep_grad(g, dparam, R, Cs, Tn, *, gamma=None, W=None, dgamma=None, u=None, beta=None, rowsub=None, tapmode=0):
     perm = torch.tensor([_tap_dst(t, tapmode) for t in range(Tn)])
+    if rowsub is not None:
+        g = g - rowsub.view(R, 1)
     gp = g.view(R, Tn, Cs)[:, perm, :].permute(0, 2, 1)  # [R, Cs, Tn] in parameter order
     if gamma is not None:
         dgamma += (gp * W.detach().reshape(R, Cs, Tn)).sum((0, 2))

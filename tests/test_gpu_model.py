@@ -454,6 +454,23 @@ def test_baseline_size_fp32_and_bf16_engines_vs_reference_golden():
     for gname, (omc, rel) in stages.items():
         assert omc <= 1.25 * ys[gname][0], (gname, omc, ys[gname])
         assert rel <= 1.25 * ys[gname][1], (gname, rel, ys[gname])
+    # the block schedules behind the other values of `mlp_fused` are held to the same yardstick: 111 = the normalised rows x^
+    # are stored (MODE 6 / 5; the default 239 re-forms them from the depthwise output, MODE 7), 47 = the pre-activation h is
+    # stored as well (MODE 2 / 4), 15 = LayerNorm as a pass of its own
+    from viscy_amd import _lib as L
+
+    saved = L.lib().vsx_get_flag(b"mlp_fused")
+    assert saved & 128, "the shipped schedule does not store the normalised rows"
+    try:
+        for flag in (111, 47, 15):
+            L.lib().vsx_set_flag(b"mlp_fused", flag)
+            fwd, lrel, stages = run_engine(torch.bfloat16)
+            print(f"bf16 engine @256, mlp_fused = {flag}: forward {fwd:.2e} loss {lrel:.2e}", {k: f"{v[0]:.1e}" for k, v in stages.items()})
+            assert fwd <= 1.25 * yf and lrel <= max(1.25 * yl, 1e-3)
+            for gname, (omc, rel) in stages.items():
+                assert omc <= 1.25 * ys[gname][0] and rel <= 1.25 * ys[gname][1], (flag, gname, omc, rel, ys[gname])
+    finally:
+        L.lib().vsx_set_flag(b"mlp_fused", saved)
 
 
 def test_gate_shape_fp32_and_bf16_engines_vs_reference_golden():

@@ -1308,6 +1308,86 @@ def test_fused_block_without_a_stored_preactivation(C, hw, B, ln_in):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,hw,B,offset", [(96, 4096, 3, 0.0), (192, 1024, 5, 3.0), (224, 4096, 2, 8.0), (96, 256, 8, 30.0)])
+def test_fused_block_without_stored_normalised_rows(C, hw, B, offset):
+    """`mlp_fused` bit 7: the block LayerNorm's output x^ is never stored.  Forward (MODE 6 with xh_out = NULL) keeps y + row mean /
+    rstd; the dh pass (MODE 7, vsx_mlp_bwd_dh_ln) re-forms x^ = bf16((y - mean) * rstd) on chip and writes dh' = dh * rstd; the fc1
+    weight gradient is dh'^T . y - u (x) 1 (plain TN GEMM on y + vsx_unprep_grad(rowsub = u)); the data gradient's LayerNorm
+    epilogue re-forms x^ from y and drops its trailing rstd.  Every piece against the x^-storing path (MODE 6 / 5) AND against
+    fp64 statements of LayerNorm -> Linear backward (timm ConvNeXtBlock.norm / .mlp.fc1, viscy_models/unet/fcmae.py:174-221); rows
+    with a DC offset of up to 30 sigma (the rank-1 term u then dwarfs the gradient it is subtracted from)."""
+    if SELF_CHECK:
+        pytest.skip("HIP-only kernel")
+    from viscy_amd import _lib as L
+    from viscy_amd import ops
+
+    dt = torch.bfloat16
+    M, H4 = B * hw, 4 * C
+    saved = L.lib().vsx_get_flag(b"mlp_fused")
+    L.lib().vsx_set_flag(b"mlp_fused", 255)
+    try:
+        assert ops.mlp_supported(C, hw, M, dt, 7)
+        y = (rnd(M, C, seed=11, scale=2.0) + offset * rnd(M, 1, seed=21)).to(dt).cuda()
+        W1 = rnd(H4, C, dt=dt, seed=12, scale=C ** -0.5).cuda()
+        W2 = rnd(C, H4, dt=dt, seed=13, scale=H4 ** -0.5).cuda()
+        W2T, W1T = W2.t().contiguous(), W1.t().contiguous()
+        b1 = (0.1 * rnd(H4, seed=14)).cuda()
+        dout = rnd(M, C, dt=dt, seed=15).cuda()
+        s = (1 + 0.2 * rnd(B, H4, seed=16)).cuda()
+        t = (0.05 * rnd(B, H4, seed=17)).cuda()
+        img, img2 = ops.mlp_pack(W1, W2, C), ops.mlp_pack(W2T, W2, C)
+        # ---- forward: same g / rstd / GRN sums, no x^; the mean is the row mean
+        q6, q7 = torch.zeros((B, H4), device="cuda"), torch.zeros((B, H4), device="cuda")
+        xh6, r6, h6, g6 = ops.mlp_fc1_ln(y, img, b1, q6, M, C, hw, 1e-6, store_h=False)
+        (y7, mean7), r7, h7, g7 = ops.mlp_fc1_ln(y, img, b1, q7, M, C, hw, 1e-6, store_h=False, store_xh=False)
+        assert h6 is None and h7 is None and y7 is y and torch.equal(g6, g7) and torch.equal(r6, r7)
+        close(q7, q6, torch.float32, "GRN sums")
+        torch.testing.assert_close(mean7, y.float().mean(1), rtol=1e-5, atol=1e-5)
+        # ---- dh pass: dh' = dh * rstd (rounded once, after the scaling), bias gradient, u
+        db5, cs2 = torch.zeros(H4, device="cuda"), torch.zeros((2, H4), device="cuda")
+        dh5 = ops.mlp_bwd_dh_re(dout, xh6, img2, img, b1, s, t, db5, M, C, hw)
+        dh7 = ops.mlp_bwd_dh_ln(dout, y, mean7, r7, img2, img, b1, s, t, cs2, M, C, hw)
+        want = dh5.float() * r7[:, None]
+        err = (dh7.float() - want).abs()
+        assert (err <= 2.0 ** -7 * want.abs() + 1e-30).all(), (err / want.abs().clamp_min(1e-30)).max().item()
+        sc_db = dh5.float().abs().sum(0).max().item()
+        close(cs2[0], db5, torch.float32, "fc1 bias gradient from the scaled tile", scale=sc_db * 2.0 ** -8 / tol(torch.float32) * 4 / M ** 0.5 + db5.abs().max().item())
+        u64 = (dh7.double() * mean7.double()[:, None]).sum(0)
+        scale_u = (dh7.double().abs() * mean7.double().abs()[:, None]).sum(0).max().item()
+        assert (cs2[1].double() - u64).abs().max().item() <= 3e-5 * scale_u + 1e-6, ((cs2[1].double() - u64).abs().max().item(), scale_u)
+        # ---- data gradient with the LayerNorm backward in its epilogue
+        dy5 = ops.dgrad_ln_bwd(dh5, W1T, xh6, r6, M, C, H4)
+        dy7 = ops.dgrad_ln_bwd(dh7, W1T, y, r7, M, C, H4, mean=mean7)
+        assert dy5 is not None and dy7 is not None
+        dx = dh5.double() @ W1.double()
+        xh = xh6.double()
+        ref = r6.double()[:, None] * (dx - dx.mean(1, keepdim=True) - xh * (dx * xh).mean(1, keepdim=True))
+        close(dy5, ref, dt, "dy (stored x^) vs fp64 statement")
+        close(dy7, ref, dt, "dy (x^ re-formed from y) vs fp64 statement")
+        # ---- fc1 weight gradient and its unfold (dW1 = dW1f . diag(gamma) + db1f (x) beta, dgamma = sum dW1f * W1)
+        gam, bet = (1 + 0.3 * rnd(C, seed=31)).cuda(), (0.2 * rnd(C, seed=32)).cuda()
+        Wp = rnd(H4, C, seed=33, scale=C ** -0.5).cuda()
+        T5, T7 = torch.zeros((H4, C), device="cuda"), torch.zeros((H4, C), device="cuda")
+        ops.gemm("tn", xh6, dh5, T5, M, H4, C, C, H4, C, dtype=dt)
+        ops.gemm("tn", y, dh7, T7, M, H4, C, C, H4, C, dtype=dt)
+        true = dh5.double().t() @ xh
+        close(T5, true, dt, "dW1f (stored x^) vs fp64", scale=true.abs().max().item())
+        close(T7 - cs2[1][:, None], true, dt, "dW1f = dh'^T y - u (x) 1 vs fp64", scale=true.abs().max().item())
+        outs = []
+        for T, db, rs in ((T5, db5, None), (T7, cs2[0], cs2[1])):
+            dW, dg = torch.zeros((H4, C), device="cuda"), torch.zeros(C, device="cuda")
+            ops.unprep_grad(T, dW, H4, C, 1, gamma=gam, W=Wp, dgamma=dg, u=db, beta=bet, rowsub=rs)
+            outs.append((dW, dg))
+        Tc = (T7 - cs2[1][:, None]).double()
+        close(outs[1][0], Tc * gam.double() + cs2[0].double()[:, None] * bet.double(), torch.float32, "unfold with rowsub: dW1")
+        close(outs[1][1], (Tc * Wp.double()).sum(0), torch.float32, "unfold with rowsub: dgamma")
+        close(outs[1][0], outs[0][0], dt, "dW1: x^-free path vs stored-x^ path")
+        close(outs[1][1], outs[0][1], dt, "dgamma: x^-free path vs stored-x^ path", scale=outs[0][1].abs().max().item() + true.abs().max().item())
+    finally:
+        L.lib().vsx_set_flag(b"mlp_fused", saved)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C,hw,B", [(192, 1024, 128), (224, 4096, 64)])
 def test_fused_passes_with_two_workgroups_per_cu(C, hw, B):
     """Regression test of a race that only large launches show (round 4): the fused GRN-MLP kernels refilled stage buffer 1 by

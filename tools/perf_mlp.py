@@ -12,7 +12,7 @@ from viscy_amd import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 SHAPES = [(96, 4096, 3), (192, 1024, 5), (224, 4096, 2)]  # C, hw per patch, blocks per forward (C = 384: training passes only, tools/perf_mlp_train.py)
-L.lib().vsx_set_flag(b"mlp_fused", 127)
+L.lib().vsx_set_flag(b"mlp_fused", 255)
 dt = torch.bfloat16
 
 

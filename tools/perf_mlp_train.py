@@ -12,7 +12,7 @@ from viscy_amd import ops  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 SHAPES = [(96, 4096), (192, 1024), (224, 4096)]
-L.lib().vsx_set_flag(b"mlp_fused", 127)
+L.lib().vsx_set_flag(b"mlp_fused", 255)
 dt = torch.bfloat16
 
 
@@ -49,4 +49,8 @@ for C, hw in SHAPES:
     r["m6 g"] = (timeit(lambda: ops.mlp_fc1_ln(y, img, b1, colsq, M, C, hw, 1e-6, store_h=False)), 2 * cw + hwd)
     r["m4 dh(h)"] = (timeit(lambda: ops.mlp_bwd_dh(dout, img2, h, s, t, db, M, C, hw)), cw + 2 * hwd)
     r["m5 dh(re)"] = (timeit(lambda: ops.mlp_bwd_dh_re(dout, xh, img2, img, b1, s, t, db, M, C, hw)), 2 * cw + hwd)
+    (_, mean), rstd, _, _ = ops.mlp_fc1_ln(y, img, b1, colsq, M, C, hw, 1e-6, store_h=False, store_xh=False)
+    cs2 = torch.zeros((2, H4), device="cuda")
+    r["m6 g, no x^"] = (timeit(lambda: ops.mlp_fc1_ln(y, img, b1, colsq, M, C, hw, 1e-6, store_h=False, store_xh=False)), cw + hwd)
+    r["m7 dh(ln)"] = (timeit(lambda: ops.mlp_bwd_dh_ln(dout, y, mean, rstd, img2, img, b1, s, t, cs2, M, C, hw)), 2 * cw + hwd)
     print(f"C={C:4d} hw={hw:5d} M={M:8d}: " + " | ".join(f"{k} {us:7.1f} us {kb / us:6.0f} GB/s" for k, (us, kb) in r.items()), flush=True)

@@ -1,7 +1,7 @@
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from viscy_amd import _lib as L, ops
-L.lib().vsx_set_flag(b"mlp_fused", 127)
+L.lib().vsx_set_flag(b"mlp_fused", 255)
 dt = torch.bfloat16
 for C, hw, B in [(96, 4096, 64), (192, 1024, 128), (224, 4096, 64), (96, 262144, 1)]:
     M, H4 = B * hw, 4 * C

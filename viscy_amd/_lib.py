@@ -47,7 +47,7 @@ class VsxGemm(C.Structure):
 class VsxWTask(C.Structure):
     """one job of vsx_weight_tasks (include/vsx.h)"""
     _fields_ = [("kind", _I32), ("dtype", _I32), ("i0", _I32), ("i1", _I32), ("i2", _I32), ("i3", _I32),
-                ("p0", _P), ("p1", _P), ("p2", _P), ("p3", _P), ("p4", _P), ("p5", _P), ("p6", _P)]
+                ("p0", _P), ("p1", _P), ("p2", _P), ("p3", _P), ("p4", _P), ("p5", _P), ("p6", _P), ("p7", _P)]
 
 
 WTASK_PREP, WTASK_TRANSPOSE, WTASK_MATVEC, WTASK_MLP_PACK, WTASK_UNPREP, WTASK_MATVEC_T, WTASK_REDUCE_ROWS = 0, 1, 2, 3, 4, 5, 6
@@ -101,17 +101,18 @@ _SIGS = {
     "vsx_mlp_fwd": (_I32, [_P] * 11 + [_I64, _I32, _I32, _I32, _I32, _P]),
     "vsx_mlp_fc1": (_I32, [_P] * 7 + [_I64, _I32, _I32, _I32, _P]),
     "vsx_mlp_fwd_ln": (_I32, [_P, _F32] + [_P] * 10 + [_I64, _I32, _I32, _I32, _I32, _P]),
-    "vsx_mlp_fc1_ln": (_I32, [_P, _F32] + [_P] * 8 + [_I64, _I32, _I32, _I32, _P]),
+    "vsx_mlp_fc1_ln": (_I32, [_P, _F32] + [_P] * 9 + [_I64, _I32, _I32, _I32, _P]),
     "vsx_grn_q_reduce": (_I32, [_P] * 10 + [_I64, _I32, _I32, _I32, _P]),
     "vsx_grn_q_reduce_ws_floats": (_I64, [_I32, _I32]),
     "vsx_mlp_bwd_stats": (_I32, [_P] * 5 + [_I64, _I32, _I32, _I32, _P]),
     "vsx_mlp_bwd_dh": (_I32, [_P] * 7 + [_I64, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "vsx_mlp_rows_per_workgroup": (_I32, [_I32, _I32, _I64]),
     "vsx_mlp_bwd_dh_re": (_I32, [_P] * 9 + [_I64, _P, _P, _I64, _I32, _I32, _I32, _P]),
+    "vsx_mlp_bwd_dh_ln": (_I32, [_P] * 11 + [_I64, _P, _P, _I64, _I32, _I32, _I32, _P]),
     "vsx_mlp_gelu_table_len": (_I32, []),
     "vsx_mlp_gelu_table": (_I32, [_P, _P]),
     "vsx_prep_weight": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
-    "vsx_unprep_grad": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "vsx_unprep_grad": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vsx_matvec": (_I32, [_P, _P, _P, _P, _I32, _I32, _P]),
     "vsx_matvec_t_add": (_I32, [_P, _P, _P, _I32, _I32, _P]),
     "vsx_transpose_f32": (_I32, [_P, _P, _I32, _I32, _I32, _P]),

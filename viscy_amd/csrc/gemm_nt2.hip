@@ -423,6 +423,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
   const float invC = 1.f / (float)p.N;
   const bf16_t* XH = reinterpret_cast<const bf16_t*>(p.aux);
   bf16_t* DY = reinterpret_cast<bf16_t*>(p.C);
+  // grn_b = the row means: `aux` then holds the UN-normalised rows y (x^ was never stored; it is re-formed here with the forward's
+  // expression), and the A operand is dh * rstd, so the accumulator already is rstd * dx^ (csrc/mlp.hip MODE 7)
+  const float* MEAN = p.grn_b;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     float v[NCG][2][8];
@@ -447,6 +450,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
         xq[cg][h] = ok ? ldvec<bf16_t>(XH + (size_t)m * p.ldx + n) : make_uint4(0u, 0u, 0u, 0u);
         float xf[8];
         unpack<bf16_t>(xq[cg][h], xf);
+        if (MEAN && ok) {
+          const float mu = MEAN[m], rsd = p.grn_s[m];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xf[e] = (xf[e] - mu) * rsd;
+          xq[cg][h] = pack<bf16_t>(xf);
+          unpack<bf16_t>(xq[cg][h], xf);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float d = ok ? round_bf16(t[e]) : 0.f;   // dx^ as the unfused pair stored it
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
       s1[h] += __shfl_xor(s1[h], 1, 64); s1[h] += __shfl_xor(s1[h], 2, 64); s1[h] += __shfl_xor(s1[h], 4, 64);
       s2[h] += __shfl_xor(s2[h], 1, 64); s2[h] += __shfl_xor(s2[h], 2, 64); s2[h] += __shfl_xor(s2[h], 4, 64);
       const int m = m0 + wave * 32 + i * 16 + er + 8 * h;
-      const float rs = p.grn_s[m];
+      const float rs = MEAN ? 1.f : p.grn_s[m];
       const float m1 = s1[h] * invC, m2 = s2[h] * invC;
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg) {

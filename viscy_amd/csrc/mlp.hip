@@ -67,6 +67,9 @@ struct MlpArgs {
   float ln_eps;         // > 0: `xh` holds the UN-normalised rows y; the kernel applies the block LayerNorm (no affine) itself (MODE 0, 1, 2)
   bf16_t* xh_out;       // [M, C]  the normalised rows, for the backward   (MODE 2 with ln_eps > 0)
   float* rstd_out;      // [M]     1 / sqrt(var + eps) of every row        (MODE 2 with ln_eps > 0)
+  float* mean_out;      // [M]     the row means (MODE 2 / 6 with ln_eps > 0; with xh_out = NULL the backward re-normalises y: MODE 7)
+  const float* ln_mean; // [M], [M]  MODE 7: `xh2` holds the UN-normalised rows y; x^ = bf16((y - mean) * rstd) as the forward formed it,
+  const float* ln_rstd; //           and dh leaves scaled by the row's rstd (see vsx_mlp_bwd_dh_ln)
   const bf16_t* tin;    // [M, 4C] stored activation g (MODE 3) / stored pre-activation h (MODE 4)
   float* red0;          // [B, 4C] += sum_hw dz * g  (MODE 3)
   float* red1;          // [B, 4C] += sum_hw dz      (MODE 3)
@@ -112,7 +115,8 @@ struct MlpGeom {
   static constexpr int H4 = 4 * C, NHS = H4 / 32, KK = C / 32, NF = C / 16;
   static constexpr int WM = 16 * MF, BM = NW * WM;
   static constexpr int W1_PIECES = 2 * KK, IMG_PIECES = 2 * KK + NF;   // KiB per hidden sub-chunk in the image
-  static constexpr int NP = MODE == 5 ? 2 * W1_PIECES : (MODE != 1 ? W1_PIECES : IMG_PIECES);  // pieces staged per sub-chunk
+  static constexpr bool RE = MODE == 5 || MODE == 7;                   // dh pass that recomputes h (7: and re-normalises y)
+  static constexpr int NP = RE ? 2 * W1_PIECES : (MODE != 1 ? W1_PIECES : IMG_PIECES);  // pieces staged per sub-chunk
   static constexpr int STAGE_BYTES = NP * 1024;
   static constexpr int OB_COLS = MODE == 0 ? 32 : 64;                  // output leaves in blocks of 64 columns (MODE 0: the
                                                                        // wave-private g tile of ONE sub-chunk, for the statistics)
@@ -122,9 +126,9 @@ struct MlpGeom {
   // C <= 256) instead of an array of its own: at C = 224 that is exactly what two workgroups per CU need (2 x 81 920 B = 160 KiB;
   // measured 1803 -> ~1600 us for that pass at B = 512, tools/perf_mlp_train.py)
   static constexpr bool B1_IN_PADS = MODE == 6;
-  static constexpr int VEC_FLOATS = MODE == 1 ? 3 * H4 + C : (MODE == 4 ? 2 * H4 : (MODE == 5 ? 3 * H4 : (MODE == 3 || B1_IN_PADS ? 4 : H4)));
-  static constexpr int RED_FLOATS = MODE == 1 ? 4 : (MODE == 3 ? 4 * NW * 32 : 2 * NW * 32);
-  static constexpr int GT_FLOATS = (MODE <= 2 || MODE == 6) ? MLP_GT_N : ((MODE == 4 || MODE == 5) ? 2 * MLP_GT_N : 4);
+  static constexpr int VEC_FLOATS = MODE == 1 ? 3 * H4 + C : (MODE == 4 ? 2 * H4 : (RE ? 3 * H4 : (MODE == 3 || B1_IN_PADS ? 4 : H4)));
+  static constexpr int RED_FLOATS = MODE == 1 ? 4 : (MODE == 3 || MODE == 7 ? 4 * NW * 32 : 2 * NW * 32);
+  static constexpr int GT_FLOATS = (MODE <= 2 || MODE == 6) ? MLP_GT_N : ((MODE == 4 || RE) ? 2 * MLP_GT_N : 4);
   static constexpr int LDS_BYTES = 2 * STAGE_BYTES + OUT_BYTES + (VEC_FLOATS + RED_FLOATS) * 4;
 };
 
@@ -136,7 +140,8 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
   typedef MlpGeom<C, MF, NW, MODE> G;
   constexpr int H4 = G::H4, NHS = G::NHS, KK = G::KK, NF = G::NF, WM = G::WM;
   constexpr bool STATS = MODE == 0 || MODE == 2 || MODE == 6, STORE = MODE == 2 || MODE == 6, STORE_H = MODE == 2;
-  constexpr bool BWD = MODE >= 3 && MODE <= 5, DH = MODE == 4 || MODE == 5, RE = MODE == 5;
+  constexpr bool RE = G::RE, LNF = MODE == 7;
+  constexpr bool BWD = (MODE >= 3 && MODE <= 5) || MODE == 7, DH = MODE == 4 || RE;
   // SEPARATE LDS objects, on purpose: the two weight stages, the per-channel vectors and the output staging are distinct
   // variables, so the compiler's alias scopes let fragment / vector reads proceed while the LDS-DMA prefetch of the OTHER
   // stage is in flight (through one array every ds_read behind a global_load_lds costs an s_waitcnt vmcnt(0): no overlap)
@@ -201,6 +206,45 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
       for (int kk = 0; kk < KK; ++kk)
         xg[mf][kk] = *reinterpret_cast<const mlp_bf16x8*>(a.xh2 + (size_t)(row0 + mf * 16 + p16) * C + kk * 32 + kq * 8);
   }
+  // MODE 7: x^ was never stored.  xg holds y: normalise it with the forward's own mean / rstd and the forward's expression
+  // (bit-identical x^, hence bit-identical h).  dh leaves multiplied by the row's rstd, and the column sums of the parked tile
+  // are weighted: lane (n, q) of an MFMA B operand holds contraction slots k = q*8 .. +7, which tile_frag fills with the pixels
+  // q*4 .. +3 and 16 + q*4 .. +3 — the weight fragments below carry sigma = 1 / rstd (-> sum of the UNSCALED dh, the fc1 bias
+  // gradient) and the row mean split into a bf16 head and tail (-> u = sum of dh' * mean to 2^-17, see vsx_mlp_bwd_dh_ln)
+  float rsr[LNF ? MF : 1];
+  mlp_bf16x8 wS, wMh, wMl;
+  if constexpr (LNF) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const size_t rowi = (size_t)(row0 + mf * 16 + p16);
+      const float mean = a.ln_mean[rowi], rstd = a.ln_rstd[rowi];
+      rsr[mf] = rstd;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        union { mlp_bf16x8 b; uint4 u; } cv;
+        cv.b = xg[mf][kk];
+        float v[8], o[8];
+        unpack<bf16_t>(cv.u, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[j] - mean) * rstd;
+        cv.u = pack<bf16_t>(o);
+        xg[mf][kk] = cv.b;
+      }
+    }
+    static_assert(!LNF || MF == 2, "the weight fragments cover the 32 pixels of a wave");
+    float sg[8], mh[8], ml[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const size_t rowi = (size_t)(row0 + (j >> 2) * 16 + kq * 4 + (j & 3));
+      const float mean = a.ln_mean[rowi];
+      sg[j] = 1.f / a.ln_rstd[rowi];
+      mh[j] = round_bf16(mean);
+      ml[j] = mean - mh[j];
+    }
+    union { mlp_bf16x8 b; uint4 u; } c1, c2, c3;
+    c1.u = pack<bf16_t>(sg); c2.u = pack<bf16_t>(mh); c3.u = pack<bf16_t>(ml);
+    wS = c1.b; wMh = c2.b; wMl = c3.b;
+  }
 
   if constexpr (!BWD) {
     if (a.ln_eps > 0.f) {
@@ -245,10 +289,15 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
           union { mlp_bf16x8 b; uint4 u; } cv;
           cv.u = pack<bf16_t>(o);
           xf[mf][kk] = cv.b;
-          if constexpr (STORE) *reinterpret_cast<uint4*>(a.xh_out + rowi * C + kk * 32 + kq * 8) = cv.u;
+          if constexpr (STORE) {
+            if (a.xh_out) *reinterpret_cast<uint4*>(a.xh_out + rowi * C + kk * 32 + kq * 8) = cv.u;
+          }
         }
         if constexpr (STORE) {
-          if (kq == 0) a.rstd_out[rowi] = rstd;
+          if (kq == 0) {
+            a.rstd_out[rowi] = rstd;
+            if (a.mean_out) a.mean_out[rowi] = mean;
+          }
         }
       }
     }
@@ -388,8 +437,18 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const mlp_bf16x8 X = tile_frag(sb, (hs & 1) * 32 + ct * 16);
-      const mlp_f32x4 D = mlp_mfma(X, one.v, (mlp_f32x4){0.f, 0.f, 0.f, 0.f});
-      if (p16 == 0) *reinterpret_cast<float4*>(rw + ct * 16 + kq * 4) = make_float4(D[0], D[1], D[2], D[3]);
+      if constexpr (LNF) {  // the parked tile holds dh' = dh * rstd: sigma-weighted sums = sums of dh; mean-weighted sums = u
+        const mlp_f32x4 D = mlp_mfma(X, wS, (mlp_f32x4){0.f, 0.f, 0.f, 0.f});
+        mlp_f32x4 U = mlp_mfma(X, wMh, (mlp_f32x4){0.f, 0.f, 0.f, 0.f});
+        U = mlp_mfma(X, wMl, U);
+        if (p16 == 0) {
+          *reinterpret_cast<float4*>(rw + ct * 16 + kq * 4) = make_float4(D[0], D[1], D[2], D[3]);
+          *reinterpret_cast<float4*>(rw + NW * 32 + ct * 16 + kq * 4) = make_float4(U[0], U[1], U[2], U[3]);
+        }
+      } else {
+        const mlp_f32x4 D = mlp_mfma(X, one.v, (mlp_f32x4){0.f, 0.f, 0.f, 0.f});
+        if (p16 == 0) *reinterpret_cast<float4*>(rw + ct * 16 + kq * 4) = make_float4(D[0], D[1], D[2], D[3]);
+      }
     }
   };
 
@@ -501,7 +560,8 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
               const vsx_v2f gv = (vsx_v2f){__uint_as_float(Rq << 16), __uint_as_float(Rq & 0xFFFF0000u)} - (vsx_v2f){tb[r].x, tb[r + 1].x};
               const vsx_v2f cs = {copysignf(tb[r].y, h0), copysignf(tb[r + 1].y, h1)};
               const vsx_v2f dgv = cs + (vsx_v2f){0.5f, 0.5f};
-              const vsx_v2f rr = (d2 * s2 + gv * t2) * dgv;
+              vsx_v2f rr = (d2 * s2 + gv * t2) * dgv;
+              if constexpr (LNF) rr = rr * (vsx_v2f){rsr[mf], rsr[mf]};
               ob[r / 2] = f32x2_to_bf16x2_bits(rr.x, rr.y);
             }
             *reinterpret_cast<uint2*>(tp) = make_uint2(ob[0], ob[1]);  // dh parked: colsum_mfma and tile_flush read it
@@ -573,6 +633,27 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
   // whole 32-row groups once two workgroups shared a CU at C = 192 / 224: tools/probe_mode6.py, tools/det_fwd.py.)
   __syncthreads();
 
+  // column sums of the sub-chunk `hq` of dh (parked in `red` before the last barrier): one workspace row per workgroup, no
+  // atomics.  MODE 7: two sums per column (lanes 0-31: of the unscaled dh, lanes 32-63: u), rows of 2 * 4C floats
+  auto ws_row = [&](int hq, bool on) {
+    if constexpr (LNF) {
+      if (on && wave == hq % NW) {
+        const float* r = red + (hq & 1) * 2 * NW * 32 + (lane >> 5) * NW * 32 + (lane & 31);
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += r[w * 32];
+        a.ws[(size_t)blockIdx.x * 2 * H4 + (lane >> 5) * H4 + hq * 32 + (lane & 31)] = t;
+      }
+    } else {
+      if (on && wave == hq % NW && lane < 32) {
+        const float* r = red + (hq & 1) * NW * 32 + lane;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += r[w * 32];
+        a.ws[(size_t)blockIdx.x * H4 + hq * 32 + lane] = t;
+      }
+    }
+  };
   auto step = [&](int hs, const char* Sb, char* other) {
     // stage hs has landed for everyone (waited + barrier by the caller); every wave is done with stage hs - 1 in `other`
     if constexpr (STORE) {
@@ -597,15 +678,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
         atomicAdd((lane < 32 ? a.red0 : a.red1) + (size_t)b * H4 + (hs - 1) * 32 + (lane & 31), t);
       }
     }
-    if constexpr (DH) {
-      if (hs > 0 && wave == (hs - 1) % NW && lane < 32) {  // column sums of dh: one workspace row per workgroup, no atomics
-        const float* r = red + ((hs - 1) & 1) * NW * 32 + lane;
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += r[w * 32];
-        a.ws[(size_t)blockIdx.x * H4 + (hs - 1) * 32 + lane] = t;
-      }
-    }
+    if constexpr (DH) ws_row(hs - 1, hs > 0);
     if constexpr (STATS) {
       if (hs > 0 && wave == (hs - 1) % NW && lane < 32) {  // column sums of the previous sub-chunk (parked before the barrier)
         const float* r = red + ((hs - 1) & 1) * NW * 32 + lane;
@@ -636,7 +709,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
     else activate(hs, hcur, zf);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DH) {
-      colsum_mfma(hs, red + (hs & 1) * NW * 32 + wave * 32);  // column sums of the parked dh (the fc1 bias gradient)
+      colsum_mfma(hs, red + (hs & 1) * (LNF ? 2 : 1) * NW * 32 + wave * 32);  // column sums of the parked dh (the fc1 bias gradient)
     } else if constexpr (BWD) {
       float* rw = red + (hs & 1) * 2 * NW * 32 + wave * 32;
 #pragma unroll
@@ -700,13 +773,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
         atomicAdd((lane < 32 ? a.red0 : a.red1) + (size_t)b * H4 + (NHS - 1) * 32 + (lane & 31), t);
       }
     } else {
-      if (wave == (NHS - 1) % NW && lane < 32) {
-        const float* r = red + ((NHS - 1) & 1) * NW * 32 + lane;
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += r[w * 32];
-        a.ws[(size_t)blockIdx.x * H4 + (NHS - 1) * 32 + lane] = t;
-      }
+      ws_row(NHS - 1, true);
     }
     return;
   } else if constexpr (STATS) {
@@ -796,14 +863,15 @@ struct MlpCfg { int C, MF, NW, modes; };  // modes: bit m set = this geometry se
 extern int g_vsx_mlp_fused;
 extern int g_vsx_nt_stream;
 static inline int mlp_nt() { return (g_vsx_nt_stream >> 2) & 3; }  // bits 2 / 3 of nt_stream: the fused passes' stores / last-reader loads
-static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 127}, {192, 2, 8, 127}, {224, 2, 8, 127}, {384, 2, 8, 4 | 8 | 16}};
+static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 255}, {192, 2, 8, 255}, {224, 2, 8, 255}, {384, 2, 8, 4 | 8 | 16}};
 
 static const MlpCfg* mlp_cfg(int C, int hw, long M, int mode) {
   for (const MlpCfg& c : kMlpCfgs) {
     const int bm = c.NW * 16 * c.MF;
     if (!(c.modes & (1 << mode))) continue;
     if (c.C == 384 && !(g_vsx_mlp_fused & 4)) continue;  // bit 2: the training passes (MODE 2 / 3 / 4) on the C = 384 blocks
-    if ((mode == 5 || mode == 6) && !(g_vsx_mlp_fused & 64)) continue;          // bit 6: the pre-activation h is recomputed, not stored
+    if ((mode == 5 || mode == 6 || mode == 7) && !(g_vsx_mlp_fused & 64)) continue;  // bit 6: the pre-activation h is recomputed, not stored
+    if (mode == 7 && !(g_vsx_mlp_fused & 128)) continue;                             // bit 7: ... and neither are the normalised rows x^
     if (c.C == C && hw % bm == 0 && M % bm == 0) return &c;
   }
   return nullptr;
@@ -814,9 +882,10 @@ extern "C" int32_t vsx_mlp_supported(int32_t C, int32_t hw, int64_t M, int32_t d
   return dtype == VSX_BF16 && mlp_cfg(C, hw, M, 0) != nullptr && mlp_cfg(C, hw, M, 1) != nullptr;
 }
 /* one pass: mode 0 statistics, 1 output, 2 training fc1, 3 backward statistics, 4 backward dh, 5 backward dh with the
- * pre-activation recomputed (vsx_mlp_bwd_dh_re), 6 training fc1 that stores g only (vsx_mlp_fc1 / _ln with h = NULL) */
+ * pre-activation recomputed (vsx_mlp_bwd_dh_re), 6 training fc1 that stores g only (vsx_mlp_fc1 / _ln with h = NULL),
+ * 7 mode 5 that also re-normalises the block's LayerNorm input (vsx_mlp_bwd_dh_ln: x^ is never stored) */
 extern "C" int32_t vsx_mlp_mode_supported(int32_t C, int32_t hw, int64_t M, int32_t mode, int32_t dtype) {
-  return dtype == VSX_BF16 && mode >= 0 && mode <= 6 && mlp_cfg(C, hw, M, mode) != nullptr;
+  return dtype == VSX_BF16 && mode >= 0 && mode <= 7 && mlp_cfg(C, hw, M, mode) != nullptr;
 }
 
 extern "C" int64_t vsx_mlp_image_bytes(int32_t C) { return (int64_t)(4 * C / 32) * (2 * (C / 32) + C / 16) * 1024; }
@@ -843,7 +912,7 @@ static int mlp_dispatch(const MlpCfg* c, const MlpArgs& a, hipStream_t s) {
   if (c->C == 96) return mlp_launch<96, 2, 8, MODE>(a, s);
   if (c->C == 192) return mlp_launch<192, 2, 8, MODE>(a, s);
   if (c->C == 224) return mlp_launch<224, 2, 8, MODE>(a, s);
-  if constexpr (MODE <= 1 || MODE >= 5) { vsx_set_error("vsx_mlp: mode %d is built for C <= 224", MODE); return 1; }
+  if constexpr (MODE <= 1 || MODE >= 5) { vsx_set_error("vsx_mlp: mode %d is built for C <= 224", MODE); return 1; }  // (5, 6, 7)
   else return mlp_launch<384, 2, 8, MODE>(a, s);
 }
 
@@ -874,6 +943,7 @@ extern "C" int32_t vsx_mlp_gelu_table(float* tab, vsx_stream_t stream) {
 static thread_local float g_mlp_ln_eps = 0.f;
 static thread_local bf16_t* g_mlp_xh_out = nullptr;
 static thread_local float* g_mlp_rstd_out = nullptr;
+static thread_local float* g_mlp_mean_out = nullptr;
 
 extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1, const float* grn_s, const float* grn_b,
                                const float* b2, const void* res, const float* rscale, void* out, float* colsq,
@@ -889,6 +959,7 @@ extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1
   a.res = (const bf16_t*)res; a.rscale = rscale; a.out = (bf16_t*)out; a.colsq = colsq; a.gtab = gtab; a.M = (int)M; a.hw = hw;
   a.hout = nullptr; a.gout = nullptr; a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.nt = 0;
   a.ln_eps = g_mlp_ln_eps; a.xh_out = nullptr; a.rstd_out = nullptr; a.xh2 = nullptr; a.wimg2 = nullptr;
+  a.mean_out = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) {
     VSX_CHECK(colsq != nullptr, "vsx_mlp_fwd: mode 0 needs colsq");
@@ -914,12 +985,15 @@ extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1
   a.tin = nullptr; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.nt = mlp_nt();
   a.M = (int)M; a.hw = hw;
   a.ln_eps = g_mlp_ln_eps; a.xh_out = g_mlp_xh_out; a.rstd_out = g_mlp_rstd_out; a.xh2 = nullptr; a.wimg2 = nullptr;
+  a.mean_out = g_mlp_mean_out; a.ln_mean = nullptr; a.ln_rstd = nullptr;
   return h ? mlp_dispatch<2>(c, a, (hipStream_t)stream) : mlp_dispatch<6>(c, a, (hipStream_t)stream);
 }
 
 /* The same passes with the block LayerNorm (eps, no affine: folded into W1' / b1) applied in the kernel's prologue: `y` holds
  * the UN-normalised rows (the depthwise convolution's output).  vsx_mlp_fwd_ln: modes 0 / 1 as vsx_mlp_fwd — the normalised
- * rows never exist in memory.  vsx_mlp_fc1_ln additionally writes them (xh_out [M, C]) and rstd_out [M] for the backward.
+ * rows never exist in memory.  vsx_mlp_fc1_ln additionally writes them (xh_out [M, C]) and rstd_out [M] for the backward —
+ * or, with xh_out = NULL and mean_out [M] given, only the two row statistics: the backward then re-normalises y itself
+ * (vsx_mlp_bwd_dh_ln, vsx_gemm_nt with VSX_EPI_LN_BWD and a mean pointer) and x^ never exists in memory in training either.
  * Replaces vsx_ln_fwd + vsx_mlp_* (timm ConvNeXtBlock.norm -> .mlp, reached from viscy_models/unet/unext2.py:79). */
 extern "C" int32_t vsx_mlp_fwd_ln(const void* y, float eps, const void* wimg, const float* b1, const float* grn_s,
                                   const float* grn_b, const float* b2, const void* res, const float* rscale, void* out,
@@ -931,13 +1005,13 @@ extern "C" int32_t vsx_mlp_fwd_ln(const void* y, float eps, const void* wimg, co
   g_mlp_ln_eps = 0.f;
   return rc;
 }
-extern "C" int32_t vsx_mlp_fc1_ln(const void* y, float eps, void* xh_out, float* rstd_out, const void* wimg, const float* b1,
-                                  float* colsq, const float* gtab, void* h, void* g, int64_t M, int32_t C, int32_t hw,
-                                  int32_t dtype, vsx_stream_t stream) {
-  VSX_CHECK(eps > 0.f && xh_out && rstd_out, "vsx_mlp_fc1_ln: eps must be positive, xh_out / rstd_out non-null");
-  g_mlp_ln_eps = eps; g_mlp_xh_out = (bf16_t*)xh_out; g_mlp_rstd_out = rstd_out;
+extern "C" int32_t vsx_mlp_fc1_ln(const void* y, float eps, void* xh_out, float* rstd_out, float* mean_out, const void* wimg,
+                                  const float* b1, float* colsq, const float* gtab, void* h, void* g, int64_t M, int32_t C,
+                                  int32_t hw, int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(eps > 0.f && rstd_out && (xh_out || mean_out), "vsx_mlp_fc1_ln: eps must be positive, rstd_out and one of xh_out / mean_out non-null");
+  g_mlp_ln_eps = eps; g_mlp_xh_out = (bf16_t*)xh_out; g_mlp_rstd_out = rstd_out; g_mlp_mean_out = mean_out;
   const int32_t rc = vsx_mlp_fc1(y, wimg, b1, colsq, gtab, h, g, M, C, hw, dtype, stream);
-  g_mlp_ln_eps = 0.f; g_mlp_xh_out = nullptr; g_mlp_rstd_out = nullptr;
+  g_mlp_ln_eps = 0.f; g_mlp_xh_out = nullptr; g_mlp_rstd_out = nullptr; g_mlp_mean_out = nullptr;
   return rc;
 }
 
@@ -949,6 +1023,7 @@ static void mlp_bwd_args(MlpArgs& a, const void* dout, const void* wimg, const v
   a.res = nullptr; a.rscale = nullptr; a.out = nullptr; a.colsq = nullptr; a.gtab = gtab; a.hout = nullptr; a.gout = nullptr;
   a.tin = (const bf16_t*)tin; a.red0 = nullptr; a.red1 = nullptr; a.ws = nullptr; a.M = (int)M; a.hw = hw; a.nt = mlp_nt();
   a.ln_eps = 0.f; a.xh_out = nullptr; a.rstd_out = nullptr; a.xh2 = nullptr; a.wimg2 = nullptr;
+  a.mean_out = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr;
 }
 
 /* MODE 3: the GRN statistics path of the block backward without a stored dz: dz = dout . W2 recomputed tile by tile
@@ -1009,6 +1084,37 @@ extern "C" int32_t vsx_mlp_bwd_dh_re(const void* dout, const void* xh, const voi
   const int R = (int)(M / bm), N = 4 * C;
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv(N, 64), vsx_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)ws, colsum, R, N);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
+/* MODE 7: vsx_mlp_bwd_dh_re for a block whose forward stored NO normalised rows (vsx_mlp_fc1_ln with xh_out = NULL): `y` [M, C]
+ * is the LayerNorm input (the depthwise convolution's output), mean / rstd [M] its row statistics; x^ = bf16((y - mean) * rstd)
+ * is re-formed on chip exactly as the forward formed it.  What leaves is dh' = dh * rstd (row-scaled), which is what the two
+ * consumers want when they, too, read y instead of x^:
+ *   fc1 weight gradient   dW1f = dh^T . x^ = dh'^T . y - u (x) 1,   u[j] = sum_r dh'[r, j] * mean[r]   (a plain TN GEMM on y)
+ *   LayerNorm backward    dy = dx' - mean_c(dx') - x^ * mean_c(dx' * x^),  dx' = dh' . W1' (the trailing * rstd is already in)
+ * colsum2 [2, 4C] += { sum_r dh[r, j] (the fc1 bias gradient, formed as sum dh' / rstd), u[j] }; ws: [M / rows-per-workgroup,
+ * 2 * 4C] floats.  Block math: viscy_models/unet/fcmae.py:174-221; LayerNorm = timm ConvNeXtBlock.norm (unext2.py:79). */
+extern "C" int32_t vsx_mlp_bwd_dh_ln(const void* dout, const void* y, const float* mean, const float* rstd, const void* wimg_bwd,
+                                     const void* wimg_fwd, const float* b1, const float* s, const float* t, void* dh, float* ws,
+                                     int64_t ws_rows, float* colsum2, const float* gtab, int64_t M, int32_t C, int32_t hw,
+                                     int32_t dtype, vsx_stream_t stream) {
+  VSX_CHECK(dtype == VSX_BF16, "vsx_mlp_bwd_dh_ln: bf16 only");
+  VSX_CHECK(dout && y && mean && rstd && wimg_bwd && wimg_fwd && b1 && s && t && dh && ws && colsum2 && gtab && M > 0 && hw > 0,
+            "vsx_mlp_bwd_dh_ln: bad arguments");
+  const MlpCfg* c = mlp_cfg(C, hw, M, 7);
+  VSX_CHECK(c != nullptr && M < (1ll << 31), "vsx_mlp_bwd_dh_ln: unsupported shape C=%d hw=%d M=%ld", C, hw, (long)M);
+  const int bm = c->NW * 16 * c->MF;
+  VSX_CHECK(ws_rows >= M / bm, "vsx_mlp_bwd_dh_ln: workspace needs %ld rows of %d floats", (long)(M / bm), 8 * C);
+  MlpArgs a;
+  mlp_bwd_args(a, dout, wimg_bwd, nullptr, M, hw, gtab);
+  a.grn_s = s; a.grn_b = t; a.hout = (bf16_t*)dh; a.ws = ws; a.xh2 = (const bf16_t*)y; a.wimg2 = (const char*)wimg_fwd; a.b1 = b1;
+  a.ln_mean = mean; a.ln_rstd = rstd;
+  if (int e = mlp_dispatch<7>(c, a, (hipStream_t)stream)) return e;
+  const int R = (int)(M / bm), N = 8 * C;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv(N, 64), vsx_cdiv(R, 64)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)ws, colsum2, R, N);
   VSX_LAUNCH_CHECK();
   return 0;
 }

@@ -154,20 +154,21 @@ extern "C" int32_t vsx_prep_weight(const float* src, void* dst, void* dstT, cons
 __global__ __launch_bounds__(256) void unprep_grad_kernel(const float* __restrict__ g, float* __restrict__ dparam,
                                                           const float* __restrict__ gamma, const float* __restrict__ W,
                                                           float* __restrict__ dgamma, const float* __restrict__ u,
-                                                          const float* __restrict__ beta, int R, int Cs, int Tn, int tapmode) {
-  wt_unprep_grad(blockIdx.x, g, dparam, gamma, W, dgamma, u, beta, R, Cs, Tn, tapmode);
+                                                          const float* __restrict__ beta, const float* __restrict__ rowsub, int R,
+                                                          int Cs, int Tn, int tapmode) {
+  wt_unprep_grad(blockIdx.x, g, dparam, gamma, W, dgamma, u, beta, rowsub, R, Cs, Tn, tapmode);
 }
 
 extern "C" int32_t vsx_unprep_grad(const float* g, float* dparam, const float* gamma, const float* W, float* dgamma,
-                                   const float* u, const float* beta, int32_t R, int32_t Cs, int32_t Tn,
+                                   const float* u, const float* beta, const float* rowsub, int32_t R, int32_t Cs, int32_t Tn,
                                    int32_t tapmode, vsx_stream_t stream) {
   VSX_CHECK(g && dparam && R > 0 && Cs > 0 && Tn > 0, "vsx_unprep_grad: bad arguments");
   VSX_CHECK((gamma == nullptr) == (dgamma == nullptr) && (gamma == nullptr || W != nullptr),
             "vsx_unprep_grad: gamma / dgamma / W must come together");
   VSX_CHECK((u == nullptr) == (beta == nullptr) && (u == nullptr || Tn == 1), "vsx_unprep_grad: u / beta need Tn == 1");
   dim3 grid(wt_unprep_bx(Cs, Tn) * vsx_cdiv(R, wt_unprep_rpb(R)));
-  hipLaunchKernelGGL(unprep_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, dparam, gamma, W, dgamma, u, beta, R,
-                     Cs, Tn, tapmode);
+  hipLaunchKernelGGL(unprep_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, dparam, gamma, W, dgamma, u, beta, rowsub,
+                     R, Cs, Tn, tapmode);
   VSX_LAUNCH_CHECK();
   return 0;
 }
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void weight_tasks_kernel(const WTaskBatch b) {
     case VSX_WTASK_MLP_PACK: wt_mlp_pack(blk, (const bf16_t*)t.p0, (const bf16_t*)t.p3, (char*)t.p1, t.i0); break;
     case VSX_WTASK_UNPREP:
       wt_unprep_grad(blk, (const float*)t.p0, (float*)t.p1, (const float*)t.p3, (const float*)t.p4, (float*)t.p2,
-                     (const float*)t.p5, (const float*)t.p6, t.i0, t.i1, t.i2, t.i3);
+                     (const float*)t.p5, (const float*)t.p6, (const float*)t.p7, t.i0, t.i1, t.i2, t.i3);
       break;
     case VSX_WTASK_MATVEC_T: wt_matvec_t(blk, (const float*)t.p0, (const float*)t.p3, (float*)t.p1, t.i0, t.i1); break;
     case VSX_WTASK_REDUCE_ROWS: wt_reduce_rows(blk, (const float*)t.p0, (float*)t.p1, t.i0, t.i1); break;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void weight_tasks_kernel(const WTaskBatch b) {
  *   VSX_WTASK_TRANSPOSE = vsx_transpose_f32(p0 src, p1 dst, i0 A, i1 Bn, i2 accumulate)
  *   VSX_WTASK_MATVEC    = vsx_matvec(p0 W, p3 v, p2 b, p1 out, i0 R, i1 C)
  *   VSX_WTASK_MLP_PACK  = vsx_mlp_pack(p0 W1, p3 W2, p1 img, i0 C)
- *   VSX_WTASK_UNPREP    = vsx_unprep_grad(p0 g, p1 dparam, p3 gamma, p4 W, p2 dgamma, p5 u, p6 beta, i0 R, i1 Cs, i2 Tn, i3 tapmode)
+ *   VSX_WTASK_UNPREP    = vsx_unprep_grad(p0 g, p1 dparam, p3 gamma, p4 W, p2 dgamma, p5 u, p6 beta, p7 rowsub, i0 R, i1 Cs, i2 Tn, i3 tapmode)
  *   VSX_WTASK_MATVEC_T  = vsx_matvec_t_add(p0 W, p3 u, p1 out, i0 R, i1 C)
  *   VSX_WTASK_REDUCE_ROWS: p1 out[n] += sum over the i0 rows of p0 ws [i0, i1]   (column sums of a workspace of partials)
  * No task may read or accumulate into what another task of the same call writes. */

@@ -92,7 +92,8 @@ __host__ __device__ inline int wt_unprep_bx(int Cs, int Tn) { return (Cs * Tn + 
 __device__ __forceinline__ void wt_unprep_grad(int blk, const float* __restrict__ g, float* __restrict__ dparam,
                                                const float* __restrict__ gamma, const float* __restrict__ W,
                                                float* __restrict__ dgamma, const float* __restrict__ u,
-                                               const float* __restrict__ beta, int R, int Cs, int Tn, int tapmode) {
+                                               const float* __restrict__ beta, const float* __restrict__ rowsub, int R, int Cs,
+                                               int Tn, int tapmode) {
   const int nbx = wt_unprep_bx(Cs, Tn), rows_per_block = wt_unprep_rpb(R);
   const int col = (blk % nbx) * 256 + threadIdx.x;
   if (col >= Cs * Tn) return;
@@ -105,7 +106,7 @@ __device__ __forceinline__ void wt_unprep_grad(int blk, const float* __restrict_
   const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
   float dg = 0.f;
   for (int r = r0; r < r1; ++r) {
-    const float gv = g[(size_t)r * K + k];
+    const float gv = g[(size_t)r * K + k] - (rowsub ? rowsub[r] : 0.f);  // rowsub: the rank-1 term of a GEMM run on un-centred rows
     const size_t pi = ((size_t)r * Cs + c) * Tn + t;
     dparam[pi] += gv * gm + (u ? u[r] * bt : 0.f);
     if (dgamma) dg += gv * W[pi];

@@ -360,6 +360,15 @@ class Engine:
         return bool(self._mlp_flag() & 64) and self._mlp_bwd_fused(C, hw, M, dt, B) != 0 and self.ops.mlp_supported(C, hw, M, dt, 5) \
             and self.ops.mlp_supported(C, hw, M, dt, 6)
 
+    def _mlp_drop_xh(self, C, hw, M, dt, B) -> bool:
+        """``mlp_fused`` bit 7 (with 5 and 6): the normalised rows x^ are not stored either — the forward keeps the depthwise
+        output y and the row mean / rstd; the dh pass re-normalises y and hands on dh * rstd (csrc/mlp.hip MODE 7), the fc1
+        weight gradient is a plain TN GEMM on y with a rank-1 correction, the data-gradient GEMM's LayerNorm epilogue re-forms
+        x^ from y.  Needs that epilogue (C <= 256): the stand-alone LayerNorm backward reads a stored x^."""
+        flag = self._mlp_flag()
+        return bool(flag & 128) and bool(flag & 32) and self._mlp_recompute_h(C, hw, M, dt, B) and self.ops.mlp_supported(C, hw, M, dt, 7) \
+            and hasattr(self.ops, "dgrad_ln_bwd") and bool(L.lib().vsx_gemm_nt_ln_bwd_supported(M, C, 4 * C, L.dtype_code(dt)))
+
     def _block_fwd(self, x, w, B, H, Wd, dt, save, rows=None):
         """One ConvNeXt-V2 block on a dense channels-last map [B*H*W, C].  ``rows = (idx, inv, keep, L)`` selects the FCMAE
         masked path (fcmae.py:196-230): ``x`` arrives already multiplied by the mask, the depthwise convolution runs dense,
@@ -422,7 +431,9 @@ class Engine:
             # normalised rows (csrc/mlp.hip MODE 6 here, MODE 5 there): one 4C-wide write and one 4C-wide read less per block
             keep_h = not self._mlp_recompute_h(C, hw, M, dt, B)
             if ln_in:
-                xh, rstd, h, gact = o.mlp_fc1_ln(xh, w.img, w.b1f, colsq, M, C, hw, 1e-6, store_h=keep_h)
+                # bit 7: ... and neither is x^ — `xh` is then the pair (y, row means) the backward re-normalises from
+                xh, rstd, h, gact = o.mlp_fc1_ln(xh, w.img, w.b1f, colsq, M, C, hw, 1e-6, store_h=keep_h,
+                                                 store_xh=keep_h or not self._mlp_drop_xh(C, hw, M, dt, B))
             else:
                 h, gact = o.mlp_fc1(xh, w.img, w.b1f, colsq, M, C, hw, store_h=keep_h)
         else:
@@ -496,7 +507,16 @@ class Engine:
         if w.v1:
             o.layer_scale_unfold(dW2, db2, blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.gamma, g(blk.mlp.fc2.weight),
                                  g(blk.mlp.fc2.bias), g(blk.gamma))
-        db1f = self._za.take(4 * C)
+        ln_re = isinstance(xh, tuple)  # (y, mean): the forward stored no normalised rows (mlp_fused bit 7)
+        if ln_re and not (fused_bwd and h is None and self._mlp_drop_xh(C, hw, M, dt, B)):
+            raise RuntimeError("this block's forward stored no normalised rows (mlp_fused bit 7) and the passes that re-normalise "
+                               "are switched off now: do not change `mlp_fused` between a forward and its backward")
+        u1 = None
+        if ln_re:
+            cs2 = self._za.take(2, 4 * C)  # {column sums of dh, u = sum_r dh' * mean}
+            db1f, u1 = cs2[0], cs2[1]
+        else:
+            db1f = self._za.take(4 * C)
         if fused_bwd:
             # the 4C-wide dz is never written: the statistics came from the per-sample products above; this pass recomputes
             # dz = dout·W2 tile by tile (K = C is short) and writes dh directly (csrc/mlp.hip MODE 4) — one 4C-wide write
@@ -511,7 +531,9 @@ class Engine:
             if fused_bwd == 2:  # statistics by recomputing dz tile by tile (P = Σ dz·g, S = Σ dz), nothing stored
                 o.mlp_bwd_stats(dout, img2, gact, PS[0], PS[1], M, C, hw)
             t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw, Sb=PS[1], dbeta=dgb)
-            if h is None:  # h recomputed on chip from the normalised rows (MODE 5)
+            if ln_re:  # h recomputed from y re-normalised on chip; dz holds dh * rstd (MODE 7)
+                dz = o.mlp_bwd_dh_ln(dout, xh[0], xh[1], rstd, img2, w.img, w.b1f, s, t, cs2, M, C, hw)
+            elif h is None:  # h recomputed on chip from the normalised rows (MODE 5)
                 dz = o.mlp_bwd_dh_re(dout, xh, img2, w.img, w.b1f, s, t, db1f, M, C, hw)
             else:
                 dz = o.mlp_bwd_dh(dout, img2, h, s, t, db1f, M, C, hw)  # (named dz below: it holds dH)
@@ -524,7 +546,13 @@ class Engine:
             o.grn_gelu_bwd(dz, h, s, t, db1f, M, 4 * C, hw)  # dz now holds dH
         # fc1 data gradient; where one column tile spans the row (C <= 256) the block LayerNorm's backward rides in the GEMM's
         # epilogue (VSX_EPI_LN_BWD): dx^ is never written, the LayerNorm-backward launch and two C-wide passes go
-        dy = o.dgrad_ln_bwd(dz, w.W1fT, xh, rstd, M, C, 4 * C) if hasattr(o, "dgrad_ln_bwd") else None
+        if ln_re:
+            # dz = dh * rstd: the accumulator is rstd * dx^ already, x^ is re-formed from y in the epilogue; the weight gradient
+            # contracts dz with y itself, dh^T x^ = dz^T y - u (x) 1 — the rank-1 term goes in the unfold below
+            dy = o.dgrad_ln_bwd(dz, w.W1fT, xh[0], rstd, M, C, 4 * C, mean=xh[1])
+            xh = xh[0]
+        else:
+            dy = o.dgrad_ln_bwd(dz, w.W1fT, xh, rstd, M, C, 4 * C) if hasattr(o, "dgrad_ln_bwd") else None
         dxh = None
         if dy is None:
             dxh = torch.empty((M, C), dtype=dt, device=dev)
@@ -534,7 +562,7 @@ class Engine:
         del dz
         # unfold the LayerNorm affine: dW1 = dW1f·diag(γ) + db1f ⊗ β, dγ = Σ_r dW1f ⊙ W1, dβ = W1ᵀ db1f, db1 = db1f
         o.unprep_grad(dW1f, g(blk.mlp.fc1.weight), 4 * C, C, 1, gamma=blk.norm.weight, W=blk.mlp.fc1.weight,
-                      dgamma=g(blk.norm.weight), u=db1f, beta=blk.norm.bias)
+                      dgamma=g(blk.norm.weight), u=db1f, beta=blk.norm.bias, rowsub=u1)
         o.matvec_t_add(blk.mlp.fc1.weight, db1f, g(blk.norm.bias), 4 * C, C)
         o.transpose_f32(db1f, g(blk.mlp.fc1.bias), 4 * C, 1, True)  # g(b1) += db1f (a [4C, 1] "transpose": no ATen launch in the step)
         if dy is None:

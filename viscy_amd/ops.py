@@ -104,14 +104,15 @@ def gemm(
     check(fn(C.byref(p), dtype_code(dtype), stream()), f"gemm_{kind}")
 
 
-def dgrad_ln_bwd(dh: Tensor, WT: Tensor, xh: Tensor, rstd: Tensor, M: int, C: int, K: int) -> Tensor | None:
+def dgrad_ln_bwd(dh: Tensor, WT: Tensor, xh: Tensor, rstd: Tensor, M: int, C: int, K: int, mean: Tensor | None = None) -> Tensor | None:
     """fc1 data gradient with the block LayerNorm's backward in the GEMM epilogue (VSX_EPI_LN_BWD, csrc/gemm_nt2.hip):
     dy = LN_backward(dh . WT^T; xh, rstd) [M, C] in ONE launch — dx^ is never written.  None if the shape is not served
-    (the caller then runs the GEMM and vsx_ln_bwd)."""
+    (the caller then runs the GEMM and vsx_ln_bwd).  With ``mean``: ``xh`` holds the UN-normalised rows y and ``dh`` the
+    row-scaled dh * rstd of mlp_bwd_dh_ln."""
     if dh.dtype != torch.bfloat16 or not lib().vsx_gemm_nt_ln_bwd_supported(M, C, K, dtype_code(dh.dtype)):
         return None
     dy = torch.empty((M, C), dtype=dh.dtype, device=dh.device)
-    gemm("nt", dh, WT, dy, M, C, K, K, K, C, dtype=dh.dtype, epi=L.EPI_LN_BWD, aux=xh, ldx=C, grn_s=rstd)
+    gemm("nt", dh, WT, dy, M, C, K, K, K, C, dtype=dh.dtype, epi=L.EPI_LN_BWD, aux=xh, ldx=C, grn_s=rstd, grn_b=mean)
     return dy
 
 
@@ -344,22 +345,22 @@ def flush() -> None:
     _BATCH_WRITTEN.clear()
 
 
-def _queue(kind: int, dtype: int, ints, p0, p1, p2, p3, p4=None, p5=None, p6=None) -> bool:
+def _queue(kind: int, dtype: int, ints, p0, p1, p2, p3, p4=None, p5=None, p6=None, p7=None) -> bool:
     if _BATCH is None:
         return False
     # The jobs of one list run CONCURRENTLY (one launch): a job must not read, write or accumulate into what another job of the
     # same list writes (UNPREP and the accumulating TRANSPOSE / MATVEC_T / REDUCE_ROWS are non-atomic read-modify-writes).
     # Outputs are p1 (+ p2 for PREP / UNPREP); a job that touches a tensor an already queued job writes — a tied parameter, two
     # finalisers on one gradient — launches the list collected so far first (same-tensor hazards, by start address).
-    tens = [t for t in (p0, p1, p2, p3, p4, p5, p6) if torch.is_tensor(t)]
+    tens = [t for t in (p0, p1, p2, p3, p4, p5, p6, p7) if torch.is_tensor(t)]
     if _BATCH_WRITTEN and any(t.data_ptr() in _BATCH_WRITTEN for t in tens):
         flush()
     for t in (p1, p2) if kind in (L.WTASK_PREP, L.WTASK_UNPREP) else (p1,):
         if torch.is_tensor(t):
             _BATCH_WRITTEN.add(t.data_ptr())
     i = list(ints) + [0] * (4 - len(ints))
-    _BATCH.append(L.VsxWTask(kind, dtype, i[0], i[1], i[2], i[3], ptr(p0), ptr(p1), ptr(p2), ptr(p3), ptr(p4), ptr(p5), ptr(p6)))
-    _BATCH_KEEP.append((p0, p1, p2, p3, p4, p5, p6))
+    _BATCH.append(L.VsxWTask(kind, dtype, i[0], i[1], i[2], i[3], ptr(p0), ptr(p1), ptr(p2), ptr(p3), ptr(p4), ptr(p5), ptr(p6), ptr(p7)))
+    _BATCH_KEEP.append((p0, p1, p2, p3, p4, p5, p6, p7))
     return True
 
 
@@ -376,10 +377,12 @@ def prep_weight(src: Tensor, R: int, Cs: int, Tn: int, dtype: torch.dtype, *, wa
 
 
 def unprep_grad(g: Tensor, dparam: Tensor, R: int, Cs: int, Tn: int, *, gamma=None, W=None, dgamma=None, u=None,
-                beta=None, tapmode=0):
-    if _queue(L.WTASK_UNPREP, 0, (R, Cs, Tn, tapmode), g, dparam, dgamma, gamma, W, u, beta):
+                beta=None, rowsub=None, tapmode=0):
+    """``rowsub`` [R]: subtracted from every column of row r of ``g`` first (the rank-1 term of a weight gradient contracted
+    with un-centred rows: mlp_bwd_dh_ln)"""
+    if _queue(L.WTASK_UNPREP, 0, (R, Cs, Tn, tapmode), g, dparam, dgamma, gamma, W, u, beta, rowsub):
         return
-    check(lib().vsx_unprep_grad(ptr(g), ptr(dparam), ptr(gamma), ptr(W), ptr(dgamma), ptr(u), ptr(beta), R, Cs, Tn,
+    check(lib().vsx_unprep_grad(ptr(g), ptr(dparam), ptr(gamma), ptr(W), ptr(dgamma), ptr(u), ptr(beta), ptr(rowsub), R, Cs, Tn,
                                 tapmode, stream()), "unprep_grad")
 
 
@@ -480,16 +483,20 @@ def mlp_fc1(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, 
     return h, g
 
 
-def mlp_fc1_ln(y: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int, eps: float = 1e-6, store_h: bool = True):
+def mlp_fc1_ln(y: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int, eps: float = 1e-6, store_h: bool = True,
+               store_xh: bool = True):
     """the block LayerNorm (no affine) + training fc1 in one pass over the depthwise convolution's output ``y``: returns
-    (xh, rstd, h, g) — what ln_fwd + mlp_fc1 return, without the LayerNorm pass (``store_h=False``: h is None, see mlp_fc1)"""
-    xh = torch.empty_like(y)
+    (xh, rstd, h, g) — what ln_fwd + mlp_fc1 return, without the LayerNorm pass (``store_h=False``: h is None, see mlp_fc1).
+    ``store_xh=False``: the normalised rows are not written either; the first item is then the pair (y, mean) the backward
+    re-normalises from (mlp_bwd_dh_ln, dgrad_ln_bwd(mean=...))"""
+    xh = torch.empty_like(y) if store_xh else None
+    mean = None if store_xh else torch.empty(M, dtype=torch.float32, device=y.device)
     rstd = torch.empty(M, dtype=torch.float32, device=y.device)
     h = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device) if store_h else None
     g = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device)
-    check(lib().vsx_mlp_fc1_ln(ptr(y), eps, ptr(xh), ptr(rstd), ptr(img), ptr(b1), ptr(colsq), ptr(_gelu_table(y.device)), ptr(h),
-                               ptr(g), M, C, hw, dtype_code(y.dtype), stream()), "mlp_fc1_ln")
-    return xh, rstd, h, g
+    check(lib().vsx_mlp_fc1_ln(ptr(y), eps, ptr(xh), ptr(rstd), ptr(mean), ptr(img), ptr(b1), ptr(colsq), ptr(_gelu_table(y.device)),
+                               ptr(h), ptr(g), M, C, hw, dtype_code(y.dtype), stream()), "mlp_fc1_ln")
+    return (xh if store_xh else (y, mean)), rstd, h, g
 
 
 def grn_q_reduce(Q: Tensor, cs: Tensor, W2: Tensor, s: Tensor, beta: Tensor, P: Tensor, S: Tensor, dW2: Tensor, db2: Tensor) -> None:
@@ -527,6 +534,20 @@ def mlp_bwd_dh_re(dout: Tensor, xh: Tensor, img2: Tensor, img: Tensor, b1: Tenso
     ws = _workspace(dout.device, rows * 4 * C)
     check(lib().vsx_mlp_bwd_dh_re(ptr(dout), ptr(xh), ptr(img2), ptr(img), ptr(b1), ptr(s), ptr(t), ptr(dh), ptr(ws), rows, ptr(colsum),
                                   ptr(_gelu_table(dout.device)), M, C, hw, dtype_code(dout.dtype), stream()), "mlp_bwd_dh_re")
+    return dh
+
+
+def mlp_bwd_dh_ln(dout: Tensor, y: Tensor, mean: Tensor, rstd: Tensor, img2: Tensor, img: Tensor, b1: Tensor, s: Tensor, t: Tensor,
+                  colsum2: Tensor, M: int, C: int, hw: int) -> Tensor:
+    """mlp_bwd_dh_re for a block that stored no normalised rows: x^ is re-formed from the LayerNorm input ``y`` and its row
+    statistics; returns dh' = dh * rstd (row-scaled); colsum2 [2, 4C] += {column sums of the UNSCALED dh, u = sum_r dh' * mean}
+    (see vsx_mlp_bwd_dh_ln for what the consumers do with them)"""
+    dh = torch.empty((M, 4 * C), dtype=dout.dtype, device=dout.device)
+    rows = M // int(lib().vsx_mlp_rows_per_workgroup(C, hw, M))
+    ws = _workspace(dout.device, rows * 8 * C)
+    check(lib().vsx_mlp_bwd_dh_ln(ptr(dout), ptr(y), ptr(mean), ptr(rstd), ptr(img2), ptr(img), ptr(b1), ptr(s), ptr(t), ptr(dh), ptr(ws),
+                                  rows, ptr(colsum2), ptr(_gelu_table(dout.device)), M, C, hw, dtype_code(dout.dtype), stream()),
+          "mlp_bwd_dh_ln")
     return dh
 
 
