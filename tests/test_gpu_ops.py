@@ -1435,7 +1435,7 @@ def test_fused_passes_with_two_workgroups_per_cu(C, hw, B):
 
 def test_weight_task_list_equals_single_launches():
     """vsx_weight_tasks (ops.batch): prep_weight / transpose_f32 / matvec / mlp_pack / unprep_grad / matvec_t_add collected into task lists give identical
-    outputs to the single launches — more tasks than one launch holds (VSX_WTASK_MAX = 48), every kind, bf16 and fp32, tap
+    outputs to the single launches — more tasks than one launch holds (VSX_WTASK_MAX = 40), every kind, bf16 and fp32, tap
     reordering, gamma fold, accumulate"""
     O = _hip()
 
