@@ -630,46 +630,51 @@ def test_dwconv7_matrix_core_path(B, Hh, Ww, C):
     M = B * Hh * Ww
     x, dy, add = rnd(M, C, dt=dt, seed=1), rnd(M, C, dt=dt, seed=2), rnd(M, C, dt=dt, seed=3)
     bias = rnd(C, seed=5)
-    assert lib().vsx_get_flag(b"dw_mfma") == 7  # shipped default: forward / data gradient (bit 0), weight gradient (bits 1, 2)
+    shipped = 15  # forward / data gradient (bit 0) with LDS-DMA tile fetches (bit 3), weight gradient (bits 1, 2)
+    assert lib().vsx_get_flag(b"dw_mfma") == shipped
     for wkind in ("bf16_exact", "fp32"):
         w = rnd(49, C, seed=4, scale=0.2)
         if wkind == "bf16_exact":
             w = w.to(torch.bfloat16).float()
         outs = {}
-        for flag in (1, 0):
-            set_flag(7 * flag)
+        for flag in (31, 7, 0):  # LDS-DMA tile fetches wherever they can run (whole 32-channel slabs), register-staged tiles, VALU stencil
+            set_flag(flag)
             try:
-                outs[flag] = (H.dwconv7_fwd(x.to(DEV), w.to(DEV), bias.to(DEV), B, Hh, Ww, C).float().cpu(),
+                outs[15 if flag == 31 else flag] = (H.dwconv7_fwd(x.to(DEV), w.to(DEV), bias.to(DEV), B, Hh, Ww, C).float().cpu(),
                               H.dwconv7_fwd(x.to(DEV), w.to(DEV), None, B, Hh, Ww, C).float().cpu(),
                               H.dwconv7_bwd_data(dy.to(DEV), w.to(DEV), add.to(DEV), B, Hh, Ww, C).float().cpu(),
                               H.dwconv7_bwd_data(dy.to(DEV), w.to(DEV), None, B, Hh, Ww, C).float().cpu())
             finally:
-                set_flag(7)
+                set_flag(shipped)
         ref = (R.dwconv7_fwd(x, w, bias, B, Hh, Ww, C).float(), R.dwconv7_fwd(x, w, None, B, Hh, Ww, C).float(),
                R.dwconv7_bwd_data(dy, w, add, B, Hh, Ww, C).float(), R.dwconv7_bwd_data(dy, w, None, B, Hh, Ww, C).float())
-        for name, a, b, r in zip(["y", "y_nobias", "dx_add", "dx"], outs[1], outs[0], ref):
-            assert torch.isfinite(a).all(), name
-            scale = r.abs().max().item()
-            close(a, r, dt, f"{name} vs reference ({wkind})")
-            if wkind == "bf16_exact":
-                # same products, fp32 accumulation in a different order, one bf16 rounding (two with `add`): a few ulps apart
-                d = (a - b).abs()
-                assert d.max().item() <= (1.6e-2 if name == "dx_add" else 8e-3) * scale, (name, d.max().item() / scale)
-                assert (d > 0).float().mean().item() < (0.5 if name == "dx_add" else 0.2), (name, (d > 0).float().mean().item())
+        for mm in (15, 7):
+            for name, a, b, r in zip(["y", "y_nobias", "dx_add", "dx"], outs[mm], outs[0], ref):
+                assert torch.isfinite(a).all(), (mm, name)
+                scale = r.abs().max().item()
+                close(a, r, dt, f"{name} vs reference ({wkind}, dw_mfma = {mm})")
+                if wkind == "bf16_exact":
+                    # same products, fp32 accumulation in a different order, one bf16 rounding (two with `add`): a few ulps apart
+                    d = (a - b).abs()
+                    assert d.max().item() <= (1.6e-2 if name == "dx_add" else 8e-3) * scale, (mm, name, d.max().item() / scale)
+                    assert (d > 0).float().mean().item() < (0.5 if name == "dx_add" else 0.2), (mm, name, (d > 0).float().mean().item())
+        # the two matrix-core kernels run the same MFMA sequence on the same operands: identical bits
+        for name, a, b in zip(["y", "y_nobias", "dx_add", "dx"], outs[15], outs[7]):
+            assert torch.equal(a, b), (name, (a - b).abs().max().item())
 
 
     # weight gradient: row contraction on the matrix cores (transpose reads) vs the VALU kernel and the fp32 reference —
     # the products are exact in both, only the fp32 summation order differs
     res = {}
     for flag in (7, 3, 0):  # 16-column tiles (shipped), 32-column tiles where the width allows, VALU kernel
-        set_flag(flag)
+        set_flag(flag | (8 if flag else 0))
         try:
             dw, db = torch.zeros(49, C, device=DEV), torch.zeros(C, device=DEV)
             H.dwconv7_bwd_weight(dy.to(DEV), x.to(DEV), dw, db, B, Hh, Ww, C)
             H.dwconv7_bwd_weight(dy.to(DEV), x.to(DEV), dw, db, B, Hh, Ww, C)  # accumulates
             res[flag] = (dw.cpu() / 2, db.cpu() / 2)
         finally:
-            set_flag(7)
+            set_flag(shipped)
     dwr, dbr = torch.zeros(49, C), torch.zeros(C)
     R.dwconv7_bwd_weight(dy, x, dwr, dbr, B, Hh, Ww, C)
     for name, a, a32, b, r in zip(["dw", "db"], res[7], res[3], res[0], (dwr, dbr)):

@@ -262,6 +262,278 @@ __global__ __launch_bounds__(DWM_THREADS) void dwconv7_mfma_kernel(const bf16_t*
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same forward / data gradient with its tiles fetched by LDS-DMA (round 4).  The register-staged kernel above issues the
+// loads of tile t + 1 at the top of iteration t and needs them 0.2 us later (14 - 28 MFMAs per wave): at the 128-register cap
+// of a 16-wave workgroup there is no room for a second register stage, so every iteration exposes most of a memory round trip
+// (SQ counters: 58 % of the wave cycles in s_waitcnt vmcnt).  `global_load_lds_dwordx4` needs no registers: a lane hands over a
+// 16-byte global address and the data lands at (wave-uniform LDS base + lane * 16).  So:
+//   * the halo tile (22 x 22 pixels x 64 B of the slab) arrives pixel-major in a RAW buffer, two tiles ahead of its use
+//     (raw[2] alternate; the shortcut operand `add` of the data gradient the same way, one tile ahead — the old kernel fetched it
+//     with a dependent load inside the store loop);
+//   * out-of-image halo pixels read a 64-byte block of zeros in global memory (a DMA cannot write a constant);
+//   * an LDS -> LDS pass (16-byte reads, the same 2-byte transposing writes as above) fills the per-channel planes; MFMAs, the
+//     write-back into the planes and the gather to 16-byte channel vectors are unchanged;
+//   * waits are counted: loads return in order, so "at most n operations outstanding" with n = the DMA pieces issued in THIS
+//     iteration proves every older DMA piece has landed whatever the (unordered) stores in between are doing; each wave waits
+//     for its own pieces, the workgroup barrier that follows makes them visible to everyone.
+// 16 x 16 tiles only (raw 2 x 31 KB + add 2 x 16 KB + planes 55 KB + taps 6 KB = 155 KB of the CU's 160).  The buffers are
+// separate __shared__ objects and the tile loop is unrolled by two so that every access names its buffer at compile time
+// (through one array every ds_read behind a DMA costs an s_waitcnt vmcnt(0): csrc/mlp.hip).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(64))) unsigned int g_dwm_zero_block[16];  // zero-initialised: the source of halo pixels outside the image
+
+constexpr int DWD_IW = 22, DWD_PITCH = 40, DWD_PLANE = DWM_ROWS * DWD_PITCH;
+// CB channels per workgroup (a wave owns two): 32 = the 64-byte slab of the register-staged kernel, one 16-wave workgroup per CU.
+// (CB = 16 — half slabs, 8 waves and 79 KB of LDS per workgroup, so that TWO workgroups share a CU and one's transposition / store
+// phase runs under the other's MFMA phase — compiles from the same source and was measured: 32-byte row pieces cost more than the
+// overlap buys, forward 266 -> 299 us, data gradient 300 -> 435 us at 64 x 64 x 96, B = 512; only CB = 32 is instantiated.)
+template <int CB>
+struct DwdGeom {
+  static constexpr int THREADS = CB * 32, NW = CB / 2, PP = CB / 8;   // PP: 16-byte pieces per pixel
+  static constexpr int XITEMS = DWM_ROWS * DWD_IW * PP;               // pieces of a halo tile (1936 / 968)
+  static constexpr int XINSTR = (XITEMS + 63) / 64;                   // wave-wide DMA instructions per halo tile (31 / 16)
+  static constexpr int XIT = (XINSTR + NW - 1) / NW;                  // ... per wave, at most
+  static constexpr int RAW = XINSTR * 1024, ADD = 256 * PP * 16;
+  static_assert(256 * PP == THREADS, "one output piece per thread");
+};
+
+// One wave-wide DMA piece: lane l's 16 bytes at `gsrc` land at LDS byte address lds_base + l * 16 (lds_base wave-uniform).  Issued
+// as inline assembly ON PURPOSE: hipcc puts `s_waitcnt vmcnt(0)` in front of LDS reads behind a `__builtin_amdgcn_global_load_lds`
+// whenever it cannot prove which LDS object the DMA writes (it could not here), which serialises the prefetch; this kernel counts
+// its own waits (dwd_wait_older_than) and orders LDS traffic with raw barriers.
+static __device__ __forceinline__ void dwd_dma16(const void* gsrc, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_base) : "memory", "m0");
+}
+static __device__ __forceinline__ uint32_t dwd_lds_addr(const void* p) {
+  return (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+// LDS traffic of this wave done, then the workgroup barrier — WITHOUT the vmcnt(0) a __syncthreads() carries
+static __device__ __forceinline__ void dwd_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <bool FLIP, int CB>
+__global__ __launch_bounds__(CB * 32, CB == 16 ? 4 : 1) void dwconv7_mfma_dma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                       const float* __restrict__ bias,
+                                                                       const bf16_t* __restrict__ add, bf16_t* __restrict__ y,
+                                                                       int B, int H, int W, int C, int nslab, int tiles_total,
+                                                                       int tiles_per_wg) {
+  typedef DwdGeom<CB> G;
+  constexpr int THREADS = G::THREADS, CPW = 2, PP = G::PP;
+  __shared__ __attribute__((aligned(1024))) char raw0[G::RAW];
+  __shared__ __attribute__((aligned(1024))) char raw1[G::RAW];
+  __shared__ __attribute__((aligned(1024))) char radd0[G::ADD];
+  __shared__ __attribute__((aligned(1024))) char radd1[G::ADD];
+  __shared__ __attribute__((aligned(16))) unsigned short planes[CB * DWD_PLANE + (CB / 8) * 16];
+  __shared__ float wsm[49 * CB];
+
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int slab = bid % nslab;
+  const int chunk = bid / nslab;
+  const int t_begin = chunk * tiles_per_wg;
+  const int t_end = min(tiles_total, t_begin + tiles_per_wg);
+  if (t_begin >= t_end) return;
+  const int c_base = slab * CB;
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p16 = lane & 15, kq = lane >> 4;
+
+  for (int i = tid; i < 49 * CB; i += THREADS) {
+    const int tap = i / CB, cl = i - tap * CB;
+    wsm[i] = w[(size_t)tap * C + c_base + cl];
+  }
+  __syncthreads();
+  dwm_bf16x8 afrag[CPW][7];
+  float bias_v[CPW];
+#pragma unroll
+  for (int cc = 0; cc < CPW; ++cc) {
+    const int cl = wave * CPW + cc;
+    bias_v[cc] = bias ? bias[c_base + cl] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+      uint32_t pk[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        float v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int t = kq * 8 + e2 * 2 + h - p16;
+          const bool in = t >= 0 && t < 7;
+          const int tt = in ? t : 0;
+          const int tap = FLIP ? 48 - (ky * 7 + tt) : ky * 7 + tt;
+          const float wv = wsm[tap * CB + cl];
+          v[h] = in ? wv : 0.f;
+        }
+        pk[e2] = f32x2_to_bf16x2_bits(v[0], v[1]);
+      }
+      uint4 q = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      afrag[cc][ky] = __builtin_bit_cast(dwm_bf16x8, q);
+    }
+  }
+  {  // pad columns of the planes: read by the K = 32 window, multiplied by zeros of A, must be finite; never written afterwards
+    constexpr int PADW = DWD_PITCH - DWD_IW;
+    for (int i = tid; i < CB * DWM_ROWS * PADW; i += THREADS) {
+      const int col = DWD_IW + i % PADW;
+      int r = i / PADW;
+      const int row = r % DWM_ROWS;
+      const int ch = r / DWM_ROWS;
+      planes[dwm_plane_base(ch, DWD_PLANE) + row * DWD_PITCH + col] = 0;
+    }
+  }
+
+  struct TileAt { int b, y0, x0; };
+  auto tile_first = [&](int t) {
+    TileAt a;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    a.b = t / tiles_y;
+    a.y0 = (t % tiles_y) * 16;
+    a.x0 = tx * 16;
+    return a;
+  };
+  auto tile_next = [&](TileAt a) {
+    a.x0 += 16;
+    if (a.x0 >= tiles_x * 16) {
+      a.x0 = 0;
+      a.y0 += 16;
+      if (a.y0 >= tiles_y * 16) { a.y0 = 0; a.b += 1; }
+    }
+    return a;
+  };
+  const char* zsrc = reinterpret_cast<const char*>(g_dwm_zero_block);
+  // this wave's DMA pieces of a halo tile are the items tid + it * THREADS (the items the same thread transposes later)
+  int nx = 0;                                              // ... how many of them (wave-uniform)
+#pragma unroll
+  for (int it = 0; it < G::XIT; ++it) nx += wave + G::NW * it < G::XINSTR ? 1 : 0;
+  auto issue_x = [&](const TileAt& at, uint32_t dst) {
+#pragma unroll
+    for (int it = 0; it < G::XIT; ++it) {
+      if (wave + G::NW * it >= G::XINSTR) break;
+      const int i = tid + it * THREADS;
+      if (i < G::XITEMS) {
+        const int cv = i % PP, p = i / PP;
+        const int col = p % DWD_IW, row = p / DWD_IW;
+        const int gy = at.y0 + row - 3, gx = at.x0 + col - 3;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const char* src = in ? reinterpret_cast<const char*>(x + (((size_t)at.b * H + gy) * W + gx) * C + c_base + cv * 8)
+                             : zsrc + cv * 16;
+        dwd_dma16(src, dst + (wave + G::NW * it) * 1024);
+      }
+    }
+  };
+  auto issue_add = [&](const TileAt& at, uint32_t dst) {
+    const int cv = tid % PP, p = tid / PP;
+    const int col = p & 15, row = p >> 4;
+    const int gy = at.y0 + row, gx = at.x0 + col;
+    const bool in = gy < H && gx < W;
+    const char* src = in ? reinterpret_cast<const char*>(add + (((size_t)at.b * H + gy) * W + gx) * C + c_base + cv * 8) : zsrc + cv * 16;
+    dwd_dma16(src, dst + wave * 1024);
+  };
+  auto transpose_in = [&](const char* rawb) {
+#pragma unroll
+    for (int it = 0; it < G::XIT; ++it) {
+      const int i = tid + it * THREADS;
+      if (i < G::XITEMS) {
+        const int cv = i % PP, p = i / PP;
+        const int col = p % DWD_IW, row = p / DWD_IW;
+        const uint4 v = *reinterpret_cast<const uint4*>(rawb + (size_t)i * 16);
+        unsigned short* dst = &planes[dwm_plane_base(cv * 8, DWD_PLANE) + row * DWD_PITCH + col];
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          dst[(e2 * 2) * DWD_PLANE] = (unsigned short)(d[e2] & 0xffffu);
+          dst[(e2 * 2 + 1) * DWD_PLANE] = (unsigned short)(d[e2] >> 16);
+        }
+      }
+    }
+  };
+  auto wait_older_than = [&](int n) {  // every vector-memory operation but the n youngest has completed (n is wave-uniform)
+    static_assert(G::XIT <= 2, "the wait below knows 0 .. 3 pieces in flight");
+    if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  // one tile: `rawc` / `addc` hold tile t (complete for this wave since the previous iteration's wait), `rawn` / `addn` receive
+  // tile t + 1's shortcut operand now and tile t + 2's halo tile once rawc has been transposed
+  auto tile_step = [&](int t, const TileAt& at, const TileAt& at1, const TileAt& at2, char* rawc, char* addc, char* addn) {
+    dwd_barrier();                                    // A: gather(t - 1) done by everyone; everyone's pieces of tile t landed
+    const bool more1 = t + 1 < t_end, more2 = t + 2 < t_end;
+    if (add && more1) issue_add(at1, dwd_lds_addr(addn));
+    transpose_in(rawc);
+    dwd_barrier();                                    // D: planes complete; rawc free
+    if (more2) issue_x(at2, dwd_lds_addr(rawc));
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+      const int chl = wave * CPW + cc;
+      unsigned short* plane = &planes[dwm_plane_base(chl, DWD_PLANE)];
+      dwm_f32x4 acc = dwm_f32x4{bias_v[cc], bias_v[cc], bias_v[cc], bias_v[cc]};
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const uint4 q = *reinterpret_cast<const uint4*>(plane + (p16 + ky) * DWD_PITCH + kq * 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[cc][ky], __builtin_bit_cast(dwm_bf16x8, q), acc, 0, 0, 0);
+      }
+      uint2 o;
+      o.x = f32x2_to_bf16x2_bits(acc[0], acc[1]);
+      o.y = f32x2_to_bf16x2_bits(acc[2], acc[3]);
+      *reinterpret_cast<uint2*>(plane + p16 * DWD_PITCH + kq * 4) = o;
+    }
+    // tile t + 1 (halo pieces issued one iteration ago, shortcut piece at the top of this one) must have landed before the
+    // next barrier A; what may stay in flight are the pieces issued in THIS iteration behind it: the halo pieces of t + 2 —
+    // and, issued BEFORE the halo pieces of t + 1?  No: order of issue is add(t+1) [this iteration], x(t+2) [this iteration];
+    // x(t+1) and add(t) are older.  add(t+1) is needed by the NEXT gather only, so it may stay in flight as well.
+    wait_older_than((add && more1 ? 1 : 0) + (more2 ? nx : 0));
+    dwd_barrier();                                    // H: every plane holds its channel's outputs
+    {
+      const int cv = tid % PP, p = tid / PP;
+      const int col = p & 15, row = p >> 4;
+      const int gy = at.y0 + row, gx = at.x0 + col;
+      if (gy < H && gx < W) {
+        const unsigned short* src = &planes[dwm_plane_base(cv * 8, DWD_PLANE) + row * DWD_PITCH + col];
+        uint32_t d[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2)
+          d[e2] = (uint32_t)src[(e2 * 2) * DWD_PLANE] | ((uint32_t)src[(e2 * 2 + 1) * DWD_PLANE] << 16);
+        const size_t off = (((size_t)at.b * H + gy) * W + gx) * C + c_base + cv * 8;
+        uint4 o = make_uint4(d[0], d[1], d[2], d[3]);
+        if (add) {
+          float a[8], f[8];
+          unpack<bf16_t>(*reinterpret_cast<const uint4*>(addc + (size_t)tid * 16), a);
+          unpack<bf16_t>(o, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] += a[j];
+          o = pack<bf16_t>(f);
+        }
+        *reinterpret_cast<uint4*>(y + off) = o;
+      }
+    }
+  };
+
+  TileAt a0 = tile_first(t_begin), a1 = tile_next(a0), a2 = tile_next(a1);
+  __syncthreads();                                    // pad zeroing done (no DMA in flight yet)
+  issue_x(a0, dwd_lds_addr(raw0));
+  if (add) issue_add(a0, dwd_lds_addr(radd0));
+  if (t_begin + 1 < t_end) issue_x(a1, dwd_lds_addr(raw1));
+  wait_older_than(t_begin + 1 < t_end ? nx : 0);      // tile t_begin complete for this wave
+  for (int t = t_begin; t < t_end; t += 2) {
+    tile_step(t, a0, a1, a2, raw0, radd0, radd1);
+    a0 = a1; a1 = a2; a2 = tile_next(a2);
+    if (t + 1 < t_end) {
+      tile_step(t + 1, a0, a1, a2, raw1, radd1, radd0);
+      a0 = a1; a1 = a2; a2 = tile_next(a2);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
 // weight gradient on the matrix cores.  dw_c[ky][kx] = sum_{y,x} dy_c[y][x] * in_c[y + ky - 3][x + kx - 3]: for one
 // channel and one ky, contract over 16 image ROWS with v_mfma_f32_16x16x16_bf16:
 //
@@ -433,7 +705,14 @@ int vsx_dwconv7_mfma_try(const void* x, const float* w, const float* bias, const
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int nxt = W >= 24 ? 2 : 1;
+  // bit 3: tiles by LDS-DMA, two ahead (16 x 16 tiles; whole slabs only) — where that kernel wins (tools/perf_dw.py, B = 512, us,
+  // register-staged / DMA): the data gradient with its shortcut operand at every size (366 / 314 at 64 x 64 x 96, 176 / 163 at
+  // 32 x 32 x 192, 107 / 83 at 16 x 16 x 384, 721 / 652 at 64 x 64 x 224: the operand rides the DMA instead of a dependent load in
+  // the store loop) and maps of one tile (forward 75 / 69 at 16 x 16 x 384); the forward of larger maps keeps the 16 x 32 tiles of
+  // the register-staged kernel (256 / 282, 125 / 133, 521 / 547: a smaller halo and half the barriers per pixel).  Bit 4: the
+  // DMA kernel wherever it can run (A/B knob)
+  const bool dma = C % DWM_CB == 0 && (((g_vsx_dw_mfma & 8) && (add != nullptr || (H <= 16 && W <= 16))) || (g_vsx_dw_mfma & 16));
+  const int nxt = (W >= 24 && !dma) ? 2 : 1;
   const int tw = 16 * nxt;
   const int nslab = vsx_cdiv(C, DWM_CB);
   const long tiles_l = (long)B * vsx_cdiv(H, 16) * vsx_cdiv(W, tw);
@@ -450,7 +729,12 @@ int vsx_dwconv7_mfma_try(const void* x, const float* w, const float* bias, const
 #define DWM_LAUNCH(NXT, FLIP)                                                                                          \
   hipLaunchKernelGGL((dwconv7_mfma_kernel<NXT, FLIP>), dim3(grid), dim3(DWM_THREADS), 0, s, (const bf16_t*)x, w, bias,  \
                      (const bf16_t*)add, (bf16_t*)y, B, H, W, C, nslab, tiles, per)
-  if (nxt == 2) {
+#define DWD_LAUNCH(FLIP, CBV)                                                                                                \
+  hipLaunchKernelGGL((dwconv7_mfma_dma_kernel<FLIP, CBV>), dim3(grid), dim3(CBV * 32), 0, s, (const bf16_t*)x, w, bias,          \
+                     (const bf16_t*)add, (bf16_t*)y, B, H, W, C, nslab, tiles, per)
+  if (dma) {
+    if (flip) DWD_LAUNCH(true, 32); else DWD_LAUNCH(false, 32);
+  } else if (nxt == 2) {
     if (flip) DWM_LAUNCH(2, true); else DWM_LAUNCH(2, false);
   } else {
     if (flip) DWM_LAUNCH(1, true); else DWM_LAUNCH(1, false);
