@@ -25,7 +25,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = co
 for f in glob.glob("gpurun_out/sq_p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
-        m = re.search(r"mlp_fused_kernel<\s*(\d+),\s*\d+,\s*\d+,\s*(\d)>", kn) or re.search(r"mlp_fused_kernelILi(\d+)ELi\d+ELi\d+ELi(\d)EE", kn)
+        m = re.search(r"mlp_fused_kernel(?:_sf)?<\s*(\d+),\s*\d+,\s*\d+,\s*(\d)>", kn) or re.search(r"mlp_fused_kernel(?:_sf)?ILi(\d+)ELi\d+ELi\d+ELi(\d)EE", kn)
         if m: k = f"mlp_fused<C={m.group(1)},MODE={m.group(2)}>"
         elif "gemm_nt2" in kn: k = "gemm_nt2 (256 x BN, LDS-DMA)"
         elif "gemm_nt_fast" in kn: k = "gemm_nt_fast (128 x 128)"

@@ -1412,6 +1412,73 @@ def test_fused_block_without_stored_normalised_rows(C, hw, B, offset):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,hw,B", [(96, 4096, 4), (224, 4096, 40), (384, 256, 16)])
+def test_fused_passes_scalar_and_packed_fp32_builds_agree(C, hw, B):
+    """Round 5: every fused GRN-MLP pass exists in two builds of the same source — packed-fp32 VALU arithmetic (v_pk_*_f32) and
+    scalar (`no-packed-fp32-ops`; the default of the forward passes, where a packed instruction next to MFMAs costs more than the
+    two scalar ones it replaces: csrc/mlp.hip).  A v_pk_fma_f32 is two v_fma_f32: the outputs must be bit-identical whichever
+    build the `mlp_sf32` flag selects (> 256 workgroups at C = 224: both builds also with two workgroups per CU)."""
+    if SELF_CHECK:
+        pytest.skip("HIP-only kernel")
+    from viscy_amd import _lib as L
+    from viscy_amd import ops
+
+    dt = torch.bfloat16
+    M, H4 = B * hw, 4 * C
+    lib = L.lib()
+    saved = lib.vsx_get_flag(b"mlp_sf32")
+    y = rnd(M, C, dt=dt, seed=1, scale=2.0).cuda()
+    W1 = rnd(H4, C, dt=dt, seed=2, scale=C ** -0.5).cuda()
+    W2 = rnd(C, H4, dt=dt, seed=3, scale=H4 ** -0.5).cuda()
+    b1 = (0.1 * rnd(H4, seed=4)).cuda()
+    dout = rnd(M, C, dt=dt, seed=5).cuda()
+    s = (1 + 0.2 * rnd(B, H4, seed=6)).cuda()
+    t = (0.05 * rnd(B, H4, seed=7)).cuda()
+    b2, beta = (0.1 * rnd(C, seed=8)).cuda(), (0.1 * rnd(H4, seed=9)).cuda()
+    img, img2 = ops.mlp_pack(W1, W2, C), ops.mlp_pack(W2.t().contiguous(), W2, C)
+
+    def passes():
+        out = {}
+        q = torch.zeros((B, H4), device="cuda")
+        xh, rstd, h, g = ops.mlp_fc1_ln(y, img, b1, q, M, C, hw, 1e-6)                       # MODE 2
+        out["fc1 h"], out["fc1 g"], out["fc1 x^"], out["fc1 sums"] = h, g, xh, q
+        P, S = torch.zeros((B, H4), device="cuda"), torch.zeros((B, H4), device="cuda")
+        if ops.mlp_supported(C, hw, M, dt, 3):
+            ops.mlp_bwd_stats(dout, img2, g, P, S, M, C, hw)                                   # MODE 3
+            out["bwd stats P"], out["bwd stats S"] = P, S
+        db = torch.zeros(H4, device="cuda")
+        out["dh (stored h)"] = ops.mlp_bwd_dh(dout, img2, h, s, t, db, M, C, hw)               # MODE 4
+        out["db1 (stored h)"] = db
+        if C <= 224:
+            q0 = torch.zeros((B, H4), device="cuda")
+            ops.mlp_stats(y, img, b1, q0, M, C, hw, ln_eps=1e-6)                               # MODE 0
+            out["stats sums"] = q0
+            out["inference out"] = ops.mlp_out(y, img, b1, s, beta, b2, dout, None, M, C, hw, ln_eps=1e-6)   # MODE 1
+            q6, cs2 = torch.zeros((B, H4), device="cuda"), torch.zeros((2, H4), device="cuda")
+            (y7, mean7), r7, _, g7 = ops.mlp_fc1_ln(y, img, b1, q6, M, C, hw, 1e-6, store_h=False, store_xh=False)   # MODE 6
+            out["fc1 g (no h, no x^)"], out["fc1 mean"], out["fc1 rstd"] = g7, mean7, r7
+            db5 = torch.zeros(H4, device="cuda")
+            out["dh (h recomputed)"] = ops.mlp_bwd_dh_re(dout, xh, img2, img, b1, s, t, db5, M, C, hw)          # MODE 5
+            out["dh' (y re-normalised)"] = ops.mlp_bwd_dh_ln(dout, y, mean7, r7, img2, img, b1, s, t, cs2, M, C, hw)  # MODE 7
+            out["column sums of dh'"] = cs2
+        return out
+
+    try:
+        lib.vsx_set_flag(b"mlp_sf32", 0)
+        packed = passes()
+        lib.vsx_set_flag(b"mlp_sf32", 255)
+        scalar = passes()
+    finally:
+        lib.vsx_set_flag(b"mlp_sf32", saved)
+    assert packed.keys() == scalar.keys() and len(packed) >= 6
+    for k in packed:
+        if packed[k].dtype == torch.float32 and ("sums" in k or "stats" in k or k.startswith("db1")):
+            close(scalar[k], packed[k], torch.float32, k)   # atomically / workspace-reduced: order of the adds differs run to run
+        else:
+            assert torch.equal(packed[k], scalar[k]), (k, (packed[k] != scalar[k]).sum().item())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C,hw,B", [(192, 1024, 128), (224, 4096, 64)])
 def test_fused_passes_with_two_workgroups_per_cu(C, hw, B):
     """Regression test of a race that only large launches show (round 4): the fused GRN-MLP kernels refilled stage buffer 1 by

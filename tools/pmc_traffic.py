@@ -13,7 +13,7 @@ def load(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             kn = r["Kernel_Name"]
-            m = re.search(r"mlp_fused_kernel<\s*\d+,\s*\d+,\s*\d+,\s*(\d)>", kn) or re.search(r"mlp_fused_kernelILi\d+ELi\d+ELi\d+ELi(\d)EE", kn)
+            m = re.search(r"mlp_fused_kernel(?:_sf)?<\s*\d+,\s*\d+,\s*\d+,\s*(\d)>", kn) or re.search(r"mlp_fused_kernel(?:_sf)?ILi\d+ELi\d+ELi\d+ELi(\d)EE", kn)
             if m:  # the pass (template MODE) is what the op classes of bench.py distinguish
                 rows.append((f"mlp_fused_kernel_mode{m.group(1)}", float(r["Counter_Value"])))
                 continue

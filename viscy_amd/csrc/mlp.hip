@@ -110,6 +110,15 @@ __device__ __forceinline__ mlp_f32x4 mlp_mfma(const mlp_bf16x8& a, const mlp_bf1
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// MLP_TS (probe builds only: hipcc -DMLP_TS=1): s_memtime stamps of ONE workgroup's waves at the phase boundaries of every
+// sub-chunk step, read back with vsx_debug_mlp_ts — where a step's cycles go (tools/mlp_timeline.py)
+#ifdef MLP_TS
+__device__ unsigned long long g_mlp_ts[8 * 64 * 8];
+#define MLP_STAMP(k) do { if (blockIdx.x == gridDim.x / 2 + 7 && lane == 0) g_mlp_ts[(wave * 64 + hs) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MLP_STAMP(k) do { } while (0)
+#endif
+
 template <int C, int MF, int NW, int MODE>
 struct MlpGeom {
   static constexpr int H4 = 4 * C, NHS = H4 / 32, KK = C / 32, NF = C / 16;
@@ -136,7 +145,7 @@ struct MlpGeom {
 // two workgroups share a CU and the pass runs 4 % faster (1018 -> ~975 us at B = 512).  The same cap on C = 192 / 224 (132 / 160
 // bytes of spill) makes the pass 30 % slower: measured, not applied.
 template <int C, int MF, int NW, int MODE>
-__global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1)) void mlp_fused_kernel(const MlpArgs a) {
+__device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
   typedef MlpGeom<C, MF, NW, MODE> G;
   constexpr int H4 = G::H4, NHS = G::NHS, KK = G::KK, NF = G::NF, WM = G::WM;
   constexpr bool STATS = MODE == 0 || MODE == 2 || MODE == 6, STORE = MODE == 2 || MODE == 6, STORE_H = MODE == 2;
@@ -667,6 +676,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
         if (hs + 2 < NHS) tile_load(hs + 2);
       }
     }
+    MLP_STAMP(1);
     if (hs + 1 < NHS) stage_load2(hs + 1, other);
     const char* S = Sb + lane * 16;
     if constexpr (MODE == 3) {
@@ -694,6 +704,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
     // LDS latency exposed — 31 waits per sub-chunk at C = 224); the activation region in between is left to the compiler
     // (it batches the eight table reads of a fragment by itself)
     __builtin_amdgcn_sched_barrier(0);
+    MLP_STAMP(2);
     gemm1(S, xf, hnxt);  // fc1 of the NEXT sub-chunk (the last step multiplies stale fragments, result unused)
     if constexpr (RE) gemm1(S + G::W1_PIECES * 1024, xg, gnxt);
     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
@@ -703,11 +714,13 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    MLP_STAMP(3);
     float q0[2][4], q1[2][4];
     if constexpr (RE) bwd_act(hs, hcur, gcur, q0, q1);
     else if constexpr (BWD) bwd_act(hs, hcur, hcur, q0, q1);
     else activate(hs, hcur, zf);
     __builtin_amdgcn_sched_barrier(0);
+    MLP_STAMP(4);
     if constexpr (DH) {
       colsum_mfma(hs, red + (hs & 1) * (LNF ? 2 : 1) * NW * 32 + wave * 32);  // column sums of the parked dh (the fc1 bias gradient)
     } else if constexpr (BWD) {
@@ -739,6 +752,7 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    MLP_STAMP(5);
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -753,11 +767,15 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
   for (int hs = 0; hs < NHS; hs += 2) {
     if (hs > 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      { const int hs_ = hs; { const int hs = hs_ - 1; MLP_STAMP(6); } }
       __syncthreads();
     }
+    MLP_STAMP(0);
     step(hs, buf0, buf1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MLP_STAMP(6);
     __syncthreads();
+    { const int hs_ = hs; { const int hs = hs_ + 1; MLP_STAMP(0); } }
     step(hs + 1, buf1, buf0);
   }
 
@@ -846,6 +864,26 @@ __global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1))
   }
 }
 
+// Two builds of the same body (round 5).  hipcc packs the fp32 arithmetic of the activation code into v_pk_add / v_pk_mul /
+// v_pk_fma_f32 — half the VALU instructions, but on gfx950 a packed-fp32 instruction next to matrix instructions is an
+// anti-lever (tools/micro/mfma_valu_overlap2.hip, MI355X: a wave that issues ONE v_pk_*_f32 behind each
+// v_mfma_f32_16x16x32_bf16 takes 4 000 cycles for 128 MFMAs instead of 2 240 — ~15 cycles per packed instruction — while up
+// to TWO plain v_fma / v_mul / v_and / v_cvt_pk_bf16 per MFMA are free; between waves of one SIMD the packed forms add to the
+// other wave's MFMA time (2 300 cycles = the sum) where the scalar forms overlap in part (1 700 - 1 800)).  The forward passes
+// (MODE 6 at 4 waves per SIMD: -15 .. -20 % at C = 192 / 224; MODE 0 -6 %; tools/perf_mlp_train.py, same box) run the SCALAR
+// build (`no-packed-fp32-ops`); the dh passes spend 13 VALU operations per hidden element at 2 waves per SIMD, are bound by
+// their VALU issue inside the activation region and keep the packed build (+2.5 % otherwise).  `mlp_sf32` (vsx_set_flag):
+// bit m = MODE m runs the scalar build.
+template <int C, int MF, int NW, int MODE>
+__global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1)) void mlp_fused_kernel(const MlpArgs a) {
+  mlp_fused_body<C, MF, NW, MODE>(a);
+}
+template <int C, int MF, int NW, int MODE>
+__global__ __launch_bounds__(NW * 64, (MODE == 4 && NW == 8 && C == 96 ? 4 : 1)) __attribute__((target("no-packed-fp32-ops")))
+void mlp_fused_kernel_sf(const MlpArgs a) {
+  mlp_fused_body<C, MF, NW, MODE>(a);
+}
+
 // ------------------------------------------------------------------------------------------------ weight image
 // (layout and body: csrc/wtasks.h — shared with the task-list kernel vsx_weight_tasks)
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const bf16_t* __restrict__ W1, const bf16_t* __restrict__ W2,
@@ -861,6 +899,7 @@ struct MlpCfg { int C, MF, NW, modes; };  // modes: bit m set = this geometry se
 // -0.7 GB per block and step at B = 512).  The C = 384 inference pair (the output pass needs 192 accumulator registers: 4 waves x
 // 32 rows at one wave per SIMD, 875 us against 614 us for the unfused GEMMs at B = 512) was removed in round 4 (flag bit 4).
 extern int g_vsx_mlp_fused;
+extern int g_vsx_mlp_sf32;
 extern int g_vsx_nt_stream;
 static inline int mlp_nt() { return (g_vsx_nt_stream >> 2) & 3; }  // bits 2 / 3 of nt_stream: the fused passes' stores / last-reader loads
 static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 255}, {192, 2, 8, 255}, {224, 2, 8, 255}, {384, 2, 8, 4 | 8 | 16}};
@@ -902,7 +941,8 @@ extern "C" int32_t vsx_mlp_pack(const void* W1, const void* W2, void* img, int32
 template <int C, int MF, int NW, int MODE>
 static int mlp_launch(const MlpArgs& a, hipStream_t s) {
   typedef MlpGeom<C, MF, NW, MODE> G;
-  hipLaunchKernelGGL((mlp_fused_kernel<C, MF, NW, MODE>), dim3(a.M / G::BM), dim3(NW * 64), 0, s, a);
+  if (g_vsx_mlp_sf32 & (1 << MODE)) hipLaunchKernelGGL((mlp_fused_kernel_sf<C, MF, NW, MODE>), dim3(a.M / G::BM), dim3(NW * 64), 0, s, a);
+  else hipLaunchKernelGGL((mlp_fused_kernel<C, MF, NW, MODE>), dim3(a.M / G::BM), dim3(NW * 64), 0, s, a);
   VSX_LAUNCH_CHECK();
   return 0;
 }
@@ -1118,6 +1158,12 @@ extern "C" int32_t vsx_mlp_bwd_dh_ln(const void* dout, const void* y, const floa
   VSX_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef MLP_TS
+extern "C" int32_t vsx_debug_mlp_ts(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mlp_ts), sizeof(g_mlp_ts)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int32_t vsx_mlp_rows_per_workgroup(int32_t C, int32_t hw, int64_t M) {
   const MlpCfg* c = mlp_cfg(C, hw, M, 4);

@@ -163,6 +163,12 @@ def intensity_augment(x: Tensor, *, gamma: Tensor | None = None, factor: Tensor 
         m1, s1 = _sample_mean_std(ret)
         div = (s1 + 1e-8) / s0
         sub = m1 - m0 * div
+        # a constant sample (blank / zero-padded patch): s0 = 0 makes div inf and sub NaN, and one such sample would poison the
+        # step.  MONAI returns the constant there ((ret - mean) = 0 is divided by 0 + 1e-8, then * 0 + mn): div = 1 and
+        # sub = m1 - m0 give ret - m1 + m0 = m0 (the curve maps a constant onto itself, and its double mean is exact)
+        flat = s0 == 0
+        div = torch.where(flat, torch.ones_like(div), div)
+        sub = torch.where(flat, m1 - m0, sub)
         if invert_image:
             div = -div
         one, zero = torch.ones_like(div), torch.zeros_like(sub)
