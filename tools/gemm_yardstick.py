@@ -89,8 +89,8 @@ def main():
     for r in rows:
         for who in ("vendor", "hand"):
             us = r[f"{who}_us"]
-            r[f"{who}_tflops"] = round(r["gflop"] * 1e3 / us / 1e3, 1)  # GFLOP / us = 1e15 FLOP/s = 1000 TFLOP/s
-            r[f"{who}_TBps"] = round(r["gbytes"] * 1e3 / us / 1e3, 3)
+            r[f"{who}_tflops"] = round(r["gflop"] / us * 1e3, 1)  # GFLOP / us = 1000 TFLOP/s
+            r[f"{who}_TBps"] = round(r["gbytes"] / us * 1e3, 3)
         r["hand_over_vendor"] = round(r["vendor_us"] / r["hand_us"], 3)
         print(f"{r['kind']:5s} {r['name']:28s} M={r['M']:8d} N={r['N']:5d} K={r['K']:5d} | vendor {r['vendor_us']:8.1f} us "
               f"{r['vendor_tflops']:7.1f} TF {r['vendor_TBps']:6.2f} TB/s | hand {r['hand_us']:8.1f} us {r['hand_tflops']:7.1f} TF "
