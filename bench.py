@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 FWD_GFLOP_PER_PATCH = 22.56  # SURVEY §8d / BASELINE.md §2 (256x256, Z=5, tiny)
 FWD_MB_PER_PATCH = 75.5  # forward "two-pass floor" 
 ALGO_MB_PER_PATCH = 226.5    # fwd+bwd two-pass-GRN floor, bf16 activations
-PROFILE_ROUND = "r04"        # prefix of this round's files under profiles/
+PROFILE_ROUND = "r05"        # prefix of this round's files under profiles/
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
@@ -127,7 +127,8 @@ class OpTimer:
 
     def __init__(self, ops, only: str | None = None, by_shape: bool = False):
         self.ops, self.only, self.by_shape = ops, only, by_shape
-        self.records = {}  # family -> list of (start, end, flops, bytes, strict bytes, floor bytes)
+        self.records = {}    # family -> list of (start, end, flops, bytes, strict bytes, floor bytes)
+        self.templates = {}  # kernel template (family + the template arguments / GEMM shape that select the code) -> same tuples
         self._orig = {}
 
     @staticmethod
@@ -155,11 +156,18 @@ class OpTimer:
                 flops = 2.0 * M * N * K * nz
                 nbytes = (M * K + M * N) * es * nz + N * K * (es if kind == "nt" else 4)
                 strict = nbytes
+                # SURVEY §8(d)'s floor counts a ConvNeXt block as "read x, write y (+ the GRN second read)": the 4C-wide hidden
+                # tensors (g, dh: the [M, max(N, K)] operand of an fc1- / fc2-shaped product, N = 4K or K = 4N) and the per-sample
+                # fp32 products Q_b are DESIGN bytes of this implementation, not floor bytes
+                wide = max(N, K) == 4 * min(N, K)
+                floor = (M * min(N, K) if wide else M * K + M * N) * es * nz + (0 if k.get("b_bstride") and kind == "tn" else N * K * (es if kind == "nt" else 4))
                 if kind == "nt":
                     # operands of the fused epilogues are part of the launch's algorithmic traffic: the second output of
                     # fc1 (g = gelu(h)), the activation the dZ epilogue reads for the GRN statistics, the residual of fc2
                     extra = sum(k.get(nm) is not None for nm in ("C2", "aux", "res")) - (a[3] is None)
                     nbytes += extra * M * N * es * nz
+                    if not (wide and N > K):  # a C-wide second operand of the epilogue (residual, LayerNorm-backward rows)
+                        floor += extra * M * N * es * nz
             elif cls == "mlp_fused":  # fused GRN-MLP passes: one (two for the output pass) M x 4C x C contraction(s)
                 ba = sig.bind(*a, **k).arguments
                 Mm, Cc = ba["M"], ba["C"]
@@ -170,12 +178,21 @@ class OpTimer:
             e0.record()
             out = fn(*a, **k)
             e1.record()
+            tmpl = name
             if is_gemm:
                 cls = lib_last_kernel() or f"gemm_{a[0]}"
+                tmpl = cls + f" M{M} N{N} K{K} z{nz} e{k.get('epi', 0)} p{k.get('pro', 0)} a{k.get('a_mode', 0)}"
                 if self.by_shape:
-                    cls += f" M{M} N{N} K{K} z{nz} e{k.get('epi', 0)} p{k.get('pro', 0)} a{k.get('a_mode', 0)}"
+                    cls = tmpl
                 if self.only is not None and cls != self.only:
                     return out
+            elif cls == "mlp_fused":
+                tmpl = f"mlp_fused_kernel<C={Cc}, MODE={mlp_mode(name, ba)}>"
+            elif "C" in sig.parameters:
+                try:
+                    tmpl = f"{name} C={sig.bind(*a, **k).arguments['C']}"
+                except TypeError:
+                    pass
             if nbytes is None:
                 ts = self._tensors(list(a) + list(k.values()), out)
                 nbytes = sum(t.numel() * t.element_size() for t in ts)
@@ -183,8 +200,9 @@ class OpTimer:
                     # SURVEY §8(d)'s floor counts a block as "read x, write y (+ the GRN second read)": the 4C-wide h / g / dh
                     # this kernel family moves are design bytes, not floor bytes
                     floor = sum(t.numel() * t.element_size() for t in ts if t.numel() != Mm * 4 * Cc)
-            self.records.setdefault(cls, []).append((e0, e1, flops, nbytes, strict if strict is not None else nbytes,
-                                                     floor if floor is not None else nbytes))
+            rec = (e0, e1, flops, nbytes, strict if strict is not None else nbytes, floor if floor is not None else nbytes)
+            self.records.setdefault(cls, []).append(rec)
+            self.templates.setdefault(tmpl, []).append(rec + (cls,))
             return out
 
         return wrapped
@@ -201,14 +219,23 @@ class OpTimer:
         for name, fn in self._orig.items():
             setattr(self.ops, name, fn)
 
-    def summary(self):
+    def summary(self, templates: bool = False):
         torch.cuda.synchronize()
         out = {}
-        for cls, recs in self.records.items():
+        for cls, recs in (self.templates if templates else self.records).items():
             ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             out[cls] = {"launches": len(recs), "ms": ms, "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs),
                         "strict_bytes": sum(r[4] for r in recs), "floor_bytes": sum(r[5] for r in recs)}
+            if templates:
+                out[cls]["family"] = recs[0][6]
         return out
+
+
+def mlp_mode(op_name: str, bound_args: dict) -> int:
+    """MODE template argument of csrc/mlp.hip that a viscy_amd.ops wrapper of the fused GRN-MLP family launches"""
+    if op_name in ("mlp_fc1", "mlp_fc1_ln"):
+        return 2 if bound_args.get("store_h", True) else 6
+    return {"mlp_stats": 0, "mlp_out": 1, "mlp_bwd_stats": 3, "mlp_bwd_dh": 4, "mlp_bwd_dh_re": 5, "mlp_bwd_dh_ln": 7}[op_name]
 
 
 def lib_last_kernel() -> str:
@@ -251,7 +278,7 @@ def gate_shape_record(dev, steps: int = 5, B: int = 8, size: int = 2048) -> dict
             "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 1e9, 1)}
 
 
-def _cpu_baseline_child():
+def _cpu_baseline_child(fixture_path: str | None = None):
     """Runs in a child process; prints one JSON line per completed measurement (the parent keeps the last)."""
     from oracle import loss_ref, unext2_ref
 
@@ -263,6 +290,13 @@ def _cpu_baseline_child():
     opt = torch.optim.AdamW(model.parameters(), lr=2e-4)
     B = 2
     x, tgt = make_batch(B, 256, 256, "cpu")
+    if fixture_path:
+        # the oracle as CHECKER of the fp32 parity engine (`fp32_parity.forward_rel_err` of the result line): its weights, one
+        # input batch and its fp32 forward go to a scratch file that the GPU process compares its own forward with
+        with torch.no_grad():
+            y_ref = model(x)
+        torch.save({"state_dict": model.state_dict(), "x": x, "y": y_ref}, fixture_path)
+        print(json.dumps({"fixture": fixture_path}), flush=True)
     times = []
     for i in range(12):
         t0 = time.perf_counter()
@@ -275,26 +309,159 @@ def _cpu_baseline_child():
             times.append(dt)
             ts = sorted(times)
             med = ts[len(ts) // 2]
-            print(json.dumps({"value": round(B / med, 3), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            print(json.dumps({"value": round(B / med, 3), "unit": "patches/s", "cores": torch.get_num_threads(),
+                              "threads_used": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
                               "sample": f"{len(times)} timed training step(s) (fwd+MixedLoss+bwd+AdamW) of the fp32 oracle "
                                         f"(pure-torch restatement of the reference) at B={B}, Z=5, 256x256, median"}), flush=True)
 
 
-def cpu_baseline(budget_s: float = 75.0):
-    """The oracle timed on the host cores over a bounded sample (child process, hard time limit)."""
-    import subprocess
+class CpuBaseline:
+    """The oracle timed on the host cores over a bounded sample: a child process with a hard time limit, started BEFORE the GPU
+    measurement's tail (gate shape, fp32 parity record) so that it runs beside them on otherwise idle host cores.  Its first act
+    is the fp32 parity fixture (`fixture()`); `result()` waits for the timing lines."""
 
-    try:
-        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child"], capture_output=True, text=True,
-                           timeout=budget_s)
-        out = p.stdout
-    except subprocess.TimeoutExpired as e:
-        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    if not lines:
-        return {"value": None, "unit": "patches/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": f"no oracle training step finished within {budget_s:.0f} s on this host"}
-    return json.loads(lines[-1])
+    def __init__(self, budget_s: float = 90.0):
+        import subprocess
+        import tempfile
+
+        self.budget_s, self.t0 = budget_s, time.perf_counter()
+        self.fixture_path = os.path.join(tempfile.mkdtemp(prefix="vsx_bench_"), "fp32_parity.pt")
+        self.out_path = self.fixture_path + ".log"
+        self._log = open(self.out_path, "w")
+        self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", self.fixture_path],
+                                  stdout=self._log, stderr=subprocess.DEVNULL, text=True)
+
+    def _lines(self):
+        try:
+            return [l for l in open(self.out_path).read().splitlines() if l.startswith("{")]
+        except OSError:
+            return []
+
+    def fixture(self, wait_s: float = 60.0):
+        """path of the oracle's (weights, input, fp32 forward) file, or None if the child did not get that far in time"""
+        t_end = time.perf_counter() + wait_s
+        while time.perf_counter() < t_end:
+            if any('"fixture"' in l for l in self._lines()):
+                return self.fixture_path
+            if self.p.poll() is not None:
+                break
+            time.sleep(0.25)
+        return self.fixture_path if any('"fixture"' in l for l in self._lines()) else None
+
+    def result(self) -> dict:
+        left = self.budget_s - (time.perf_counter() - self.t0)
+        try:
+            self.p.wait(timeout=max(left, 1.0))
+        except Exception:  # noqa: BLE001 — subprocess.TimeoutExpired: the bounded sample ends here
+            self.p.kill()
+            self.p.wait()
+        self._log.close()
+        lines = [l for l in self._lines() if '"value"' in l]
+        try:
+            os.remove(self.fixture_path)
+        except OSError:
+            pass
+        if not lines:
+            return {"value": None, "unit": "patches/s", "cores": min(os.cpu_count() or 1, 32), "threads_used": min(os.cpu_count() or 1, 32),
+                    "host_cores": os.cpu_count(), "kind": "port",
+                    "sample": f"no oracle training step finished within {self.budget_s:.0f} s on this host"}
+        return json.loads(lines[-1])
+
+
+def fp32_parity_record(dev, fixture_path: str | None, B: int = 128, steps: int = 3) -> dict:
+    """The path that meets the north star's <= 1e-3 tolerance is the fp32 engine (exact-fp32 MFMA GEMMs, `precision: 32-true`);
+    the headline number is the bf16 engine.  This record says what the 1e-3 path costs: ms / step of the SAME training step on
+    the fp32 engine at a batch that fits, and — computed in this run — its forward error against the oracle's fp32 forward
+    (max |y - y_ref| / max |y_ref| on the oracle child's fixture: same weights, same input)."""
+    from viscy_amd.losses import MixedLoss
+    from viscy_amd.optim import FlatAdamW
+    from viscy_amd.step import TrainStep
+    from viscy_amd.unext2 import UNeXt2
+
+    torch.manual_seed(42)
+    model = UNeXt2(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True,
+                   head_expansion_ratio=4, decoder_conv_blocks=2).to(dev)
+    rec = {"dtype": "fp32", "per_gpu_batch": B, "tolerance": 1e-3}
+    if fixture_path and os.path.exists(fixture_path):
+        fx = torch.load(fixture_path, map_location="cpu")
+        model.load_state_dict(fx["state_dict"], strict=True)
+        model.compute_dtype, model.grad_mode = torch.float32, "autograd"
+        with torch.no_grad():
+            y = model(fx["x"].to(dev)).float().cpu()
+        err = ((y - fx["y"]).abs().max() / fx["y"].abs().max()).item()
+        rec["forward_rel_err_vs_oracle"] = float(f"{err:.3e}")
+        rec["forward_within_tolerance"] = bool(err <= 1e-3)
+        rec["checked_on"] = f"oracle fp32 forward, B={fx['x'].shape[0]}, Z=5, 256x256, same weights and input"
+        model._engine = None
+    else:
+        rec["forward_rel_err_vs_oracle"] = None
+        rec["checked_on"] = "the oracle child did not deliver its fixture in time"
+    nonzero_grn_(model)
+    model.compute_dtype, model.grad_mode = torch.float32, "flat"
+    opt = FlatAdamW(model.engine(), lr=2e-4, schedule="WarmupCosine", warmup_steps=3, t_total=steps + 4, warmup_multiplier=1e-3)
+    x, tgt = make_batch(B, 256, 256, dev, seed=11)
+    step = TrainStep(model, MixedLoss(0.5, 0.0, 0.5), opt, None, use_graph=False)
+    step(x, tgt)
+    step(x, tgt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(x, tgt)
+    torch.cuda.synchronize()
+    dt_s = (time.perf_counter() - t0) / steps
+    rec.update({"ms_per_step": round(dt_s * 1e3, 3), "patches_per_s": round(B / dt_s, 1), "steps": steps,
+                "loss_finite": bool(torch.isfinite(loss).item())})
+    return rec
+
+
+class Watchdog:
+    """A phase of a multi-rank run that does not finish in `seconds` ends the process with a message that names the rank and
+    the phase (exit code 17) instead of hanging the launcher: a collective whose peer never arrives has no other way out."""
+
+    def __init__(self, phase: str, seconds: float, rank: int):
+        import threading
+
+        self.phase, self.seconds, self.rank = phase, seconds, rank
+        self.timer = threading.Timer(seconds, self._expire)
+        self.timer.daemon = True
+
+    def _expire(self):
+        sys.stderr.write(f"bench.py: rank {self.rank} did not finish '{self.phase}' within {self.seconds:.0f} s — giving up (exit 17)\n")
+        sys.stderr.flush()
+        os._exit(17)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+
+
+def ranks_agree(flat: torch.Tensor) -> tuple[bool, float]:
+    """every rank holds the same parameters: an order-independent checksum of the flat fp32 buffer (sum of its bit patterns as
+    int64, and the float64 sum) is all-reduced with MIN and MAX — identical on every rank iff the two agree.  Backend-agnostic
+    (RCCL in the bench, gloo in tests/test_bench_cpu.py)."""
+    import torch.distributed as dist
+
+    bits = flat.detach().view(torch.int32).to(torch.int64).sum().reshape(1)
+    fsum = flat.detach().double().sum().reshape(1)
+    lo = torch.cat([bits.double(), fsum])
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi)), float(fsum.item())
+
+
+def rank_times(elapsed_s: float, steps: int, device) -> dict:
+    """per-rank ms / step of the timed region, gathered on every rank: min, max and the list"""
+    import torch.distributed as dist
+
+    t = torch.tensor([elapsed_s * 1e3 / steps], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    v = [round(o.item(), 3) for o in out]
+    return {"min": min(v), "max": max(v), "per_rank": v}
 
 
 def launch_command(n: int, argv: list[str], port: int | None = None) -> list[str]:
@@ -332,7 +499,8 @@ def resolve_world(gpus: int, env: dict, visible_devices: int) -> tuple[str, int]
 
 def main():
     if "--cpu-baseline-child" in sys.argv:
-        _cpu_baseline_child()
+        i = sys.argv.index("--cpu-baseline-child")
+        _cpu_baseline_child(sys.argv[i + 1] if i + 1 < len(sys.argv) else None)
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node to run on: one rank per GPU.  Started as a single process "
@@ -340,7 +508,13 @@ def main():
     ap.add_argument("--dry-launch", action="store_true", help="print the N-rank launch command as JSON and exit (no GPU needed)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("VSX_BENCH_BATCH", 512)), help="patches per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("VSX_BENCH_BATCH", 512)),
+                    help="patches per GPU per step (weak scaling: the same value at --gpus 1 / 2 / 4 / 8; 512 needs ~130 GB of the 288 GB "
+                         "per GPU and is the pixel count of the north star's B = 8 x 2048^2 stack; 128 / 256 run at 57 / 63 %% of its rate)")
+    ap.add_argument("--no-fp32-parity", action="store_true", help="skip the fp32-engine sub-record (ms / step of the <= 1e-3 path + its "
+                    "forward error against the oracle)")
+    ap.add_argument("--collective-timeout", type=float, default=180.0, help="seconds a rank waits in process-group initialisation, in "
+                    "the first all-reduce and in the first training step before it gives up and names itself (N > 1)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -375,14 +549,26 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.force_dp:
+    multi = world > 1 or args.force_dp
+    if multi:
+        import datetime
+
         import torch.distributed as dist
 
+        # No NCCL_* / RCCL_* variable is set or relied on (HSA_ENABLE_IPC_MODE_LEGACY=0 comes from the image: dmabuf IPC).  A rank
+        # whose peer never arrives leaves through the watchdog with its rank and phase on stderr instead of hanging the launcher.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        with Watchdog("init_process_group (RCCL communicator over xGMI)", args.collective_timeout + 30, rank):
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.collective_timeout))
+        with Watchdog("first all-reduce", args.collective_timeout, rank):
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != int(os.environ["WORLD_SIZE"]):
+                raise SystemExit(f"bench.py: rank {rank}: the first all-reduce summed to {probe.item()} over {os.environ['WORLD_SIZE']} ranks")
 
     from viscy_amd import ops
     from viscy_amd.losses import MixedLoss
@@ -428,11 +614,20 @@ def main():
             for c, v in sorted(tm.summary().items(), key=lambda kv: -kv[1]["ms"])[:40]:
                 print(f"[shape] {c:58s} {v['launches']:3d}x {v['ms'] / v['launches'] * 1e3:9.1f} us  "
                       f"{v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s {v['flops'] / max(v['ms'], 1e-9) / 1e9:8.1f} TFLOP/s", file=sys.stderr)
-    if not args.profile_ops:
-        eager(x, tgt)  # first launches load code objects / size workspaces: keep that out of the instrumented step
-    with OpTimer(ops) as tm:  # one eager, instrumented step: per-op-class times → dominant kernel class
-        l0 = eager(x, tgt)
-    table = tm.summary()
+    with Watchdog("first training step", args.collective_timeout + 120, rank):
+        if not args.profile_ops:
+            eager(x, tgt)  # first launches load code objects / size workspaces: keep that out of the instrumented step
+        with OpTimer(ops) as tm:  # one eager, instrumented step: per-op-class times → dominant kernel class
+            l0 = eager(x, tgt)
+        table = tm.summary()
+    agree = None
+    if multi:
+        # data parallel means identical parameters on every rank after every step: checked once, after the first two steps
+        # (different batches per rank, all-reduced gradients, AdamW) — a rank that diverged makes the whole line meaningless
+        with Watchdog("parameter checksum all-reduce", args.collective_timeout, rank):
+            agree, _ = ranks_agree(eng.flat)
+        if not agree:
+            raise SystemExit(f"bench.py: rank {rank}: parameters differ between ranks after the first optimisation steps")
     for _ in range(max(args.warmup, 1)):
         step()
     if args.profile_ops and rank == 0:
@@ -470,19 +665,27 @@ def main():
     barrier()
     fwd_s = (time.perf_counter() - tf0) / nf
     model.train()
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = tt.item()
+    per_rank = None
+    if multi:
+        per_rank = rank_times(elapsed, args.steps, dev)
+        elapsed = per_rank["max"] * args.steps / 1e3  # the contract: MAX over ranks
     fam_table = tm.summary()
-    dominant = max(fam_table, key=lambda c: fam_table[c]["ms"]) if fam_table else None  # largest summed launch time, by kernel family
-    dom = fam_table.get(dominant) if dominant else None
+    tmpl_table = tm.summary(templates=True)
+    # the dominant KERNEL: the template instantiation (kernel family + the template arguments / GEMM shape that select the code)
+    # with the largest summed launch time of the step; `roofline_classes` keeps the family view next to it
+    dominant = max(tmpl_table, key=lambda c: tmpl_table[c]["ms"]) if tmpl_table else None
+    dom = tmpl_table.get(dominant) if dominant else None
 
     binfo = build_info()
-    gate, peak_main = None, None
-    if rank == 0 and world == 1 and args.size == 256 and args.dtype == "bf16" and not args.no_gate:
-        # the north star's roofline gate shape, driver-timed in the same run: (B = 8, Z = 5, 2048 x 2048) training step.
-        # The headline model / graph / batch are released first (both workloads need ~166 GB of the 288 GB).
+    cpu_leg = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_leg = CpuBaseline()  # runs on the host cores beside the gate-shape / fp32 records below (the timed region is over)
+    gate, peak_main, parity = None, None, None
+    sub = rank == 0 and world == 1 and args.size == 256 and args.dtype == "bf16"
+    want_gate, want_parity = sub and not args.no_gate, sub and not args.no_fp32_parity
+    if want_gate or want_parity:
+        # Sub-records measured in the same driver run.  The headline model / graph / batch are released first (the headline and
+        # the gate shape each need ~130 GB of the 288 GB).
         loss_keep = loss.detach().clone()
         peak_main = torch.cuda.max_memory_reserved()
         del graphed, eager, infer, tm, loss, step
@@ -493,7 +696,12 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
-        gate = gate_shape_record(dev, steps=args.gate_steps)
+        if want_gate:  # the north star's roofline gate shape: (B = 8, Z = 5, 2048 x 2048) training step
+            gate = gate_shape_record(dev, steps=args.gate_steps)
+            gc.collect()
+            torch.cuda.empty_cache()
+        if want_parity:  # the fp32 engine (the <= 1e-3 path): its step time and its forward error against the oracle
+            parity = fp32_parity_record(dev, cpu_leg.fixture() if cpu_leg else None)
         loss = loss_keep
     if rank == 0:
         patches = world * B * args.steps
@@ -505,12 +713,13 @@ def main():
         # FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a launch with a known byte count as MI355X_MICROARCH.md
         # prescribes).  The file records the kernel-source hash and the flag set it was measured with; a file from other
         # sources / flags is refused (traffic stays null).
-        tfam, trefused, tf_path = {}, None, os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_traffic_b{B}.json")
+        tfam, tfam_k, trefused, tf_path = {}, {}, None, os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_traffic_b{B}.json")
         if args.size == 256 and args.dtype == "bf16" and os.path.exists(tf_path):
             try:
                 tfj = json.load(open(tf_path))
                 if tfj.get("source_hash") == binfo["source_hash"] and tfj.get("flags") == binfo["flags"]:
                     tfam = tfj.get("families", {})
+                    tfam_k = tfj.get("templates", {})
                 else:
                     trefused = "profiles file was measured on other kernel sources / flags"
             except (OSError, ValueError, KeyError):
@@ -525,12 +734,11 @@ def main():
                    "hbm_frac": round(gb / (ms_step * 1e-3) / HBM_PEAK_GBS, 4),
                    "tflops": round(d["flops"] / REPLAYS / (ms_step * 1e-3) / 1e12, 1),
                    "mfma_frac": round(d["flops"] / REPLAYS / (ms_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
-            if fam == "mlp_fused":
-                # priced both ways: design bytes (what the passes are built to move, incl. the 4C-wide h / g / dh) and the bytes
-                # SURVEY §8(d)'s floor contains for them (C-wide tensors only)
-                fgb = d["floor_bytes"] / REPLAYS / 1e9
-                rec["floor_GB_per_step"] = round(fgb, 3)
-                rec["hbm_frac_floor_bytes"] = round(fgb / (ms_step * 1e-3) / HBM_PEAK_GBS, 4)
+            # priced both ways: design bytes (what the launches are built to move, incl. the 4C-wide g / dh and the per-sample
+            # fp32 products) and the bytes SURVEY §8(d)'s floor contains for them (layer-boundary tensors only)
+            fgb = d["floor_bytes"] / REPLAYS / 1e9
+            rec["floor_GB_per_step"] = round(fgb, 3)
+            rec["hbm_frac_floor_bytes"] = round(fgb / (ms_step * 1e-3) / HBM_PEAK_GBS, 4)
             t = tfam.get(fam)
             if t:
                 rec["traffic_GB_per_step"] = round(t["read_GB_per_step"] + t["write_GB_per_step"], 3)
@@ -554,12 +762,14 @@ def main():
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 5),
                         "launches": dom["launches"], "mfma_frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
+            roof["family"] = dom["family"]
+            roof["launches_per_step"] = round(dom["launches"] / REPLAYS, 1)
             roof["ms_per_step"] = round(dom["ms"] / REPLAYS, 3)
             roof["strict_frac"] = round(dom["strict_bytes"] / dom["launches"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)  # operands + ONE output only
             roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / dom["launches"])
-            if dominant == "mlp_fused":
-                roof["frac_floor_bytes"] = round(dom["floor_bytes"] / dom["launches"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            t = tfam.get(dominant)
+            roof["frac_floor_bytes"] = round(dom["floor_bytes"] / dom["launches"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            # PMC traffic of this template from the committed --pmc passes (per kernel name: tools/pmc_traffic.py `kernels`)
+            t = (tfam_k or {}).get(dominant)
             if t:
                 roof["traffic"] = round((t["read_GB_per_step"] + t["write_GB_per_step"]) * 1e9 / max(t["launches_per_step"], 1e-9))
                 roof["traffic_source"] = os.path.relpath(tf_path, ROOT)
@@ -590,6 +800,7 @@ def main():
             "roofline": roof,
             "roofline_classes": roof_classes,
             "gate_shape": gate,
+            "fp32_parity": parity,
             "build": binfo,
             "fwd": {"ms_per_pass": round(fwd_s * 1e3, 3), "patches_per_s_per_gpu": round(B / fwd_s, 1),
                     "algorithmic_hbm_GBps": round(B / fwd_s * FWD_MB_PER_PATCH * scale / 1e3, 1),
@@ -599,10 +810,13 @@ def main():
         if not res["whole_path"]["loss_finite"]:
             print("bench.py: WARNING: the training loss is not finite after the timed steps — this measurement is INVALID",
                   file=sys.stderr)
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N = 1 only (the other ranks would idle)
-            res["cpu_baseline"] = cpu_baseline()
-    if world > 1 or args.force_dp:
-        torch.distributed.barrier()
+        if multi:
+            res["ranks"] = {"ms_per_step": per_rank, "parameters_identical_across_ranks": agree}
+        if cpu_leg is not None:  # the CPU leg is reported at N = 1 only (the other ranks would idle)
+            res["cpu_baseline"] = cpu_leg.result()
+    if multi:
+        with Watchdog("final barrier", args.collective_timeout, rank):
+            torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
         os.write(result_fd, (json.dumps(res) + "\n").encode())

@@ -85,3 +85,54 @@ def test_kernel_families_cover_the_step_kernels():
     # every family the live timer can emit for a wrapper is one the trace side knows
     trace_side = {f for _, f in bench.KERNEL_FAMILY}
     assert set(bench.OP_FAMILY.values()) <= trace_side
+
+
+# ------------------------------------------------------------------ multi-rank helpers of the bench line
+def _rank_logic_worker(rank, world, init_file, out_dir, diverge):
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    flat = torch.randn(1000)
+    if diverge and rank == 1:
+        flat[123] += 1e-7 * flat[123].abs() + 1e-12  # one parameter, one ulp-sized step away: still a different checksum
+    agree, fsum = bench.ranks_agree(flat)
+    rt = bench.rank_times(0.010 * (rank + 1) * 5, 5, "cpu")  # rank r took 10 (r + 1) ms / step
+    with open(os.path.join(out_dir, f"r{rank}.json"), "w") as f:
+        json.dump({"agree": agree, "times": rt}, f)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("diverge", [False, True])
+def test_rank_consistency_and_rank_times_world2_gloo(tmp_path, diverge):
+    """the two collectives the N > 1 bench line adds — the parameter checksum and the per-rank step times — with world size 2 on
+    gloo: identical parameters agree, ONE element differing by an ulp does not, and every rank reports the same min / max"""
+    import torch.multiprocessing as mp
+
+    init_file = str(tmp_path / "init")
+    mp.spawn(_rank_logic_worker, args=(2, init_file, str(tmp_path), diverge), nprocs=2, join=True)
+    r = [json.load(open(tmp_path / f"r{i}.json")) for i in range(2)]
+    assert r[0]["agree"] == r[1]["agree"] == (not diverge)
+    assert r[0]["times"] == r[1]["times"]
+    assert r[0]["times"]["per_rank"] == [10.0, 20.0] and r[0]["times"]["min"] == 10.0 and r[0]["times"]["max"] == 20.0
+
+
+def test_watchdog_names_rank_and_phase_and_exits_nonzero():
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.Watchdog('first all-reduce', 0.5, 3):\n"
+            "    time.sleep(30)\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 17 and "rank 3" in p.stderr and "first all-reduce" in p.stderr
+    # a phase that finishes in time leaves no trace
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "with bench.Watchdog('x', 30, 0):\n"
+            "    pass\nprint('done')\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == "done"
+
+
+def test_mlp_mode_names_the_kernel_template():
+    assert bench.mlp_mode("mlp_fc1_ln", {"store_h": False}) == 6 and bench.mlp_mode("mlp_fc1_ln", {}) == 2
+    assert bench.mlp_mode("mlp_bwd_dh_ln", {}) == 7 and bench.mlp_mode("mlp_stats", {}) == 0
+    assert bench.kernel_family("void mlp_fused_kernel_sf<224, 2, 8, 6>(MlpArgs)") == "mlp_fused"
