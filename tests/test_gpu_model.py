@@ -544,6 +544,127 @@ def test_gate_shape_fp32_and_bf16_engines_vs_reference_golden():
         assert v <= max(1.25 * yg[k], 2e-3), (k, v, yg[k])
 
 
+def test_gate_shape_gradients_vs_reference_golden():
+    """the BACKWARD at the north star's gate shape pinned on the reference.  G8c (tests/golden/
+    unext2_tiny_2048.pt) holds, for tiny at B = 1, 2048 x 2048, strided samples of the reference's own fp32 gradient of the linear
+    functional <y, c> (c: seeded) with respect to five parameters — at least one in each gradient bucket of the engine.  fp32
+    engine: every sample within 1e-3 of the tensor's largest gradient; bf16 engine (the production kernels at the large-map
+    selections: grid caps, sub-split weight gradients, per-sample products with sub-splits + atomics): no further from the
+    reference than 1.25 x the oracle module under torch.autocast(bfloat16) on the same input (direction: 1 - cos of the sample;
+    size: relative error of the sample)."""
+    from viscy_amd.unext2 import UNeXt2
+
+    gold = load_golden("unext2_tiny_2048.pt")
+    if "grads" not in gold:
+        pytest.skip("fixture without gradient samples (regenerate with oracle/validate_against_reference.py)")
+    kw = gold["kwargs"]
+    B, S = gold["shape"]
+    ref = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=gold["seed"]).eval()
+    x = torch.randn((B, 1, 5, S, S), generator=torch.Generator().manual_seed(gold["x_seed"])).cuda()
+    ysh = (B, kw["out_channels"], 5, S, S)
+    n = 1
+    for d in ysh:
+        n *= d
+    cot = (torch.randn(ysh, generator=torch.Generator().manual_seed(gold["cot_seed"])) / n ** 0.5).cuda()
+
+    def sample_of(named_grads):
+        out = {}
+        for name, gs in gold["grads"].items():
+            out[name] = named_grads[name].detach().float().flatten()[:: gs["stride"]].cpu()
+        return out
+
+    def errors(samples):
+        e = {}
+        for name, gs in gold["grads"].items():
+            a, b_ = samples[name].double(), gs["sample"].double()
+            e[name] = ((a - b_).abs().max().item() / gs["absmax"], 1.0 - torch.nn.functional.cosine_similarity(a, b_, dim=0).item(),
+                       ((a - b_).norm() / b_.norm()).item())
+        return e
+
+    def run_engine(dt):
+        m = UNeXt2(**kw)
+        m.load_state_dict(ref.state_dict(), strict=True)
+        m = m.cuda()
+        m.compute_dtype, m.grad_mode = dt, "flat"
+        eng = m.engine()
+        eng.flat_grad.zero_()
+        y = m(x)
+        (y * cot).sum().backward()
+        out = errors(sample_of({k: eng.g(p) for k, p in m.named_parameters()}))
+        del y, m, eng
+        torch.cuda.empty_cache()
+        return out
+
+    def run_autocast_yardstick():
+        o = unext2_ref.UNeXt2(**kw)
+        o.load_state_dict(ref.state_dict(), strict=True)
+        o = o.cuda().eval()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = o(x)
+        (y.float() * cot).sum().backward()
+        out = errors(sample_of({k: p.grad for k, p in o.named_parameters()}))
+        del o, y
+        torch.cuda.empty_cache()
+        return out
+
+    e32 = run_engine(torch.float32)
+    for name, (mx, oc, rel) in e32.items():
+        print(f"fp32 engine @2048 d/d {name}: max err / max |g| {mx:.2e}  1-cos {oc:.2e}  rel {rel:.2e}")
+    yard = run_autocast_yardstick()
+    e16 = run_engine(torch.bfloat16)
+    for name, (mx, oc, rel) in e16.items():
+        ymx, yoc, yrel = yard[name]
+        print(f"bf16 engine @2048 d/d {name}: 1-cos {oc:.2e} (autocast {yoc:.2e})  rel {rel:.2e} (autocast {yrel:.2e})")
+    # The fp32 bar.  The forward holds 1e-3 at this size (test above: 4e-6).  A GRADIENT of this network in fp32 does not, on either
+    # side: InstanceNorm outputs within rounding of 0 fall on either side of the PReLU kink, and every flipped voxel moves the whole
+    # upstream gradient.  The reference's own fp32 gradient deviates from its fp64 gradient by 1.2e-4 at 256^2, 5e-4 at 512^2 and
+    # ~1e-3 at 1024^2 (G8d, tests/golden/unext2_tiny_1024_fp64.pt; the test below holds the engine to THAT yardstick at 1024^2,
+    # where an fp64 truth is affordable).  Here, against the fp32 golden (itself ~2e-3 from the truth): direction to 2e-6 and
+    # size to 3e-3 — two fp32 evaluations of the same gradient, each within its own noise of the truth.
+    for name, (mx, oc, rel) in e32.items():
+        assert oc <= 2e-6 and rel <= 3e-3 and mx <= 4e-3, (name, mx, oc, rel)
+    for name, (mx, oc, rel) in e16.items():
+        ymx, yoc, yrel = yard[name]
+        assert oc <= 1.25 * yoc + 1e-6 and rel <= 1.25 * yrel + 1e-4, (name, oc, yoc, rel, yrel)
+
+
+def test_large_image_fp32_gradient_is_as_accurate_as_the_reference_fp32_arithmetic():
+    """G8d: at 1024 x 1024 (tiny, B = 1) the fixture holds strided samples of the reference's fp64 gradient of <y, c> and the
+    deviation of the reference's OWN fp32 gradient from it (up to ~1e-3: PReLU-kink flips, see the generator's docstring).  The
+    fp32 engine must be no further from the fp64 gradient than 1.5 x that (and never further than 3e-3): the parity bar for a
+    quantity that the reference itself only knows to 1e-3."""
+    from viscy_amd.unext2 import UNeXt2
+
+    gold = load_golden("unext2_tiny_1024_fp64.pt")
+    kw = gold["kwargs"]
+    B, S = gold["shape"]
+    ref = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=gold["seed"]).eval()
+    x = torch.randn((B, 1, 5, S, S), generator=torch.Generator().manual_seed(gold["x_seed"])).cuda()
+    ysh = (B, kw["out_channels"], 5, S, S)
+    n = 1
+    for d in ysh:
+        n *= d
+    cot = (torch.randn(ysh, generator=torch.Generator().manual_seed(gold["cot_seed"])) / n ** 0.5).cuda()
+    m = UNeXt2(**kw)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m = m.cuda()
+    m.compute_dtype, m.grad_mode = torch.float32, "flat"
+    eng = m.engine()
+    eng.flat_grad.zero_()
+    y = m(x)
+    (y * cot).sum().backward()
+    named = dict(m.named_parameters())
+    for name, gs in gold["grads"].items():
+        a = eng.g(named[name]).detach().double().flatten()[:: gs["stride"]].cpu()
+        b_ = gs["sample64"]
+        rel = ((a - b_).norm() / b_.norm()).item()
+        oc = 1.0 - torch.nn.functional.cosine_similarity(a, b_, dim=0).item()
+        print(f"fp32 engine @1024 d/d {name}: vs fp64 reference rel {rel:.2e} (reference fp32: {gs['ref32_rel']:.2e})  1-cos {oc:.2e} "
+              f"(reference fp32: {gs['ref32_1mcos']:.2e})")
+        assert rel <= max(1.5 * gs["ref32_rel"], 2e-4) and rel <= 3e-3, (name, rel, gs["ref32_rel"])
+        assert oc <= max(2.25 * gs["ref32_1mcos"], 4e-8), (name, oc, gs["ref32_1mcos"])
+
+
 def test_large_batch_gradient_equals_sum_of_pinned_small_batches():
     """VERDICT r3 item 7, second half: the bf16 engine is pinned against the reference at B = 4 (above); the bench runs B = 512, where
     other kernel selections are taken (tile counts decide between GEMM instantiations, split counts, grid caps, the per-sample

@@ -229,11 +229,56 @@ def test_prediction_writer_blends_z_windows_and_appends_channels(tiny_hcs_zarr, 
     w2.on_predict_start(_StubTrainer(dm), None)
     for j, batch in enumerate(dm.predict_dataloader()):
         w2.write_on_batch_end(None, None, torch.ones(batch["source"].shape[0], 2, zw, 128, 128), None, batch, j, 0)
+    w2.on_predict_end(None, None)   # the last open stack reaches the store here (round 5: every slice is written once)
     p0 = next(iter(open_ome_zarr(both).positions()))[1]
     assert p0.channel_names[-2:] == ["Nuclei_prediction", "Membrane_prediction"] and p0["0"].shape[1] == len(p0.channel_names)
     raw = pos[next(iter(pos))]
     np.testing.assert_array_equal(p0["0"].oindex[slice(0, 1), [0], slice(0, 5)][0, 0], raw[0, 0])
     np.testing.assert_allclose(p0["0"].oindex[slice(0, 1), [len(p0.channel_names) - 1], slice(0, 5)], 1.0)
+
+
+def test_prediction_writer_writes_every_slice_once_and_reads_nothing_back(tiny_hcs_zarr, tmp_path, monkeypatch):
+    """round 5: consecutive Z windows are blended in a running stack next to the prediction; the store sees each (channel, slice)
+    chunk exactly once and is never read.  Windows in another order take the reference's read-blend-write path: same result."""
+    from viscy_amd.data import ome_zarr
+    from viscy_amd.prediction_writer import HCSPredictionWriter
+
+    path, pos = tiny_hcs_zarr
+    zw, Z = 3, 5
+    dm = HCSDataModule(path, "Phase3D", ["Nuclei", "Membrane"], z_window_size=zw, batch_size=2, num_workers=0)
+    dm.setup("predict")
+    batches = list(dm.predict_dataloader())
+    rng = np.random.default_rng(1)
+    preds = [torch.from_numpy(rng.random((b["source"].shape[0], 2, zw, 128, 128), dtype=np.float32)) for b in batches]
+    writes, reads = [], []
+    orig_w, orig_r = ome_zarr.ImageArray._write_chunk, ome_zarr.ImageArray._chunk
+    monkeypatch.setattr(ome_zarr.ImageArray, "_write_chunk", lambda self, idx, data: (writes.append((self.path, idx)), orig_w(self, idx, data))[1])
+    monkeypatch.setattr(ome_zarr.ImageArray, "_chunk", lambda self, idx: (reads.append((self.path, idx)), orig_r(self, idx))[1])
+
+    def run(out, order):
+        w = HCSPredictionWriter(out)
+        w.on_predict_start(_StubTrainer(dm), None)
+        for j in order:
+            w.write_on_batch_end(None, None, preds[j], None, batches[j], j, 0)
+        w.on_predict_end(None, None)
+
+    a = str(tmp_path / "in_order.zarr")
+    run(a, range(len(batches)))
+    n_pos = len(list(open_ome_zarr(a).positions()))
+    assert len(writes) == len(set(writes)) == n_pos * 2 * Z and reads == []   # every chunk once, nothing read back
+    writes.clear()
+    b = str(tmp_path / "reversed.zarr")
+    run(b, reversed(range(len(batches))))                                      # windows arrive z-descending across batches
+    assert len(reads) > 0                                                      # ... so the store had to be consulted
+    reads.clear()
+    monkeypatch.undo()
+    sent = {}
+    for bt, pr in zip(batches, preds):
+        for i in range(pr.shape[0]):
+            sent.setdefault(bt["index"][0][i], []).append(pr[i].numpy())
+    for n, p in open_ome_zarr(a).positions():
+        got = p["0"].oindex[slice(0, 1), [0, 1], slice(0, Z)][0]
+        np.testing.assert_allclose(got, _expected_blend(sent["/" + n + "/0"], Z, zw), rtol=1e-6, atol=1e-7)
 
 
 def test_prediction_writer_2d_target_and_write_input(tiny_hcs_zarr, tmp_path):

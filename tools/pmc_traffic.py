@@ -22,6 +22,20 @@ def load(path, counter):
     return rows
 
 
+def load_templates(path, counter):
+    """(template, counts) rows keyed the way bench.py names a kernel TEMPLATE in `roofline.kernel` — the fused GRN-MLP passes by
+    width and MODE (their names carry both; a GEMM's shape is not in its kernel name, so GEMM templates have no row here)"""
+    rows = []
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        kn = r["Kernel_Name"]
+        m = re.search(r"mlp_fused_kernel(?:_sf)?<\s*(\d+),\s*\d+,\s*\d+,\s*(\d)>", kn) or re.search(r"mlp_fused_kernel(?:_sf)?ILi(\d+)ELi\d+ELi\d+ELi(\d)EE", kn)
+        if m:
+            rows.append((f"mlp_fused_kernel<C={m.group(1)}, MODE={m.group(2)}>", float(r["Counter_Value"])))
+    return rows
+
+
 def main(fetch_csv, write_csv, steps, batch, out):
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     cal = {}
@@ -80,6 +94,13 @@ def main(fetch_csv, write_csv, steps, batch, out):
             for f in ("launches_per_step", "read_GB_per_step", "write_GB_per_step"):
                 fam[kernel_family(k)][f] += v[f]
     res["families"] = dict(fam)
+    tmpl = collections.defaultdict(lambda: {"launches_per_step": 0.0, "read_GB_per_step": 0.0, "write_GB_per_step": 0.0})
+    for k, v in load_templates(fetch_csv, "FETCH_SIZE"):
+        tmpl[k]["launches_per_step"] += 1.0 / steps
+        tmpl[k]["read_GB_per_step"] += v * cal["read"]["bytes_per_count"] / steps / 1e9
+    for k, v in load_templates(write_csv, "WRITE_SIZE"):
+        tmpl[k]["write_GB_per_step"] += v * cal["write"]["bytes_per_count"] / steps / 1e9
+    res["templates"] = dict(tmpl)
     tot = sum(v["read_GB_per_step"] + v["write_GB_per_step"] for v in res["kernels"].values())
     res["total_GB_per_step"] = tot
     res["total_MB_per_patch"] = tot * 1e3 / batch

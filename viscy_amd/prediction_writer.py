@@ -10,9 +10,14 @@ store's scale transform; a window written at Z offset ``z`` is feathered into wh
 ``old * (f - 1) / f + new / f``, ``f = min(i + 1, min(z + 1, depth))`` counted from the far end of the window
 (prediction_writer.py:74-111).
 
-Disk I/O is host work: the prediction arrives from the device once per batch and the blend runs in numpy on the chunks
-being rewritten (the in-memory sliding-window path of ``VSUNet.predict_sliding_windows`` blends on the device with
-``vsx_blend_in``).  Derives from Lightning's ``BasePredictionWriter`` when Lightning is installed; otherwise
+Round 5 — where the blend happens.  The reference re-reads and re-writes the overlapped slices of the store for every window
+(``old = image.oindex[...]``, blend, write back: 5 chunk reads + 5 chunk writes per channel and window at depth 5).  Here the
+windows of one (image, timepoint) are blended **where the prediction already is**: a running stack of the not-yet-final slices
+stays on the prediction's device (``viscy_amd.vsunet.blend_in`` = ``vsx_blend_in`` on the GPU; the same arithmetic in torch for
+CPU predictions), a slice is written to the store ONCE — when the next window starts behind it or prediction ends — and nothing
+is read back.  Windows that do not continue the running stack (a store being overwritten, shuffled or resumed prediction)
+take the reference's read-blend-write path on the host, so the on-disk result is the reference's in every order of arrival.
+Derives from Lightning's ``BasePredictionWriter`` when Lightning is installed; otherwise
 ``viscy_amd.trainer.Trainer(callbacks=[...])`` drives the same hooks.
 """
 
@@ -110,21 +115,74 @@ class HCSPredictionWriter(_Base):
 
     def write_on_batch_end(self, trainer, pl_module, prediction: torch.Tensor, batch_indices: Optional[Sequence[int]], batch,
                            batch_idx: int, dataloader_idx: int) -> None:
-        pred = prediction.detach().float().cpu().numpy()  # ONE device -> host copy per batch
+        pred = prediction.detach().float()   # stays where it is: blended windows leave the device once, when they are final
         for sample_index, _ in enumerate(batch["index"][0]):
             self.write_sample(batch, pred[sample_index], sample_index)
 
     def on_predict_end(self, trainer, pl_module) -> None:
+        for key in list(getattr(self, "_running", {})):
+            self._flush(key)
         self.plate.close()
 
+    # ---- running blend of the open (image, timepoint) stacks
+    MAX_OPEN = 4  # stacks held at once: the loader walks one field of view after the other
+
+    def _flush(self, key, upto: int | None = None) -> None:
+        """write the slices [z0, upto) of a running stack (all of it by default) — each slice reaches the store exactly once"""
+        run = self._running[key]
+        n = run["stack"].shape[1] if upto is None else min(max(upto - run["z0"], 0), run["stack"].shape[1])
+        if n > 0:
+            img_name, t_index = key
+            image = self.plate[img_name]
+            image.oindex[t_index, self.prediction_index, slice(run["z0"], run["z0"] + n)] = run["stack"][:, :n].cpu().numpy()
+        if upto is None or n == run["stack"].shape[1]:
+            del self._running[key]
+        else:
+            run["stack"], run["z0"] = run["stack"][:, n:], run["z0"] + n
+
+    def _blend_running(self, key, pred: torch.Tensor, z_slice: slice) -> bool:
+        """merge one Z window into the running stack of its (image, timepoint); False if the window does not continue it (the
+        caller then blends against the store, the reference's way)"""
+        running = self.__dict__.setdefault("_running", {})
+        depth = z_slice.stop - z_slice.start
+        run = running.get(key)
+        if run is None:
+            if z_slice.start != 0:
+                return False   # the middle of a volume with nothing held: whatever is in the store has to be read
+            while len(running) >= self.MAX_OPEN:
+                self._flush(next(iter(running)))
+            running[key] = {"z0": 0, "last": 0, "stack": pred.clone()}
+            return True
+        if z_slice.start != run["last"] + 1 or z_slice.start < run["z0"] or z_slice.start > run["z0"] + run["stack"].shape[1]:
+            self._flush(key)
+            return False
+        self._flush(key, upto=z_slice.start)          # slices behind this window are final
+        run = running.get(key)
+        held = 0 if run is None else run["stack"].shape[1]
+        old = pred.new_zeros(pred.shape)              # beyond the held slices the window meets a weight of (f - 1) / f = 0
+        if held:
+            old[:, :held] = run["stack"]
+        if pred.is_cuda:
+            from .vsunet import blend_in
+
+            merged = blend_in(old, pred, z_slice)
+        else:
+            samples = min(z_slice.start + 1, depth)
+            f = torch.tensor([float(min(i + 1, samples)) for i in reversed(range(depth))], dtype=torch.float64).view(1, -1, 1, 1)
+            merged = (old.double() * (f - 1) / f + pred.double() / f).to(pred.dtype)
+        running[key] = {"z0": z_slice.start, "last": z_slice.start, "stack": merged}
+        return True
+
     def write_sample(self, batch, sample_prediction, sample_index: int) -> None:
-        if torch.is_tensor(sample_prediction):
-            sample_prediction = sample_prediction.detach().float().cpu().numpy()
+        if not torch.is_tensor(sample_prediction):
+            sample_prediction = torch.as_tensor(np.asarray(sample_prediction))
+        sample_prediction = sample_prediction.detach().float()
         img_name, t_index, z_index = [batch["index"][i][sample_index] for i in range(3)]
         t_index, z_index = int(t_index), int(z_index)
         z_index += self.z_padding  # slices lost at the borders in 2.5-D
-        z_slice = slice(z_index, z_index + sample_prediction.shape[-3])
-        image = self._create_image(img_name, sample_prediction.shape, sample_prediction.dtype)
+        depth = sample_prediction.shape[-3]
+        z_slice = slice(z_index, z_index + depth)
+        image = self._create_image(img_name, tuple(sample_prediction.shape), np.float32)
         if image.shape[0] <= t_index or image.shape[2] < z_slice.stop:
             image.resize((max(t_index + 1, image.shape[0]), image.channels, max(z_slice.stop, image.shape[2]), *image.shape[-2:]))
         if self.write_input:
@@ -134,10 +192,14 @@ class HCSPredictionWriter(_Base):
             if "target" in batch:
                 target_stack = batch["target"][sample_index].detach().float().cpu().numpy()
                 image[t_index, self.target_index, z_index] = target_stack[:, target_stack.shape[-3] // 2]
-        if self.z_padding == 0 and sample_prediction.shape[-3] > 1:
+        if self.z_padding == 0 and depth > 1:
+            if self._blend_running((img_name, t_index), sample_prediction, z_slice):
+                return
+            host = sample_prediction.cpu().numpy()
             old_stack = image.oindex[slice(t_index, t_index + 1), self.prediction_index, z_slice][0]
-            sample_prediction = blend_in_host(old_stack, sample_prediction, z_slice)
-        image.oindex[t_index, self.prediction_index, z_slice] = sample_prediction
+            image.oindex[t_index, self.prediction_index, z_slice] = blend_in_host(old_stack, host, z_slice)
+            return
+        image.oindex[t_index, self.prediction_index, z_slice] = sample_prediction.cpu().numpy()
 
     def _create_image(self, img_name: str, shape, dtype):
         try:
