@@ -541,7 +541,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
                                 __uint_as_float(tw.y & 0xFFFF0000u)};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float dz = round_bf16(acc[hf][mf][r]);
+              const float dz = acc[hf][mf][r];   // (fp32: the per-sample-product route to the same statistics never rounds dz either)
               r0[hf][r] = fmaf(dz, e[r], r0[hf][r]);
               r1[hf][r] += dz;
             }
@@ -562,8 +562,9 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
             for (int r = 0; r < 4; r += 2) {
               const uint32_t w = r < 2 ? tw.x : tw.y;
               const float h0 = __uint_as_float(w << 16), h1 = __uint_as_float(w & 0xFFFF0000u);
-              const uint32_t Dq = f32x2_to_bf16x2_bits(acc[hf][mf][r], acc[hf][mf][r + 1]);  // dz as the unfused GEMM stores it
-              const vsx_v2f d2 = {__uint_as_float(Dq << 16), __uint_as_float(Dq & 0xFFFF0000u)};
+              // dz enters in fp32, straight from the accumulator (until round 5 it was first rounded to bf16, "as the unfused GEMM
+              // stores it" — 1.5 VALU operations per element for a LESS accurate dh; the unfused pair differs by that rounding)
+              const vsx_v2f d2 = {acc[hf][mf][r], acc[hf][mf][r + 1]};
               const vsx_v2f s2 = {sv[hf][r], sv[hf][r + 1]}, t2 = {tv[hf][r], tv[hf][r + 1]};
               const uint32_t Rq = mlp_relu_pair(w);
               const vsx_v2f gv = (vsx_v2f){__uint_as_float(Rq << 16), __uint_as_float(Rq & 0xFFFF0000u)} - (vsx_v2f){tb[r].x, tb[r + 1].x};
