@@ -41,6 +41,13 @@ const char* vsx_last_kernel(void);
 /* debug / A-B knobs: "tn_tr" (1 = ds_read_b64_tr_b16 fragments in the wgrad GEMM, default 1) */
 int32_t vsx_set_flag(const char* name, int32_t value);
 int32_t vsx_get_flag(const char* name);
+/* vsx_set_flag("det_reduce", 1): the forward's per-sample sums (GRN sum of squares of the fused GRN-MLP passes and of gemm_nt's
+ * GELU epilogue on the 256-row-tile kernel, InstanceNorm sum / sum of squares of vsx_head_conv_fwd) are formed in a fixed order
+ * — per-workgroup partials in this caller-owned scratch (`floats` fp32 values, thread-local, used by the NEXT launches of this
+ * thread; every launch checks the size and names what it needs), then one ordered pass — instead of by fp32 atomics, whose order
+ * differs from run to run (timm GlobalResponseNorm / nn.InstanceNorm3d reduce deterministically on the CPU: reference behaviour
+ * restated at viscy_models/unet/fcmae.py:174-221, components/heads.py:617-627).  NULL / 0 releases the scratch. */
+int32_t vsx_det_workspace(float* ws, int64_t floats);
 
 /* ---------------------------------------------------------------------------------------------
  * Operand "gather" description shared by the two GEMM kernels.  Row m of the logical

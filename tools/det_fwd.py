@@ -21,17 +21,33 @@ with torch.no_grad():
 m.compute_dtype, m.grad_mode = torch.bfloat16, "flat"
 eng = m.engine()
 x = torch.randn((B, 1, 5, S, S), device="cuda")
-for flags in ([("mlp_fused", 111)], [("mlp_fused", 47)], [("mlp_fused", 111)]):
+def timed_forward():
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    y, sv = eng.forward(x, torch.bfloat16, need_bwd=True)
+    e1.record()
+    torch.cuda.synchronize()
+    eng._pending_bwd = 0
+    return y.clone(), e0.elapsed_time(e1)
+
+
+# round 5: fp32 atomics (default) against vsx_set_flag("det_reduce", 1) — fixed-order GRN / InstanceNorm sums — and what it costs
+for flags in ([("det_reduce", 0)], [("det_reduce", 1)], [("det_reduce", 0), ("mlp_fused", 47)], [("det_reduce", 1), ("mlp_fused", 47)]):
+    L.lib().vsx_set_flag(b"mlp_fused", 239)
     for k, v in flags:
         L.lib().vsx_set_flag(k.encode(), v)
-    ys = []
+    timed_forward()
+    ys, ms = [], []
     for i in range(4):
-        y, sv = eng.forward(x, torch.bfloat16, need_bwd=True)
-        eng._pending_bwd = 0
-        ys.append(y.clone())
-        del sv, y
+        y, t = timed_forward()
+        ys.append(y)
+        ms.append(t)
     ref = ys[0]
     for i in range(1, 4):
         d = (ys[i] - ref).abs()
         print(flags, f"run {i}: max diff / max |y| = {(d.max() / ref.abs().max()).item():.3e}, differing {int((d > 0).sum())} of {d.numel()}, "
               f"> 1e-2 * max: {int((d > 1e-2 * ref.abs().max()).sum())}", flush=True)
+    print(flags, f"forward (training schedule, eager) {sorted(ms)[len(ms) // 2]:.2f} ms", flush=True)
+L.lib().vsx_set_flag(b"det_reduce", 0)
+L.lib().vsx_set_flag(b"mlp_fused", 239)

@@ -59,6 +59,7 @@ _SIGS = {
     "vsx_last_kernel": (C.c_char_p, []),
     "vsx_set_flag": (_I32, [C.c_char_p, _I32]),
     "vsx_get_flag": (_I32, [C.c_char_p]),
+    "vsx_det_workspace": (_I32, [_P, _I64]),
     "vsx_gemm_nt": (_I32, [C.POINTER(VsxGemm), _I32, _P]),
     "vsx_gemm_tn": (_I32, [C.POINTER(VsxGemm), _I32, _P]),
     "vsx_gemm_nt_ln_bwd_supported": (_I32, [_I64, _I32, _I32, _I32]),

@@ -25,6 +25,9 @@ int g_vsx_tn_stream = 3;  // lean TN kernel: non-temporal loads of an operand th
 int g_vsx_tn_contig = 1;  // lean TN kernel: contiguous step range per split
 int g_vsx_mlp_fused = 239;  // fused GRN-MLP kernels (csrc/mlp.hip): bit 0 = inference forward (statistics + output passes, hidden activation on chip), bit 1 = training fc1 (statistics pass that also stores h and g), bit 3 = block backward without a stored dz (statistics from the per-sample weight-gradient products or MODE 3, then MODE 4 writes dh once) — on the C = 96 / 192 / 224 blocks; bit 2 = the training passes also on the C = 384 blocks (same step time, 7.7 GB less traffic per step); (bit 4 was the inference pair on the C = 384 blocks, slower than the unfused GEMMs there: removed in round 4); bit 5 = the block LayerNorm in the prologue of the fused passes (vsx_mlp_fwd_ln / vsx_mlp_fc1_ln: no separate LayerNorm pass); bit 6 = the pre-activation h is never stored on the C <= 224 blocks: the training fc1 writes g only (MODE 6) and the dh pass recomputes h from the C-wide normalised rows (MODE 5, vsx_mlp_bwd_dh_re); bit 7 (with 5 and 6) = the normalised rows x^ are not stored either: the forward keeps the depthwise output y + the row mean / rstd, the dh pass re-normalises y and writes dh * rstd (MODE 7, vsx_mlp_bwd_dh_ln), the fc1 weight gradient is a plain TN GEMM on y with a rank-1 correction, the LayerNorm backward in the data-gradient GEMM re-forms x^ from y
 int g_vsx_mlp_sf32 = 1 | 4 | 64;  // fused GRN-MLP kernels: bit m = MODE m runs the build without packed-fp32 VALU instructions (csrc/mlp.hip, round 5: a v_pk_*_f32 next to MFMAs costs ~15 cycles; the forward passes gain 6 - 20 %, the dh passes are VALU-bound and keep the packed build)
+int g_vsx_det_reduce = 0;  // 1: the forward's per-sample sums — GRN sum g^2 of the fused GRN-MLP passes and of gemm_nt2's GELU epilogue, InstanceNorm sum / sum^2 of the direct head convolution — are formed in a FIXED order (per-workgroup partials in a caller-owned workspace, vsx_det_workspace, then one ordered pass) instead of by fp32 atomics: the bf16 forward is then bit-identical from run to run (with atomics: 7e-3 of the output maximum at 2048^2).  Cost: one small launch per pass, tools/det_fwd.py
+thread_local float* g_vsx_det_ws = nullptr;
+thread_local long g_vsx_det_ws_floats = 0;
 int g_vsx_nt2 = 1;  // second-generation NT kernel (gemm_nt2.hip: 256 x 128 tiles, LDS-DMA operand path, wave-private epilogue): bit 0 = on for the launches it supports, bit 1 = also below 512 tiles
 int g_vsx_loss_fused = 1;  // MixedLoss training forward: one pass per scale (SSIM sums + gradient field + next scale's pooling / data range + L1 / L2 sums: vsx_ssim_scale_fwd_fused) instead of a pooling pass and an SSIM pass; read by viscy_amd/losses.py
 
@@ -35,6 +38,13 @@ void vsx_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+/* det_reduce: scratch for the per-workgroup partial sums of the NEXT launches on this thread (caller-owned, `floats` fp32 values;
+ * each launch that needs it checks the size and says how much it wants).  NULL / 0 takes it away again. */
+extern "C" int32_t vsx_det_workspace(float* ws, int64_t floats) {
+  g_vsx_det_ws = ws;
+  g_vsx_det_ws_floats = ws ? (long)floats : 0;
+  return 0;
+}
 extern "C" int32_t vsx_version(void) { return 1; }
 extern "C" const char* vsx_last_error(void) { return g_err; }
 extern "C" const char* vsx_last_kernel(void) { return g_vsx_last_kernel; }
@@ -59,6 +69,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "mlp_fused")) { g_vsx_mlp_fused = value; return 0; }
   if (name && !strcmp(name, "loss_fused")) { g_vsx_loss_fused = value; return 0; }
   if (name && !strcmp(name, "mlp_sf32")) { g_vsx_mlp_sf32 = value; return 0; }
+  if (name && !strcmp(name, "det_reduce")) { g_vsx_det_reduce = value; return 0; }
   vsx_set_error("vsx_set_flag: unknown flag '%s'", name ? name : "(null)");
   return 1;
 }
@@ -83,5 +94,6 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "mlp_fused")) return g_vsx_mlp_fused;
   if (name && !strcmp(name, "loss_fused")) return g_vsx_loss_fused;
   if (name && !strcmp(name, "mlp_sf32")) return g_vsx_mlp_sf32;
+  if (name && !strcmp(name, "det_reduce")) return g_vsx_det_reduce;
   return -1;
 }

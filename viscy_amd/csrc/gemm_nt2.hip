@@ -317,8 +317,14 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
           a0 += red[((w * 2 + w0) * 2 + 0) * WN + c];
           if constexpr (EPI == VSX_EPI_DZ) a1 += red[((w * 2 + w0) * 2 + 1) * WN + c];
         }
-        atomicAdd(p.red0 + (size_t)b_tile * p.N + n0 + tid, a0);
-        if constexpr (EPI == VSX_EPI_DZ) atomicAdd(p.red1 + (size_t)b_tile * p.N + n0 + tid, a1);
+        if (EPI == VSX_EPI_BIAS_GELU_SQ && p.aux != nullptr) {
+          // det_reduce (the dispatcher put the workspace into the otherwise unused `aux`): one row of column sums per row tile,
+          // added up per sample in tile order by vsx_det_group_sum
+          reinterpret_cast<float*>(const_cast<void*>(p.aux))[(size_t)tile_m * p.N + n0 + tid] = a0;
+        } else {
+          atomicAdd(p.red0 + (size_t)b_tile * p.N + n0 + tid, a0);
+          if constexpr (EPI == VSX_EPI_DZ) atomicAdd(p.red1 + (size_t)b_tile * p.N + n0 + tid, a1);
+        }
       }
     }
   }
@@ -555,6 +561,9 @@ bool vsx_gemm_nt2_ok(const VsxGemm* p) {
   if (p->hw > 0 && p->hw % BM != 0 && p->hw != 64 && p->hw != 128) return false;
   if ((unsigned long long)BM * p->lda * 2 >= (1ull << 32) || (unsigned long long)p->N * p->ldb * 2 >= (1ull << 32)) return false;
   if (g_vsx_nt2 & 2) return true;  // (tests / A-B runs: every supported launch)
+  // det_reduce: this kernel is the one whose GELU / sum-of-squares epilogue has the fixed-order path (the first-generation kernels
+  // reduce with atomics) — it takes every such launch it supports, also the small ones the heuristics below leave to them
+  if (g_vsx_det_reduce && p->epi == VSX_EPI_BIAS_GELU_SQ) return true;
   // Where the wide tiles pay (tools/perf_nt_gen2.py, B = 512, against the first-generation kernel): the K-heavy launches
   // whose output is C-wide — fc2 / fc1 data gradient of the C = 384 / 768 stages -10 .. -25 %, of the 224-channel decoder
   // stage -4 .. -10 % — and the C = 384 fc1 (-14 %).  Not the dz epilogue (its second operand stream eats the gain), not
@@ -567,8 +576,22 @@ bool vsx_gemm_nt2_ok(const VsxGemm* p) {
   return p->K >= 768 && p->N > 192;
 }
 
-int vsx_gemm_nt2(const VsxGemm* p, hipStream_t s) {
+int vsx_gemm_nt2(const VsxGemm* p0, hipStream_t s) {
   g_vsx_last_kernel = "gemm_nt2";
+  VsxGemm det = *p0;
+  const VsxGemm* p = p0;
+  const bool det_sums = g_vsx_det_reduce && p0->epi == VSX_EPI_BIAS_GELU_SQ && p0->hw > 0 && p0->hw % BM == 0 && p0->hw > BM;
+  if (det_sums) {  // (hw <= 256: at most two adds per address — already independent of their order)
+    const long need = (long)(p0->M / BM) * p0->N;
+    VSX_CHECK(g_vsx_det_ws != nullptr && g_vsx_det_ws_floats >= need, "vsx_gemm_nt: det_reduce needs vsx_det_workspace(>= %ld floats)", need);
+    det.aux = g_vsx_det_ws;
+    p = &det;
+  }
+  if (det_sums) {
+    int e = launch<VSX_EPI_BIAS_GELU_SQ>(p, s);
+    if (e) return e;
+    return vsx_det_group_sum(g_vsx_det_ws, p->N, 0, p->red0, p->M / p->hw, p->hw / BM, p->N, s);
+  }
   if (p->epi == VSX_EPI_LN_BWD) {
     const int tiles = p->M / BM;
     if (p->N <= 128) hipLaunchKernelGGL((gemm_nt2_lnbwd_kernel<128>), dim3(tiles), dim3(512), 0, s, *p);

@@ -47,7 +47,8 @@ __device__ __forceinline__ bf16x8 hc_tr(const char* a0, const char* a1) {
 constexpr int HF_PS = HC_D7 * HC_C3 * 2;  // 112 B per halo pixel: 16 consecutive pixels hit 16 distinct 16-byte bank groups
 __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16_t* __restrict__ hin, const bf16_t* __restrict__ Wc,
                                                             const float* __restrict__ bias, bf16_t* __restrict__ U,
-                                                            float* __restrict__ ssum, float* __restrict__ ssq, int H2, int W2) {
+                                                            float* __restrict__ ssum, float* __restrict__ ssq, int H2, int W2,
+                                                            float* __restrict__ det_ws) {
   __shared__ __attribute__((aligned(16))) char tile[18 * 18 * HF_PS];
   __shared__ float red[4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -159,7 +160,11 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16_t* __rest
   __syncthreads();
   if (tid < 64) {
     const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    atomicAdd((tid < 32 ? ssum : ssq) + (size_t)b * HC_CMID + (tid & 31), v);
+    if (det_ws) {  // det_reduce: one row of 64 partials per workgroup, added up in tile order by vsx_det_group_sum
+      det_ws[((size_t)b * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + tid] = v;
+    } else {
+      atomicAdd((tid < 32 ? ssum : ssq) + (size_t)b * HC_CMID + (tid & 31), v);
+    }
   }
 }
 
@@ -422,9 +427,20 @@ extern "C" int32_t vsx_head_conv_fwd(const void* hin, const void* Wc, const floa
                                      vsx_stream_t stream) {
   if (int e = hc_check("vsx_head_conv_fwd", B, H2, W2, c3, cmid, zo, dtype)) return e;
   VSX_CHECK(hin && Wc && U && ssum && ssq, "vsx_head_conv_fwd: null pointer");
+  float* det_ws = nullptr;
+  const int tiles = (W2 / 16) * (H2 / 16);
+  if (g_vsx_det_reduce) {  // fixed-order InstanceNorm sums: 64 partials per workgroup, then one ordered pass per array
+    const long need = (long)B * tiles * 64;
+    VSX_CHECK(g_vsx_det_ws != nullptr && g_vsx_det_ws_floats >= need, "vsx_head_conv_fwd: det_reduce needs vsx_det_workspace(>= %ld floats)", need);
+    det_ws = g_vsx_det_ws;
+  }
   hipLaunchKernelGGL(head_conv_fwd_kernel, dim3(W2 / 16, H2 / 16, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hin,
-                     (const bf16_t*)Wc, bias, (bf16_t*)U, ssum, ssq, H2, W2);
+                     (const bf16_t*)Wc, bias, (bf16_t*)U, ssum, ssq, H2, W2, det_ws);
   VSX_LAUNCH_CHECK();
+  if (det_ws) {
+    if (int e = vsx_det_group_sum(det_ws, 64, 0, ssum, B, tiles, HC_CMID, (hipStream_t)stream)) return e;
+    return vsx_det_group_sum(det_ws, 64, 32, ssq, B, tiles, HC_CMID, (hipStream_t)stream);
+  }
   return 0;
 }
 extern "C" int32_t vsx_head_conv_wgrad(const void* hin, const void* dU, float* dW, float* db, int32_t B, int32_t H2, int32_t W2,

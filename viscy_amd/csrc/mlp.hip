@@ -696,7 +696,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) t += r[w * 32];
-        atomicAdd(a.colsq + (size_t)b * H4 + (hs - 1) * 32 + lane, t);
+        if (a.ws) a.ws[(size_t)blockIdx.x * H4 + (hs - 1) * 32 + lane] = t;   // det_reduce: one workspace row per workgroup
+        else atomicAdd(a.colsq + (size_t)b * H4 + (hs - 1) * 32 + lane, t);
       }
     }
     mlp_bf16x8 zf[MF];
@@ -803,7 +804,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) t += r[w * 32];
-      atomicAdd(a.colsq + (size_t)b * H4 + (NHS - 1) * 32 + lane, t);
+      if (a.ws) a.ws[(size_t)blockIdx.x * H4 + (NHS - 1) * 32 + lane] = t;
+      else atomicAdd(a.colsq + (size_t)b * H4 + (NHS - 1) * 32 + lane, t);
     }
     return;
   } else {
@@ -957,6 +959,22 @@ static int mlp_dispatch(const MlpCfg* c, const MlpArgs& a, hipStream_t s) {
   else return mlp_launch<384, 2, 8, MODE>(a, s);
 }
 
+// det_reduce: the statistics passes (MODE 0 / 2 / 6) leave one row of column sums per workgroup in the thread's workspace
+// (vsx_det_workspace) and an ordered pass adds a sample's rows into colsq — no atomics, the same bits in every run
+static int mlp_det_begin(MlpArgs& a, const MlpCfg* c, const char* who) {
+  a.ws = nullptr;
+  if (!g_vsx_det_reduce) return 0;
+  const long need = (long)(a.M / (c->NW * 16 * c->MF)) * 4 * c->C;
+  VSX_CHECK(g_vsx_det_ws != nullptr && g_vsx_det_ws_floats >= need, "%s: det_reduce needs vsx_det_workspace(>= %ld floats)", who, need);
+  a.ws = g_vsx_det_ws;
+  return 0;
+}
+static int mlp_det_end(const MlpArgs& a, const MlpCfg* c, hipStream_t s) {
+  if (!a.ws) return 0;
+  const int bm = c->NW * 16 * c->MF;
+  return vsx_det_group_sum(a.ws, 4 * c->C, 0, a.colsq, a.M / a.hw, a.hw / bm, 4 * c->C, s);
+}
+
 /* mode 0: colsq[b, 4C] += sum over the sample's pixels of gelu(fc1(xh))^2 (bf16-rounded g, as the unfused fc1 epilogue);
  * mode 1: out = res + rscale[b] * (fc2(gelu(fc1(xh)) * s[b] + beta) + b2). */
 extern "C" int32_t vsx_mlp_gelu_table_len(void) { return 2 * MLP_GT_N; }
@@ -1004,7 +1022,9 @@ extern "C" int32_t vsx_mlp_fwd(const void* xh, const void* wimg, const float* b1
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) {
     VSX_CHECK(colsq != nullptr, "vsx_mlp_fwd: mode 0 needs colsq");
-    return mlp_dispatch<0>(c, a, s);
+    if (int e = mlp_det_begin(a, c, "vsx_mlp_fwd")) return e;
+    if (int e = mlp_dispatch<0>(c, a, s)) return e;
+    return mlp_det_end(a, c, s);
   }
   VSX_CHECK(mode == 1 && grn_s && grn_b && b2 && res && out, "vsx_mlp_fwd: mode 1 needs s, beta, b2, res, out");
   return mlp_dispatch<1>(c, a, s);
@@ -1027,7 +1047,9 @@ extern "C" int32_t vsx_mlp_fc1(const void* xh, const void* wimg, const float* b1
   a.M = (int)M; a.hw = hw;
   a.ln_eps = g_mlp_ln_eps; a.xh_out = g_mlp_xh_out; a.rstd_out = g_mlp_rstd_out; a.xh2 = nullptr; a.wimg2 = nullptr;
   a.mean_out = g_mlp_mean_out; a.ln_mean = nullptr; a.ln_rstd = nullptr;
-  return h ? mlp_dispatch<2>(c, a, (hipStream_t)stream) : mlp_dispatch<6>(c, a, (hipStream_t)stream);
+  if (int e = mlp_det_begin(a, c, "vsx_mlp_fc1")) return e;
+  if (int e = h ? mlp_dispatch<2>(c, a, (hipStream_t)stream) : mlp_dispatch<6>(c, a, (hipStream_t)stream)) return e;
+  return mlp_det_end(a, c, (hipStream_t)stream);
 }
 
 /* The same passes with the block LayerNorm (eps, no affine: folded into W1' / b1) applied in the kernel's prologue: `y` holds

@@ -360,6 +360,29 @@ __global__ __launch_bounds__(256) void grn_bwd_stats_kernel(const float* __restr
 }
 __global__ void reduce_rows_kernel(const float* __restrict__ ws, float* __restrict__ out, int R, int N);
 
+// det_reduce: a workgroup owns (one group, 64 columns); its 4 row slots add every fourth row of the group in ascending order and
+// the four partial sums are combined in slot order — a fixed tree, the same bits in every run (1 024 rows per sample at 2048^2:
+// one thread per column alone took milliseconds)
+__global__ __launch_bounds__(256) void det_group_sum_kernel(const float* __restrict__ ws, int ld, int col0, float* __restrict__ out,
+                                                            int groups, int rpg, int N) {
+  __shared__ float part[4][64];
+  const int g = blockIdx.y, cl = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (n < N) {
+    const float* p = ws + (size_t)g * rpg * ld + col0 + n;
+    for (int r = slot; r < rpg; r += 4) acc += p[(size_t)r * ld];
+  }
+  part[slot][cl] = acc;
+  __syncthreads();
+  if (slot == 0 && n < N) out[(size_t)g * N + n] += (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+}
+int vsx_det_group_sum(const float* ws, int ld, int col0, float* out, int groups, int rows_per_group, int N, hipStream_t s) {
+  hipLaunchKernelGGL(det_group_sum_kernel, dim3(vsx_cdiv(N, 64), groups), dim3(256), 0, s, ws, ld, col0, out, groups, rows_per_group, N);
+  VSX_LAUNCH_CHECK();
+  return 0;
+}
+
 /* K7: timm GlobalResponseNorm statistics.  colsq[b,n] = sum_hw gelu(h)^2 comes from the fc1 GEMM epilogue. */
 extern "C" int32_t vsx_grn_scale(const float* colsq, const float* gamma, float* s, int32_t nb, int32_t N, float eps,
                                  vsx_stream_t stream) {

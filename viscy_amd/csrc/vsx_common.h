@@ -12,6 +12,11 @@ typedef __bf16 bf16_t;
 
 // ------------------------------------------------------------------ error plumbing (host)
 void vsx_set_error(const char* fmt, ...);
+extern int g_vsx_det_reduce;                 // api.hip: fixed-order forward sums (vsx_set_flag("det_reduce", 1))
+extern thread_local float* g_vsx_det_ws;     // api.hip: vsx_det_workspace
+extern thread_local long g_vsx_det_ws_floats;
+// out[g * N + n] += sum over r < rows_per_group, IN ORDER, of ws[(g * rows_per_group + r) * ld + col0 + n]   (norm.hip)
+int vsx_det_group_sum(const float* ws, int ld, int col0, float* out, int groups, int rows_per_group, int N, hipStream_t s);
 extern thread_local const char* g_vsx_last_kernel;  // api.hip: set by the GEMM dispatchers, read by vsx_last_kernel()
 #define VSX_CHECK(cond, ...)            \
   do {                                  \

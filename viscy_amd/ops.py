@@ -30,6 +30,20 @@ def _workspace(dev, numel: int) -> Tensor:
     return w
 
 
+_DET_WS: dict = {}
+
+
+def _det(dev, floats: int) -> None:
+    """``det_reduce`` flag on: hand the library the scratch for the per-workgroup partial sums of the next launch (grown, never
+    freed: a captured hipGraph keeps pointing at it)"""
+    if not lib().vsx_get_flag(b"det_reduce"):
+        return
+    held = _DET_WS.setdefault(dev, [])
+    if not held or held[-1].numel() < floats:
+        held.append(torch.empty(max(int(floats), 1 << 20), dtype=torch.float32, device=dev))
+    check(lib().vsx_det_workspace(ptr(held[-1]), held[-1].numel()), "det_workspace")
+
+
 def _fill8(arr, vals: Sequence[int] | None):
     if vals:
         for i, v in enumerate(vals):
@@ -100,6 +114,8 @@ def gemm(
     p.C2 = ptr(C2)
     p.b_bstride = b_bstride
     p.rscale = ptr(rscale)
+    if kind == "nt" and epi == L.EPI_BIAS_GELU_SQ:
+        _det(A.device, (M // 256 + 1) * N)
     fn = lib().vsx_gemm_nt if kind == "nt" else lib().vsx_gemm_tn
     check(fn(C.byref(p), dtype_code(dtype), stream()), f"gemm_{kind}")
 
@@ -465,6 +481,7 @@ def _gelu_table(dev) -> Tensor:
 def mlp_stats(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int, ln_eps: float = 0.0) -> None:
     """colsq[b, 4C] += per-sample column sums of gelu(fc1(xh))^2 — nothing 4C-wide is written.  ``ln_eps`` > 0: ``xh`` holds the
     UN-normalised rows and the kernel applies the block LayerNorm (no affine) in its prologue"""
+    _det(xh.device, (M // 256) * 4 * C)
     if ln_eps > 0.0:
         check(lib().vsx_mlp_fwd_ln(ptr(xh), ln_eps, ptr(img), ptr(b1), None, None, None, None, None, None, ptr(colsq),
                                    ptr(_gelu_table(xh.device)), M, C, hw, 0, dtype_code(xh.dtype), stream()), "mlp_stats")
@@ -478,6 +495,7 @@ def mlp_fc1(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, 
     (where ``mlp_supported(.., 6)``): h is None — the backward recomputes it (mlp_bwd_dh_re)"""
     h = torch.empty((M, 4 * C), dtype=xh.dtype, device=xh.device) if store_h else None
     g = torch.empty((M, 4 * C), dtype=xh.dtype, device=xh.device)
+    _det(xh.device, (M // 256) * 4 * C)
     check(lib().vsx_mlp_fc1(ptr(xh), ptr(img), ptr(b1), ptr(colsq), ptr(_gelu_table(xh.device)), ptr(h), ptr(g), M, C, hw,
                             dtype_code(xh.dtype), stream()), "mlp_fc1")
     return h, g
@@ -494,6 +512,7 @@ def mlp_fc1_ln(y: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int
     rstd = torch.empty(M, dtype=torch.float32, device=y.device)
     h = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device) if store_h else None
     g = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device)
+    _det(y.device, (M // 256) * 4 * C)
     check(lib().vsx_mlp_fc1_ln(ptr(y), eps, ptr(xh), ptr(rstd), ptr(mean), ptr(img), ptr(b1), ptr(colsq), ptr(_gelu_table(y.device)),
                                ptr(h), ptr(g), M, C, hw, dtype_code(y.dtype), stream()), "mlp_fc1_ln")
     return (xh if store_xh else (y, mean)), rstd, h, g
@@ -579,6 +598,7 @@ def head_conv_supported(H2: int, W2: int, c3: int, cmid: int, zo: int, dtype: to
 def head_conv_fwd(hin: Tensor, Wc: Tensor, bias: Tensor | None, ssum: Tensor, ssq: Tensor, B: int, H2: int, W2: int, c3: int,
                   cmid: int, zo: int) -> Tensor:
     U = torch.empty((B * H2 * W2, zo * cmid), dtype=hin.dtype, device=hin.device)
+    _det(hin.device, B * (H2 // 16) * (W2 // 16) * 64)
     check(lib().vsx_head_conv_fwd(ptr(hin), ptr(Wc), ptr(bias), ptr(U), ptr(ssum), ptr(ssq), B, H2, W2, c3, cmid, zo,
                                   dtype_code(hin.dtype), stream()), "head_conv_fwd")
     return U
