@@ -1421,6 +1421,64 @@ def test_fused_block_without_stored_normalised_rows(C, hw, B, offset):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,hw,B", [(384, 256, 24), (768, 64, 40), (96, 1024, 6), (224, 4096, 3)])
+def test_fc2_weight_gradient_that_also_delivers_the_grn_statistics(C, hw, B):
+    """Round 5 (csrc/gemm.hip, gemm_tn_fast_kernel PRO == 2): `gemm("tn", g, dout, dW2, pro=GRN, aux=W2, red0=P)` — one launch for
+    the fc2 weight gradient dW2 = dout^T (g * s_b + beta), the bias gradient (column sums of dout) and the GRN backward statistics
+    P[b, k] = sum_hw dz * g, dz = dout . W2 — against fp64 statements of timm's GlobalResponseNormMlp backward (fcmae.py:174-221)
+    and against the two launches it replaces (the GRN-prologue weight gradient; csrc/mlp.hip MODE 3 where that exists)."""
+    if SELF_CHECK:
+        pytest.skip("HIP-only kernel")
+    from viscy_amd import _lib as L
+    from viscy_amd import ops
+
+    dt = torch.bfloat16
+    M, H4 = B * hw, 4 * C
+    assert ops.tn_grn_stats_ok(M, C, H4, hw, dt)
+    g = rnd(M, H4, dt=dt, seed=1, scale=0.7).cuda()
+    dout = rnd(M, C, dt=dt, seed=2).cuda()
+    W2 = rnd(C, H4, dt=dt, seed=3, scale=H4 ** -0.5).cuda()
+    s = (1 + 0.3 * rnd(B, H4, seed=4)).cuda()
+    beta = (0.2 * rnd(H4, seed=5)).cuda()
+    dW2 = torch.zeros((C, H4), device="cuda")
+    cs = torch.zeros(C, device="cuda")
+    P = torch.zeros((B, H4), device="cuda")
+    ops.gemm("tn", g, dout, dW2, M, C, H4, H4, C, H4, dtype=dt, pro=L.PRO_GRN, grn_s=s, grn_b=beta, hw=hw, colsum=cs, aux=W2, ldx=H4, red0=P)
+    assert L.lib().vsx_last_kernel() == b"gemm_tn_fast"
+    d64, g64 = dout.double().view(B, hw, C), g.double().view(B, hw, H4)
+    z64 = g64 * s.double()[:, None] + beta.double()
+    dW64 = torch.einsum("bhc,bhk->ck", d64, z64)
+    cs64 = d64.sum((0, 1))
+    P64 = ((d64 @ W2.double()) * g64).sum(1)
+    # bounds: products of bf16 values accumulated in fp32 — 6 sigma of eps32 * sqrt(sum of squared terms), + the bf16 W2 in P is exact
+    bW = 6 * 2.0 ** -22 * torch.einsum("bhc,bhk->ck", d64 ** 2, z64 ** 2).sqrt().max().item() * (M ** 0.5) ** 0 + 1e-3 * dW64.abs().max().item()
+    assert (dW2.double() - dW64).abs().max().item() <= bW, ((dW2.double() - dW64).abs().max().item(), bW)
+    close(cs, cs64.float(), torch.float32, "bias gradient = column sums of dout", scale=cs64.abs().max().item() + float(M) ** 0.5)
+    bP = 1e-3 * P64.abs().max().item() + 1e-4
+    assert (P.double() - P64).abs().max().item() <= bP, ((P.double() - P64).abs().max().item(), bP)
+    # the launches it replaces: the prologue weight gradient rounds z to bf16 (so it is the LESS accurate of the two) ...
+    dW2p, csp = torch.zeros((C, H4), device="cuda"), torch.zeros(C, device="cuda")
+    ops.gemm("tn", g, dout, dW2p, M, C, H4, H4, C, H4, dtype=dt, pro=L.PRO_GRN, grn_s=s, grn_b=beta, hw=hw, colsum=csp)
+    close(dW2, dW2p, dt, "dW2: post-scaled products vs GRN-prologue operand")
+    assert (dW2.double() - dW64).abs().mean().item() <= (dW2p.double() - dW64).abs().mean().item() * 1.02
+    close(cs, csp, torch.float32, "column sums", scale=cs64.abs().max().item() + float(M) ** 0.5)
+    # ... and MODE 3 recomputes dz for the same P
+    if ops.mlp_supported(C, hw, M, dt, 3):
+        img2 = ops.mlp_pack(W2.t().contiguous(), W2, C)
+        P3, S3 = torch.zeros((B, H4), device="cuda"), torch.zeros((B, H4), device="cuda")
+        ops.mlp_bwd_stats(dout, img2, g, P3, S3, M, C, hw)
+        close(P, P3, torch.float32, "P: from the weight-gradient tiles vs MODE 3", scale=P64.abs().max().item())
+        # what S was used for: dbeta = sum_b S_b = (column sums of dout) . W2
+        close((cs.double() @ W2.double()).float(), S3.sum(0), torch.float32, "dbeta", scale=S3.sum(0).abs().max().item() + 1.0)
+    # run-to-run: the split-K atomics only move round-off
+    dW2b, Pb = torch.zeros((C, H4), device="cuda"), torch.zeros((B, H4), device="cuda")
+    ops.gemm("tn", g, dout, dW2b, M, C, H4, H4, C, H4, dtype=dt, pro=L.PRO_GRN, grn_s=s, grn_b=beta, hw=hw, colsum=torch.zeros(C, device="cuda"),
+             aux=W2, ldx=H4, red0=Pb)
+    close(dW2b, dW2, torch.float32, "dW2 run to run", scale=dW64.abs().max().item())
+    close(Pb, P, torch.float32, "P run to run", scale=P64.abs().max().item())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_stem_patch_gemm_vs_directly_imported_reference_stem(dt):
     """G1 on the device: tests/golden/stem.pt holds weights, input and output of the REFERENCE's own

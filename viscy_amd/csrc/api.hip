@@ -12,7 +12,7 @@ int g_vsx_nt_wide = 1;
 int g_vsx_nt_fast = 1;
 int g_vsx_tn_wide = 1;
 int g_vsx_ggb_blocks = 2048;  // grn_gelu_bwd: target workgroup count (tuning knob, see norm.hip)
-int g_vsx_tn_rect = 3;  // rectangular TN tiles: bit 0 = when N or K is 224..256 wide, bit 1 = 256x128 when 256 divides N (no prologue), bit 2 = 128x256 when 256 divides K (slower: off)
+int g_vsx_tn_rect = 11;  // rectangular TN tiles: bit 0 = when N or K is 224..256 wide, bit 1 = 256x128 when 256 divides N (no prologue), bit 2 = 128x256 when 256 divides K (slower: off), bit 3 (round 5) = where the block backward takes its GRN statistics by recomputation (C = 384), the fc2 weight gradient delivers them instead: per-sample products scaled / contracted in the accumulators (gemm_tn_fast_kernel PRO == 2; read by viscy_amd.ops.tn_grn_stats_ok)
 int g_vsx_dw_mfma = 15;  // depthwise conv on the matrix cores (dwconv_mfma.hip): bit 0 forward / data gradient (banded Toeplitz tiles), bit 3 the same with its tiles fetched by LDS-DMA two tiles ahead (round 4; whole 32-channel slabs only), bit 1 weight gradient (row contraction, transpose reads), bit 2 16-column weight-gradient tiles at every width (the 32-column variant spills: 471 vs 285 us at 64x64x96, B = 512); 0: VALU stencils
 int g_vsx_ln_fblk = 32768;  // LayerNorm forward: cap on workgroups per launch (each sweeps rows / cap windows).  Measured at B = 512 (64x64x96 / x224): 2048 -> 209 / 438 us, 8192 -> 172 / 351, 32768 -> 162 / 331 (a grid-stride sweep by few workgroups streams at 5.0 TB/s where one vector per thread reaches 6.8: tools/micro/write_rate.hip)
 int g_vsx_ln_bblk = 8192;   // LayerNorm backward WITHOUT affine gradients (the block LayerNorms): cap on workgroups (with dgamma: 512, same-address atomics).  512 -> 319 / 651 us, 2048 -> 254 / 586, 8192 -> 240 / 541 (16x16x384: 83 -> 61), 32768 -> 225 / 516 but 78 at 16x16x384

@@ -1120,8 +1120,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
 // gradient (dW2: N = C, dW1: K = C, C <= 256) makes the 4C-wide activation operand stream through exactly ONE workgroup per
 // pixel split instead of two (PMC: the square-tile TN launches fetched 1.7x their algorithmic bytes) and halves the fragment
 // reads per MFMA (12 transposing reads per 32 MFMAs instead of 8 per 16).
-template <typename T, int BT, bool TR, bool PRO, int BMS = 32, int NBUF = 2, int BTK_ = 0>
-__global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1)) void gemm_tn_fast_kernel(const VsxGemm p) {
+// PRO: 0 = plain operands; 1 = GRN prologue on the Y operand as it is staged (y = g * s[b, k] + beta[k], rounded to bf16 again);
+// 2 (round 5) = the fc2 weight gradient of a whole-sample stage TOGETHER WITH the GRN statistics of the block backward.  The
+// operand is not touched: Q_b = X_b^T . g_b is accumulated per SAMPLE, and behind the last step of a sample
+//   * a second accumulator set takes acc2 += s[b, k] * Q_b       (dW[n, k] = sum_b s[b, k] Q_b[n, k] + beta[k] * sum_r x[r, n]),
+//   * P[b, k] += sum_n W2[n, k] * Q_b[n, k] over the tile's rows n  (= sum_hw dz * g with dz = dout . W2: dz is linear in dout, so
+//     the statistics that csrc/mlp.hip MODE 3 recomputes dz for — a full M x 4C x C contraction per block — fall out of the
+//     per-sample tile that sits in the accumulators anyway; the W2 tile waits in LDS in accumulator order).
+// The beta term is the rank-1 product (column sums of X) x beta, added once at the end; the column sums come from one extra MFMA
+// per X fragment against a ones operand.  By itself the post-scaled form is as fast as the prologue form (the launch is bound by
+// its operand stream, not by the prologue: 320 us plain vs 343 us at C = 384, B = 512); what it buys is the MODE 3 launch.
+template <typename T, int BT, bool TR, int PRO, int BMS = 32, int NBUF = 2, int BTK_ = 0>
+__global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1)) void gemm_tn_fast_kernel(const VsxGemm p) {
   constexpr int ES = sizeof(T);
   constexpr int VN = VT<T>::N;
   constexpr int BTN = BT, BTK = BTK_ != 0 ? BTK_ : BT;
@@ -1134,6 +1144,8 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
   typedef typename VT<T>::vec vec;
   typedef typename Frag<T>::type frag_t;
   __shared__ __attribute__((aligned(16))) char smem[NBUF * (TILE_X + TILE_Y)];
+  // PRO == 2: this workgroup's W2 tile (bf16) in accumulator order — lane t finds the 4 rows r of fragment (i, j) at [(i * FK_ + j) * 256 + t]
+  __shared__ __attribute__((aligned(16))) uint2 w2img[PRO == 2 ? FN_ * FK_ * 256 : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1201,14 +1213,14 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
   // (the first version re-read them from global memory for every chunk of every step)
   float gsr[VN], gbr[VN];
   int gcur = -1;
-  if constexpr (PRO) {
+  if constexpr (PRO == 1) {
 #pragma unroll
     for (int j = 0; j < VN; ++j) gbr[j] = p.grn_b[kcol[0] + j];
   }
   auto store_tiles = [&](int step, int buf, const vec* xr, const vec* yr) {
     char* Xs = smem + buf * (TILE_X + TILE_Y);
     char* Ys = Xs + TILE_X;
-    if constexpr (PRO) {
+    if constexpr (PRO == 1) {
       const int bnow = (step * BMS) / p.hw;  // (uniform)
       if (bnow != gcur) {
         gcur = bnow;
@@ -1228,7 +1240,7 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
     for (int i = 0; i < NCHY; ++i) {
       if (livey[i]) {
         vec yv = yr[i];
-        if constexpr (PRO) {
+        if constexpr (PRO == 1) {
           float f[VN];
           unpack<T>(yv, f);
 #pragma unroll
@@ -1247,6 +1259,37 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
     for (int j = 0; j < FK_; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;
   const bool do_colsum = p.colsum != nullptr && tile_k == 0 && tid < BTN;
+  f32x4 acc2[PRO == 2 ? FN_ : 1][PRO == 2 ? FK_ : 1];
+  float sreg[PRO == 2 ? FK_ : 1];
+  f32x4 acc1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // PRO == 2: column sums of X (fragments 2 wk, 2 wk + 1 of this wave's rows)
+  frag_t ones_frag;
+  const bool want_p = PRO == 2 && p.aux != nullptr && p.red0 != nullptr;
+  if constexpr (PRO == 2) {
+    union { unsigned short h[8]; frag_t v; } one;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) one.h[j] = 0x3F80;
+    ones_frag = one.v;
+#pragma unroll
+    for (int i = 0; i < FN_; ++i)
+#pragma unroll
+      for (int j = 0; j < FK_; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (want_p) {
+      const unsigned short* W2 = reinterpret_cast<const unsigned short*>(p.aux);
+#pragma unroll
+      for (int i = 0; i < FN_; ++i)
+#pragma unroll
+        for (int j = 0; j < FK_; ++j) {
+          const int k = k0 + (wk * FK_ + j) * 16 + p16;
+          unsigned short w[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = n0 + (wn * FN_ + i) * 16 + kq * 4 + r;
+            w[r] = (n < p.N && k < p.K) ? W2[(size_t)n * p.ldx + k] : (unsigned short)0;
+          }
+          w2img[(i * FK_ + j) * 256 + tid] = make_uint2((uint32_t)w[0] | ((uint32_t)w[1] << 16), (uint32_t)w[2] | ((uint32_t)w[3] << 16));
+        }
+    }
+  }
 
   // steps of this split: interleaved with the other splits (by, by + nsplit, ...) or, with bit 10 of p.pro set by the
   // launcher, one contiguous range — the GRN prologue then reloads s[b, k..] once per hw / BMS steps instead of on every
@@ -1271,10 +1314,69 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
       for (int i = 0; i < FN_; ++i)
 #pragma unroll
         for (int j = 0; j < FK_; ++j) acc[i][j] = mfma16(xf[i], yf[j], acc[i][j]);
+      if constexpr (PRO == 2) {
+        // column sums of X (beta term, bias gradient) on the matrix cores: X^T . 1 has them in every column; the two waves that
+        // share an X row range take two fragments each (a scalar loop over the tile cost as much as the step's MFMAs)
+        static_assert(PRO != 2 || FN_ == 4, "two X fragments per wave");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc1[h] = mfma16(wk == 0 ? xf[h] : xf[2 + h], ones_frag, acc1[h]);
+      }
     }
-    if (do_colsum) {
+    if constexpr (PRO == 2) {
+    } else if (do_colsum) {
 #pragma unroll 8
       for (int r = 0; r < BMS; ++r) csum += to_f32<T>(*reinterpret_cast<const T*>(Xs + r * LDBX + tid * ES));
+    }
+  };
+  // PRO == 2: steps per sample, and what happens at the two ends of a sample
+  const int sps = PRO == 2 ? p.hw / BMS : 1;
+  auto sample_begin = [&](int gstep) {
+    if constexpr (PRO == 2) {
+      const float* gs = p.grn_s + (size_t)(gstep / sps) * p.K;
+#pragma unroll
+      for (int j = 0; j < FK_; ++j) {
+        const int k = k0 + (wk * FK_ + j) * 16 + p16;
+        sreg[j] = gs[k < p.K ? k : p.K - 1];
+      }
+    }
+  };
+  auto sample_end = [&](int gstep) {
+    if constexpr (PRO == 2) {
+      if (want_p) {
+        float pj[FK_];
+#pragma unroll
+        for (int j = 0; j < FK_; ++j) {
+          float a = 0.f;
+#pragma unroll
+          for (int i = 0; i < FN_; ++i) {
+            const uint2 w = w2img[(i * FK_ + j) * 256 + tid];
+            a = fmaf(acc[i][j][0], __uint_as_float(w.x << 16), a);
+            a = fmaf(acc[i][j][1], __uint_as_float(w.x & 0xFFFF0000u), a);
+            a = fmaf(acc[i][j][2], __uint_as_float(w.y << 16), a);
+            a = fmaf(acc[i][j][3], __uint_as_float(w.y & 0xFFFF0000u), a);
+          }
+          a += __shfl_xor(a, 16, 64);
+          a += __shfl_xor(a, 32, 64);
+          pj[j] = a;
+        }
+        if (kq == 0) {
+          float* P = p.red0 + (size_t)(gstep / sps) * p.K;
+#pragma unroll
+          for (int j = 0; j < FK_; ++j) {
+            const int k = k0 + (wk * FK_ + j) * 16 + p16;
+            if (k < p.K) atomicAdd(P + k, pj[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < FN_; ++i)
+#pragma unroll
+        for (int j = 0; j < FK_; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            acc2[i][j][r] = fmaf(acc[i][j][r], sreg[j], acc2[i][j][r]);
+            acc[i][j][r] = 0.f;
+          }
     }
   };
   load_tiles(step_of(0), xreg, yreg);
@@ -1290,12 +1392,42 @@ __global__ __launch_bounds__(256, BTK_ != 0 ? 2 : ((BMS == 64 && TR && sizeof(T)
       __syncthreads();
     }
   } else {
+    static_assert(PRO != 2 || NBUF == 1, "the post-scaled weight gradient lives on the single-buffer geometry");
     for (int st = 0; st < nsteps; ++st) {
       store_tiles(step_of(st), 0, xreg, yreg);
       __syncthreads();
       if (st + 1 < nsteps) load_tiles(step_of(st + 1), xreg, yreg);
+      if constexpr (PRO == 2) {
+        if ((sbase + st) % sps == 0) sample_begin(sbase + st);   // (the launcher aligns every split with whole samples)
+      }
       mma_step(smem, smem + TILE_X);
+      if constexpr (PRO == 2) {
+        if ((sbase + st + 1) % sps == 0) sample_end(sbase + st);
+      }
       __syncthreads();
+    }
+  }
+  if constexpr (PRO == 2) {
+    // beta term: dW[n, k] += beta[k] * (column sum of X over this workgroup's rows)[n]; the sums pass through LDS (the operand
+    // tiles are dead).  The same sums are the bias gradient (tile_k == 0 workgroups only).
+    float* cs = reinterpret_cast<float*>(smem);
+    __syncthreads();
+    if (p16 == 0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[(wn * FN_ + 2 * wk + h) * 16 + kq * 4 + r] = acc1[h][r];
+    }
+    __syncthreads();
+    if (tid < BTN) csum = cs[tid];
+#pragma unroll
+    for (int j = 0; j < FK_; ++j) {
+      const int k = k0 + (wk * FK_ + j) * 16 + p16;
+      const float bk = p.grn_b[k < p.K ? k : p.K - 1];
+#pragma unroll
+      for (int i = 0; i < FN_; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(bk, cs[(wn * FN_ + i) * 16 + kq * 4 + r], acc2[i][j][r]);
     }
   }
 
@@ -1389,6 +1521,28 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
       return 1;
     }
   }
+  if constexpr (sizeof(T) == 2 && BT == 128 && TR) {
+    // GRN-prologue weight gradient + GRN backward statistics in one launch (kernel header, PRO == 2): the caller asks for it by
+    // passing the bf16 fc2 weight as `aux` ([N, ldx]) and the statistics target as `red0` ([M / hw, K], zeroed); whole samples per
+    // split, 64-row steps inside one sample.  (Without aux / red0 the prologue kernel below is as fast: nothing to gain.)
+    if (p->pro == VSX_PRO_GRN && p->aux != nullptr && p->red0 != nullptr) {
+      VSX_CHECK(g_vsx_nt_fast && p->a_mode == VSX_A_ROWS && nz == 1 && p->hw > 0 && p->hw % 64 == 0 && p->M % p->hw == 0 && p->N >= 96 &&
+                    p->K >= 128 && p->N % 8 == 0 && p->K % 8 == 0 && p->ldx >= p->K &&
+                    (unsigned long long)64 * (p->lda > p->ldb ? p->lda : p->ldb) * sizeof(T) < (1ull << 31),
+                "vsx_gemm_tn: the weight gradient with GRN statistics (aux = W2, red0 = P) needs plain bf16 row operands, hw %% 64 == 0, N >= 96, K >= 128");
+      const int nb = p->M / p->hw;
+      int wantp = vsx_cdiv(g_vsx_tn_want * 2, tiles), sp = 1;   // ~3 rounds of 2 workgroups per CU (36 tiles at C = 384 fill no round evenly)
+      for (int d = wantp < nb ? wantp : nb; d >= 1; --d)
+        if (nb % d == 0) { sp = d; break; }                      // whole samples per split: the largest divisor of the batch <= the target
+      VsxGemm pq = *p;
+      pq.pro = 1024 | ((g_vsx_tn_stream & 3) << 13);
+      dim3 g2(tiles, sp, 1);
+      g_vsx_last_kernel = "gemm_tn_fast";
+      hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 128, TR, 2, 64, 1>), g2, dim3(256), 0, s, pq);
+      VSX_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   dim3 grid(tiles, splits, nz);
   const bool fast = g_vsx_nt_fast && p->a_mode == VSX_A_ROWS && p->M % 32 == 0 && p->N >= VT<T>::N && p->K >= VT<T>::N &&
                     (p->pro == VSX_PRO_NONE || (p->pro == VSX_PRO_GRN && p->hw > 0 && p->hw % 32 == 0)) &&
@@ -1462,6 +1616,10 @@ extern "C" int32_t vsx_gemm_tn(const VsxGemm* p, int32_t dtype, vsx_stream_t str
   long t128 = (long)vsx_cdiv(p->N, 128) * vsx_cdiv(p->K, 128);
   bool small = (p->N < 96 || p->K < 96) || (t128 < 24 && p->M < 65536);
   if (p->b_bstride != 0) small = false;  // per-sample outputs live on the 128-wide lean instantiations
+  if (p->pro == VSX_PRO_GRN && p->aux != nullptr && p->red0 != nullptr) {  // ... and so does the weight gradient with GRN statistics
+    VSX_CHECK(dtype == VSX_BF16 && g_vsx_tn_tr, "vsx_gemm_tn: the weight gradient with GRN statistics (aux = W2, red0 = P) is a bf16 kernel");
+    small = false;
+  }
   if (dtype == VSX_BF16) {
     if (g_vsx_tn_tr) return small ? launch_tn<bf16_t, 64, true>(p, s) : launch_tn<bf16_t, 128, true>(p, s);
     return small ? launch_tn<bf16_t, 64, false>(p, s) : launch_tn<bf16_t, 128, false>(p, s);

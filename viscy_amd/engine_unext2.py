@@ -500,6 +500,21 @@ class Engine:
             o.gemm("tn", gact, dout, Qb, M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, hw=hw, colsum=csb, b_bstride=C * 4 * C)
             o.grn_q_reduce(Qb, csb, w.W2, s, w.grn_b, PS[0], PS[1], dW2, db2)
             del Qb
+        stats_in_tn = False
+        if fused_bwd == 1:
+            pass
+        elif fused_bwd == 2 and hasattr(o, "tn_grn_stats_ok") and o.tn_grn_stats_ok(M, C, 4 * C, hw, dt):
+            # round 5: the products are too large to store (C = 384 at B = 512), but each per-sample TILE of Q_b passes through the
+            # accumulators of the fc2 weight-gradient GEMM anyway — that launch scales it by s_b into dW2 and contracts it with its
+            # W2 tile into P_b on the way (csrc/gemm.hip, gemm_tn_fast_kernel PRO == 2).  The statistics pass that recomputed dz for
+            # P and S (csrc/mlp.hip MODE 3, a full M x 4C x C contraction per block) is gone; S only ever fed dbeta = sum_b S_b =
+            # (column sums of dout) . W2, a matvec on the sums this launch produces for the bias gradient.
+            cs = self._za.take(C)
+            o.gemm("tn", gact, dout, dW2, M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s, grn_b=w.grn_b, hw=hw,
+                   colsum=cs, aux=w.W2, ldx=4 * C, red0=PS[0])
+            o.transpose_f32(cs, db2, C, 1, True)         # db2 += cs
+            o.matvec_t_add(w.fc2_w, cs, dgb, C, 4 * C)   # dbeta += W2^T cs
+            stats_in_tn = True
         else:
             # fc2: weight gradient (Z recomputed in the operand prologue) + bias gradient
             o.gemm("tn", gact, dout, dW2, M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s,
@@ -528,9 +543,12 @@ class Engine:
                 # read the image right away — launch the list before going on
                 img2 = w.img2 = o.mlp_pack(w.W2T, w.W2, C)
                 o.flush()
-            if fused_bwd == 2:  # statistics by recomputing dz tile by tile (P = Σ dz·g, S = Σ dz), nothing stored
+            if fused_bwd == 2 and not stats_in_tn:  # statistics by recomputing dz tile by tile (P = Σ dz·g, S = Σ dz), nothing stored
                 o.mlp_bwd_stats(dout, img2, gact, PS[0], PS[1], M, C, hw)
-            t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw, Sb=PS[1], dbeta=dgb)
+            if stats_in_tn:
+                t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw)
+            else:
+                t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw, Sb=PS[1], dbeta=dgb)
             if ln_re:  # h recomputed from y re-normalised on chip; dz holds dh * rstd (MODE 7)
                 dz = o.mlp_bwd_dh_ln(dout, xh[0], xh[1], rstd, img2, w.img, w.b1f, s, t, cs2, M, C, hw)
             elif h is None:  # h recomputed on chip from the normalised rows (MODE 5)

@@ -120,6 +120,14 @@ def gemm(
     check(fn(C.byref(p), dtype_code(dtype), stream()), f"gemm_{kind}")
 
 
+def tn_grn_stats_ok(M: int, N: int, K: int, hw: int, dtype: torch.dtype) -> bool:
+    """``gemm("tn", g, dout, dW2, ..., pro=PRO_GRN, aux=W2 (bf16 [N, K]), ldx=K, red0=P)`` — the fc2 weight gradient that also
+    delivers the GRN backward statistics P[b, k] = sum_hw dz * g from the per-sample tiles in its accumulators (csrc/gemm.hip,
+    gemm_tn_fast_kernel PRO == 2) — serves this shape"""
+    return dtype == torch.bfloat16 and hw > 0 and hw % 64 == 0 and M % hw == 0 and N >= 96 and K >= 128 and N % 8 == 0 and K % 8 == 0 \
+        and bool(lib().vsx_get_flag(b"tn_rect") & 8)
+
+
 def dgrad_ln_bwd(dh: Tensor, WT: Tensor, xh: Tensor, rstd: Tensor, M: int, C: int, K: int, mean: Tensor | None = None) -> Tensor | None:
     """fc1 data gradient with the block LayerNorm's backward in the GEMM epilogue (VSX_EPI_LN_BWD, csrc/gemm_nt2.hip):
     dy = LN_backward(dh . WT^T; xh, rstd) [M, C] in ONE launch — dx^ is never written.  None if the shape is not served
