@@ -25,7 +25,18 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(verbose: bool = True) -> str:
+SF32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]  # whole-file scalar fp32 VALU (A/B variants only)
+
+
+def build(verbose: bool = True, variant: str | None = None, sf32_files: tuple[str, ...] = (), defines: tuple[str, ...] = ()) -> str:
+    """``variant`` (A/B builds, `VSX_LIB=viscy_amd/libvsx_<variant>.so` selects one at load time): objects go to
+    ``_build_<variant>/``, the library to ``libvsx_<variant>.so``; ``sf32_files`` are compiled without packed-fp32 VALU
+    instructions, ``defines`` are passed as -D to every file.  The shipped library is the plain ``build()``."""
+    global BUILD, LIB
+    if variant:
+        BUILD, LIB = os.path.join(HERE, "_build_" + variant), os.path.join(HERE, f"libvsx_{variant}.so")
+    else:
+        BUILD, LIB = os.path.join(HERE, "_build"), os.path.join(HERE, "libvsx.so")
     os.makedirs(BUILD, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
@@ -38,7 +49,8 @@ def build(verbose: bool = True) -> str:
         obj = os.path.join(BUILD, s[:-4] + ".o")
         objs.append(obj)
         if _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            extra = (SF32 if s in sf32_files else []) + ["-D" + d for d in defines]
+            jobs.append([hipcc, *FLAGS, *extra, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -75,5 +87,9 @@ def _write_build_info() -> None:
 
 
 if __name__ == "__main__":
-    print(build())
+    # python -m viscy_amd.build [variant [sf32:file.hip,file.hip] [-DNAME ...]]
+    var = sys.argv[1] if len(sys.argv) > 1 else None
+    sf = tuple(f for a in sys.argv[2:] if a.startswith("sf32:") for f in a[5:].split(",") if f)
+    dd = tuple(a[2:] for a in sys.argv[2:] if a.startswith("-D"))
+    print(build(variant=var, sf32_files=sf, defines=dd))
     sys.exit(0)

@@ -19,6 +19,9 @@ int g_vsx_ln_bblk = 8192;   // LayerNorm backward WITHOUT affine gradients (the 
 int g_vsx_nt_stream = 3;  // (round 4: a non-temporal LDS-DMA of the A panel in the second-generation NT kernel measured 14.9 -> 17.1 ms for the class: not kept) lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B).  ON since round 3: the streaming stores are compiler builtins now (round 1 used inline asm, see vsx_common.h stvec_stream), soak / determinism / poison tests run with them
 int g_vsx_grn_stream = 2;  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
 int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup instead of grid-strided rows
+int g_vsx_tn_fill = 1;  // TN split counts chosen to fill their last round of workgroups (csrc/gemm.hip fill_splits)
+int g_vsx_tn_want2 = 512;  // TN split target of the rectangular (256 x 128 / 128 x 256) tiles: workgroups per launch
+int g_vsx_tn_p2_rounds = 1;  // weight gradient with GRN statistics (gemm_tn_fast_kernel PRO == 2): rounds of 512 workgroups the split count aims at (0 = power-of-two splits, round-5 first version)
 int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x splits)
 int g_vsx_ln_stream = 3;  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
 int g_vsx_tn_stream = 3;  // lean TN kernel: non-temporal loads of an operand that the launch reads exactly once (its dimension fits one tile): bit 0 = X [M, N], bit 1 = Y [M, K] (round 4)
@@ -58,6 +61,9 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "grn_stream")) { g_vsx_grn_stream = value; return 0; }
   if (name && !strcmp(name, "ggb_contig")) { g_vsx_ggb_contig = value; return 0; }
   if (name && !strcmp(name, "tn_want")) { g_vsx_tn_want = value; return 0; }
+  if (name && !strcmp(name, "tn_p2_rounds")) { g_vsx_tn_p2_rounds = value; return 0; }
+  if (name && !strcmp(name, "tn_want2")) { g_vsx_tn_want2 = value; return 0; }
+  if (name && !strcmp(name, "tn_fill")) { g_vsx_tn_fill = value; return 0; }
   if (name && !strcmp(name, "tn_contig")) { g_vsx_tn_contig = value; return 0; }
   if (name && !strcmp(name, "tn_stream")) { g_vsx_tn_stream = value; return 0; }
   if (name && !strcmp(name, "ln_stream")) { g_vsx_ln_stream = value; return 0; }
@@ -83,6 +89,9 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "grn_stream")) return g_vsx_grn_stream;
   if (name && !strcmp(name, "ggb_contig")) return g_vsx_ggb_contig;
   if (name && !strcmp(name, "tn_want")) return g_vsx_tn_want;
+  if (name && !strcmp(name, "tn_p2_rounds")) return g_vsx_tn_p2_rounds;
+  if (name && !strcmp(name, "tn_want2")) return g_vsx_tn_want2;
+  if (name && !strcmp(name, "tn_fill")) return g_vsx_tn_fill;
   if (name && !strcmp(name, "tn_contig")) return g_vsx_tn_contig;
   if (name && !strcmp(name, "tn_stream")) return g_vsx_tn_stream;
   if (name && !strcmp(name, "ln_stream")) return g_vsx_ln_stream;

@@ -24,6 +24,9 @@ extern int g_vsx_nt_fast;
 extern int g_vsx_tn_wide;
 extern int g_vsx_nt_stream;
 extern int g_vsx_tn_want;
+extern int g_vsx_tn_p2_rounds;
+extern int g_vsx_tn_want2;
+extern int g_vsx_tn_fill;
 extern int g_vsx_tn_contig;
 extern int g_vsx_tn_stream;
 bool vsx_gemm_nt2_ok(const VsxGemm* p);           // gemm_nt2.hip
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
   // one split stream the SAME 32-row windows of X / Y, so they are placed on one XCD (one L2) and adjacent in time —
   // measured with FETCH_SIZE: without this every tile re-fetched its operands through the fabric
   int bx = blockIdx.x, by = blockIdx.y;
-  if ((gridDim.y & 7) == 0) {
+  if (by < (int)(gridDim.y & ~7u)) {  // (the splits past the last whole group of 8 keep the launch order)
     const int L = bx + gridDim.x * by;
     const int j = L >> 3;
     bx = j % gridDim.x;
@@ -1154,7 +1157,7 @@ __global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && T
   const int z = blockIdx.z;
   const int tiles_k = (p.K + BTK - 1) / BTK;
   int bx = blockIdx.x, by = blockIdx.y;
-  if ((gridDim.y & 7) == 0) {  // XCD-aware (see gemm_tn_kernel)
+  if (by < (int)(gridDim.y & ~7u)) {  // XCD-aware (see gemm_tn_kernel); split counts need not be multiples of 8 (round 5)
     const int L = bx + gridDim.x * by;
     const int j = L >> 3;
     bx = j % gridDim.x;
@@ -1295,9 +1298,13 @@ __global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && T
   // launcher, one contiguous range — the GRN prologue then reloads s[b, k..] once per hw / BMS steps instead of on every
   // step (a split stride of nsplit * BMS rows crosses a sample boundary each time on the small feature maps)
   const bool contig = (p.pro & 1024) != 0;
-  const int sq = total_steps / nsplit, sr = total_steps % nsplit;
-  const int sbase = by * sq + (by < sr ? by : sr);
-  const int nsteps = contig ? sq + (by < sr ? 1 : 0) : (total_steps - by + nsplit - 1) / nsplit;
+  // PRO == 2: a split is a range of WHOLE samples (sps steps each); the ranges may differ by one sample, so that the launcher is
+  // free to pick the split count that fills its rounds of workgroups (36 tiles at C = 384 divide no power of two evenly)
+  const int sps = PRO == 2 ? p.hw / BMS : 1;
+  const int units = total_steps / sps;
+  const int sq = units / nsplit, sr = units % nsplit;
+  const int sbase = (by * sq + (by < sr ? by : sr)) * sps;
+  const int nsteps = contig ? (sq + (by < sr ? 1 : 0)) * sps : (total_steps - by + nsplit - 1) / nsplit;
   auto step_of = [&](int st) { return contig ? sbase + st : st * nsplit + by; };
   auto mma_step = [&](const char* Xs, const char* Ys) {
 #pragma unroll
@@ -1328,8 +1335,7 @@ __global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && T
       for (int r = 0; r < BMS; ++r) csum += to_f32<T>(*reinterpret_cast<const T*>(Xs + r * LDBX + tid * ES));
     }
   };
-  // PRO == 2: steps per sample, and what happens at the two ends of a sample
-  const int sps = PRO == 2 ? p.hw / BMS : 1;
+  // PRO == 2: what happens at the two ends of a sample
   auto sample_begin = [&](int gstep) {
     if constexpr (PRO == 2) {
       const float* gs = p.grn_s + (size_t)(gstep / sps) * p.K;
@@ -1463,6 +1469,28 @@ __global__ __launch_bounds__(256) void tn_zero_kernel(float* __restrict__ p, lon
   else for (; i < n; ++i) p[i] = 0.f;
 }
 
+// Split count for a split-K launch of `tiles` output tiles whose workgroups fit `per_cu` to a CU: the count in [want * 2 / 3,
+// want * 4 / 3] whose tiles x splits fill their last round of 256 x per_cu workgroups best (round 5, tools/rounds.py: the
+// stage-3 weight gradients ran 1.12 rounds — the last eighth of their workgroups alone on the chip — stage 2's dW1 0.84).  A tie
+// goes to the count nearest `want`.  tn_fill = 0 switches it off.
+static int fill_splits(int tiles, int per_cu, int want, int max_splits) {
+  if (!g_vsx_tn_fill) return want;
+  const int slots = 256 * per_cu;
+  int lo = want * 2 / 3, hi = want * 4 / 3;
+  lo = lo < 1 ? 1 : lo;
+  hi = hi > max_splits ? max_splits : hi;
+  int best = want < lo ? lo : (want > hi ? hi : want);
+  double best_fill = -1.0;
+  for (int sp = lo; sp <= hi; ++sp) {
+    const long wgs = (long)tiles * sp;
+    const long rounds = (wgs + slots - 1) / slots;
+    const double fill = (double)wgs / (double)(rounds * slots);
+    const int d = sp > want ? sp - want : want - sp, bd = best > want ? best - want : want - best;
+    if (fill > best_fill + 1e-9 || (fill > best_fill - 1e-9 && d < bd)) { best_fill = fill; best = sp; }
+  }
+  return best;
+}
+
 template <typename T, int BT, bool TR>
 static int launch_tn(const VsxGemm* p, hipStream_t s) {
   g_vsx_last_kernel = "gemm_tn_fast";  // (the generic kernel overrides this at its launch below)
@@ -1531,9 +1559,18 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
                     (unsigned long long)64 * (p->lda > p->ldb ? p->lda : p->ldb) * sizeof(T) < (1ull << 31),
                 "vsx_gemm_tn: the weight gradient with GRN statistics (aux = W2, red0 = P) needs plain bf16 row operands, hw %% 64 == 0, N >= 96, K >= 128");
       const int nb = p->M / p->hw;
-      int wantp = vsx_cdiv(g_vsx_tn_want * 2, tiles), sp = 1;   // ~3 rounds of 2 workgroups per CU (36 tiles at C = 384 fill no round evenly)
-      for (int d = wantp < nb ? wantp : nb; d >= 1; --d)
-        if (nb % d == 0) { sp = d; break; }                      // whole samples per split: the largest divisor of the batch <= the target
+      // two workgroups per CU (68 KB of LDS each): the split count that fills `tn_p2_rounds` rounds of 512 workgroups as evenly as
+      // whole tiles allow (36 tiles at C = 384: 28 splits = 1008 workgroups; the power-of-two split of the first version ran 2.25
+      // rounds).  tn_p2_rounds = 0: that first version (the largest divisor of the batch below 2 * tn_want / tiles).
+      int sp = 1;
+      if (g_vsx_tn_p2_rounds > 0) {
+        sp = (g_vsx_tn_p2_rounds * 512) / tiles;
+      } else {
+        const int wantp = vsx_cdiv(g_vsx_tn_want * 2, tiles);
+        for (int d = wantp < nb ? wantp : nb; d >= 1; --d)
+          if (nb % d == 0) { sp = d; break; }
+      }
+      sp = sp < 1 ? 1 : (sp > nb ? nb : sp);
       VsxGemm pq = *p;
       pq.pro = 1024 | ((g_vsx_tn_stream & 3) << 13);
       dim3 g2(tiles, sp, 1);
@@ -1553,6 +1590,11 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
     pq.pro |= (g_vsx_tn_stream & 3) << 13;
     if constexpr (sizeof(T) == 2 && BT == 128) {
       if (g_vsx_tn_wide && p->M % 64 == 0 && (p->pro == VSX_PRO_NONE || p->hw % 64 == 0) && p->M / 64 >= 2 * splits) {
+        if (g_vsx_tn_fill && TR) {  // 128 x 128 tiles, 64-row steps, one LDS buffer: 160 - 168 registers, three workgroups per CU
+          int spf = fill_splits(tiles * nz, 3, splits, p->M / 128);
+          if (spf > cap) spf = cap;
+          grid.y = splits = spf < 1 ? 1 : spf;
+        }
         if constexpr (TR) {
           // rectangular tiles when one side of the weight gradient fits a single 256-wide tile (see the kernel's header)
           // measured (tools/perf_nt.py, B = 512): C = 224 -9 % (dW1) / -14 % (dW2); C = 192 +4..8 % (a quarter of the
@@ -1566,9 +1608,10 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
           const bool k_full = ((g_vsx_tn_rect & 1) && !n_full && p->K >= 224 && p->K <= 256 && p->N >= 256) || (k_div && !n_full);
           if (n_full || k_full) {
             const int t2 = n_full ? vsx_cdiv(p->N, 256) * vsx_cdiv(p->K, 128) : vsx_cdiv(p->N, 128) * vsx_cdiv(p->K, 256);
-            int want2 = vsx_cdiv(512, t2 * nz), sp2 = want2 < 1 ? 1 : (want2 > max_splits ? max_splits : want2);
+            int want2 = vsx_cdiv(g_vsx_tn_want2, t2 * nz), sp2 = want2 < 1 ? 1 : (want2 > max_splits ? max_splits : want2);
             if (sp2 > p->M / 128) sp2 = p->M / 128;
-            if (sp2 >= 8) sp2 &= ~7;
+            if (g_vsx_tn_fill) sp2 = fill_splits(t2 * nz, 2, sp2, p->M / 128);  // 256 registers: two workgroups per CU
+            else if (sp2 >= 8) sp2 &= ~7;
             if (sp2 < 1) sp2 = 1;
             dim3 g2(t2, sp2, nz);
             if (n_full) {
