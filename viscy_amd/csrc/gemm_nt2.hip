@@ -113,10 +113,22 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
   };
 
   if constexpr (PRO) {
+    // s[b, :] and beta travel by LDS-DMA too (64 floats per wave instruction), issued AHEAD of the first operand slab: they are the
+    // oldest pieces outstanding, so the first slab's counted wait covers them (round 5).  As ordinary loads + ds_writes they cost
+    // every workgroup a cold global round trip — each tile is another sample — before its first operand DMA was even issued.
+    // (Round 5 also built the prologue IN LDS one slab ahead of the matrix cores — the A panel a slab ahead of the B panel in a
+    // four-slot ring, two 16-byte chunks per thread rescaled in place in 2-VALU micro-steps behind individual MFMAs; an ablation of
+    // that kernel priced the whole rescaling at 15 us of the 50 us a prologue launch loses against the plain launch at C = 384,
+    // B = 512 — the rest stayed with BOTH forms when the arithmetic was compiled out — and the hand-fenced loop ran no faster than
+    // this fragment form: 232 vs 236 us.  Not kept)
     const float* gs = p.grn_s + (size_t)b_tile * p.K;
-    for (int i = tid; i < p.K; i += 512) {
-      gsb[i] = gs[i];
-      gsb[3072 + i] = p.grn_b[i];
+    for (int c = wave; c * 64 < p.K; c += 8) {
+      int i = c * 64 + lane;
+      i = i < p.K ? i : p.K - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gs + i),
+                                       (__attribute__((address_space(3))) void*)(gsb + c * 64), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.grn_b + i),
+                                       (__attribute__((address_space(3))) void*)(gsb + 3072 + c * 64), 4, 0, 0);
     }
   }
 

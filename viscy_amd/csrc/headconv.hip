@@ -45,21 +45,31 @@ __device__ __forceinline__ bf16x8 hc_tr(const char* a0, const char* a1) {
 // workgroup = 16x16 output pixels of one sample, all 5 planes; wave w owns pixel rows 4w..4w+3 (4 pixel fragments).
 // MFMA roles: A = weights (rows = output channel), B = pixels -> a lane ends up with 4 consecutive channels of one pixel.
 constexpr int HF_PS = HC_D7 * HC_C3 * 2;  // 112 B per halo pixel: 16 consecutive pixels hit 16 distinct 16-byte bank groups
-__global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16_t* __restrict__ hin, const bf16_t* __restrict__ Wc,
+// Round 5: a workgroup is 16 x 8 pixels (a wave owns 2 pixel rows) and the outputs leave through a wave-private staging row.  The
+// first version (16 x 16 pixels, z outer) stored 8 bytes per lane straight from the accumulator layout: 32-byte runs at a
+// 320-byte pixel stride, 2.7 TB/s for a pass that is 3/4 stores.  With the loops turned (pixel row outer, plane inner: the same
+// fragment reads and MFMAs) all 5 planes x 32 channels of 16 consecutive pixels — 5 120 contiguous bytes — are parked in LDS and
+// leave as five fully coalesced 1 KiB store instructions.  The smaller tile pays for the staging (20 + 21 KB: still three
+// workgroups per CU by registers).
+constexpr int HF_TY = 8;                           // pixel rows per workgroup
+constexpr int HF_SR = HC_ZO * HC_CMID * 2 + 16;    // staging bytes per pixel (+16: the 16 lanes of a store group hit 16 bank pairs)
+__global__ __launch_bounds__(256, 3) void head_conv_fwd_kernel(const bf16_t* __restrict__ hin, const bf16_t* __restrict__ Wc,
                                                             const float* __restrict__ bias, bf16_t* __restrict__ U,
                                                             float* __restrict__ ssum, float* __restrict__ ssq, int H2, int W2,
                                                             float* __restrict__ det_ws) {
-  __shared__ __attribute__((aligned(16))) char tile[18 * 18 * HF_PS];
+  __shared__ __attribute__((aligned(16))) char tile[(HF_TY + 2) * 18 * HF_PS];
+  __shared__ __attribute__((aligned(16))) char stage[4 * 16 * HF_SR];
   __shared__ float red[4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p16 = lane & 15, kq = lane >> 4;
-  const int b = blockIdx.z, ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
+  const int b = blockIdx.z, ty0 = blockIdx.y * HF_TY, tx0 = blockIdx.x * 16;
   const size_t img = (size_t)b * H2 * W2;
   {
     // staging: every thread's loads first, then its LDS stores.  Written as `load; store` in one strided loop the compiler
     // kept a real loop with `s_waitcnt vmcnt(0)` in front of each store — one memory round trip per iteration, 9–15 per tile
     // (rocprofv3: the data-gradient kernel ran at 1.6 TB/s with its MFMAs idle 3/4 of the time)
-    constexpr int NST = (18 * 18 * HC_D7 + 255) / 256;
+    constexpr int NPIX = (HF_TY + 2) * 18;
+    constexpr int NST = (NPIX * HC_D7 + 255) / 256;
     uint4 sv[NST];
 #pragma unroll
     for (int it = 0; it < NST; ++it) {
@@ -68,14 +78,14 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16_t* __rest
       const int py = pix / 18, px = pix - py * 18;
       const int y = ty0 + py - 1, x = tx0 + px - 1;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (c < 18 * 18 * HC_D7 && y >= 0 && y < H2 && x >= 0 && x < W2)
+      if (c < NPIX * HC_D7 && y >= 0 && y < H2 && x >= 0 && x < W2)
         v = *reinterpret_cast<const uint4*>(hin + (img + (size_t)y * W2 + x) * (HC_D7 * HC_C3) + zc * HC_C3);
       sv[it] = v;
     }
 #pragma unroll
     for (int it = 0; it < NST; ++it) {
       const int c = tid + it * 256;
-      if (c < 18 * 18 * HC_D7) {
+      if (c < NPIX * HC_D7) {
         const int pix = c / HC_D7, zc = c - pix * HC_D7;
         const uint4 v = sv[it];
         *reinterpret_cast<uint4*>(tile + pix * HF_PS + zc * 16) = v;
@@ -106,38 +116,28 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16_t* __rest
       s2[nf][r] = 0.f;
     }
   __syncthreads();
-  const int pbase = ((wave * 4) * 18 + p16) * HF_PS;
+  char* st = stage + wave * (16 * HF_SR);
 #pragma unroll 1
-  for (int z = 0; z < HC_ZO; ++z) {
-    f32x4 acc[4][2];
+  for (int mf = 0; mf < 2; ++mf) {
+    const int pbase = ((wave * 2 + mf) * 18 + p16) * HF_PS;
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf)
+    for (int z = 0; z < HC_ZO; ++z) {
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int nf = 0; nf < 2; ++nf) acc[mf][nf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < 7; ++kk) {
+        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(tile + pbase + toff[kk] + z * 16);
 #pragma unroll
-    for (int kk = 0; kk < 7; ++kk) {
-      bf16x8 pf[4];
-#pragma unroll
-      for (int mf = 0; mf < 4; ++mf)
-        pf[mf] = *reinterpret_cast<const bf16x8*>(tile + pbase + mf * 18 * HF_PS + toff[kk] + z * 16);
-#pragma unroll
-      for (int mf = 0; mf < 4; ++mf)
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf) acc[mf][nf] = hc_mfma(wf[nf][kk], pf[mf], acc[mf][nf]);
-    }
-#pragma unroll
-    for (int mf = 0; mf < 4; ++mf) {
-      const size_t pix = img + (size_t)(ty0 + wave * 4 + mf) * W2 + tx0 + p16;
-      bf16_t* dst = U + pix * (HC_ZO * HC_CMID) + z * HC_CMID + kq * 4;
+        for (int nf = 0; nf < 2; ++nf) acc[nf] = hc_mfma(wf[nf][kk], pf, acc[nf]);
+      }
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
         float c[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[r] = acc[mf][nf][r] + bs[nf][r];
+        for (int r = 0; r < 4; ++r) c[r] = acc[nf][r] + bs[nf][r];
         uint2 o;
         o.x = f32x2_to_bf16x2_bits(c[0], c[1]);
         o.y = f32x2_to_bf16x2_bits(c[2], c[3]);
-        *reinterpret_cast<uint2*>(dst + nf * 16) = o;
+        *reinterpret_cast<uint2*>(st + p16 * HF_SR + (z * HC_CMID + nf * 16 + kq * 4) * 2) = o;
         // InstanceNorm statistics of the STORED (rounded) value, like VSX_EPI_BIAS_STATS
         const float q0 = __uint_as_float(o.x << 16), q1 = __uint_as_float(o.x & 0xffff0000u);
         const float q2 = __uint_as_float(o.y << 16), q3 = __uint_as_float(o.y & 0xffff0000u);
@@ -145,6 +145,19 @@ __global__ __launch_bounds__(256) void head_conv_fwd_kernel(const bf16_t* __rest
         s2[nf][0] += q0 * q0; s2[nf][1] += q1 * q1; s2[nf][2] += q2 * q2; s2[nf][3] += q3 * q3;
       }
     }
+    // the row of 16 pixels x 320 bytes is contiguous in U: 320 16-byte chunks, 64 per store instruction
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    char* dst = reinterpret_cast<char*>(U + (img + (size_t)(ty0 + wave * 2 + mf) * W2 + tx0) * (HC_ZO * HC_CMID));
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int c = lane + it * 64;
+      const int px = c / 20, ch = c - px * 20;
+      const uint4 v = *reinterpret_cast<const uint4*>(st + px * HF_SR + ch * 16);
+      *reinterpret_cast<uint4*>(dst + c * 16) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   // lanes of one kq group (16 pixels) -> one partial per channel; waves -> LDS; one atomic per (sample, channel) per workgroup
 #pragma unroll
@@ -428,13 +441,13 @@ extern "C" int32_t vsx_head_conv_fwd(const void* hin, const void* Wc, const floa
   if (int e = hc_check("vsx_head_conv_fwd", B, H2, W2, c3, cmid, zo, dtype)) return e;
   VSX_CHECK(hin && Wc && U && ssum && ssq, "vsx_head_conv_fwd: null pointer");
   float* det_ws = nullptr;
-  const int tiles = (W2 / 16) * (H2 / 16);
+  const int tiles = (W2 / 16) * (H2 / HF_TY);
   if (g_vsx_det_reduce) {  // fixed-order InstanceNorm sums: 64 partials per workgroup, then one ordered pass per array
     const long need = (long)B * tiles * 64;
     VSX_CHECK(g_vsx_det_ws != nullptr && g_vsx_det_ws_floats >= need, "vsx_head_conv_fwd: det_reduce needs vsx_det_workspace(>= %ld floats)", need);
     det_ws = g_vsx_det_ws;
   }
-  hipLaunchKernelGGL(head_conv_fwd_kernel, dim3(W2 / 16, H2 / 16, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hin,
+  hipLaunchKernelGGL(head_conv_fwd_kernel, dim3(W2 / 16, H2 / HF_TY, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hin,
                      (const bf16_t*)Wc, bias, (bf16_t*)U, ssum, ssq, H2, W2, det_ws);
   VSX_LAUNCH_CHECK();
   if (det_ws) {

@@ -119,6 +119,14 @@ __device__ unsigned long long g_mlp_ts[8 * 64 * 8];
 #define MLP_STAMP(k) do { } while (0)
 #endif
 
+// Waves that issue the LDS-DMA of the weight stages and fold the per-step column sums.  A workgroup's first four waves are the
+// FIRST wave on each SIMD; the arbiter favours the older wave, so waves 0 - 3 reach every step's barrier ~1 000 cycles before
+// waves 4 - 7 (profiles/r05_mlp_timeline.txt: barrier wait 1 050 vs 220 cycles at C = 224, MODE 7) while a DMA piece costs its
+// issuing wave ~175 cycles (610 cycles per wave and step when all eight share them): the early waves take all of them.
+#ifndef MLP_DMA_WAVES
+#define MLP_DMA_WAVES 4
+#endif
+
 template <int C, int MF, int NW, int MODE>
 struct MlpGeom {
   static constexpr int H4 = 4 * C, NHS = H4 / 32, KK = C / 32, NF = C / 16;
@@ -151,6 +159,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
   constexpr bool STATS = MODE == 0 || MODE == 2 || MODE == 6, STORE = MODE == 2 || MODE == 6, STORE_H = MODE == 2;
   constexpr bool RE = G::RE, LNF = MODE == 7;
   constexpr bool BWD = (MODE >= 3 && MODE <= 5) || MODE == 7, DH = MODE == 4 || RE;
+  constexpr int DW = MLP_DMA_WAVES < NW ? MLP_DMA_WAVES : NW;
   // SEPARATE LDS objects, on purpose: the two weight stages, the per-channel vectors and the output staging are distinct
   // variables, so the compiler's alias scopes let fragment / vector reads proceed while the LDS-DMA prefetch of the OTHER
   // stage is in flight (through one array every ds_read behind a global_load_lds costs an s_waitcnt vmcnt(0): no overlap)
@@ -592,7 +601,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
     // next sub-chunk's two accumulator sets)
     const char* src2 = RE ? a.wimg2 + (size_t)(s + 1) * (G::IMG_PIECES * 1024) - G::W1_PIECES * 1024 + lane * 16
                           : a.wimg + (size_t)s * (G::IMG_PIECES * 1024) + lane * 16;
-    for (int p = wave; p < G::NP; p += NW) {
+    if (wave >= DW) return;
+    for (int p = wave; p < G::NP; p += DW) {
       if ((RE || p < G::W1_PIECES) && s + 1 >= NHS) continue;
       const char* src = p < G::W1_PIECES ? src1 : src2;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * 1024),
@@ -647,7 +657,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
   // atomics.  MODE 7: two sums per column (lanes 0-31: of the unscaled dh, lanes 32-63: u), rows of 2 * 4C floats
   auto ws_row = [&](int hq, bool on) {
     if constexpr (LNF) {
-      if (on && wave == hq % NW) {
+      if (on && wave == hq % DW) {
         const float* r = red + (hq & 1) * 2 * NW * 32 + (lane >> 5) * NW * 32 + (lane & 31);
         float t = 0.f;
 #pragma unroll
@@ -655,7 +665,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
         a.ws[(size_t)blockIdx.x * 2 * H4 + (lane >> 5) * H4 + hq * 32 + (lane & 31)] = t;
       }
     } else {
-      if (on && wave == hq % NW && lane < 32) {
+      if (on && wave == hq % DW && lane < 32) {
         const float* r = red + (hq & 1) * NW * 32 + lane;
         float t = 0.f;
 #pragma unroll
@@ -681,7 +691,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
     if (hs + 1 < NHS) stage_load2(hs + 1, other);
     const char* S = Sb + lane * 16;
     if constexpr (MODE == 3) {
-      if (hs > 0 && wave == (hs - 1) % NW) {  // P (lanes 0-31) and S (lanes 32-63) of the previous sub-chunk
+      if (hs > 0 && wave == (hs - 1) % DW) {  // P (lanes 0-31) and S (lanes 32-63) of the previous sub-chunk
         const float* r = red + ((hs - 1) & 1) * 2 * NW * 32 + (lane >> 5) * NW * 32 + (lane & 31);
         float t = 0.f;
 #pragma unroll
@@ -691,7 +701,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
     }
     if constexpr (DH) ws_row(hs - 1, hs > 0);
     if constexpr (STATS) {
-      if (hs > 0 && wave == (hs - 1) % NW && lane < 32) {  // column sums of the previous sub-chunk (parked before the barrier)
+      if (hs > 0 && wave == (hs - 1) % DW && lane < 32) {  // column sums of the previous sub-chunk (parked before the barrier)
         const float* r = red + ((hs - 1) & 1) * NW * 32 + lane;
         float t = 0.f;
 #pragma unroll
@@ -785,7 +795,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
     tile_flush(NHS - 1);
     __syncthreads();
     if constexpr (MODE == 3) {
-      if (wave == (NHS - 1) % NW) {
+      if (wave == (NHS - 1) % DW) {
         const float* r = red + ((NHS - 1) & 1) * 2 * NW * 32 + (lane >> 5) * NW * 32 + (lane & 31);
         float t = 0.f;
 #pragma unroll
@@ -799,7 +809,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
   } else if constexpr (STATS) {
     store_pending(NHS - 1);
     __syncthreads();
-    if (wave == (NHS - 1) % NW && lane < 32) {
+    if (wave == (NHS - 1) % DW && lane < 32) {
       const float* r = red + ((NHS - 1) & 1) * NW * 32 + lane;
       float t = 0.f;
 #pragma unroll

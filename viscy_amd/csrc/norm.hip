@@ -554,7 +554,11 @@ extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, con
 //     sm[b] += W2[c, j] * cs[b, c]          (-> S[b, j])
 //     acc   += s[b, j] * Q[b, c, j]         (-> the group's partial of dW2[c, j], plain store into ws[group][c][j])
 // and reduce_rows_kernel folds the groups' partials into dW2 (<= nb / (64 QR_SB) atomics per address).
-constexpr int QR_SB = 8, QR_CB = 32, QR_TH = 128;
+#ifndef VSX_QR_CB
+#define VSX_QR_CB 32   // (round 5, B = 512, us per launch at C = 192 / 224 / 96: 16-channel blocks 167 / 237 / 58, 32-channel blocks 112 / 157 / 51 —
+                       // the pass is bound by its P / S atomics (C / QR_CB adds per address), not by the workgroup count)
+#endif
+constexpr int QR_SB = 8, QR_CB = VSX_QR_CB, QR_TH = 128;
 template <typename T>
 __global__ __launch_bounds__(QR_TH) void grn_q_reduce_kernel(const float* __restrict__ Q, const float* __restrict__ cs,
                                                              const T* __restrict__ W2, const float* __restrict__ s,

@@ -606,7 +606,7 @@ def head_conv_supported(H2: int, W2: int, c3: int, cmid: int, zo: int, dtype: to
 def head_conv_fwd(hin: Tensor, Wc: Tensor, bias: Tensor | None, ssum: Tensor, ssq: Tensor, B: int, H2: int, W2: int, c3: int,
                   cmid: int, zo: int) -> Tensor:
     U = torch.empty((B * H2 * W2, zo * cmid), dtype=hin.dtype, device=hin.device)
-    _det(hin.device, B * (H2 // 16) * (W2 // 16) * 64)
+    _det(hin.device, B * (H2 // 8) * (W2 // 16) * 64)  # one row of 64 partials per 16 x 8-pixel workgroup
     check(lib().vsx_head_conv_fwd(ptr(hin), ptr(Wc), ptr(bias), ptr(U), ptr(ssum), ptr(ssq), B, H2, W2, c3, cmid, zo,
                                   dtype_code(hin.dtype), stream()), "head_conv_fwd")
     return U
