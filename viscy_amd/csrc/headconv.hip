@@ -336,34 +336,51 @@ __global__ void head_conv_dgrad_prep_kernel(const bf16_t* __restrict__ Wc, bf16_
   }
 }
 
+// Round 5: the packed weights travel L2 -> LDS ONCE per workgroup, one tap (5 steps x 2 fragments = 10 KiB) ahead of the MFMAs, by
+// LDS-DMA into two alternating buffers; every wave reads its fragments from there (lane-linear, conflict-free ds_read_b128).  The
+// first version had every wave fetch the fragments of every step from global memory — 360 KB of L1 traffic per workgroup for a
+// 58 KB halo tile: the pass ran at 2.5 TB/s of its bytes with the texture path busy on weights.
 template <int Z>
-__device__ __forceinline__ void hd_step(const char* halo, int pb, const uint4* __restrict__ wp, int step, int lane,
-                                        f32x4 (&acc)[2][4], uint4& w0, uint4& w1) {
+__device__ __forceinline__ void hd_step(const char* halo, int pb, const char* wl, f32x4 (&acc)[2][4]) {
   constexpr int FA = (Z & 1) ? (Z - 1) / 2 : Z / 2;
-  // weights of THIS step arrive in (w0, w1); the next step's pair is requested before the MFMAs so that its L2 latency
-  // hides behind them (the loop is fully unrolled: `step` is a literal, the last prefetch is dropped by the compiler)
-  union { uint4 u; bf16x8 v; } a0, a1;
-  a0.u = w0;
-  a1.u = w1;
-  if (step + 1 < 45) {
-    w0 = wp[((step + 1) * 2 + 0) * 64 + lane];
-    w1 = wp[((step + 1) * 2 + 1) * 64 + lane];
-  }
+  const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(wl + (Z * 2 + 0) * 1024);
+  const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(wl + (Z * 2 + 1) * 1024);
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf) {
     const bf16x8 pf = *reinterpret_cast<const bf16x8*>(halo + pb + mf * 18 * HD_PS);
-    acc[mf][FA] = hc_mfma(a0.v, pf, acc[mf][FA]);
-    acc[mf][FA + 1] = hc_mfma(a1.v, pf, acc[mf][FA + 1]);
+    acc[mf][FA] = hc_mfma(a0, pf, acc[mf][FA]);
+    acc[mf][FA + 1] = hc_mfma(a1, pf, acc[mf][FA + 1]);
   }
 }
 
 __global__ __launch_bounds__(256) void head_conv_dgrad_kernel(const bf16_t* __restrict__ dU, const bf16_t* __restrict__ Wp,
                                                               bf16_t* __restrict__ dhin, int H2, int W2) {
+  // separate LDS objects: the compiler's alias scopes then let the halo / fragment reads proceed while the DMA into the OTHER
+  // weight buffer is in flight (csrc/mlp.hip)
   __shared__ __attribute__((aligned(16))) char halo[10 * 18 * HD_PS];  // 60 KB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(1024))) char wb0[10 * 1024];
+  __shared__ __attribute__((aligned(1024))) char wb1[10 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p16 = lane & 15, kq = lane >> 4;
   const int b = blockIdx.z, ty0 = blockIdx.y * 8, tx0 = blockIdx.x * 16;
   const size_t img = (size_t)b * H2 * W2;
+  // the 10 KiB of tap `tap` -> buffer: pieces wave, wave + 4, wave + 8 (1 KiB = one wave instruction)
+  const char* wsrc = reinterpret_cast<const char*>(Wp) + lane * 16;
+  auto wdma = [&](int tap, char* dst) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int pc = wave + 4 * i;
+      // (inline assembly on purpose: behind the builtin hipcc drains vmcnt(0) in front of every LDS read whose object it cannot
+      // tell from the DMA's — here in every second tap — which serialises the prefetch; this kernel counts its own waits)
+      if (pc < 10) {
+        const char* src = wsrc + (size_t)(tap * 10 + pc) * 1024;
+        const uint32_t d = (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)(dst + pc * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(d) : "memory", "m0");
+      }
+    }
+  };
+  wdma(0, wb0);
   {  // all loads of the halo tile in flight together, then the LDS stores (see head_conv_fwd_kernel)
     constexpr int NST = (180 * 20 + 255) / 256;
     uint4 sv[NST];
@@ -393,20 +410,23 @@ __global__ __launch_bounds__(256) void head_conv_dgrad_kernel(const bf16_t* __re
   for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[mf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const uint4* wp = reinterpret_cast<const uint4*>(Wp);
-  uint4 w0 = wp[0 * 64 + lane], w1 = wp[1 * 64 + lane];  // step 0, requested before the barrier
-  __syncthreads();
   // wave w: output pixel rows 2w, 2w + 1; lane: pixel x = p16, channel quarter kq (8 of the 32 n per plane)
   const int pb0 = ((wave * 2) * 18 + p16) * HD_PS + kq * 16;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
+    // tap's weights (this wave's pieces: everything it has outstanding) and, at tap 0, the halo tile have landed for every wave;
+    // every wave is done with the buffer that is refilled next
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tap + 1 < 9) wdma(tap + 1, (tap & 1) ? wb0 : wb1);
+    const char* wl = ((tap & 1) ? wb1 : wb0) + lane * 16;
     const int ey = tap / 3, ex = tap - ey * 3;
     const int pb = pb0 + (ey * 18 + ex) * HD_PS;
-    hd_step<0>(halo, pb + 0 * 64, wp, tap * 5 + 0, lane, acc, w0, w1);
-    hd_step<1>(halo, pb + 1 * 64, wp, tap * 5 + 1, lane, acc, w0, w1);
-    hd_step<2>(halo, pb + 2 * 64, wp, tap * 5 + 2, lane, acc, w0, w1);
-    hd_step<3>(halo, pb + 3 * 64, wp, tap * 5 + 3, lane, acc, w0, w1);
-    hd_step<4>(halo, pb + 4 * 64, wp, tap * 5 + 4, lane, acc, w0, w1);
+    hd_step<0>(halo, pb + 0 * 64, wl, acc);
+    hd_step<1>(halo, pb + 1 * 64, wl, acc);
+    hd_step<2>(halo, pb + 2 * 64, wl, acc);
+    hd_step<3>(halo, pb + 3 * 64, wl, acc);
+    hd_step<4>(halo, pb + 4 * 64, wl, acc);
   }
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf) {

@@ -554,17 +554,16 @@ extern "C" int32_t vsx_grn_gelu_bwd(void* dz, const void* h, const float* s, con
 //     sm[b] += W2[c, j] * cs[b, c]          (-> S[b, j])
 //     acc   += s[b, j] * Q[b, c, j]         (-> the group's partial of dW2[c, j], plain store into ws[group][c][j])
 // and reduce_rows_kernel folds the groups' partials into dW2 (<= nb / (64 QR_SB) atomics per address).
-#ifndef VSX_QR_CB
-#define VSX_QR_CB 32   // (round 5, B = 512, us per launch at C = 192 / 224 / 96: 16-channel blocks 167 / 237 / 58, 32-channel blocks 112 / 157 / 51 —
-                       // the pass is bound by its P / S atomics (C / QR_CB adds per address), not by the workgroup count)
-#endif
-constexpr int QR_SB = 8, QR_CB = VSX_QR_CB, QR_TH = 128;
+// channel block per workgroup: round 5 measured (B = 512, us per launch at C = 96 / 192 / 224) 16-channel blocks 58 / 167 / 237, 32-channel
+// blocks 50 / 111 / 156, 64-channel blocks 74 / 103 / 129 — the pass is bound by its P / S atomics (C / block adds per address), not
+// by the workgroup count, until the blocks get too few: 32 below C = 192, 64 from there
+constexpr int QR_SB = 8, QR_TH = 128;
 template <typename T>
 __global__ __launch_bounds__(QR_TH) void grn_q_reduce_kernel(const float* __restrict__ Q, const float* __restrict__ cs,
                                                              const T* __restrict__ W2, const float* __restrict__ s,
                                                              const float* __restrict__ beta, float* __restrict__ P,
                                                              float* __restrict__ S, float* __restrict__ ws,
-                                                             float* __restrict__ db2, int nb, int C) {
+                                                             float* __restrict__ db2, int nb, int C, int QR_CB) {
   const int N = 4 * C;  // a multiple of 4: every thread's 4 columns are all inside or all outside
   const int j = (blockIdx.x * QR_TH + threadIdx.x) * 4;
   const int g = blockIdx.y;
@@ -645,11 +644,12 @@ extern "C" int32_t vsx_grn_q_reduce(const float* Q, const float* cs, const void*
             (long)((int64_t)G * C * N));
   VSX_CHECK((int64_t)C * N < (1ll << 31), "vsx_grn_q_reduce: C too large");
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(vsx_cdiv(N, QR_TH * 4), G, vsx_cdiv(C, QR_CB));
+  const int cb = C >= 192 ? 64 : 32;
+  dim3 grid(vsx_cdiv(N, QR_TH * 4), G, vsx_cdiv(C, cb));
   if (dtype == VSX_BF16)
-    hipLaunchKernelGGL(grn_q_reduce_kernel<bf16_t>, grid, dim3(QR_TH), 0, st, Q, cs, (const bf16_t*)W2, s, beta, P, S, ws, db2, nb, C);
+    hipLaunchKernelGGL(grn_q_reduce_kernel<bf16_t>, grid, dim3(QR_TH), 0, st, Q, cs, (const bf16_t*)W2, s, beta, P, S, ws, db2, nb, C, cb);
   else
-    hipLaunchKernelGGL(grn_q_reduce_kernel<float>, grid, dim3(QR_TH), 0, st, Q, cs, (const float*)W2, s, beta, P, S, ws, db2, nb, C);
+    hipLaunchKernelGGL(grn_q_reduce_kernel<float>, grid, dim3(QR_TH), 0, st, Q, cs, (const float*)W2, s, beta, P, S, ws, db2, nb, C, cb);
   // dW2[c, j] += sum over the groups' partials (the [C, 4C] matrix seen as one row of C * 4C columns)
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(vsx_cdiv((long)C * N, 64), vsx_cdiv(G, 64)), dim3(256), 0, st, (const float*)ws, dW2, G,
                      C * N);
