@@ -791,3 +791,45 @@ def test_datamodule_serves_aligned_masks_and_rejects_empty_windows(sampling_plat
     assert dm.predict_dataset.fg_mask_support is None  # hcs.py:669-671
     with pytest.raises(NotImplementedError, match="ground_truth_masks"):
         HCSDataModule(path, "Phase", "Nuclei", 4, ground_truth_masks=tmp_path)
+
+
+def test_task_list_hazards_are_tracked_by_byte_range(monkeypatch):
+    """ops._queue (the weight-space task lists, one concurrent launch per list): a job that reads or writes memory an already queued
+    job writes, or writes memory an already queued job reads — through ANY view, not only the same start address — launches the
+    list collected so far first; the bookkeeping is cleared also when that launch fails."""
+    from viscy_amd import _lib as L
+    from viscy_amd import ops
+
+    flushed = []
+
+    def fake_flush():
+        flushed.append(len(ops._BATCH))
+        del ops._BATCH[:], ops._BATCH_KEEP[:], ops._BATCH_WRITTEN[:], ops._BATCH_READ[:]
+
+    monkeypatch.setattr(ops, "flush", fake_flush)
+    monkeypatch.setattr(ops, "ptr", lambda t: None if t is None else t.data_ptr())
+    monkeypatch.setattr(ops, "_BATCH", [])
+    flat = torch.zeros(1024)
+    a, b, c = flat[0:256], flat[128:384], flat[512:768]   # a and b overlap, with different start addresses
+    src = torch.zeros(256)
+    assert ops._span(flat[0:256].view(16, 16).t()) == (flat.data_ptr(), flat.data_ptr() + 256 * 4)
+    assert ops._queue(L.WTASK_TRANSPOSE, 0, (16, 16, 1), src, a, None, None) and flushed == []
+    assert ops._queue(L.WTASK_TRANSPOSE, 0, (16, 16, 1), src, c, None, None) and flushed == []       # disjoint output: same list
+    assert ops._queue(L.WTASK_TRANSPOSE, 0, (16, 16, 1), src, b, None, None) and flushed == [2]      # write overlaps a queued write
+    assert ops._queue(L.WTASK_MATVEC, 0, (16, 16), c, torch.zeros(16), None, src) and flushed == [2]  # reads c: nothing queued writes it now
+    assert ops._queue(L.WTASK_MATVEC, 0, (16, 16), a, torch.zeros(16), None, src) and flushed == [2, 2]  # a overlaps b, which is being written
+    assert ops._queue(L.WTASK_TRANSPOSE, 0, (16, 16, 1), b, src, None, None) and flushed == [2, 2, 1]    # writes (src) what a queued job reads
+    # the real flush clears its bookkeeping when the launch raises
+    monkeypatch.undo()
+    monkeypatch.setattr(ops, "_BATCH", [L.VsxWTask()])
+    ops._BATCH_WRITTEN.append((0, 1)), ops._BATCH_READ.append((0, 1)), ops._BATCH_KEEP.append(None)
+
+    class Boom:
+        def vsx_weight_tasks(self, *a):
+            raise RuntimeError("launch failed")
+
+    monkeypatch.setattr(ops, "lib", lambda: Boom())
+    monkeypatch.setattr(ops, "stream", lambda: None)
+    with pytest.raises(RuntimeError):
+        ops.flush()
+    assert ops._BATCH_WRITTEN == [] and ops._BATCH_READ == [] and ops._BATCH_KEEP == [] and ops._BATCH == []

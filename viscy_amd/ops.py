@@ -326,7 +326,8 @@ def head_out_bwd2(U, ssum, ssq, w2, alpha, dv, S1, S2, B, H2, W2, Z, Cmid, Cout,
 _BATCH: list | None = None
 _BATCH_ON = os.environ.get("VSX_WBATCH", "1") != "0"  # VSX_WBATCH=0: every job its own launch (A/B measurements)
 _BATCH_KEEP: list = []  # the queued jobs' tensors stay alive (and their memory un-recycled) until the list is launched
-_BATCH_WRITTEN: set = set()  # start addresses the queued jobs write: a later job touching one of them flushes first (see _queue)
+_BATCH_WRITTEN: list = []  # byte ranges [lo, hi) the queued jobs write / read: a later job that overlaps a written range, or writes
+_BATCH_READ: list = []     # into a range an earlier job reads, launches the list collected so far first (see _queue)
 
 
 @contextlib.contextmanager
@@ -364,9 +365,24 @@ def flush() -> None:
         return
     arr = (L.VsxWTask * len(_BATCH))(*_BATCH)
     del _BATCH[:]
-    check(lib().vsx_weight_tasks(C.addressof(arr), len(arr), stream()), "weight_tasks")
-    del _BATCH_KEEP[:]
-    _BATCH_WRITTEN.clear()
+    try:
+        check(lib().vsx_weight_tasks(C.addressof(arr), len(arr), stream()), "weight_tasks")
+    finally:  # (a failed launch must not leave stale addresses behind for the next list: ADVICE r4)
+        del _BATCH_KEEP[:]
+        del _BATCH_WRITTEN[:]
+        del _BATCH_READ[:]
+
+
+def _span(t: Tensor):
+    """byte range [lo, hi) a (possibly strided) tensor touches"""
+    if t.numel() == 0:
+        return (t.data_ptr(), t.data_ptr())
+    ext = 1 + sum((n - 1) * abs(st) for n, st in zip(t.shape, t.stride()))
+    return (t.data_ptr(), t.data_ptr() + ext * t.element_size())
+
+
+def _overlaps(a, ranges) -> bool:
+    return any(a[0] < hi and lo < a[1] for lo, hi in ranges)
 
 
 def _queue(kind: int, dtype: int, ints, p0, p1, p2, p3, p4=None, p5=None, p6=None, p7=None) -> bool:
@@ -374,14 +390,16 @@ def _queue(kind: int, dtype: int, ints, p0, p1, p2, p3, p4=None, p5=None, p6=Non
         return False
     # The jobs of one list run CONCURRENTLY (one launch): a job must not read, write or accumulate into what another job of the
     # same list writes (UNPREP and the accumulating TRANSPOSE / MATVEC_T / REDUCE_ROWS are non-atomic read-modify-writes).
-    # Outputs are p1 (+ p2 for PREP / UNPREP); a job that touches a tensor an already queued job writes — a tied parameter, two
-    # finalisers on one gradient — launches the list collected so far first (same-tensor hazards, by start address).
-    tens = [t for t in (p0, p1, p2, p3, p4, p5, p6, p7) if torch.is_tensor(t)]
-    if _BATCH_WRITTEN and any(t.data_ptr() in _BATCH_WRITTEN for t in tens):
+    # Outputs are p1 (+ p2 for PREP / UNPREP); a job that touches memory an already queued job writes — a tied parameter, two
+    # finalisers on one gradient, overlapping views of the flat buffers — or WRITES what an already queued job reads launches the
+    # list collected so far first (read-after-write, write-after-write and write-after-read, by byte range).
+    outs = [t for t in ((p1, p2) if kind in (L.WTASK_PREP, L.WTASK_UNPREP) else (p1,)) if torch.is_tensor(t)]
+    ins = [t for t in (p0, p1, p2, p3, p4, p5, p6, p7) if torch.is_tensor(t) and not any(t is o for o in outs)]
+    wr, rd = [_span(t) for t in outs], [_span(t) for t in ins]
+    if (_BATCH_WRITTEN and any(_overlaps(a, _BATCH_WRITTEN) for a in wr + rd)) or (_BATCH_READ and any(_overlaps(a, _BATCH_READ) for a in wr)):
         flush()
-    for t in (p1, p2) if kind in (L.WTASK_PREP, L.WTASK_UNPREP) else (p1,):
-        if torch.is_tensor(t):
-            _BATCH_WRITTEN.add(t.data_ptr())
+    _BATCH_WRITTEN.extend(wr)
+    _BATCH_READ.extend(rd)
     i = list(ints) + [0] * (4 - len(ints))
     _BATCH.append(L.VsxWTask(kind, dtype, i[0], i[1], i[2], i[3], ptr(p0), ptr(p1), ptr(p2), ptr(p3), ptr(p4), ptr(p5), ptr(p6), ptr(p7)))
     _BATCH_KEEP.append((p0, p1, p2, p3, p4, p5, p6, p7))

@@ -74,10 +74,23 @@ class Trainer:
             if len(self._train_steps) >= self._MAX_CAPTURED_SHAPES:
                 # every captured shape holds a private graph memory pool of about the step's activation footprint: release the
                 # least recently used one instead of growing (a second shape at a large batch could run out of memory where the
-                # eager loop would not)
+                # eager loop would not) — but only for a shape that COMES BACK: a first sighting runs eagerly, so that
+                # three or more alternating shapes do not pay two warm-up steps, a state restore and a capture per batch
+                seen = getattr(self, "_seen_once", None)
+                if seen is None:
+                    seen = self._seen_once = set()
+                if key not in seen:
+                    seen.add(key)
+                    return None
+                seen.discard(key)
                 old_key = next(iter(self._train_steps))
                 del self._train_steps[old_key]
+                import gc
+                import logging
+
+                gc.collect()  # a TrainStep with reference cycles would keep its graph pool alive past empty_cache()
                 torch.cuda.empty_cache()
+                logging.getLogger("viscy_amd").info("Trainer.fit: released the captured step of batch %s for batch %s", old_key[0], key[0])
             from .step import TrainStep
 
             # hipGraph replay or eager launches of the SAME direct engine step: measured on the bench workload, the replay pays
