@@ -21,6 +21,8 @@ from viscy_amd import ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--size", type=int, default=256, help="patch edge (2048 with --batch 8 = the gate shape)")
+ap.add_argument("--eager-only", action="store_true", help="N eager steps and nothing else (for a rocprofv3 kernel trace)")
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--ops", action="store_true", help="per-(op, shape) event timing of one eager step")
@@ -48,9 +50,15 @@ eng = model.engine()
 opt = FlatAdamW(eng, lr=2e-4, schedule="WarmupCosine", warmup_steps=3, t_total=1000, warmup_multiplier=1e-3)
 ddp = FlatDataParallel(eng, opt)
 crit = MixedLoss(0.5, 0.0, 0.5)
-x, tgt = bench.make_batch(a.batch, 256, 256, dev)
+x, tgt = bench.make_batch(a.batch, a.size, a.size, dev)
 eager = TrainStep(model, crit, opt, ddp, use_graph=False)
 eager(x, tgt)
+if a.eager_only:
+    for _ in range(a.steps):
+        loss = eager(x, tgt)
+    torch.cuda.synchronize()
+    print("loss", float(loss))
+    sys.exit(0)
 if a.ops:
     with bench.OpTimer(ops, by_shape=True) as tm:
         eager(x, tgt)

@@ -12,7 +12,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(HERE, "csrc")
+CSRC = os.environ.get("VSX_CSRC", os.path.join(HERE, "csrc"))  # VSX_CSRC: build a variant from another source tree (same-box A/B of two commits)
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libvsx.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]

@@ -644,7 +644,10 @@ extern "C" int32_t vsx_grn_q_reduce(const float* Q, const float* cs, const void*
             (long)((int64_t)G * C * N));
   VSX_CHECK((int64_t)C * N < (1ll << 31), "vsx_grn_q_reduce: C too large");
   hipStream_t st = (hipStream_t)stream;
-  const int cb = C >= 192 ? 64 : 32;
+  int cb = C >= 192 ? 64 : 32;
+  // few samples (the 2048^2 gate shape: 8): 6 - 18 workgroups of 64-channel blocks ran 64 us per launch on an empty chip; halve the
+  // block until the launch has ~256 workgroups (the atomics per address grow to C / 8 at most)
+  while (cb > 8 && (long)vsx_cdiv(N, QR_TH * 4) * G * vsx_cdiv(C, cb) < 256) cb /= 2;
   dim3 grid(vsx_cdiv(N, QR_TH * 4), G, vsx_cdiv(C, cb));
   if (dtype == VSX_BF16)
     hipLaunchKernelGGL(grn_q_reduce_kernel<bf16_t>, grid, dim3(QR_TH), 0, st, Q, cs, (const bf16_t*)W2, s, beta, P, S, ws, db2, nb, C, cb);
