@@ -973,6 +973,30 @@ __device__ __forceinline__ float lds_frag_mn<float, true>(const char* t, int LDB
   return *reinterpret_cast<const float*>(t + (kk * 4 + kq) * LDB + (c0 + p16) * 4);
 }
 
+// XCD-aware order of a (tiles x splits) TN grid.  Workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest); all
+// output tiles of one split stream the SAME row windows of X / Y, so they belong on one XCD (one L2) and adjacent in time —
+// measured with FETCH_SIZE: without this every tile re-fetched its operands through the fabric.  Whole groups of 8 splits: XCD x
+// takes split 8 g + x.  The splits past the last whole group (round 5: split counts are chosen to fill rounds of workgroups, not
+// to be multiples of 8) are cut into 8 runs of consecutive (split, tile) pairs, one run per XCD: a run holds tiles of one or two
+// splits (in launch order they would be scattered one tile per XCD: FETCH_SIZE of the rectangular-tile class 30.4 -> 35.9 GB / step).
+__device__ __forceinline__ void tn_xcd_order(int& bx, int& by) {
+  const int T = gridDim.x, S = gridDim.y;
+  const int L = bx + T * by;
+  const int full = (S & ~7) * T;
+  if (L < full) {
+    const int j = L >> 3;
+    bx = j % T;
+    by = (j / T) * 8 + (L & 7);
+  } else {
+    const int rT = (S & 7) * T, Lt = L - full;
+    const int x = Lt & 7, q = Lt >> 3;
+    const int start = x * (rT >> 3) + (x < (rT & 7) ? x : (rT & 7));
+    const int pidx = start + q;
+    bx = pidx % T;
+    by = (S & ~7) + pidx / T;
+  }
+}
+
 template <typename T, int BT, bool TR>  // BT x BT output tile of W
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_per_block) {
   constexpr int BMS = 32;                       // contraction rows per step
@@ -1000,12 +1024,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
   // one split stream the SAME 32-row windows of X / Y, so they are placed on one XCD (one L2) and adjacent in time —
   // measured with FETCH_SIZE: without this every tile re-fetched its operands through the fabric
   int bx = blockIdx.x, by = blockIdx.y;
-  if (by < (int)(gridDim.y & ~7u)) {  // (the splits past the last whole group of 8 keep the launch order)
-    const int L = bx + gridDim.x * by;
-    const int j = L >> 3;
-    bx = j % gridDim.x;
-    by = (j / gridDim.x) * 8 + (L & 7);
-  }
+  tn_xcd_order(bx, by);
   const int tile_k = bx % tiles_k, tile_n = bx / tiles_k;
   const int n0 = tile_n * BT, k0 = tile_k * BT;
   // the 32-row contraction steps are dealt round-robin to the gridDim.y splits: at any instant the
@@ -1157,12 +1176,7 @@ __global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && T
   const int z = blockIdx.z;
   const int tiles_k = (p.K + BTK - 1) / BTK;
   int bx = blockIdx.x, by = blockIdx.y;
-  if (by < (int)(gridDim.y & ~7u)) {  // XCD-aware (see gemm_tn_kernel); split counts need not be multiples of 8 (round 5)
-    const int L = bx + gridDim.x * by;
-    const int j = L >> 3;
-    bx = j % gridDim.x;
-    by = (j / gridDim.x) * 8 + (L & 7);
-  }
+  tn_xcd_order(bx, by);  // XCD-aware (see gemm_tn_kernel)
   const int tile_k = bx % tiles_k, tile_n = bx / tiles_k;
   const int n0 = tile_n * BTN, k0 = tile_k * BTK;
   const int total_steps = p.M / BMS;
@@ -1529,6 +1543,19 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
       int ks = 1;
       const int spp = p->hw / 64;  // 64-row steps per sample
       while ((long)nb * ks * t2 < 768 && ks < 64 && spp % (2 * ks) == 0) ks *= 2;
+      if (g_vsx_tn_fill && ks > 1) {
+        // ... and of the power-of-two counts from there up to 4 x, the one that fills its last round of workgroups best (2 per CU for
+        // the 256-wide tiles, 3 for the square ones): 8 samples x 36 tiles x 4 ran 1.5 rounds at the gate shape's C = 384 blocks
+        const int slots = 256 * (n_full ? 2 : 3);
+        int best = ks;
+        double bf = -1.0;
+        for (int k2 = ks; k2 <= 4 * ks && k2 <= 64 && spp % k2 == 0; k2 *= 2) {
+          const long wgs = (long)nb * k2 * t2, rounds = (wgs + slots - 1) / slots;
+          const double f = (double)wgs / (double)(rounds * slots);
+          if (f > bf + 1e-9) { bf = f; best = k2; }
+        }
+        ks = best;
+      }
       if (ks > 1) {
         pq.pro |= 4096;
         const long nq = (long)nb * p->b_bstride, nc = p->colsum ? (long)nb * p->N : 0;
