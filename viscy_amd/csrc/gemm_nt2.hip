@@ -177,8 +177,43 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
   };
 
   const int nk = p.K / BK;
+  // Round 5 (VSX_EPI_BIAS_RES): the shortcut rows the epilogue adds are requested RES_D passes (16 rows x 64 columns each) ahead of
+  // their use — the first RES_D while the last slabs are still being multiplied (BN <= 256; at BN = 384 the accumulators leave no
+  // registers for that and the prefetch starts with the epilogue) — instead of inside each pass, where every one of the FN passes
+  // of a wave began with a cold global round trip (the fc1 data gradient's LayerNorm epilogue lost 19 % to the same pattern).
+  constexpr bool RES = EPI == VSX_EPI_BIAS_RES;
+  constexpr int RES_D = RES ? (BN == 384 ? 2 : (BN == 256 ? 4 : 1)) : 1;   // (BN = 128 runs at a 128-register cap: one pass ahead only)
+  constexpr bool RES_INLOOP = RES && BN == 256;
+  uint4 rq[RES_D][2];
+  float rsv[RES ? 4 : 1][2];
+  const int e_r = lane >> 3, e_c = (lane & 7) * 8;
+  auto res_fetch = [&](int q, int slot) {   // pass q = cg * 4 + i
+    if constexpr (RES) {
+      const int cgq = q >> 2, iq = q & 3;
+      const int nq = n0 + wn * WN + cgq * 64 + e_c;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int m = m0 + wm * 64 + iq * 16 + e_r + 8 * h;
+        rq[slot][h] = (nq < p.N && m < p.M) ? ldvec<bf16_t>(reinterpret_cast<const bf16_t*>(p.res) + (size_t)m * p.ldr + nq) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  auto res_prologue = [&]() {
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int m = m0 + wm * 64 + i * 16 + e_r + 8 * h;
+          rsv[i][h] = (p.rscale && m < p.M) ? p.rscale[p.hw > 0 ? m / p.hw : 0] : 1.f;
+        }
+#pragma unroll
+      for (int q = 0; q < RES_D && q < FN; ++q) res_fetch(q, q);
+    }
+  };
   issue(0, 0);
   if (nk > 1) issue(1, 1);
+  if (RES_INLOOP && nk < 3) res_prologue();
   int st = 0, stn = NST - 1;
   for (int kt = 0; kt < nk; ++kt) {
     // slab kt has landed for this wave (its pieces are the oldest outstanding); slab kt + 1 may still be in flight
@@ -191,12 +226,14 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
     }
     __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading the stage that is refilled next
     if (kt + 2 < nk) issue(kt + 2, stn);
+    if (RES_INLOOP && kt == nk - 3) res_prologue();
     compute(st, kt);
     st = st == NST - 1 ? 0 : st + 1;
     stn = stn == NST - 1 ? 0 : stn + 1;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // the operand stages are dead: the staging patches overlay them
+  if (RES && !RES_INLOOP) res_prologue();
 
   // ---- epilogue, wave-private: (BN / 128) column groups x 4 row passes of 16 rows x 64 columns
   float* Cw = reinterpret_cast<float*>(smem + wave * CW_BYTES);
@@ -248,8 +285,8 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
           if (m < p.M) {
             if constexpr (EPI == VSX_EPI_BIAS_RES) {
               float rf[8];
-              unpack<bf16_t>(ldvec<bf16_t>(reinterpret_cast<const bf16_t*>(p.res) + (size_t)m * p.ldr + n), rf);
-              const float rs = p.rscale ? p.rscale[p.hw > 0 ? m / p.hw : 0] : 1.f;
+              unpack<bf16_t>(rq[(cg * 4 + i) % RES_D][h], rf);
+              const float rs = rsv[i][h];
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[h][j] = fmaf(v[h][j], rs, rf[j]);
             } else if constexpr (EPI == VSX_EPI_BIAS_GELU_SQ) {
@@ -280,6 +317,9 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
               stvec<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ccol, pack<bf16_t>(v[h]));
           }
         }
+      }
+      if constexpr (RES) {  // this pass's slot is free: request the rows of pass q + RES_D
+        if (cg * 4 + i + RES_D < FN) res_fetch(cg * 4 + i + RES_D, (cg * 4 + i) % RES_D);
       }
     }
 
@@ -415,8 +455,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
   };
 
   const int nk = p.K / BK;
+  // Round 5: the epilogue's row operands — this lane's 16-byte pieces of y / x^ (and the row means / rstd) — are requested while
+  // the last slabs are still being multiplied (behind the LAST operand DMA, at slab nk - 3), not inside the epilogue: there every
+  // 16-row pass began with a cold global round trip that nothing covered (one workgroup per CU).  The counted waits of the last
+  // two slabs then see these loads as the youngest outstanding operations: they make slab nk - 1 land one step early, no more.
+  constexpr int er_ = 0;
+  const int erow = lane >> 3, ecol = (lane & 7) * 8;
+  const bf16_t* XHp = reinterpret_cast<const bf16_t*>(p.aux);
+  // (the first 16-row pass's operands from inside the K loop, the second pass's at the top of the first: both sets live across the
+  // K loop would spill 39 registers at BN = 256)
+  uint4 xpre[2][NCG][2];
+  float mupre[2][2], rspre[2][2];
+  auto prefetch_pass = [&](int i) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = m0 + wave * 32 + i * 16 + erow + 8 * h;
+      mupre[i][h] = p.grn_b ? p.grn_b[m] : 0.f;
+      rspre[i][h] = p.grn_s[m];
+#pragma unroll
+      for (int cg = 0; cg < NCG; ++cg) {
+        const int n = cg * 64 + ecol;
+        xpre[i][cg][h] = n < p.N ? ldvec<bf16_t>(XHp + (size_t)m * p.ldx + n) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  auto prefetch_rows = [&]() { prefetch_pass(0); };
+  (void)er_;
   issue(0, 0);
   if (nk > 1) issue(1, 1);
+  if (nk < 3) prefetch_rows();
   int st = 0, stn = NST - 1;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) {
@@ -427,6 +494,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
     }
     __builtin_amdgcn_s_barrier();
     if (kt + 2 < nk) issue(kt + 2, stn);
+    if (kt == nk - 3) prefetch_rows();
     compute(st);
     st = st == NST - 1 ? 0 : st + 1;
     stn = stn == NST - 1 ? 0 : stn + 1;
@@ -447,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     float v[NCG][2][8];
-    uint4 xq[NCG][2];
+    uint4 (&xq)[NCG][2] = xpre[i];
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) {
@@ -464,12 +532,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
         const float4 t0 = *reinterpret_cast<const float4*>(Cw + (er + 8 * h) * CW_LD + ec);
         const float4 t1 = *reinterpret_cast<const float4*>(Cw + (er + 8 * h) * CW_LD + ec + 4);
         const float t[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        const int m = m0 + wave * 32 + i * 16 + er + 8 * h;
-        xq[cg][h] = ok ? ldvec<bf16_t>(XH + (size_t)m * p.ldx + n) : make_uint4(0u, 0u, 0u, 0u);
         float xf[8];
         unpack<bf16_t>(xq[cg][h], xf);
         if (MEAN && ok) {
-          const float mu = MEAN[m], rsd = p.grn_s[m];
+          const float mu = mupre[i][h], rsd = rspre[i][h];
 #pragma unroll
           for (int e = 0; e < 8; ++e) xf[e] = (xf[e] - mu) * rsd;
           xq[cg][h] = pack<bf16_t>(xf);
@@ -486,13 +552,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+    if (i == 0) prefetch_pass(1);  // (behind the accumulator hand-over of this pass: its staging registers are free)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       // the 8 lanes er * 8 .. + 7 hold the row's column groups
       s1[h] += __shfl_xor(s1[h], 1, 64); s1[h] += __shfl_xor(s1[h], 2, 64); s1[h] += __shfl_xor(s1[h], 4, 64);
       s2[h] += __shfl_xor(s2[h], 1, 64); s2[h] += __shfl_xor(s2[h], 2, 64); s2[h] += __shfl_xor(s2[h], 4, 64);
       const int m = m0 + wave * 32 + i * 16 + er + 8 * h;
-      const float rs = MEAN ? 1.f : p.grn_s[m];
+      const float rs = MEAN ? 1.f : rspre[i][h];
       const float m1 = s1[h] * invC, m2 = s2[h] * invC;
 #pragma unroll
       for (int cg = 0; cg < NCG; ++cg) {

@@ -177,36 +177,77 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
   const int b = m0 / a.hw;
   const int row0 = m0 + wave * WM;
 
-  if constexpr (!BWD) {
-    for (int i = tid; i < MLP_GT_N; i += NW * 64) gt[i] = a.gtab[i];
-  } else if constexpr (DH) {  // {r(a), d(a)} pairs: one 8-byte gather per element yields gelu AND its derivative
-    for (int i = tid; i < MLP_GT_N; i += NW * 64) {
-      gt[2 * i] = a.gtab[i];
-      gt[2 * i + 1] = a.gtab[MLP_GT_N + i];
-    }
-  }
-  // ---- per-channel vectors -> LDS (once)
-  if constexpr (G::B1_IN_PADS) {
-    static_assert(!G::B1_IN_PADS || (NW * WM * 4 >= H4 && G::OB_RS == 144), "b1 rides in the pad bytes of the staging rows");
-    for (int i = tid; i < H4; i += NW * 64) *reinterpret_cast<float*>(obuf + (i >> 2) * G::OB_RS + 128 + (i & 3) * 4) = a.b1[i];
-  } else if constexpr (!BWD) {
-    for (int i = tid; i < H4; i += NW * 64) {
-      vec[i] = a.b1[i];
-      if constexpr (MODE == 1) {
-        vec[H4 + i] = a.grn_s[(size_t)b * H4 + i];
-        vec[2 * H4 + i] = a.grn_b[i];
+  // Round 5: every load of the workgroup's set-up — GELU table, per-channel vectors, and (below) the row fragments — is ISSUED before
+  // the first of them is waited for.  Written as `for (i) lds[i] = global[i]` the table copy compiled to seven dependent
+  // load -> wait -> ds_write round trips (the vectors to two or three more) in front of the row-fragment loads: 5 - 10 us of set-up
+  // for a workgroup that lives 90 us, with nothing else on the CU to cover them (one workgroup per CU in the backward passes).
+  constexpr int TPB = NW * 64;
+  constexpr int NTB = (MLP_GT_N + TPB - 1) / TPB, NVB = (H4 + TPB - 1) / TPB;
+  float tb0[(!BWD || DH) ? NTB : 1], tb1[DH ? NTB : 1];
+  if constexpr (!BWD || DH) {
+#pragma unroll
+    for (int k = 0; k < NTB; ++k) {
+      const int i = tid + k * TPB;
+      if (i < MLP_GT_N) {
+        tb0[k] = a.gtab[i];
+        if constexpr (DH) tb1[k] = a.gtab[MLP_GT_N + i];
       }
     }
-  } else if constexpr (DH) {
-    for (int i = tid; i < H4; i += NW * 64) {  // this sample's GRN scale s and statistics-path factor t
-      vec[i] = a.grn_s[(size_t)b * H4 + i];
-      vec[H4 + i] = a.grn_b[(size_t)b * H4 + i];
-      if constexpr (RE) vec[2 * H4 + i] = a.b1[i];
+  }
+  float vb0[NVB], vb1[(MODE == 1 || DH) ? NVB : 1], vb2[(MODE == 1 || RE) ? NVB : 1];
+  if constexpr (!BWD || DH) {
+#pragma unroll
+    for (int k = 0; k < NVB; ++k) {
+      const int i = tid + k * TPB;
+      if (i < H4) {
+        if constexpr (!BWD) {
+          vb0[k] = a.b1[i];
+          if constexpr (MODE == 1) {
+            vb1[k] = a.grn_s[(size_t)b * H4 + i];
+            vb2[k] = a.grn_b[i];
+          }
+        } else {  // this sample's GRN scale s and statistics-path factor t
+          vb0[k] = a.grn_s[(size_t)b * H4 + i];
+          vb1[k] = a.grn_b[(size_t)b * H4 + i];
+          if constexpr (RE) vb2[k] = a.b1[i];
+        }
+      }
     }
   }
-  if constexpr (MODE == 1) {
-    for (int i = tid; i < C; i += NW * 64) vec[3 * H4 + i] = a.b2[i];
-  }
+  auto setup_to_lds = [&]() {
+    if constexpr (!BWD || DH) {
+#pragma unroll
+      for (int k = 0; k < NTB; ++k) {
+        const int i = tid + k * TPB;
+        if (i < MLP_GT_N) {
+          if constexpr (DH) {  // {r(a), d(a)} pairs: one 8-byte gather per element yields gelu AND its derivative
+            gt[2 * i] = tb0[k];
+            gt[2 * i + 1] = tb1[k];
+          } else {
+            gt[i] = tb0[k];
+          }
+        }
+      }
+      // ---- per-channel vectors -> LDS (once)
+#pragma unroll
+      for (int k = 0; k < NVB; ++k) {
+        const int i = tid + k * TPB;
+        if (i < H4) {
+          if constexpr (G::B1_IN_PADS) {
+            static_assert(!G::B1_IN_PADS || (NW * WM * 4 >= H4 && G::OB_RS == 144), "b1 rides in the pad bytes of the staging rows");
+            *reinterpret_cast<float*>(obuf + (i >> 2) * G::OB_RS + 128 + (i & 3) * 4) = vb0[k];
+          } else {
+            vec[i] = vb0[k];
+            if constexpr (MODE == 1 || DH) vec[H4 + i] = vb1[k];
+            if constexpr (MODE == 1 || RE) vec[2 * H4 + i] = vb2[k];
+          }
+        }
+      }
+    }
+    if constexpr (MODE == 1) {
+      for (int i = tid; i < C; i += NW * 64) vec[3 * H4 + i] = a.b2[i];
+    }
+  };
   // ---- this wave's LayerNorm rows as fc1 B fragments: lane (p, q) holds row p, k = kk*32 + q*8 .. +7
   mlp_bf16x8 xf[MF][KK];
 #pragma unroll
@@ -229,6 +270,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
   // are weighted: lane (n, q) of an MFMA B operand holds contraction slots k = q*8 .. +7, which tile_frag fills with the pixels
   // q*4 .. +3 and 16 + q*4 .. +3 — the weight fragments below carry sigma = 1 / rstd (-> sum of the UNSCALED dh, the fc1 bias
   // gradient) and the row mean split into a bf16 head and tail (-> u = sum of dh' * mean to 2^-17, see vsx_mlp_bwd_dh_ln)
+  setup_to_lds();   // (behind the row-fragment loads: everything is in flight together)
   float rsr[LNF ? MF : 1];
   mlp_bf16x8 wS, wMh, wMl;
   if constexpr (LNF) {
