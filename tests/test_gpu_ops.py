@@ -514,6 +514,37 @@ def test_gemm_tn(dt, tr, M, N, K):
     close(cg, cr, dt, "colsum")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(16384, 384, 768), (32768, 1536, 384), (16384, 224, 896), (8192, 768, 3072)],
+                         ids=["square_tiles", "rect_n_divisible", "rect_n_full", "many_tiles"])
+def test_gemm_tn_any_split_count(M, N, K):
+    """Round 5: the TN split count is chosen to fill rounds of workgroups (csrc/gemm.hip fill_splits) and is no multiple of 8 any
+    more; the XCD-aware workgroup order (tn_xcd_order) must stay a bijection of (tile, split) for every count — a tile computed
+    twice or not at all shows up as a wrong weight gradient.  Sweep the split target over odd values, with and without the fill."""
+    if SELF_CHECK:
+        pytest.skip("HIP-only launch geometry")
+    from viscy_amd import _lib, ops
+
+    l, dt = _lib.lib(), torch.bfloat16
+    X, Y = rnd(M, N, dt=dt, seed=1).cuda(), rnd(M, K, dt=dt, seed=2).cuda()
+    ref = X.double().t() @ Y.double()
+    csr = X.double().sum(0)
+    saved = {n: l.vsx_get_flag(n) for n in (b"tn_want", b"tn_want2", b"tn_fill")}
+    try:
+        for fill in (1, 0):
+            for want in (97, 200, 333, 555, 768, 1100):
+                l.vsx_set_flag(b"tn_fill", fill)
+                l.vsx_set_flag(b"tn_want", want)
+                l.vsx_set_flag(b"tn_want2", want)
+                W, cs = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+                ops.gemm("tn", Y, X, W, M, N, K, K, N, K, dtype=dt, colsum=cs)
+                close(W, ref.float(), dt, f"W (tn_fill={fill}, tn_want={want})", scale=ref.abs().max().item())
+                close(cs, csr.float(), dt, f"colsum (tn_fill={fill}, tn_want={want})", scale=csr.abs().max().item() + float(M) ** 0.5)
+    finally:
+        for n, v in saved.items():
+            l.vsx_set_flag(n, v)
+
+
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K,hw", [(300, 40, 160, 100), (4096, 224, 896, 1024), (1024, 96, 384, 256), (4096, 896, 224, 1024)],
                          ids=["generic", "lean_wide_rect_n", "lean", "rect_k"])
