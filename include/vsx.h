@@ -542,8 +542,12 @@ int32_t vsx_crop3d(const float* x, float* y, const int32_t* starts, int32_t B, i
 
 /* K18 kornia warp_affine3d as used by BatchedRandAffined (viscy_transforms/_affine.py:33-47,358-393): trilinear (or
  * nearest) resampling; Minv[B][3][4] maps output-voxel to input-voxel coordinates (x, y, z order).
- * mode: bit 0 = nearest-neighbour; bits 1-2 = padding_mode of _affine.py:102-108 as torch's grid_sample(align_corners=True)
- * treats it: 0 "zeros", 1 "border" (coordinates clamped to the volume), 2 "reflection" (mirrored about 0 and n-1). */
+ * The kernel applies Minv as given; the caller folds kornia's align_corners convention into it (with align_corners=False — kornia's
+ * RandomAffine3D default, which the reference forwards — output voxel i reads Da^-1 (R Da (i + 1/2) + t) - 1/2, a = (size - 1) / size
+ * per axis: viscy_amd.transforms.kornia_sampling_matrix).
+ * mode: bit 0 = nearest-neighbour; bits 1-2 = padding_mode of _affine.py:102-108 as torch's grid_sample treats it: 0 "zeros",
+ * 1 "border" (coordinates clamped to the volume), 2 "reflection" with align_corners=True (mirrored about 0 and n-1),
+ * 3 "reflection" with align_corners=False (mirrored about -1/2 and n-1/2, then clamped). */
 int32_t vsx_warp_affine3d(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D, int32_t H,
     int32_t W, int32_t mode, vsx_stream_t stream);
 /* the same warp restricted to the output window [z0,z0+Do) x [y0,y0+Ho) x [x0,x0+Wo) of the (D,H,W) frame: fuses the

@@ -120,23 +120,26 @@ def gaussian_smooth(x: Tensor, sigma: Tensor, apply: Tensor, truncated: float = 
     return out
 
 
-def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear", padding_mode: str = "zeros") -> Tensor:
-    """What kornia ``warp_affine3d(..., padding_mode=..., align_corners=True)`` (called at _affine.py:33-47)
-    computes, stated with torch's own ``affine_grid`` / ``grid_sample``: output voxel (x, y, z) samples the input at
-    ``Minv · (x, y, z, 1)`` (voxel coordinates)."""
+def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear", padding_mode: str = "zeros", align_corners: bool = False) -> Tensor:
+    """What kornia ``warp_affine3d(..., padding_mode=..., align_corners=...)`` (called at _affine.py:33-47) computes, stated with
+    torch's own ``affine_grid`` / ``grid_sample``.  ``Minv`` maps output voxels (x, y, z) to input voxels in kornia's pixel frame;
+    kornia normalises it with (size - 1) denominators (``normalize_homography3d``) WHATEVER ``align_corners`` is and hands the flag
+    to ``affine_grid`` and ``grid_sample``.  The reference forwards ``flags["align_corners"]`` of ``RandomAffine3D`` and never sets
+    it: kornia's default there is False (third-party, absent from /root/reference: restated from its published source, unpinned —
+    ADVICE r4).  With True, output voxel i samples ``Minv·(i, 1)`` exactly; with False see viscy_amd.transforms.kornia_sampling_matrix."""
     import torch.nn.functional as F
 
     B, C, D, H, W = x.shape
 
-    def norm_mat(d, h, w):  # voxel → [-1, 1] (align_corners=True)
+    def norm_mat(d, h, w):  # voxel → [-1, 1], the (size - 1) convention kornia uses for the matrix
         return torch.tensor([[2.0 / max(w - 1, 1), 0, 0, -1.0], [0, 2.0 / max(h - 1, 1), 0, -1.0],
                              [0, 0, 2.0 / max(d - 1, 1), -1.0], [0, 0, 0, 1.0]])
 
     N = norm_mat(D, H, W)
     M4 = torch.cat([Minv.float(), torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(B, 1, 4)], dim=1)
     theta = (N @ M4 @ torch.linalg.inv(N))[:, :3]
-    grid = F.affine_grid(theta, (B, C, D, H, W), align_corners=True)
-    return F.grid_sample(x.float(), grid, mode=mode, padding_mode=padding_mode, align_corners=True)
+    grid = F.affine_grid(theta, (B, C, D, H, W), align_corners=align_corners)
+    return F.grid_sample(x.float(), grid, mode=mode, padding_mode=padding_mode, align_corners=align_corners)
 
 
 def affine_matrix_zyx(angle_z_deg: Tensor, scale_xyz: Tensor, shape_dhw, shear_xy: Tensor | None = None) -> Tensor:

@@ -207,8 +207,10 @@ extern "C" int32_t vsx_blend_in(const float* oldp, const float* newp, float* out
 // A workgroup owns a 32 x 8 output tile of one z-slice: under an in-plane rotation its input footprint is a compact
 // ~30 x 30 patch per tap plane, so the 8 gathers per voxel hit L1 lines shared by the whole tile (a 256 x 1 row of outputs
 // would sweep up to 180 input rows).  The matrix is wave-uniform (scalar registers).
-// out-of-volume source coordinates as torch's grid_sample treats them with align_corners=True (kornia warp_affine3d hands
-// padding_mode through, _affine.py:33-47): 1 "border" = clamp to [0, n-1]; 2 "reflection" = mirror about 0 and n-1, then clamp
+// out-of-volume source coordinates as torch's grid_sample treats them (kornia warp_affine3d hands padding_mode and align_corners
+// through, _affine.py:33-47): 1 "border" = clamp to [0, n-1]; 2 "reflection" with align_corners=True = mirror about 0 and n-1, then
+// clamp; 3 (round 5) "reflection" with align_corners=False — what kornia's RandomAffine3D passes by default and the reference never
+// overrides — = mirror about -0.5 and n-0.5 (the voxel EDGES), then clamp
 __device__ __forceinline__ float warp_pad_coord(float v, int n, int pad) {
   if (pad == 2) {
     const float span = (float)(n - 1);
@@ -217,6 +219,12 @@ __device__ __forceinline__ float warp_pad_coord(float v, int n, int pad) {
     const float extra = fmodf(v, span);
     const int flips = (int)floorf(v / span);
     v = (flips & 1) ? span - extra : extra;
+  } else if (pad == 3) {
+    const float span = (float)n;
+    v = fabsf(v + 0.5f);
+    const float extra = fmodf(v, span);
+    const int flips = (int)floorf(v / span);
+    v = ((flips & 1) ? span - extra : extra) - 0.5f;
   }
   return fminf(fmaxf(v, 0.f), (float)(n - 1));
 }
@@ -303,13 +311,14 @@ __global__ __launch_bounds__(256) void conv1d_axis_kernel(const float* __restric
 
 /* K18 kornia warp_affine3d as used by BatchedRandAffined (viscy_transforms/_affine.py:33-47,358-393): trilinear (or
  * nearest) resampling; Minv[B][3][4] = output-voxel → input-voxel coordinates (x, y, z order).
- * mode: bit 0 = nearest; bits 1-2 = padding_mode (0 "zeros", 1 "border", 2 "reflection", _affine.py:102-108).
+ * mode: bit 0 = nearest; bits 1-2 = padding_mode (0 "zeros", 1 "border", 2 "reflection" about the voxel centres 0 / n - 1,
+ * 3 "reflection" about the voxel edges -0.5 / n - 0.5 = grid_sample with align_corners=False; _affine.py:102-108).
  * vsx_warp_affine3d_roi produces only the output window [z0,z0+Do) x [y0,y0+Ho) x [x0,x0+Wo) of the full (D,H,W) frame:
  * the warp fused with the BatchedCenterSpatialCrop that follows it in the recipes (_crop.py:164-187). */
 extern "C" int32_t vsx_warp_affine3d_roi(const float* x, float* y, const float* Minv, int32_t B, int32_t C, int32_t D,
                                          int32_t H, int32_t W, int32_t z0, int32_t y0, int32_t x0, int32_t Do, int32_t Ho,
                                          int32_t Wo, int32_t mode, vsx_stream_t stream) {
-  VSX_CHECK(x && y && Minv && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 5, "vsx_warp_affine3d: bad arguments");
+  VSX_CHECK(x && y && Minv && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 7, "vsx_warp_affine3d: bad arguments");
   VSX_CHECK(Do > 0 && Ho > 0 && Wo > 0 && z0 >= 0 && y0 >= 0 && x0 >= 0 && z0 + Do <= D && y0 + Ho <= H && x0 + Wo <= W,
             "vsx_warp_affine3d: output window (%d,%d,%d)+(%d,%d,%d) outside the (%d,%d,%d) frame", z0, y0, x0, Do, Ho, Wo, D, H, W);
   VSX_CHECK(B <= 65535 && Do <= 65535, "vsx_warp_affine3d: B and the output depth must be <= 65535");

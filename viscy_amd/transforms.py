@@ -405,20 +405,41 @@ def _center_window(shape, roi_size):
 _PADDING_MODES = {"zeros": 0, "border": 1, "reflection": 2}
 
 
-def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear", window=None, padding_mode: str = "zeros") -> Tensor:
+def kornia_sampling_matrix(Minv: Tensor, shape_dhw, align_corners: bool) -> Tensor:
+    """The voxel mapping kornia's ``warp_affine3d`` REALLY applies for an output→input voxel matrix ``Minv`` (B,3,4; x, y, z order).
+    kornia normalises the matrix with (size - 1) denominators whatever ``align_corners`` is, then calls ``affine_grid`` /
+    ``grid_sample`` with the flag: with ``align_corners=True`` the two conventions agree and output voxel i samples ``Minv·i``; with
+    ``align_corners=False`` — the default of ``kornia.augmentation.RandomAffine3D``, which the reference forwards untouched
+    (_affine.py:33-47) — output voxel i sits at (i + 0.5)·a in the matrix' frame, a = (size - 1) / size per axis, and the result
+    is mapped back by 1 / a and - 0.5:  x' = Da^-1 (R·Da·(i + 0.5) + t) - 0.5  (third-party behaviour, restated)."""
+    if align_corners:
+        return Minv
+    D, H, W = (int(v) for v in shape_dhw)
+    a = torch.tensor([(n - 1) / n if n > 1 else 1.0 for n in (W, H, D)], dtype=torch.float64, device=Minv.device)
+    M = Minv.to(torch.float64)
+    R, t = M[:, :, :3], M[:, :, 3]
+    Rp = R * a.view(1, 1, 3) / a.view(1, 3, 1)
+    tp = (0.5 * (R * a.view(1, 1, 3)).sum(-1) + t) / a.view(1, 3) - 0.5
+    return torch.cat([Rp, tp.unsqueeze(-1)], dim=-1).to(Minv.dtype)
+
+
+def warp_affine3d(x: Tensor, Minv: Tensor, mode: str = "bilinear", window=None, padding_mode: str = "zeros",
+                  align_corners: bool = False) -> Tensor:
     """resample (B,C,D,H,W) with the output→input voxel matrices Minv (B,3,4) (csrc/transforms.hip); ``padding_mode`` as in
-    the reference (_affine.py:102-108): "zeros", "border" (edge voxels replicated) or "reflection".
+    the reference (_affine.py:102-108): "zeros", "border" (edge voxels replicated) or "reflection"; ``align_corners`` as kornia's
+    ``warp_affine3d`` receives it from ``RandomAffine3D`` (default False, see ``kornia_sampling_matrix``).
     ``window = (z0, y0, x0, Do, Ho, Wo)`` produces only that region of the output frame (warp + crop in one pass)."""
     if padding_mode not in _PADDING_MODES:
         raise ValueError(f"padding_mode must be one of {sorted(_PADDING_MODES)}, got {padding_mode!r}")
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 5):
         raise RuntimeError("viscy_amd GPU augmentations need a contiguous float32 (B,C,Z,Y,X) batch on the HIP device (no CPU fallback)")
     B, C, D, H, W = x.shape
-    m = Minv.to(x.device, torch.float32).contiguous()
+    m = kornia_sampling_matrix(Minv.to(x.device), (D, H, W), align_corners).to(torch.float32).contiguous()
+    pad_code = 3 if (padding_mode == "reflection" and not align_corners) else _PADDING_MODES[padding_mode]
     z0, y0, x0, Do, Ho, Wo = window if window is not None else (0, 0, 0, D, H, W)
     y = torch.empty((B, C, Do, Ho, Wo), dtype=torch.float32, device=x.device)
     check(lib().vsx_warp_affine3d_roi(ptr(x), ptr(y), ptr(m), B, C, D, H, W, z0, y0, x0, Do, Ho, Wo,
-                                      int(mode == "nearest") | (_PADDING_MODES[padding_mode] << 1), stream()), "warp_affine3d")
+                                      int(mode == "nearest") | (pad_code << 1), stream()), "warp_affine3d")
     return y
 
 
@@ -470,7 +491,9 @@ def kornia_affine_matrix3d(angles_xyz_deg: Tensor, scale_xyz: Tensor, shears_deg
 
 class BatchedRandAffined(_BatchedRand):
     """``viscy_transforms.BatchedRandAffined`` (_affine.py:107-393): one random 3-D affine per sample, the same matrix for
-    every key, trilinear resampling with zero / border / reflection padding (``vsx_warp_affine3d``).  Arguments as in the reference:
+    every key, trilinear resampling with zero / border / reflection padding (``vsx_warp_affine3d``).  ``align_corners`` (class
+    attribute, False) is what kornia's ``RandomAffine3D`` hands to ``warp_affine3d`` by default; the reference never sets it
+    (_affine.py:33-47, :180-200).  Arguments as in the reference:
 
     * ``rotate_range`` — radians per axis in (Z, Y, X) order, a value ``v`` meaning ``(-v, v)`` (or explicit ``(lo, hi)``);
     * ``shear_range`` — degrees: ``(min, max)`` for all six facets, six ``(min, max)`` pairs, or MONAI's three-value
@@ -485,6 +508,8 @@ class BatchedRandAffined(_BatchedRand):
     (``kornia_affine_matrix3d``).  ``params=Minv`` (B, 3, 4: output -> input voxel) injects the matrices."""
 
     is_spatial = True
+
+    align_corners = False
 
     def __init__(self, keys, prob: float = 0.1, rotate_range=None, shear_range=None, translate_range=None, scale_range=None,
                  isotropic_scale: bool = False, scale_z_shear: bool = True, mode: str = "bilinear", padding_mode: str = "zeros",
@@ -587,7 +612,7 @@ class BatchedRandAffined(_BatchedRand):
         for k in self.keys:
             if k in sample:
                 win = _center_window(sample[k].shape, crop_roi_size) if crop_roi_size is not None else None
-                sample[k] = warp_affine3d(sample[k], Minv, self.mode, win, self.padding_mode)
+                sample[k] = warp_affine3d(sample[k], Minv, self.mode, win, self.padding_mode, self.align_corners)
         return sample
 
 
