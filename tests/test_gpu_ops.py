@@ -1416,6 +1416,11 @@ def test_fused_block_without_stored_normalised_rows(C, hw, B, offset):
         assert (err <= 2.0 ** -7 * want.abs() + 1e-30).all(), (err / want.abs().clamp_min(1e-30)).max().item()
         sc_db = dh5.float().abs().sum(0).max().item()
         close(cs2[0], db5, torch.float32, "fc1 bias gradient from the scaled tile", scale=sc_db * 2.0 ** -8 / tol(torch.float32) * 4 / M ** 0.5 + db5.abs().max().item())
+        # round 5: sigma = 1 / rstd enters the matrix-core sum as a bf16 head + tail, so the sum reproduces the fp64
+        # statement of what it adds up — the stored dh' times sigma — to fp32 round-off, not to 2^-9 per row
+        db64 = (dh7.double() / r7.double()[:, None]).sum(0)
+        scale_db = (dh7.double().abs() / r7.double()[:, None]).sum(0).max().item()
+        assert (cs2[0].double() - db64).abs().max().item() <= 3e-5 * scale_db + 1e-6, ((cs2[0].double() - db64).abs().max().item(), scale_db)
         u64 = (dh7.double() * mean7.double()[:, None]).sum(0)
         scale_u = (dh7.double().abs() * mean7.double().abs()[:, None]).sum(0).max().item()
         assert (cs2[1].double() - u64).abs().max().item() <= 3e-5 * scale_u + 1e-6, ((cs2[1].double() - u64).abs().max().item(), scale_u)

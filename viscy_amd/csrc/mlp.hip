@@ -272,7 +272,7 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
   // gradient) and the row mean split into a bf16 head and tail (-> u = sum of dh' * mean to 2^-17, see vsx_mlp_bwd_dh_ln)
   setup_to_lds();   // (behind the row-fragment loads: everything is in flight together)
   float rsr[LNF ? MF : 1];
-  mlp_bf16x8 wS, wMh, wMl;
+  mlp_bf16x8 wS, wSl, wMh, wMl;
   if constexpr (LNF) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
@@ -292,18 +292,20 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
       }
     }
     static_assert(!LNF || MF == 2, "the weight fragments cover the 32 pixels of a wave");
-    float sg[8], mh[8], ml[8];
+    float sg[8], sl[8], mh[8], ml[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const size_t rowi = (size_t)(row0 + (j >> 2) * 16 + kq * 4 + (j & 3));
       const float mean = a.ln_mean[rowi];
-      sg[j] = 1.f / a.ln_rstd[rowi];
+      const float sig = 1.f / a.ln_rstd[rowi];
+      sg[j] = round_bf16(sig);   // sigma split into a bf16 head and tail like the mean (round 5, ADVICE r4: a bf16 sigma alone put
+      sl[j] = sig - sg[j];       // 2^-9 of relative error per row into the fc1 bias gradient)
       mh[j] = round_bf16(mean);
       ml[j] = mean - mh[j];
     }
-    union { mlp_bf16x8 b; uint4 u; } c1, c2, c3;
-    c1.u = pack<bf16_t>(sg); c2.u = pack<bf16_t>(mh); c3.u = pack<bf16_t>(ml);
-    wS = c1.b; wMh = c2.b; wMl = c3.b;
+    union { mlp_bf16x8 b; uint4 u; } c1, c2, c3, c4;
+    c1.u = pack<bf16_t>(sg); c2.u = pack<bf16_t>(mh); c3.u = pack<bf16_t>(ml); c4.u = pack<bf16_t>(sl);
+    wS = c1.b; wMh = c2.b; wMl = c3.b; wSl = c4.b;
   }
 
   if constexpr (!BWD) {
@@ -498,7 +500,8 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
     for (int ct = 0; ct < 2; ++ct) {
       const mlp_bf16x8 X = tile_frag(sb, (hs & 1) * 32 + ct * 16);
       if constexpr (LNF) {  // the parked tile holds dh' = dh * rstd: sigma-weighted sums = sums of dh; mean-weighted sums = u
-        const mlp_f32x4 D = mlp_mfma(X, wS, (mlp_f32x4){0.f, 0.f, 0.f, 0.f});
+        mlp_f32x4 D = mlp_mfma(X, wS, (mlp_f32x4){0.f, 0.f, 0.f, 0.f});
+        D = mlp_mfma(X, wSl, D);
         mlp_f32x4 U = mlp_mfma(X, wMh, (mlp_f32x4){0.f, 0.f, 0.f, 0.f});
         U = mlp_mfma(X, wMl, U);
         if (p16 == 0) {
