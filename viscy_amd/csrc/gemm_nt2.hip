@@ -390,6 +390,16 @@ __global__ __launch_bounds__(512, Nt2Geom<BN>::WAVES_PER_SIMD) void gemm_nt2_ker
 // the two row means are sums over the lanes of ONE wave.  dx^ is rounded to bf16 where the unfused pair stored it; it is never
 // written: the launch that wrote it, the LayerNorm-backward launch that read it back with x^, and 2 C-wide passes per block go.
 // ------------------------------------------------------------------------------------------------
+// NT2_TS (probe builds only: -DNT2_TS=1): s_memtime stamps of ONE workgroup's waves along a tile of the fused data-gradient /
+// LayerNorm kernel, read back with vsx_debug_nt2_ts (tools/nt2_timeline.py): entry, first slab landed, K loop done (+ per-slab
+// stamps), first 16-row pass done, exit.
+#ifdef NT2_TS
+__device__ unsigned long long g_nt2_ts[8 * 80];
+#define NT2_STAMP(k) do { if (blockIdx.x == gridDim.x / 2 + 3 && lane == 0) g_nt2_ts[wave * 80 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NT2_STAMP(k) do { } while (0)
+#endif
+
 template <int BN>
 __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p) {
   typedef Nt2Geom<BN> G;
@@ -400,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
   const int p16 = lane & 15, kq = lane >> 4;
   int bid = blockIdx.x;
   const int m0 = bid * BM;
+  NT2_STAMP(0);
 
   const int dr = lane >> 2;
   const int dc = (lane & 3) ^ ((lane >> 4) & 2);
@@ -493,14 +504,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    if (kt < 64) NT2_STAMP(8 + kt);
     if (kt + 2 < nk) issue(kt + 2, stn);
     if (kt == nk - 3) prefetch_rows();
     compute(st);
     st = st == NST - 1 ? 0 : st + 1;
     stn = stn == NST - 1 ? 0 : stn + 1;
   }
+  NT2_STAMP(1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  NT2_STAMP(2);
 
   // ---- epilogue: per 16-row fragment, all column groups are read back into registers (dx^ as bf16 values, x^), the row
   // means are reduced over the 8 lanes that share a row, then dy is formed and stored
@@ -552,6 +566,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+    NT2_STAMP(3 + i);
     if (i == 0) prefetch_pass(1);  // (behind the accumulator hand-over of this pass: its staging registers are free)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -574,6 +589,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt2_lnbwd_kernel(const VsxGemm p)
       }
     }
   }
+  NT2_STAMP(5);
 }
 
 template <int EPI, int BN>
@@ -686,3 +702,9 @@ int vsx_gemm_nt2(const VsxGemm* p0, hipStream_t s) {
     default: return launch<VSX_EPI_DZ>(p, s);
   }
 }
+
+#ifdef NT2_TS
+extern "C" int32_t vsx_debug_nt2_ts(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt2_ts), sizeof(g_nt2_ts)) == hipSuccess ? 0 : 1;
+}
+#endif
