@@ -1,4 +1,5 @@
-"""Fill the @@PLACEHOLDER@@ figures of DESIGN.md / README.md / profiles/README.md from the committed round-4 profile files (run once
+"""(Round-4 helper, kept for the record: round 5 refilled its documents by explicit old -> new replacements from the refreshed
+profile files, see the commit history.)  Fill the @@PLACEHOLDER@@ figures of DESIGN.md / README.md / profiles/README.md from the committed round-4 profile files (run once
 after `bash scripts/refresh_profiles.sh --collect`): the documents quote exactly what the tracked files hold."""
 import csv
 import json
