@@ -665,6 +665,11 @@ def test_det_reduce_makes_the_bf16_forward_bit_identical_from_run_to_run():
         lib.vsx_set_flag(b"det_reduce", 0)
     d = ((y_det.float() - y_atomic.float()).abs().max() / y_det.float().abs().max()).item()
     assert d <= 2e-2, d   # the same sums in another order: bf16 rounding noise, not a different result
+    # round 6: a forward with no backward behind it (predict / validation) takes the fixed order by itself, flag untouched
+    assert lib.vsx_get_flag(b"det_reduce") == 0
+    y0 = fwd(False)
+    assert torch.equal(fwd(False), y0) and torch.equal(fwd(False), y0)
+    assert lib.vsx_get_flag(b"det_reduce") == 0
 
 
 def test_large_image_fp32_gradient_is_as_accurate_as_the_reference_fp32_arithmetic():
@@ -1114,6 +1119,45 @@ def test_contrastive_paired_forward_matches_two_forwards():
         assert relerr(res[0][1][n], res[1][1][n]) <= 1e-3, n
     for k in res[0][2]:
         torch.testing.assert_close(res[0][2][k].float(), res[1][2][k].float(), rtol=1e-5, atol=1e-6)
+
+
+def test_v1_backbone_fc2_bias_gradient_on_the_statistics_in_tn_path():
+    """ConvNeXt-V1 blocks on the C = 384 stage with a per-rank batch whose per-sample products would not fit
+    (B >= 228, 8 x 8 maps) take the fc2 weight gradient that also delivers the GRN statistics (gemm_tn_fast_kernel PRO == 2); the
+    column sums of that launch must reach fc2.bias (and, through it, gamma) before `layer_scale_unfold` reads them.  Checked
+    against the same backward with that launch switched off (`tn_rect` bit 3: statistics from the MODE 3 pass, colsum = db2)."""
+    from viscy_amd.contrastive import ContrastiveEncoder
+
+    lib = L.lib()
+    old = lib.vsx_get_flag(b"tn_rect")
+    g = torch.Generator().manual_seed(3)
+    B = 232
+    a = torch.randn(B, 1, 5, 128, 128, generator=g).cuda()
+    res = []
+    try:
+        for on in (True, False):
+            lib.vsx_set_flag(b"tn_rect", (old | 8) if on else (old & ~8))
+            torch.manual_seed(0)
+            enc = ContrastiveEncoder("convnext_tiny", in_channels=1, in_stack_depth=5, embedding_dim=768, projection_dim=32,
+                                     depths=(1, 1, 2, 1)).cuda().train()
+            enc.compute_dtype = torch.bfloat16
+            with torch.no_grad():  # a layer scale of 1e-6 would leave nothing to see in bf16
+                for n, p in enc.named_parameters():
+                    if n.endswith("gamma"):
+                        p.fill_(0.5)
+            emb, proj = enc(a)
+            cot = torch.randn(proj.shape, generator=torch.Generator().manual_seed(4)).cuda()
+            (proj * cot).sum().backward()
+            res.append({n: p.grad.float().clone() for n, p in enc.named_parameters() if ".stages.2." in n or n.startswith("stages.2.")})
+    finally:
+        lib.vsx_set_flag(b"tn_rect", old)
+    names = [n for n in res[0] if n.endswith("mlp.fc2.bias") or n.endswith("gamma")]
+    assert len(names) == 4, list(res[0])
+    for n in names:
+        a_, b_ = res[0][n].flatten(), res[1][n].flatten()
+        assert b_.abs().max() > 0 and a_.abs().max() > 0.2 * b_.abs().max(), n
+        cos = torch.dot(a_, b_) / (a_.norm() * b_.norm())
+        assert cos > 0.99, (n, float(cos))
 
 
 def test_fcmae_finetune_with_frozen_encoder():

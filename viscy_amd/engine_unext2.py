@@ -14,6 +14,8 @@ itself on CPU (tests/ref_ops.py); nothing in the package does.
 
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -509,10 +511,14 @@ class Engine:
             # W2 tile into P_b on the way (csrc/gemm.hip, gemm_tn_fast_kernel PRO == 2).  The statistics pass that recomputed dz for
             # P and S (csrc/mlp.hip MODE 3, a full M x 4C x C contraction per block) is gone; S only ever fed dbeta = sum_b S_b =
             # (column sums of dout) . W2, a matvec on the sums this launch produces for the bias gradient.
-            cs = self._za.take(C)
+            # ConvNeXt-V1 blocks: db2 is zeroed scratch that `layer_scale_unfold` reads in a DIRECT launch right below, while
+            # `transpose_f32` is only queued inside the backward segment's task-list batch — the GEMM writes the column sums into
+            # db2 itself there (fc2.bias gradient and its share of dgamma were lost on v1 backbones at this path)
+            cs = db2 if w.v1 else self._za.take(C)
             o.gemm("tn", gact, dout, dW2, M, C, 4 * C, 4 * C, C, 4 * C, dtype=dt, pro=L.PRO_GRN, grn_s=s, grn_b=w.grn_b, hw=hw,
                    colsum=cs, aux=w.W2, ldx=4 * C, red0=PS[0])
-            o.transpose_f32(cs, db2, C, 1, True)         # db2 += cs
+            if not w.v1:
+                o.transpose_f32(cs, db2, C, 1, True)     # db2 += cs
             o.matvec_t_add(w.fc2_w, cs, dgb, C, 4 * C)   # dbeta += W2^T cs
             stats_in_tn = True
         else:
@@ -598,6 +604,22 @@ class Engine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: Tensor, dt: torch.dtype, need_bwd: bool, masks=None, bn_groups: int = 1):
+        """A forward WITHOUT a backward behind it (predict / validation / `InferStep` captures) forms the per-sample GRN and
+        InstanceNorm sums in a fixed order (`det_reduce`), as the reference's CPU path is deterministic: with fp32 atomics the
+        bf16 forward at 2048^2 differs by 7e-3 of the output maximum from run to run, the fixed order costs 0.3 % of a pass
+        (profiles/r05_det_reduce.txt; VERDICT r5).  Training forwards keep the atomics unless the flag is set by hand;
+        ``VSX_DET_INFER=0`` in the environment switches the automatic setting off."""
+        auto = (not need_bwd) and self.ops.__name__.endswith("viscy_amd.ops") and os.environ.get("VSX_DET_INFER", "1") != "0" \
+            and L.lib().vsx_get_flag(b"det_reduce") == 0
+        if not auto:
+            return self._forward(x, dt, need_bwd, masks, bn_groups)
+        L.lib().vsx_set_flag(b"det_reduce", 1)
+        try:
+            return self._forward(x, dt, need_bwd, masks, bn_groups)
+        finally:
+            L.lib().vsx_set_flag(b"det_reduce", 0)
+
+    def _forward(self, x: Tensor, dt: torch.dtype, need_bwd: bool, masks=None, bn_groups: int = 1):
         """``masks``: None (dense) or, per encoder stage, ``(idx, inv, keep, L)`` int32 row maps of the FCMAE mask at that
         stage's resolution (see ``viscy_amd.fcmae.stage_row_maps``)."""
         o, cfg, m = self.ops, self.cfg, self.model

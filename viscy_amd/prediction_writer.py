@@ -162,7 +162,7 @@ class HCSPredictionWriter(_Base):
         old = pred.new_zeros(pred.shape)              # beyond the held slices the window meets a weight of (f - 1) / f = 0
         if held:
             old[:, :held] = run["stack"]
-        if pred.is_cuda:
+        if pred.is_cuda and (pred.shape[-1] * pred.shape[-2]) % 4 == 0:  # the device kernel moves 16-byte vectors of a plane
             from .vsunet import blend_in
 
             merged = blend_in(old, pred, z_slice)

@@ -76,14 +76,15 @@ class Trainer:
                 # least recently used one instead of growing (a second shape at a large batch could run out of memory where the
                 # eager loop would not) — but only for a shape that COMES BACK: a first sighting runs eagerly, so that
                 # three or more alternating shapes do not pay two warm-up steps, a state restore and a capture per batch
-                seen = getattr(self, "_seen_once", None)
-                if seen is None:
-                    seen = self._seen_once = set()
-                if key not in seen:
-                    seen.add(key)
-                    return None
-                seen.discard(key)
+                # ... and with a per-shape sighting count that is NOT reset by a capture (with A, B, C, A, B, C ... a set
+                # that forgot a shape at its capture re-captured on every other cycle): a shape takes a captured slot only when it
+                # has been seen more often than the least recently used captured shape since THAT one was captured
+                hits = self.__dict__.setdefault("_shape_hits", {})
+                hits[key] = hits.get(key, 0) + 1
                 old_key = next(iter(self._train_steps))
+                if hits[key] < 2 or hits[key] <= hits.get(old_key, 0):
+                    return None
+                hits[key] = hits[old_key] = 0
                 del self._train_steps[old_key]
                 import gc
                 import logging
@@ -105,6 +106,8 @@ class Trainer:
                                                 "hipGraph replay" if use_graph else "eager launches")
         else:
             self._train_steps[key] = self._train_steps.pop(key)  # most recently used last
+            hits = self.__dict__.setdefault("_shape_hits", {})
+            hits[key] = hits.get(key, 0) + 1
         return step
 
     def fit(self, module, datamodule) -> None:
@@ -208,21 +211,25 @@ class Trainer:
             if hasattr(cb, "on_predict_start"):
                 cb.on_predict_start(self, module)
         outs = []
-        with torch.no_grad():
-            for j, batch in enumerate(datamodule.predict_dataloader()):
-                batch = self._to_device(batch)
-                if hasattr(datamodule, "on_after_batch_transfer"):
-                    was = getattr(datamodule, "training", False)
-                    datamodule.training = False
-                    batch = datamodule.on_after_batch_transfer(batch, 0)
-                    datamodule.training = was
-                pred = module.predict_step(batch, j)
-                if self.return_predictions:
-                    outs.append(pred)
-                for cb in self.callbacks:
-                    if hasattr(cb, "write_on_batch_end") and getattr(cb, "interval", "batch") in ("batch", "batch_and_epoch"):
-                        cb.write_on_batch_end(self, module, pred, None, batch, j, 0)
-        for cb in self.callbacks:
-            if hasattr(cb, "on_predict_end"):
-                cb.on_predict_end(self, module)
+        try:
+            with torch.no_grad():
+                for j, batch in enumerate(datamodule.predict_dataloader()):
+                    batch = self._to_device(batch)
+                    if hasattr(datamodule, "on_after_batch_transfer"):
+                        was = getattr(datamodule, "training", False)
+                        datamodule.training = False
+                        batch = datamodule.on_after_batch_transfer(batch, 0)
+                        datamodule.training = was
+                    pred = module.predict_step(batch, j)
+                    if self.return_predictions:
+                        outs.append(pred)
+                    for cb in self.callbacks:
+                        if hasattr(cb, "write_on_batch_end") and getattr(cb, "interval", "batch") in ("batch", "batch_and_epoch"):
+                            cb.write_on_batch_end(self, module, pred, None, batch, j, 0)
+        finally:
+            # also on an exception / interrupt: a writer with a running device-side blend still holds predicted slices that the
+            # reference would have on disk by now — on_predict_end flushes them and closes the store
+            for cb in self.callbacks:
+                if hasattr(cb, "on_predict_end"):
+                    cb.on_predict_end(self, module)
         return outs
