@@ -37,7 +37,8 @@ def _free():
 
 
 def test_gate_shape_training_step_properties_bf16():
-    """(B = 4, Z = 5, 2048 x 2048): one sample is 64 bench patches; B = 4 keeps the test at ~90 GB (the bench runs B = 8)."""
+    """(B = 8, Z = 5, 2048 x 2048) — the batch `bench.py`'s gate_shape record runs (the test ran B = 4): one sample is
+    64 bench patches; the replay / learning parts take the full batch (~130 GB), the property parts sub-batches of it."""
     import bench
     from viscy_amd.losses import MixedLoss
     from viscy_amd.optim import FlatAdamW
@@ -45,7 +46,7 @@ def test_gate_shape_training_step_properties_bf16():
 
     m = _model(torch.bfloat16)
     eng = m.engine()
-    x, t = bench.make_batch(4, 2048, 2048, "cuda", seed=5)
+    x, t = bench.make_batch(8, 2048, 2048, "cuda", seed=5)
     # ---- batch independence of the forward (per-sample GRN / InstanceNorm statistics, tiles inside one sample)
     m.eval()
     with torch.no_grad():

@@ -21,6 +21,8 @@ from torch import Tensor
 
 from . import _lib as L
 
+CHUNK_MB_DEFAULT = "0"  # see Engine._sample_chunk
+
 
 class _BlockW:
     """prepared operands + parameter handles of one ConvNeXt-V2 block"""
@@ -371,6 +373,18 @@ class Engine:
         return bool(flag & 128) and bool(flag & 32) and self._mlp_recompute_h(C, hw, M, dt, B) and self.ops.mlp_supported(C, hw, M, dt, 7) \
             and hasattr(self.ops, "dgrad_ln_bwd") and bool(L.lib().vsx_gemm_nt_ln_bwd_supported(M, C, 4 * C, L.dtype_code(dt)))
 
+    def _sample_chunk(self, B, hw, C, which: str = "bwd") -> int:
+        """samples per chunk of the sample-chunk-major schedule, 0 = whole batch in one launch.  ``VSX_CHUNK_MB`` = target size of
+        the 4C-wide chunk in MiB (0 / unset: off); a chunk holds at least 256 row tiles of 256 rows (one per CU) and the
+        schedule only applies when the batch has at least two chunks"""
+        mb = float(os.environ.get("VSX_CHUNK_MB", CHUNK_MB_DEFAULT))
+        if mb <= 0 or hw % 256 or os.environ.get("VSX_CHUNK_" + which.upper(), "1") == "0":
+            return 0
+        per_sample = hw * 4 * C * 2
+        n = max(int(mb * (1 << 20)) // per_sample, 1)
+        n = max(n, -(-256 * 256 // hw))
+        return n if n * 2 <= B else 0
+
     def _block_fwd(self, x, w, B, H, Wd, dt, save, rows=None):
         """One ConvNeXt-V2 block on a dense channels-last map [B*H*W, C].  ``rows = (idx, inv, keep, L)`` selects the FCMAE
         masked path (fcmae.py:196-230): ``x`` arrives already multiplied by the mask, the depthwise convolution runs dense,
@@ -424,6 +438,37 @@ class Engine:
         # fc1 writes the pre-activation h (needed for gelu' in backward) AND the activation g = gelu(h):
         # fc2, the fc2 weight gradient and the GRN statistics path all consume g, so GELU is evaluated once
         # (inference keeps the activation only: C = NULL skips the pre-activation store, a third of the block's 4C-wide traffic)
+        chunk = 0
+        if save is not None and rows is None and ln_in and self._mlp_mode(C, hw, M, dt, True) and self._mlp_drop_xh(C, hw, M, dt, B) \
+                and C > 64 and hw % 128 == 0 and hw // 128 >= 8:
+            chunk = self._sample_chunk(B, hw, C, "fwd")
+        if chunk:
+            # round 6: sample-chunk-major forward of the block's two GEMM-shaped launches — fc1 (MODE 6) writes the activation g
+            # of `chunk` samples, the per-sample GRN scale of exactly those samples follows, and fc2 reads that g chunk while it
+            # is still in the Infinity Cache (g is needed again in the backward, so the whole tensor is kept as before)
+            if w.img is None:
+                w.img = o.mlp_pack(w.W1f, w.W2, C)
+                o.flush()
+            mean = torch.empty(M, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+            gact = torch.empty((M, 4 * C), dtype=dt, device=x.device)
+            s = torch.empty_like(colsq)
+            out = torch.empty((M, C), dtype=dt, device=x.device)
+            b2 = w.b2f
+            if b2 is None:
+                b2 = o.matvec(w.fc2_w, w.grn_b, w.fc2_b, C, 4 * C)
+                o.flush()
+            for b0 in range(0, B, chunk):
+                b1_ = min(B, b0 + chunk)
+                r0, r1 = b0 * hw, b1_ * hw
+                o.mlp_fc1_ln(y[r0:r1], w.img, w.b1f, colsq[b0:b1_], r1 - r0, C, hw, 1e-6, store_h=False, store_xh=False,
+                             outs=(mean[r0:r1], rstd[r0:r1], gact[r0:r1]))
+                o.grn_scale(colsq[b0:b1_], w.grn_w, out=s[b0:b1_])
+                Ws = o.scale_weight_samples(w.fc2_w, s[b0:b1_], dt)
+                o.gemm("nt", gact[r0:r1], Ws, out[r0:r1], r1 - r0, C, 4 * C, 4 * C, 4 * C, C, dtype=dt, hw=hw, b_bstride=C * 4 * C,
+                       epi=L.EPI_BIAS_RES, bias=b2, res=xres[r0:r1], ldr=C, rscale=None if dpm is None else dpm[b0:b1_])
+            save.append((x, (y, mean), rstd, None, gact, colsq, s, rows, dpm))
+            return out
         if save is not None and self._mlp_mode(C, hw, M, dt, True):
             # training fc1 on the fused kernel's statistics pass, which also stores h and g (csrc/mlp.hip MODE 2)
             if w.img is None:
@@ -555,7 +600,26 @@ class Engine:
                 t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw)
             else:
                 t = o.grn_bwd_stats(colsq, PS[0], w.grn_w, dgw, Sb=PS[1], dbeta=dgb)
-            if ln_re:  # h recomputed from y re-normalised on chip; dz holds dh * rstd (MODE 7)
+            chunk = self._sample_chunk(B, hw, C) if ln_re and rows is None else 0
+            if chunk:
+                # round 6: sample-chunk-major schedule of the three launches that touch the 4C-wide dh — the
+                # dh pass writes a chunk of `chunk` samples into ONE reused buffer sized for the 256 MiB Infinity Cache, and its two
+                # readers (fc1 data gradient with the LayerNorm backward, fc1 weight gradient) run right behind it, so that both
+                # re-reads are served memory-side instead of from HBM; the full [M, 4C] dh is never allocated
+                buf = torch.empty((chunk * hw, 4 * C), dtype=dt, device=dev)
+                dy = torch.empty((M, C), dtype=dt, device=dev)
+                dW1f = self._za.take(4 * C, C)
+                y_, mean_ = xh
+                for b0 in range(0, B, chunk):
+                    b1_ = min(B, b0 + chunk)
+                    r0, r1 = b0 * hw, b1_ * hw
+                    dzc = o.mlp_bwd_dh_ln(dout[r0:r1], y_[r0:r1], mean_[r0:r1], rstd[r0:r1], img2, w.img, w.b1f, s[b0:b1_], t[b0:b1_],
+                                          cs2, r1 - r0, C, hw, out=buf[: r1 - r0])
+                    o.dgrad_ln_bwd(dzc, w.W1fT, y_[r0:r1], rstd[r0:r1], r1 - r0, C, 4 * C, mean=mean_[r0:r1], out=dy[r0:r1])
+                    o.gemm("tn", y_[r0:r1], dzc, dW1f, r1 - r0, 4 * C, C, C, 4 * C, C, dtype=dt)
+                del buf, dzc
+                dz = None
+            elif ln_re:  # h recomputed from y re-normalised on chip; dz holds dh * rstd (MODE 7)
                 dz = o.mlp_bwd_dh_ln(dout, xh[0], xh[1], rstd, img2, w.img, w.b1f, s, t, cs2, M, C, hw)
             elif h is None:  # h recomputed on chip from the normalised rows (MODE 5)
                 dz = o.mlp_bwd_dh_re(dout, xh, img2, w.img, w.b1f, s, t, db1f, M, C, hw)
@@ -570,7 +634,10 @@ class Engine:
             o.grn_gelu_bwd(dz, h, s, t, db1f, M, 4 * C, hw)  # dz now holds dH
         # fc1 data gradient; where one column tile spans the row (C <= 256) the block LayerNorm's backward rides in the GEMM's
         # epilogue (VSX_EPI_LN_BWD): dx^ is never written, the LayerNorm-backward launch and two C-wide passes go
-        if ln_re:
+        chunked = fused_bwd and ln_re and dz is None
+        if chunked:
+            xh = xh[0]
+        elif ln_re:
             # dz = dh * rstd: the accumulator is rstd * dx^ already, x^ is re-formed from y in the epilogue; the weight gradient
             # contracts dz with y itself, dh^T x^ = dz^T y - u (x) 1 — the rank-1 term goes in the unfold below
             dy = o.dgrad_ln_bwd(dz, w.W1fT, xh[0], rstd, M, C, 4 * C, mean=xh[1])
@@ -581,8 +648,9 @@ class Engine:
         if dy is None:
             dxh = torch.empty((M, C), dtype=dt, device=dev)
             o.gemm("nt", dz, w.W1fT, dxh, M, C, 4 * C, 4 * C, 4 * C, C, dtype=dt)
-        dW1f = self._za.take(4 * C, C)
-        o.gemm("tn", xh, dz, dW1f, M, 4 * C, C, C, 4 * C, C, dtype=dt)
+        if not chunked:
+            dW1f = self._za.take(4 * C, C)
+            o.gemm("tn", xh, dz, dW1f, M, 4 * C, C, C, 4 * C, C, dtype=dt)
         del dz
         # unfold the LayerNorm affine: dW1 = dW1f·diag(γ) + db1f ⊗ β, dγ = Σ_r dW1f ⊙ W1, dβ = W1ᵀ db1f, db1 = db1f
         o.unprep_grad(dW1f, g(blk.mlp.fc1.weight), 4 * C, C, 1, gamma=blk.norm.weight, W=blk.mlp.fc1.weight,

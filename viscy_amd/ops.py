@@ -128,14 +128,15 @@ def tn_grn_stats_ok(M: int, N: int, K: int, hw: int, dtype: torch.dtype) -> bool
         and bool(lib().vsx_get_flag(b"tn_rect") & 8)
 
 
-def dgrad_ln_bwd(dh: Tensor, WT: Tensor, xh: Tensor, rstd: Tensor, M: int, C: int, K: int, mean: Tensor | None = None) -> Tensor | None:
+def dgrad_ln_bwd(dh: Tensor, WT: Tensor, xh: Tensor, rstd: Tensor, M: int, C: int, K: int, mean: Tensor | None = None,
+                 out: Tensor | None = None) -> Tensor | None:
     """fc1 data gradient with the block LayerNorm's backward in the GEMM epilogue (VSX_EPI_LN_BWD, csrc/gemm_nt2.hip):
     dy = LN_backward(dh . WT^T; xh, rstd) [M, C] in ONE launch — dx^ is never written.  None if the shape is not served
     (the caller then runs the GEMM and vsx_ln_bwd).  With ``mean``: ``xh`` holds the UN-normalised rows y and ``dh`` the
     row-scaled dh * rstd of mlp_bwd_dh_ln."""
     if dh.dtype != torch.bfloat16 or not lib().vsx_gemm_nt_ln_bwd_supported(M, C, K, dtype_code(dh.dtype)):
         return None
-    dy = torch.empty((M, C), dtype=dh.dtype, device=dh.device)
+    dy = torch.empty((M, C), dtype=dh.dtype, device=dh.device) if out is None else out
     gemm("nt", dh, WT, dy, M, C, K, K, K, C, dtype=dh.dtype, epi=L.EPI_LN_BWD, aux=xh, ldx=C, grn_s=rstd, grn_b=mean)
     return dy
 
@@ -165,8 +166,8 @@ def ln_bwd(dy: Tensor, x: Tensor, mean: Tensor | None, rstd: Tensor, gamma: Tens
     return dx
 
 
-def grn_scale(colsq: Tensor, gamma: Tensor, eps: float = 1e-6) -> Tensor:
-    s = torch.empty_like(colsq)
+def grn_scale(colsq: Tensor, gamma: Tensor, eps: float = 1e-6, out: Tensor | None = None) -> Tensor:
+    s = torch.empty_like(colsq) if out is None else out
     check(lib().vsx_grn_scale(ptr(colsq), ptr(gamma), ptr(s), colsq.shape[0], colsq.shape[1], eps, stream()), "grn_scale")
     return s
 
@@ -528,16 +529,21 @@ def mlp_fc1(xh: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, 
 
 
 def mlp_fc1_ln(y: Tensor, img: Tensor, b1: Tensor, colsq: Tensor, M: int, C: int, hw: int, eps: float = 1e-6, store_h: bool = True,
-               store_xh: bool = True):
+               store_xh: bool = True, outs=None):
     """the block LayerNorm (no affine) + training fc1 in one pass over the depthwise convolution's output ``y``: returns
     (xh, rstd, h, g) — what ln_fwd + mlp_fc1 return, without the LayerNorm pass (``store_h=False``: h is None, see mlp_fc1).
     ``store_xh=False``: the normalised rows are not written either; the first item is then the pair (y, mean) the backward
     re-normalises from (mlp_bwd_dh_ln, dgrad_ln_bwd(mean=...))"""
-    xh = torch.empty_like(y) if store_xh else None
-    mean = None if store_xh else torch.empty(M, dtype=torch.float32, device=y.device)
-    rstd = torch.empty(M, dtype=torch.float32, device=y.device)
-    h = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device) if store_h else None
-    g = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device)
+    if outs is not None:  # (mean, rstd, g) views of caller-owned buffers: the sample-chunked schedule (store_h = store_xh = False)
+        assert not store_h and not store_xh
+        xh, h = None, None
+        mean, rstd, g = outs
+    else:
+        xh = torch.empty_like(y) if store_xh else None
+        mean = None if store_xh else torch.empty(M, dtype=torch.float32, device=y.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=y.device)
+        h = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device) if store_h else None
+        g = torch.empty((M, 4 * C), dtype=y.dtype, device=y.device)
     _det(y.device, (M // 256) * 4 * C)
     check(lib().vsx_mlp_fc1_ln(ptr(y), eps, ptr(xh), ptr(rstd), ptr(mean), ptr(img), ptr(b1), ptr(colsq), ptr(_gelu_table(y.device)),
                                ptr(h), ptr(g), M, C, hw, dtype_code(y.dtype), stream()), "mlp_fc1_ln")
@@ -583,11 +589,11 @@ def mlp_bwd_dh_re(dout: Tensor, xh: Tensor, img2: Tensor, img: Tensor, b1: Tenso
 
 
 def mlp_bwd_dh_ln(dout: Tensor, y: Tensor, mean: Tensor, rstd: Tensor, img2: Tensor, img: Tensor, b1: Tensor, s: Tensor, t: Tensor,
-                  colsum2: Tensor, M: int, C: int, hw: int) -> Tensor:
+                  colsum2: Tensor, M: int, C: int, hw: int, out: Tensor | None = None) -> Tensor:
     """mlp_bwd_dh_re for a block that stored no normalised rows: x^ is re-formed from the LayerNorm input ``y`` and its row
     statistics; returns dh' = dh * rstd (row-scaled); colsum2 [2, 4C] += {column sums of the UNSCALED dh, u = sum_r dh' * mean}
-    (see vsx_mlp_bwd_dh_ln for what the consumers do with them)"""
-    dh = torch.empty((M, 4 * C), dtype=dout.dtype, device=dout.device)
+    (see vsx_mlp_bwd_dh_ln for what the consumers do with them).  ``out``: a caller-owned [M, 4C] buffer (sample-chunked schedule)"""
+    dh = torch.empty((M, 4 * C), dtype=dout.dtype, device=dout.device) if out is None else out
     rows = M // int(lib().vsx_mlp_rows_per_workgroup(C, hw, M))
     ws = _workspace(dout.device, rows * 8 * C)
     check(lib().vsx_mlp_bwd_dh_ln(ptr(dout), ptr(y), ptr(mean), ptr(rstd), ptr(img2), ptr(img), ptr(b1), ptr(s), ptr(t), ptr(dh), ptr(ws),
