@@ -1126,6 +1126,7 @@ def test_v1_backbone_fc2_bias_gradient_on_the_statistics_in_tn_path():
     (B >= 228, 8 x 8 maps) take the fc2 weight gradient that also delivers the GRN statistics (gemm_tn_fast_kernel PRO == 2); the
     column sums of that launch must reach fc2.bias (and, through it, gamma) before `layer_scale_unfold` reads them.  Checked
     against the same backward with that launch switched off (`tn_rect` bit 3: statistics from the MODE 3 pass, colsum = db2)."""
+    from viscy_amd import _lib as L
     from viscy_amd.contrastive import ContrastiveEncoder
 
     lib = L.lib()

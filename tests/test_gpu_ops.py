@@ -355,9 +355,13 @@ def test_gemm_nt_per_sample_weights_fold_grn(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
-def test_gemm_nt_patch2_gather_and_scatter(dt):
+@pytest.mark.parametrize("B,gh,gw,cin,cout", [(2, 6, 5, 16, 24),      # generic kernel (cs % 32 != 0)
+                                              (3, 8, 8, 96, 192),     # lean kernel (round 6), 32-deep slabs, tiles across samples
+                                              (2, 16, 12, 64, 96),    # lean, 64-deep slabs, ragged last M tile (384 rows)
+                                              (5, 4, 4, 32, 80),      # lean, 16-pixel samples: 8 samples per 128-row tile
+                                              (1, 20, 36, 192, 384)]) # lean, wide grid (a tile spans < 4 grid rows)
+def test_gemm_nt_patch2_gather_and_scatter(dt, B, gh, gw, cin, cout):
     H = _hip()
-    B, gh, gw, cin, cout = 2, 6, 5, 16, 24
     M = B * gh * gw
     src = rnd(B * 4 * gh * gw, cin, dt=dt, seed=1)
     Wd = rnd(cout, 4 * cin, dt=dt, seed=2, scale=0.2)

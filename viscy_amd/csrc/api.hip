@@ -9,7 +9,7 @@ static thread_local char g_err[512] = "";
 thread_local const char* g_vsx_last_kernel = "";  // kernel template the last GEMM entry point on this thread dispatched (vsx_last_kernel)
 int g_vsx_tn_tr = 1;
 int g_vsx_nt_wide = 1;
-int g_vsx_nt_fast = 1;
+int g_vsx_nt_fast = 3;  // bit 0: the lean NT / TN instantiations; bit 1 (round 6): K tails and the 2 x 2 patch gather on the lean NT kernel
 int g_vsx_tn_wide = 1;
 int g_vsx_ggb_blocks = 2048;  // grn_gelu_bwd: target workgroup count (tuning knob, see norm.hip)
 int g_vsx_tn_rect = 11;  // rectangular TN tiles: bit 0 = when N or K is 224..256 wide, bit 1 = 256x128 when 256 divides N (no prologue), bit 2 = 128x256 when 256 divides K (slower: off), bit 3 (round 5) = where the block backward takes its GRN statistics by recomputation (C = 384), the fc2 weight gradient delivers them instead: per-sample products scaled / contracted in the accumulators (gemm_tn_fast_kernel PRO == 2; read by viscy_amd.ops.tn_grn_stats_ok)

@@ -514,7 +514,20 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
   const int b_tile = p.hw > 0 ? m0 / p.hw : 0;  // the tile lies inside one sample (dispatch guarantees it)
   // the A panel is addressed from the tile's own first row (64-bit scalar base per workgroup), so the per-lane 32-bit
   // offsets stay below BM * lda bytes whatever M is (M * lda * es passes 4 GB at B = 640 patches / B = 16 at 2048^2)
-  const char* Abase = reinterpret_cast<const char*>(p.A) + ((size_t)p.a_coff[z] + (size_t)m0 * (size_t)p.lda) * ES;
+  // round 6: the 2 x 2 stride-2 patch gather (VSX_A_PATCH2: the downsampling projections) on the lean kernel.  Row m = output
+  // pixel (b, y, x) of the gh x gw grid reads input pixel (2y + ky, 2x + kx) of the [B, 2gh, 2gw, cs] tensor for k = (ky, kx, c):
+  // the K slab picks (ky, kx, c0) — one scalar offset per slab (cs % BK == 0, dispatch) — and the lane offset is the distance of
+  // the row's top-left input pixel from the tile's first one (monotonic in m, < 2^32 bytes: dispatch)
+  const bool patch = p.a_mode == VSX_A_PATCH2;
+  auto pix0 = [&](int m) -> size_t {
+    const int hwg = p.gh * p.gw;
+    const int bb = m / hwg, rem = m - bb * hwg;
+    const int yy = rem / p.gw, xx = rem - yy * p.gw;
+    return ((size_t)bb * (2 * p.gh) + 2 * yy) * (size_t)(2 * p.gw) + 2 * xx;
+  };
+  const size_t pixm0 = patch ? pix0(m0) : 0;
+  const char* Abase = reinterpret_cast<const char*>(p.A) +
+                      ((size_t)p.a_coff[z] + (patch ? pixm0 : (size_t)m0) * (size_t)p.lda) * ES;
   const char* Bbase = reinterpret_cast<const char*>(p.B) + ((size_t)p.b_off[z] + (size_t)b_tile * (size_t)p.b_bstride) * ES;
   uint32_t offA[NA], offB[NB];
   int ldsA[NA], ldsB[NB];
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
     const int cid = tid + i * 256, row = cid / CPR, ch = cid % CPR;
     int m = m0 + row;
     m = m < p.M ? m : p.M - 1;
-    offA[i] = (uint32_t)(m - m0) * (uint32_t)(p.lda * ES) + ch * 16;
+    offA[i] = (patch ? (uint32_t)(pix0(m) - pixm0) : (uint32_t)(m - m0)) * (uint32_t)(p.lda * ES) + ch * 16;
     ldsA[i] = row * RS + ch * 16;
   }
 #pragma unroll
@@ -540,9 +553,33 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
   const bool split_tile = BM == 128 && p.hw > 0 && (p.hw % 128) != 0;
 
   vec ar[NA], br[NB];
+  const int nk = (p.K + BK - 1) / BK;
+  const int ktail = p.K % BK;  // round 6: K need not be a multiple of BK (K = 144 of the 64 x 64 decoder projection): the chunks of
+                               // the LAST slab at k >= K are loaded from the row's first chunk instead and zeroed (both operands)
   auto gload = [&](int kt, vec* ar, vec* br) {
-    const char* Ak = Abase + (size_t)kt * (BK * ES);
+    size_t aoff = (size_t)kt * (BK * ES);
+    if (patch) {
+      const int k0 = kt * BK, tap = k0 / p.cs, c0 = k0 - tap * p.cs;
+      aoff = ((size_t)((tap >> 1) * (2 * p.gw) + (tap & 1)) * (size_t)p.lda + c0) * ES;
+    }
+    const char* Ak = Abase + aoff;
     const char* Bk = Bbase + (size_t)kt * (BK * ES);
+    if (ktail != 0 && kt == nk - 1) {
+      const int ch = tid % CPR;  // (256 % CPR == 0: every chunk of this thread sits at the same K position)
+      const bool ok = ch * VN < ktail;
+      const int back = ok ? 0 : ch * 16;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const vec v = *reinterpret_cast<const vec*>(Ak + offA[i] - back);
+        ar[i] = ok ? v : vzero<T>();
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const vec v = *reinterpret_cast<const vec*>(Bk + offB[i] - back);
+        br[i] = ok ? v : vzero<T>();
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) ar[i] = *reinterpret_cast<const vec*>(Ak + offA[i]);  // (non-temporal loads of a read-once A panel: +-0, round 4)
 #pragma unroll
@@ -605,7 +642,6 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
   // one K-slab of register staging ahead of the MFMA work, LDS double buffer.  (Measured: staging two slabs ahead —
   // with unconditional loads so that the compiler really keeps `s_waitcnt vmcnt(4)` — changes nothing: the loop is
   // bound by LDS bandwidth (48 KB of LDS traffic per 16 MFMAs per wave tile of 64x64), not by load latency.)
-  const int nk = p.K / BK;
   gload(0, ar, br);
   if constexpr (NBUF == 2) {
     lstore(0, 0, ar, br);
@@ -713,6 +749,14 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : ((BK == 64 && NBUF == 1) ? 3 :
             }
           }
           // inference passes C = nullptr with EPI_BIAS_GELU_SQ: only the activation (C2) is kept, not the pre-activation
+          if constexpr (EPI == VSX_EPI_NONE || EPI == VSX_EPI_BIAS) {
+            if (p.c_mode == VSX_A_PATCH2) {  // round 6: scatter the row back to its 2 x 2 input patch, n = (ky, kx, c) (dispatch: bit 1)
+              const int tap = n / p.c_cs, c = n - tap * p.c_cs;
+              const size_t pix = pix0(m) + (size_t)(tap >> 1) * (2 * p.gw) + (tap & 1);
+              stvec<T>(reinterpret_cast<T*>(p.C) + pix * p.ldc + (size_t)p.c_coff[z] + c, pack<T>(v));
+              continue;
+            }
+          }
           if (EPI != VSX_EPI_BIAS_GELU_SQ || p.C != nullptr)
             stvec_stream(reinterpret_cast<T*>(p.C) + (size_t)m * p.ldc + ccol, pack<T>(v), ntst);
         }
@@ -782,12 +826,13 @@ static int launch_nt_fast(const VsxGemm* pin, hipStream_t s) {
   int tiles = vsx_cdiv(p->M, 128) * vsx_cdiv(p->N, 128);
   dim3 grid(tiles, 1, p->nz > 0 ? p->nz : 1);
   if constexpr (sizeof(T) == 2) {
-    if (g_vsx_nt_wide == 1 && p->K % 64 == 0 && p->K >= 256) {
+    const bool k64 = p->K % 64 == 0 && p->K >= 256 && (p->a_mode == VSX_A_ROWS || p->cs % 64 == 0);
+    if (g_vsx_nt_wide == 1 && k64) {
       hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 64, 1>), grid, dim3(256), 0, s, *p);
       VSX_LAUNCH_CHECK();
       return 0;
     }
-    if (g_vsx_nt_wide == 2 && p->K % 64 == 0 && p->K >= 256) {
+    if (g_vsx_nt_wide == 2 && k64) {
       hipLaunchKernelGGL((gemm_nt_fast_kernel<T, EPI, PRO, 64, 2>), grid, dim3(256), 0, s, *p);
       VSX_LAUNCH_CHECK();
       return 0;
@@ -808,7 +853,17 @@ static int launch_nt_fast(const VsxGemm* pin, hipStream_t s) {
 }
 
 static bool nt_fast_ok(const VsxGemm* p, int es) {
-  if (!g_vsx_nt_fast || p->N <= 64 || p->a_mode != VSX_A_ROWS || p->c_mode != VSX_A_ROWS || p->K % 32 != 0) return false;
+  // round 6 (nt_fast bit 1): K tails (K % 32 != 0: whole 16-byte chunks, zero-filled last slab) and the 2 x 2 patch gather
+  const bool ext = (g_vsx_nt_fast & 2) != 0;
+  if (!g_vsx_nt_fast || p->N <= 64) return false;
+  if (p->c_mode != VSX_A_ROWS && !(ext && p->c_mode == VSX_A_PATCH2 && p->a_mode == VSX_A_ROWS && p->pro != VSX_PRO_GRN && p->b_bstride == 0 &&
+                                   (p->epi == VSX_EPI_NONE || p->epi == VSX_EPI_BIAS)))
+    return false;
+  if (p->a_mode != VSX_A_ROWS && !(ext && p->a_mode == VSX_A_PATCH2 && p->cs % 32 == 0 && p->pro != VSX_PRO_GRN && p->b_bstride == 0 &&
+                                   (p->epi == VSX_EPI_NONE || p->epi == VSX_EPI_BIAS)))
+    return false;
+  if (p->K % 32 != 0 && !(ext && p->a_mode == VSX_A_ROWS && p->K > 32 && p->pro != VSX_PRO_GRN)) return false;
+  if (p->a_mode == VSX_A_PATCH2 && (unsigned long long)8 * p->gw * p->lda * es * (128 / p->gw + 2) >= (1ull << 32)) return false;
   if (p->epi == VSX_EPI_BIAS_STATS) return false;
   const bool reduce = p->epi == VSX_EPI_BIAS_GELU_SQ || p->epi == VSX_EPI_DZ;
   if (p->b_bstride != 0 && (p->hw <= 0 || p->hw % 128 != 0)) return false;

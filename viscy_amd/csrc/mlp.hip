@@ -819,6 +819,11 @@ __device__ __forceinline__ void mlp_fused_body(const MlpArgs& a) {
       }
   };
 
+  // A/B knob (round 6; MI355X_MICROARCH.md "two waves per SIMD", item 4): one static s_setprio for the second-dispatched half of
+  // the workgroup (a.nt bit 2) or for the first half (bit 3) — the arbiter serves priority, then age, so waves 0 - 3 reach every
+  // barrier ~1 000 cycles before waves 4 - 7 (profiles/r05_mlp_timeline.txt).  `wave` and a.nt are scalar: a scalar branch.
+  if (a.nt & 4) { if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1); }
+  if (a.nt & 8) { if (wave < NW / 2) __builtin_amdgcn_s_setprio(1); }
   static_assert(NHS % 2 == 0, "the hidden axis is walked two sub-chunks (one per stage buffer) per loop trip");
 #pragma unroll 1
   for (int hs = 0; hs < NHS; hs += 2) {
@@ -959,7 +964,7 @@ struct MlpCfg { int C, MF, NW, modes; };  // modes: bit m set = this geometry se
 extern int g_vsx_mlp_fused;
 extern int g_vsx_mlp_sf32;
 extern int g_vsx_nt_stream;
-static inline int mlp_nt() { return (g_vsx_nt_stream >> 2) & 3; }  // bits 2 / 3 of nt_stream: the fused passes' stores / last-reader loads
+static inline int mlp_nt() { return (g_vsx_nt_stream >> 2) & 15; }  // bits 2 / 3 of nt_stream: the fused passes' stores / last-reader loads; bits 4 / 5: static wave priority (A/B knob, see the kernel)
 static const MlpCfg kMlpCfgs[] = {{96, 2, 8, 255}, {192, 2, 8, 255}, {224, 2, 8, 255}, {384, 2, 8, 4 | 8 | 16}};
 
 static const MlpCfg* mlp_cfg(int C, int hw, long M, int mode) {
