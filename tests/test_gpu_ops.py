@@ -574,6 +574,29 @@ def test_gemm_tn_grn_and_patch2(dt, M, N, K, hw):
         close(a, b, dt, name)
 
 
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("B,gh,gw,cin,cout", [(4, 8, 8, 96, 192),      # lean TN kernel (round 6): 64-row steps = 8 grid rows, across samples
+                                              (3, 32, 32, 32, 96),     # gw = 32: two grid rows per step
+                                              (2, 16, 16, 192, 384),   # the 192 -> 384 projection's shape per sample
+                                              (6, 4, 4, 64, 128),      # 16-pixel samples
+                                              (2, 12, 24, 32, 96)])    # gw does not divide 32: generic kernel
+def test_gemm_tn_patch2_gather_shapes(dt, B, gh, gw, cin, cout):
+    """weight gradient of a 2 x 2 stride-2 projection: W[cout, (ky, kx, c)] = sum over output pixels of d^T . patch(src)"""
+    H = _hip()
+    Mp = B * gh * gw
+    src, d = rnd(B * 4 * gh * gw, cin, dt=dt, seed=5), rnd(Mp, cout, dt=dt, seed=6)
+
+    def run(ops, dev):
+        W2 = torch.zeros(cout, 4 * cin, device=dev)
+        cs = torch.zeros(cout, device=dev)
+        ops.gemm("tn", src.to(dev), d.to(dev), W2, Mp, cout, 4 * cin, cin, cout, 4 * cin, dtype=dt, a_mode=R.A_PATCH2,
+                 gh=gh, gw=gw, cs=cin, colsum=cs)
+        return W2, cs
+
+    for name, a, b in zip(["patch2 wgrad", "colsum"], run(H, DEV), run(R, "cpu")):
+        close(a, b, dt, name, scale=b.abs().max().item())
+
+
 # ------------------------------------------------------------------ LayerNorm / GRN
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("rows,C", [(300, 96), (64, 768), (17, 40), (100, 144), (33, 1024), (50, 224)])

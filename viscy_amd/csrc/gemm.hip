@@ -1240,7 +1240,12 @@ __global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && T
 
   const char* Xb = reinterpret_cast<const char*>(p.B) + (size_t)p.b_off[z] * ES;
   const char* Yb = reinterpret_cast<const char*>(p.A) + (size_t)p.a_coff[z] * ES;
-  const size_t xstep = (size_t)BMS * p.ldb * ES, ystep = (size_t)BMS * p.lda * ES;
+  // round 6: the Y operand gathered from 2 x 2 stride-2 patches (VSX_A_PATCH2: weight gradient of the downsampling projections).
+  // Row m = output pixel of the gh x gw grid; with gw | BMS (dispatch) a step of BMS rows is BMS / gw whole grid rows, the input
+  // pixel of row m is 4 gw (m / gw) + 2 (m % gw) whatever the sample, so a step advances the operand by 4 BMS input pixels and
+  // the lane offsets below never change
+  const bool ypatch = p.a_mode == VSX_A_PATCH2;
+  const size_t xstep = (size_t)BMS * p.ldb * ES, ystep = (size_t)(ypatch ? 4 * BMS : BMS) * p.lda * ES;
   uint32_t xoff[NCHX], yoff[NCHY];
   int ldsx[NCHX], ldsy[NCHY], kcol[NCHY];
   bool livex[NCHX], livey[NCHY];
@@ -1260,6 +1265,11 @@ __global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && T
     int kk = k0 + cch * VN;
     kk = kk < p.K ? kk : p.K - VN;
     kcol[i] = kk;
+    if (ypatch) {
+      const int tap = kk / p.cs, c = kk - tap * p.cs;
+      const int pix = (crow / p.gw) * (4 * p.gw) + 2 * (crow % p.gw) + (tap >> 1) * (2 * p.gw) + (tap & 1);
+      yoff[i] = (uint32_t)(pix * p.lda + c) * ES;
+    } else
     yoff[i] = (uint32_t)(crow * p.lda + kk) * ES;
     ldsy[i] = crow * LDBY + cch * 16;
   }
@@ -1663,7 +1673,9 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
     }
   }
   dim3 grid(tiles, splits, nz);
-  const bool fast = g_vsx_nt_fast && p->a_mode == VSX_A_ROWS && p->M % 32 == 0 && p->N >= VT<T>::N && p->K >= VT<T>::N &&
+  const bool patch_ok = (g_vsx_nt_fast & 2) && p->a_mode == VSX_A_PATCH2 && p->pro == VSX_PRO_NONE && p->gw > 0 && 32 % p->gw == 0 &&
+                        p->cs % VT<T>::N == 0 && (unsigned long long)512 * p->lda * sizeof(T) < (1ull << 31);
+  const bool fast = g_vsx_nt_fast && (p->a_mode == VSX_A_ROWS || patch_ok) && p->M % 32 == 0 && p->N >= VT<T>::N && p->K >= VT<T>::N &&
                     (p->pro == VSX_PRO_NONE || (p->pro == VSX_PRO_GRN && p->hw > 0 && p->hw % 32 == 0)) &&
                     (unsigned long long)32 * (p->lda > p->ldb ? p->lda : p->ldb) * sizeof(T) < (1ull << 31);
   if (fast) {
