@@ -695,7 +695,7 @@ def test_dwconv7_matrix_core_path(B, Hh, Ww, C):
         if wkind == "bf16_exact":
             w = w.to(torch.bfloat16).float()
         outs = {}
-        for flag in (31, 7, 0):  # LDS-DMA tile fetches wherever they can run (whole 32-channel slabs), register-staged tiles, VALU stencil
+        for flag in (31, 63, 7, 0):  # LDS-DMA tile fetches wherever they can run (whole 32-channel slabs), the same with two pixels per LDS access (bit 5, round 6), register-staged tiles, VALU stencil
             set_flag(flag)
             try:
                 outs[15 if flag == 31 else flag] = (H.dwconv7_fwd(x.to(DEV), w.to(DEV), bias.to(DEV), B, Hh, Ww, C).float().cpu(),
@@ -716,9 +716,10 @@ def test_dwconv7_matrix_core_path(B, Hh, Ww, C):
                     d = (a - b).abs()
                     assert d.max().item() <= (1.6e-2 if name == "dx_add" else 8e-3) * scale, (mm, name, d.max().item() / scale)
                     assert (d > 0).float().mean().item() < (0.5 if name == "dx_add" else 0.2), (mm, name, (d > 0).float().mean().item())
-        # the two matrix-core kernels run the same MFMA sequence on the same operands: identical bits
-        for name, a, b in zip(["y", "y_nobias", "dx_add", "dx"], outs[15], outs[7]):
-            assert torch.equal(a, b), (name, (a - b).abs().max().item())
+        # the matrix-core kernels run the same MFMA sequence on the same operands: identical bits
+        for other in (7, 63):
+            for name, a, b in zip(["y", "y_nobias", "dx_add", "dx"], outs[15], outs[other]):
+                assert torch.equal(a, b), (other, name, (a - b).abs().max().item())
 
 
     # weight gradient: row contraction on the matrix cores (transpose reads) vs the VALU kernel and the fp32 reference —

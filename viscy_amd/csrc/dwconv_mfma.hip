@@ -314,7 +314,16 @@ static __device__ __forceinline__ void dwd_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <bool FLIP, int CB>
+// PAIR (round 6): the LDS -> LDS transposition and the gather back out of the planes move TWO horizontally adjacent pixels per
+// access — 32-bit words [col, col + 1] of a channel plane instead of 2-byte elements: 8 ds_write_b32 per 2 x 16-byte piece where
+// the first version issued 16 ds_write_b16, 8 ds_read_b32 by half of the threads where all of them issued 8 ds_read_u16.  A tile
+// of this kernel is ~43 LDS instructions per wave against 14 MFMAs (profiles/r05_sq_counters.txt: 4.14e8 / 1.42e8), 24 of them these
+// 2-byte accesses.  Planes of PAIR builds are skewed by 32 elements per 8 channels (the four 8-channel vectors of 16 pixel pairs
+// land on 4 x 16 distinct banks).  Same arithmetic, bit-identical outputs.
+template <bool PAIR>
+static __device__ __forceinline__ int dwd_plane_base(int ch) { return ch * DWD_PLANE + (ch >> 3) * (PAIR ? 32 : 16); }
+
+template <bool FLIP, int CB, bool PAIR = false>
 __global__ __launch_bounds__(CB * 32, CB == 16 ? 4 : 1) void dwconv7_mfma_dma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                                        const float* __restrict__ bias,
                                                                        const bf16_t* __restrict__ add, bf16_t* __restrict__ y,
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(CB * 32, CB == 16 ? 4 : 1) void dwconv7_mfma_dma_ke
   __shared__ __attribute__((aligned(1024))) char raw1[G::RAW];
   __shared__ __attribute__((aligned(1024))) char radd0[G::ADD];
   __shared__ __attribute__((aligned(1024))) char radd1[G::ADD];
-  __shared__ __attribute__((aligned(16))) unsigned short planes[CB * DWD_PLANE + (CB / 8) * 16];
+  __shared__ __attribute__((aligned(16))) unsigned short planes[CB * DWD_PLANE + (CB / 8) * 32];
   __shared__ float wsm[49 * CB];
 
   int bid = blockIdx.x;
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(CB * 32, CB == 16 ? 4 : 1) void dwconv7_mfma_dma_ke
       int r = i / PADW;
       const int row = r % DWM_ROWS;
       const int ch = r / DWM_ROWS;
-      planes[dwm_plane_base(ch, DWD_PLANE) + row * DWD_PITCH + col] = 0;
+      planes[dwd_plane_base<PAIR>(ch) + row * DWD_PITCH + col] = 0;
     }
   }
 
@@ -411,31 +420,69 @@ __global__ __launch_bounds__(CB * 32, CB == 16 ? 4 : 1) void dwconv7_mfma_dma_ke
   int nx = 0;                                              // ... how many of them (wave-uniform)
 #pragma unroll
   for (int it = 0; it < G::XIT; ++it) nx += wave + G::NW * it < G::XINSTR ? 1 : 0;
+  // Round 6: addresses = one 64-bit SCALAR tile origin + a 32-bit byte offset that a thread computes ONCE.  Written per piece
+  // as (((b * H + gy) * W + gx) * C + ...) the index chain compiled to seven quarter-rate 32 / 64-bit multiplies per address, four
+  // addresses per tile: ~450 issue cycles per wave and tile, four waves per SIMD (the kernel is bound by its instruction issue:
+  // profiles/r05_sq_counters.txt, waves active 19 % each).  (dispatch: 32 rows of the image stay below 2^31 bytes)
+  // (few live registers on purpose: the kernel sits at its 128-register cap, a spilled thread constant is reloaded from scratch
+  // in front of the DMA issue and costs more than the multiplies did — measured: +30 % per launch with ten constants held)
+  static_assert(G::XIT <= 2 && THREADS % PP == 0, "row / column of the thread's two halo pieces packed into one register");
+  int xbyte[G::XIT];
+  uint32_t xrc = 0;  // (row, col) of halo piece `it` in bits [16 it, 16 it + 16)
+#pragma unroll
+  for (int it = 0; it < G::XIT; ++it) {
+    const int i = tid + it * THREADS;
+    const int cv = i % PP, p = i / PP;
+    const int col = p % DWD_IW, row = p / DWD_IW;
+    xrc |= (uint32_t)((row << 8) | col) << (16 * it);
+    xbyte[it] = (((row - 3) * W + (col - 3)) * C + cv * 8) * 2;
+  }
+  const int ocv = tid % PP;
+#define ocol ((tid / PP) & 15)
+#define orow ((tid / PP) >> 4)
+  const int obyte = ((orow * W + ocol) * C + ocv * 8) * 2;
+  auto tile_origin = [&](const TileAt& at) -> long long {   // element index of (b, y0, x0, c_base): scalar
+    return (((long long)at.b * H + at.y0) * W + at.x0) * (long long)C + c_base;
+  };
   auto issue_x = [&](const TileAt& at, uint32_t dst) {
+    const char* xt = reinterpret_cast<const char*>(x + tile_origin(at));
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it) {
       if (wave + G::NW * it >= G::XINSTR) break;
       const int i = tid + it * THREADS;
       if (i < G::XITEMS) {
-        const int cv = i % PP, p = i / PP;
-        const int col = p % DWD_IW, row = p / DWD_IW;
-        const int gy = at.y0 + row - 3, gx = at.x0 + col - 3;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const char* src = in ? reinterpret_cast<const char*>(x + (((size_t)at.b * H + gy) * W + gx) * C + c_base + cv * 8)
-                             : zsrc + cv * 16;
+        const int gy = at.y0 + (int)((xrc >> (16 * it + 8)) & 0xff) - 3, gx = at.x0 + (int)((xrc >> (16 * it)) & 0xff) - 3;
+        const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const char* src = in ? xt + xbyte[it] : zsrc + ocv * 16;
         dwd_dma16(src, dst + (wave + G::NW * it) * 1024);
       }
     }
   };
   auto issue_add = [&](const TileAt& at, uint32_t dst) {
-    const int cv = tid % PP, p = tid / PP;
-    const int col = p & 15, row = p >> 4;
-    const int gy = at.y0 + row, gx = at.x0 + col;
-    const bool in = gy < H && gx < W;
-    const char* src = in ? reinterpret_cast<const char*>(add + (((size_t)at.b * H + gy) * W + gx) * C + c_base + cv * 8) : zsrc + cv * 16;
+    const bool in = at.y0 + orow < H && at.x0 + ocol < W;
+    const char* src = in ? reinterpret_cast<const char*>(add + tile_origin(at)) + obyte : zsrc + ocv * 16;
     dwd_dma16(src, dst + wave * 1024);
   };
   auto transpose_in = [&](const char* rawb) {
+    if constexpr (PAIR) {
+      constexpr int XPAIRS = DWM_ROWS * (DWD_IW / 2) * PP;  // (pixel pair, 8-channel vector) items of a halo tile: 968 at CB = 32
+      static_assert(!PAIR || (XPAIRS <= THREADS && DWD_IW % 2 == 0), "one pixel pair per thread");
+      if (tid < XPAIRS) {
+        const int cv = tid % PP, pp = tid / PP;
+        const int colp = pp % (DWD_IW / 2), row = pp / (DWD_IW / 2);
+        const int ia = (row * DWD_IW + 2 * colp) * PP + cv;     // raw piece of the left pixel; the right one is PP pieces on
+        const uint4 va = *reinterpret_cast<const uint4*>(rawb + (size_t)ia * 16);
+        const uint4 vb = *reinterpret_cast<const uint4*>(rawb + (size_t)(ia + PP) * 16);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&planes[dwd_plane_base<PAIR>(cv * 8) + row * DWD_PITCH + 2 * colp]);
+        const uint32_t da[4] = {va.x, va.y, va.z, va.w}, db[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          dst[(e2 * 2) * (DWD_PLANE / 2)] = __builtin_amdgcn_perm(db[e2], da[e2], 0x05040100u);      // {a.lo, b.lo}
+          dst[(e2 * 2 + 1) * (DWD_PLANE / 2)] = __builtin_amdgcn_perm(db[e2], da[e2], 0x07060302u);  // {a.hi, b.hi}
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < G::XIT; ++it) {
       const int i = tid + it * THREADS;
@@ -443,7 +490,7 @@ __global__ __launch_bounds__(CB * 32, CB == 16 ? 4 : 1) void dwconv7_mfma_dma_ke
         const int cv = i % PP, p = i / PP;
         const int col = p % DWD_IW, row = p / DWD_IW;
         const uint4 v = *reinterpret_cast<const uint4*>(rawb + (size_t)i * 16);
-        unsigned short* dst = &planes[dwm_plane_base(cv * 8, DWD_PLANE) + row * DWD_PITCH + col];
+        unsigned short* dst = &planes[dwd_plane_base<PAIR>(cv * 8) + row * DWD_PITCH + col];
         const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2) {
@@ -473,7 +520,7 @@ __global__ __launch_bounds__(CB * 32, CB == 16 ? 4 : 1) void dwconv7_mfma_dma_ke
 #pragma unroll
     for (int cc = 0; cc < CPW; ++cc) {
       const int chl = wave * CPW + cc;
-      unsigned short* plane = &planes[dwm_plane_base(chl, DWD_PLANE)];
+      unsigned short* plane = &planes[dwd_plane_base<PAIR>(chl)];
       dwm_f32x4 acc = dwm_f32x4{bias_v[cc], bias_v[cc], bias_v[cc], bias_v[cc]};
 #pragma unroll
       for (int ky = 0; ky < 7; ++ky) {
@@ -491,17 +538,54 @@ __global__ __launch_bounds__(CB * 32, CB == 16 ? 4 : 1) void dwconv7_mfma_dma_ke
     // x(t+1) and add(t) are older.  add(t+1) is needed by the NEXT gather only, so it may stay in flight as well.
     wait_older_than((add && more1 ? 1 : 0) + (more2 ? nx : 0));
     dwd_barrier();                                    // H: every plane holds its channel's outputs
-    {
-      const int cv = tid % PP, p = tid / PP;
-      const int col = p & 15, row = p >> 4;
+    if constexpr (PAIR) {
+      if (tid < 128 * PP) {  // (pixel pair, 8-channel vector) items of the 16 x 16 outputs
+        const int cv = tid % PP, pp = tid / PP;
+        const int colp = pp & 7, row = pp >> 3;
+        const int gy = at.y0 + row, gx = at.x0 + 2 * colp;
+        if (gy < H && gx < W) {
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(&planes[dwd_plane_base<PAIR>(cv * 8) + row * DWD_PITCH + 2 * colp]);
+          uint32_t w[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = src[e * (DWD_PLANE / 2)];
+          uint4 oa, ob;
+          oa.x = __builtin_amdgcn_perm(w[1], w[0], 0x05040100u); ob.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
+          oa.y = __builtin_amdgcn_perm(w[3], w[2], 0x05040100u); ob.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+          oa.z = __builtin_amdgcn_perm(w[5], w[4], 0x05040100u); ob.z = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u);
+          oa.w = __builtin_amdgcn_perm(w[7], w[6], 0x05040100u); ob.w = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
+          const int ip = (row * 16 + 2 * colp) * PP + cv;  // shortcut piece of the left pixel in `addc`
+          const size_t off = (size_t)tile_origin(at) + (size_t)((row * W + 2 * colp) * C + cv * 8);
+          if (add) {
+            float a[8], f[8];
+            unpack<bf16_t>(*reinterpret_cast<const uint4*>(addc + (size_t)ip * 16), a);
+            unpack<bf16_t>(oa, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += a[j];
+            oa = pack<bf16_t>(f);
+          }
+          *reinterpret_cast<uint4*>(y + off) = oa;
+          if (gx + 1 < W) {
+            if (add) {
+              float a[8], f[8];
+              unpack<bf16_t>(*reinterpret_cast<const uint4*>(addc + (size_t)(ip + PP) * 16), a);
+              unpack<bf16_t>(ob, f);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) f[j] += a[j];
+              ob = pack<bf16_t>(f);
+            }
+            *reinterpret_cast<uint4*>(y + off + C) = ob;
+          }
+        }
+      }
+    } else {
+      const int cv = ocv, col = ocol, row = orow;
       const int gy = at.y0 + row, gx = at.x0 + col;
       if (gy < H && gx < W) {
-        const unsigned short* src = &planes[dwm_plane_base(cv * 8, DWD_PLANE) + row * DWD_PITCH + col];
+        const unsigned short* src = &planes[dwd_plane_base<PAIR>(cv * 8) + row * DWD_PITCH + col];
         uint32_t d[4];
 #pragma unroll
         for (int e2 = 0; e2 < 4; ++e2)
           d[e2] = (uint32_t)src[(e2 * 2) * DWD_PLANE] | ((uint32_t)src[(e2 * 2 + 1) * DWD_PLANE] << 16);
-        const size_t off = (((size_t)at.b * H + gy) * W + gx) * C + c_base + cv * 8;
         uint4 o = make_uint4(d[0], d[1], d[2], d[3]);
         if (add) {
           float a[8], f[8];
@@ -511,7 +595,7 @@ __global__ __launch_bounds__(CB * 32, CB == 16 ? 4 : 1) void dwconv7_mfma_dma_ke
           for (int j = 0; j < 8; ++j) f[j] += a[j];
           o = pack<bf16_t>(f);
         }
-        *reinterpret_cast<uint4*>(y + off) = o;
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y + tile_origin(at)) + obyte) = o;
       }
     }
   };
@@ -533,6 +617,8 @@ __global__ __launch_bounds__(CB * 32, CB == 16 ? 4 : 1) void dwconv7_mfma_dma_ke
 }
 
 
+#undef ocol
+#undef orow
 // ---------------------------------------------------------------------------------------------------------------------
 // weight gradient on the matrix cores.  dw_c[ky][kx] = sum_{y,x} dy_c[y][x] * in_c[y + ky - 3][x + kx - 3]: for one
 // channel and one ky, contract over 16 image ROWS with v_mfma_f32_16x16x16_bf16:
@@ -711,7 +797,8 @@ int vsx_dwconv7_mfma_try(const void* x, const float* w, const float* bias, const
   // the store loop) and maps of one tile (forward 75 / 69 at 16 x 16 x 384); the forward of larger maps keeps the 16 x 32 tiles of
   // the register-staged kernel (256 / 282, 125 / 133, 521 / 547: a smaller halo and half the barriers per pixel).  Bit 4: the
   // DMA kernel wherever it can run (A/B knob)
-  const bool dma = C % DWM_CB == 0 && (((g_vsx_dw_mfma & 8) && (add != nullptr || (H <= 16 && W <= 16))) || (g_vsx_dw_mfma & 16));
+  const bool dma = C % DWM_CB == 0 && (long)32 * W * C * 2 < 0x7fffffffL &&
+                   (((g_vsx_dw_mfma & 8) && (add != nullptr || (H <= 16 && W <= 16))) || (g_vsx_dw_mfma & 16));
   const int nxt = (W >= 24 && !dma) ? 2 : 1;
   const int tw = 16 * nxt;
   const int nslab = vsx_cdiv(C, DWM_CB);
@@ -729,11 +816,13 @@ int vsx_dwconv7_mfma_try(const void* x, const float* w, const float* bias, const
 #define DWM_LAUNCH(NXT, FLIP)                                                                                          \
   hipLaunchKernelGGL((dwconv7_mfma_kernel<NXT, FLIP>), dim3(grid), dim3(DWM_THREADS), 0, s, (const bf16_t*)x, w, bias,  \
                      (const bf16_t*)add, (bf16_t*)y, B, H, W, C, nslab, tiles, per)
-#define DWD_LAUNCH(FLIP, CBV)                                                                                                \
-  hipLaunchKernelGGL((dwconv7_mfma_dma_kernel<FLIP, CBV>), dim3(grid), dim3(CBV * 32), 0, s, (const bf16_t*)x, w, bias,          \
+#define DWD_LAUNCH(FLIP, CBV, PAIRV)                                                                                            \
+  hipLaunchKernelGGL((dwconv7_mfma_dma_kernel<FLIP, CBV, PAIRV>), dim3(grid), dim3(CBV * 32), 0, s, (const bf16_t*)x, w, bias,   \
                      (const bf16_t*)add, (bf16_t*)y, B, H, W, C, nslab, tiles, per)
-  if (dma) {
-    if (flip) DWD_LAUNCH(true, 32); else DWD_LAUNCH(false, 32);
+  if (dma && (g_vsx_dw_mfma & 32)) {  // bit 5 (round 6): two pixels per LDS access in the transposition / gather phases
+    if (flip) DWD_LAUNCH(true, 32, true); else DWD_LAUNCH(false, 32, true);
+  } else if (dma) {
+    if (flip) DWD_LAUNCH(true, 32, false); else DWD_LAUNCH(false, 32, false);
   } else if (nxt == 2) {
     if (flip) DWM_LAUNCH(2, true); else DWM_LAUNCH(2, false);
   } else {
