@@ -5,7 +5,7 @@
 #   hit / miss counters of the GEMM kernels, the un-profiled default bench line.
 # Run through gpurun, then `bash scripts/refresh_profiles.sh --collect` locally copies gpurun_out/* into profiles/.
 cd "$(dirname "$0")/.."
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 if [ "$1" == "--collect" ]; then
   cp gpurun_out/kernel_stats.csv profiles/${R}_kernel_stats.csv
   cp gpurun_out/kernel_stats_train.csv profiles/${R}_kernel_stats_train.csv

@@ -574,6 +574,31 @@ def test_gemm_tn_grn_and_patch2(dt, M, N, K, hw):
         close(a, b, dt, name)
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 896, 224), (4096, 768, 192), (16384, 1536, 384), (4096, 640, 200)])
+def test_gemm_tn_eight_wave_tiles(M, N, K):
+    """tn_rect bits 4 / 5 (round 6, off by default: +-0 on the step): 256 x 256 and 256 x 192 output tiles on eight-wave workgroups
+    give the products of the shipped tiles (other fp32 summation order)"""
+    from viscy_amd._lib import lib
+
+    H = _hip()
+    dt = torch.bfloat16
+    X, Y = rnd(M, N, dt=dt, seed=1).to(DEV), rnd(M, K, dt=dt, seed=2).to(DEV)
+    old = lib().vsx_get_flag(b"tn_rect")
+    res = []
+    try:
+        for f in (old & ~48, old | 48):
+            assert lib().vsx_set_flag(b"tn_rect", f) == 0
+            out, cs = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+            H.gemm("tn", Y, X, out, M, N, K, K, N, K, dtype=dt, colsum=cs)
+            res.append((out.cpu(), cs.cpu()))
+    finally:
+        lib().vsx_set_flag(b"tn_rect", old)
+    ref = X.float().t().cpu() @ Y.float().cpu()
+    for (o, c) in res:
+        assert ((o - ref).abs().max() / ref.abs().max()).item() < 2e-5
+        assert ((c - X.float().sum(0).cpu()).abs().max() / X.float().sum(0).abs().max().cpu()).item() < 1e-4
+
+
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("B,gh,gw,cin,cout", [(4, 8, 8, 96, 192),      # lean TN kernel (round 6): 64-row steps = 8 grid rows, across samples
                                               (3, 32, 32, 32, 96),     # gw = 32: two grid rows per step

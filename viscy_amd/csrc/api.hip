@@ -12,7 +12,7 @@ int g_vsx_nt_wide = 1;
 int g_vsx_nt_fast = 3;  // bit 0: the lean NT / TN instantiations; bit 1 (round 6): K tails and the 2 x 2 patch gather on the lean NT kernel
 int g_vsx_tn_wide = 1;
 int g_vsx_ggb_blocks = 2048;  // grn_gelu_bwd: target workgroup count (tuning knob, see norm.hip)
-int g_vsx_tn_rect = 11;  // rectangular TN tiles: bit 0 = when N or K is 224..256 wide, bit 1 = 256x128 when 256 divides N (no prologue), bit 2 = 128x256 when 256 divides K (slower: off), bit 3 (round 5) = where the block backward takes its GRN statistics by recomputation (C = 384), the fc2 weight gradient delivers them instead: per-sample products scaled / contracted in the accumulators (gemm_tn_fast_kernel PRO == 2; read by viscy_amd.ops.tn_grn_stats_ok)
+int g_vsx_tn_rect = 11;  // rectangular TN tiles: bit 0 = when N or K is 224..256 wide, bit 1 = 256x128 when 256 divides N (no prologue), bit 2 = 128x256 when 256 divides K (slower: off), bit 3 (round 5) = where the block backward takes its GRN statistics by recomputation (C = 384), the fc2 weight gradient delivers them instead: per-sample products scaled / contracted in the accumulators (gemm_tn_fast_kernel PRO == 2; read by viscy_amd.ops.tn_grn_stats_ok); bits 4 / 5 / 6 (round 6, off): eight-wave workgroups on 256 x 256 tiles for the plain weight gradients with K in [192, 256] (isolated -8 .. -15 %, step +-0), 256 x 192 tiles for K = 384 / 768 (+7 %), 256 x 256 tiles for the per-sample products (+4 .. +10 %)
 int g_vsx_dw_mfma = 15;  // depthwise conv on the matrix cores (dwconv_mfma.hip): bit 0 forward / data gradient (banded Toeplitz tiles), bit 3 the same with its tiles fetched by LDS-DMA two tiles ahead (round 4; whole 32-channel slabs only), bit 1 weight gradient (row contraction, transpose reads), bit 2 16-column weight-gradient tiles at every width (the 32-column variant spills: 471 vs 285 us at 64x64x96, B = 512); 0: VALU stencils
 int g_vsx_ln_fblk = 32768;  // LayerNorm forward: cap on workgroups per launch (each sweeps rows / cap windows).  Measured at B = 512 (64x64x96 / x224): 2048 -> 209 / 438 us, 8192 -> 172 / 351, 32768 -> 162 / 331 (a grid-stride sweep by few workgroups streams at 5.0 TB/s where one vector per thread reaches 6.8: tools/micro/write_rate.hip)
 int g_vsx_ln_bblk = 8192;   // LayerNorm backward WITHOUT affine gradients (the block LayerNorms): cap on workgroups (with dgamma: 512, same-address atomics).  512 -> 319 / 651 us, 2048 -> 254 / 586, 8192 -> 240 / 541 (16x16x384: 83 -> 61), 32768 -> 225 / 516 but 78 at 16x16x384
@@ -20,6 +20,7 @@ int g_vsx_nt_stream = 3;  // (round 4: a non-temporal LDS-DMA of the A panel in 
 int g_vsx_grn_stream = 2;  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
 int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup instead of grid-strided rows
 int g_vsx_tn_fill = 1;  // TN split counts chosen to fill their last round of workgroups (csrc/gemm.hip fill_splits)
+int g_vsx_tn_want3 = 256;  // TN split target of the eight-wave 256 x 256 / 256 x 384 tiles (tn_rect bit 4): workgroups per launch, one per CU
 int g_vsx_tn_want2 = 512;  // TN split target of the rectangular (256 x 128 / 128 x 256) tiles: workgroups per launch
 int g_vsx_tn_p2_rounds = 1;  // weight gradient with GRN statistics (gemm_tn_fast_kernel PRO == 2): rounds of 512 workgroups the split count aims at (0 = power-of-two splits, round-5 first version)
 int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x splits)
@@ -63,6 +64,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "tn_want")) { g_vsx_tn_want = value; return 0; }
   if (name && !strcmp(name, "tn_p2_rounds")) { g_vsx_tn_p2_rounds = value; return 0; }
   if (name && !strcmp(name, "tn_want2")) { g_vsx_tn_want2 = value; return 0; }
+  if (name && !strcmp(name, "tn_want3")) { g_vsx_tn_want3 = value; return 0; }
   if (name && !strcmp(name, "tn_fill")) { g_vsx_tn_fill = value; return 0; }
   if (name && !strcmp(name, "tn_contig")) { g_vsx_tn_contig = value; return 0; }
   if (name && !strcmp(name, "tn_stream")) { g_vsx_tn_stream = value; return 0; }
@@ -91,6 +93,7 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "tn_want")) return g_vsx_tn_want;
   if (name && !strcmp(name, "tn_p2_rounds")) return g_vsx_tn_p2_rounds;
   if (name && !strcmp(name, "tn_want2")) return g_vsx_tn_want2;
+  if (name && !strcmp(name, "tn_want3")) return g_vsx_tn_want3;
   if (name && !strcmp(name, "tn_fill")) return g_vsx_tn_fill;
   if (name && !strcmp(name, "tn_contig")) return g_vsx_tn_contig;
   if (name && !strcmp(name, "tn_stream")) return g_vsx_tn_stream;

@@ -26,6 +26,7 @@ extern int g_vsx_nt_stream;
 extern int g_vsx_tn_want;
 extern int g_vsx_tn_p2_rounds;
 extern int g_vsx_tn_want2;
+extern int g_vsx_tn_want3;
 extern int g_vsx_tn_fill;
 extern int g_vsx_tn_contig;
 extern int g_vsx_tn_stream;
@@ -1207,16 +1208,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const VsxGemm p, int rows_
 // The beta term is the rank-1 product (column sums of X) x beta, added once at the end; the column sums come from one extra MFMA
 // per X fragment against a ones operand.  By itself the post-scaled form is as fast as the prologue form (the launch is bound by
 // its operand stream, not by the prologue: 320 us plain vs 343 us at C = 384, B = 512); what it buys is the MODE 3 launch.
-template <typename T, int BT, bool TR, int PRO, int BMS = 32, int NBUF = 2, int BTK_ = 0>
-__global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1)) void gemm_tn_fast_kernel(const VsxGemm p) {
+// WG = 512 (round 6): eight waves as a 4 (N) x 2 (K) grid on ONE workgroup per CU — 256 x 256 and 256 x 384 output tiles.  The
+// split-K launches are bound by their operand stream L2 -> LDS (~10 TB/s chip-wide, section 3 item 18): a 128 x 256 tile moves
+// (128 + 256) / (128 * 256) operand elements per MAC, a 256 x 384 tile 1.8 x fewer, and an operand whose whole width fits the tile
+// is read exactly once by the launch.
+template <typename T, int BT, bool TR, int PRO, int BMS = 32, int NBUF = 2, int BTK_ = 0, int WG = 256>
+__global__ __launch_bounds__(WG, WG == 512 ? 1 : ((BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && TR && sizeof(T) == 2) ? 3 : 1))) void gemm_tn_fast_kernel(const VsxGemm p) {
   constexpr int ES = sizeof(T);
   constexpr int VN = VT<T>::N;
   constexpr int BTN = BT, BTK = BTK_ != 0 ? BTK_ : BT;
   constexpr int LDBX = (BTN + 16) * ES, LDBY = (BTK + 16) * ES;
   constexpr int CPRX = BTN / VN, CPRY = BTK / VN;
-  constexpr int NCHX = (BMS * CPRX + 255) / 256, NCHY = (BMS * CPRY + 255) / 256;
+  constexpr int NCHX = (BMS * CPRX + WG - 1) / WG, NCHY = (BMS * CPRY + WG - 1) / WG;
+  constexpr int WN = WG / 128;  // wave rows (N) x 2 wave columns (K)
+  static_assert(WG == 256 || (WG == 512 && PRO == 0), "the eight-wave geometry serves the plain weight gradients");
   constexpr int TILE_X = BMS * LDBX, TILE_Y = BMS * LDBY;
-  constexpr int FN_ = BTN / 2 / 16, FK_ = BTK / 2 / 16;
+  constexpr int FN_ = BTN / WN / 16, FK_ = BTK / 2 / 16;
   constexpr int MK = Frag<T>::MK;
   typedef typename VT<T>::vec vec;
   typedef typename Frag<T>::type frag_t;
@@ -1251,7 +1258,7 @@ __global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && T
   bool livex[NCHX], livey[NCHY];
 #pragma unroll
   for (int i = 0; i < NCHX; ++i) {
-    const int cid = tid + i * 256, crow = cid / CPRX, cch = cid % CPRX;
+    const int cid = tid + i * WG, crow = cid / CPRX, cch = cid % CPRX;
     livex[i] = cid < BMS * CPRX;
     int nn = n0 + cch * VN;
     nn = nn < p.N ? nn : p.N - VN;
@@ -1260,7 +1267,7 @@ __global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && T
   }
 #pragma unroll
   for (int i = 0; i < NCHY; ++i) {
-    const int cid = tid + i * 256, crow = cid / CPRY, cch = cid % CPRY;
+    const int cid = tid + i * WG, crow = cid / CPRY, cch = cid % CPRY;
     livey[i] = cid < BMS * CPRY;
     int kk = k0 + cch * VN;
     kk = kk < p.K ? kk : p.K - VN;
@@ -1391,15 +1398,22 @@ __global__ __launch_bounds__(256, (BTK_ != 0 || PRO == 2) ? 2 : ((BMS == 64 && T
       // bf16: one MFMA contraction step = 32 tile rows (the transposing read addresses rows r, r + 16 of them)
       const char* Xk = Xs + (sizeof(T) == 2 ? kk * 32 * LDBX : 0);
       const char* Yk = Ys + (sizeof(T) == 2 ? kk * 32 * LDBY : 0);
-      frag_t xf[FN_], yf[FK_];
+      // (the Y fragments in groups of at most 6: with all 12 of the 384-wide tile live next to 192 accumulator registers the
+      // kernel spilled 105 registers)
+      constexpr int JH = FK_ > 8 ? 2 : 1, JW = FK_ / JH;
+      static_assert(FK_ % JH == 0, "Y fragments split evenly");
+      frag_t xf[FN_], yf[JW];
 #pragma unroll
       for (int i = 0; i < FN_; ++i) xf[i] = lds_frag_mn<T, TR>(Xk, LDBX, (wn * FN_ + i) * 16, p16, kq, kk);
 #pragma unroll
-      for (int j = 0; j < FK_; ++j) yf[j] = lds_frag_mn<T, TR>(Yk, LDBY, (wk * FK_ + j) * 16, p16, kq, kk);
+      for (int jh = 0; jh < JH; ++jh) {
 #pragma unroll
-      for (int i = 0; i < FN_; ++i)
+        for (int j = 0; j < JW; ++j) yf[j] = lds_frag_mn<T, TR>(Yk, LDBY, (wk * FK_ + jh * JW + j) * 16, p16, kq, kk);
 #pragma unroll
-        for (int j = 0; j < FK_; ++j) acc[i][j] = mfma16(xf[i], yf[j], acc[i][j]);
+        for (int i = 0; i < FN_; ++i)
+#pragma unroll
+          for (int j = 0; j < JW; ++j) acc[i][jh * JW + j] = mfma16(xf[i], yf[j], acc[i][jh * JW + j]);
+      }
       if constexpr (PRO == 2) {
         // column sums of X (beta term, bias gradient) on the matrix cores: X^T . 1 has them in every column; the two waves that
         // share an X row range take two fragments each (a scalar loop over the tile cost as much as the step's MFMAs)
@@ -1602,7 +1616,8 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
       // N = 192 too since round 4: a quarter of the 256-wide tile idles, but the 4C-wide operand is read once instead of twice and,
       // with its loads non-temporal (tn_stream), the launch is 4 % faster than on 128 x 128 tiles (328 -> 315 us at B = 512)
       const bool n_full = p->N >= 192 && p->N <= 256 && p->K >= 128;
-      const int t2 = n_full ? vsx_cdiv(p->N, 256) * vsx_cdiv(p->K, 128) : tiles;
+      const bool big = TR && (g_vsx_tn_rect & 64) && n_full && p->K >= 512;  // round 6, bit 6 (off: 1 210 -> 1 340 us at C = 224, 308 -> 320 at C = 192): eight-wave 256 x 256 tiles, one workgroup per CU
+      const int t2 = big ? vsx_cdiv(p->K, 256) : (n_full ? vsx_cdiv(p->N, 256) * vsx_cdiv(p->K, 128) : tiles);
       // few samples with large maps (the 2048^2 gate shape: 8 samples of 262 144 rows): ks splits per sample so that the launch
       // still fills the chip; their partial products meet in zero-filled outputs through atomics (<= ks adds per address)
       int ks = 1;
@@ -1611,7 +1626,7 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
       if (g_vsx_tn_fill && ks > 1) {
         // ... and of the power-of-two counts from there up to 4 x, the one that fills its last round of workgroups best (2 per CU for
         // the 256-wide tiles, 3 for the square ones): 8 samples x 36 tiles x 4 ran 1.5 rounds at the gate shape's C = 384 blocks
-        const int slots = 256 * (n_full ? 2 : 3);
+        const int slots = 256 * (big ? 1 : (n_full ? 2 : 3));
         int best = ks;
         double bf = -1.0;
         for (int k2 = ks; k2 <= 4 * ks && k2 <= 64 && spp % k2 == 0; k2 *= 2) {
@@ -1627,7 +1642,10 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
         hipLaunchKernelGGL(tn_zero_kernel, dim3(vsx_cdiv(nq, 1024L)), dim3(256), 0, s, reinterpret_cast<float*>(p->C) + p->c_coff[0], nq);
         if (nc) hipLaunchKernelGGL(tn_zero_kernel, dim3(vsx_cdiv(nc, 1024L)), dim3(256), 0, s, p->colsum, nc);
       }
-      if (n_full) {
+      if (big) {
+        dim3 g2(t2, nb * ks, 1);
+        hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, false, 32, 2, 256, 512>), g2, dim3(512), 0, s, pq);
+      } else if (n_full) {
         dim3 g2(t2, nb * ks, 1);
         hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, false, 64, 1, 128>), g2, dim3(256), 0, s, pq);
       } else {
@@ -1690,6 +1708,25 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
           grid.y = splits = spf < 1 ? 1 : spf;
         }
         if constexpr (TR) {
+          // round 6, tn_rect bit 4: eight-wave workgroups on 256 x 256 / 256 x 384 tiles (one per CU) for the plain weight gradients
+          // whose K side fits (or divides into) such a tile: dW1 of the C = 192 / 224 (256 wide), C = 384 / 768 (384 wide) blocks
+          if ((g_vsx_tn_rect & 16) && p->pro == VSX_PRO_NONE && p->a_mode == VSX_A_ROWS && p->N >= 512 && p->M % 32 == 0) {
+            // (a 256 x 384 tile — the K side of the C = 384 / 768 gradients in one tile — needs 192 accumulator registers and spilled
+            // 60 - 105: 228 -> 410 us.  Those launches take 192-wide K tiles instead: tn_rect bit 5)
+            const int btk = (p->K >= 192 && p->K <= 256) ? 256 : (((g_vsx_tn_rect & 32) && p->K > 256 && p->K % 192 == 0) ? 192 : 0);
+            if (btk) {
+              const int t3 = vsx_cdiv(p->N, 256) * vsx_cdiv(p->K, btk);
+              int sp3 = vsx_cdiv(g_vsx_tn_want3, t3 * nz);
+              if (sp3 > p->M / 64) sp3 = p->M / 64;
+              if (g_vsx_tn_fill) sp3 = fill_splits(t3 * nz, 1, sp3, p->M / 64);
+              if (sp3 < 1) sp3 = 1;
+              dim3 g3(t3, sp3, nz);
+              if (btk == 192) hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, false, 32, 2, 192, 512>), g3, dim3(512), 0, s, pq);
+              else hipLaunchKernelGGL((gemm_tn_fast_kernel<T, 256, TR, false, 32, 2, 256, 512>), g3, dim3(512), 0, s, pq);
+              VSX_LAUNCH_CHECK();
+              return 0;
+            }
+          }
           // rectangular tiles when one side of the weight gradient fits a single 256-wide tile (see the kernel's header)
           // measured (tools/perf_nt.py, B = 512): C = 224 -9 % (dW1) / -14 % (dW2); C = 192 +4..8 % (a quarter of the
           // 256-wide tile idles) -> only when the tile is >= 7/8 full
