@@ -32,7 +32,7 @@ int g_vsx_mlp_sf32 = 1 | 4 | 64;  // fused GRN-MLP kernels: bit m = MODE m runs 
 int g_vsx_det_reduce = 0;  // 1: the forward's per-sample sums — GRN sum g^2 of the fused GRN-MLP passes and of gemm_nt2's GELU epilogue, InstanceNorm sum / sum^2 of the direct head convolution — are formed in a FIXED order (per-workgroup partials in a caller-owned workspace, vsx_det_workspace, then one ordered pass) instead of by fp32 atomics: the bf16 forward is then bit-identical from run to run (with atomics: 7e-3 of the output maximum at 2048^2).  Cost: one small launch per pass, tools/det_fwd.py
 thread_local float* g_vsx_det_ws = nullptr;
 thread_local long g_vsx_det_ws_floats = 0;
-int g_vsx_nt2 = 1;  // second-generation NT kernel (gemm_nt2.hip: 256 x 128 tiles, LDS-DMA operand path, wave-private epilogue): bit 0 = on for the launches it supports, bit 1 = also below 512 tiles
+int g_vsx_nt2 = 17;  // second-generation NT kernel (gemm_nt2.hip: 256 x 128 tiles, LDS-DMA operand path, wave-private epilogue): bit 0 = on for the launches it supports, bit 1 = also below 512 tiles
 int g_vsx_loss_fused = 1;  // MixedLoss training forward: one pass per scale (SSIM sums + gradient field + next scale's pooling / data range + L1 / L2 sums: vsx_ssim_scale_fwd_fused) instead of a pooling pass and an SSIM pass; read by viscy_amd/losses.py
 
 void vsx_set_error(const char* fmt, ...) {

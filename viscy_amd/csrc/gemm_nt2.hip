@@ -668,7 +668,7 @@ bool vsx_gemm_nt2_ok(const VsxGemm* p) {
   if (p->epi == VSX_EPI_DZ) return false;
   if (p->pro == VSX_PRO_GRN) return p->K >= 768 && p->N >= 192;  // the fc2 forward of the 16 x 16 maps (C = 384)
   if (p->epi == VSX_EPI_BIAS_GELU_SQ) return bn == 384 && p->N % 384 == 0 && p->K >= 384 && p->K <= 768;
-  return p->K >= 768 && p->N > 192;
+  return p->K >= 768 && (p->N > 192 || ((g_vsx_nt2 & 16) && p->N == 192));  // bit 4 (round 6, A/B): the C = 192 fc2 forward too
 }
 
 int vsx_gemm_nt2(const VsxGemm* p0, hipStream_t s) {
