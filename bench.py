@@ -279,17 +279,19 @@ def gate_shape_record(dev, steps: int = 5, B: int = 8, size: int = 2048) -> dict
             "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 1e9, 1)}
 
 
-def _cpu_baseline_child(fixture_path: str | None = None):
+def _cpu_baseline_child(fixture_path: str | None = None, only_threads: int | None = None):
     """Runs in a child process; prints one JSON line per completed measurement (the parent keeps the last).  Phase 1 writes the
     fp32 parity fixture; the timing phase starts only when the parent has finished its GPU sub-records (`<fixture>.go` appears):
     a multi-threaded oracle step beside the gate-shape / fp32 sub-runs perturbed both sides."""
     from oracle import loss_ref, unext2_ref
 
     ncpu = os.cpu_count() or 1
+    if only_threads:  # the all-cores leg: a FRESH process that starts with that many threads (re-sizing the thread pool of a
+        fixture_path = None  # process that already ran at 32 threads did not finish one step in 87 s on the 256-thread host)
     # torch's CPU kernels stop scaling (and then regress) well below the 256 hardware threads of the GPU host: 32 threads
     # measured fastest there (tools/cpu_probe.py).  BOTH figures are reported (VERDICT r5): `value` / `cores` = the 32-thread
     # run, `all_cores` = the same step under set_num_threads(os.cpu_count()), which is what BASELINE.md section 3 prescribes.
-    torch.set_num_threads(min(ncpu, 32))
+    torch.set_num_threads(only_threads or min(ncpu, 32))
     kw = dict(in_channels=1, out_channels=2, in_stack_depth=5, backbone="convnextv2_tiny", head_pool=True)
     model = unext2_ref.randomize_(unext2_ref.UNeXt2(**kw), seed=0)
     opt = torch.optim.AdamW(model.parameters(), lr=2e-4)
@@ -329,13 +331,25 @@ def _cpu_baseline_child(fixture_path: str | None = None):
                 break
         return rec
 
+    if only_threads:
+        run(only_threads, 4, 30.0, {"_partial": True})
+        return
     first = run(min(ncpu, 32), 10, 25.0, {})
     if first is not None and ncpu > 32:
+        import subprocess
+
         print(json.dumps({"_all_cores_started": time.time(), "threads": ncpu}), flush=True)
-        allc = run(ncpu, 4, 30.0, {"_partial": True})
-        if allc is not None:
-            first["all_cores"] = {"value": allc["value"], "threads_used": ncpu,
-                                  "note": "same step under torch.set_num_threads(os.cpu_count()), BASELINE.md section 3"}
+        env = dict(os.environ, OMP_NUM_THREADS=str(ncpu), MKL_NUM_THREADS=str(ncpu))
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "-", "--threads", str(ncpu)],
+                                 capture_output=True, text=True, timeout=60.0, env=env).stdout
+        except subprocess.TimeoutExpired as e:
+            out = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        vals = [json.loads(l) for l in out.splitlines() if l.startswith("{") and '"value"' in l]
+        if vals:
+            first["all_cores"] = {"value": vals[-1]["value"], "threads_used": ncpu,
+                                  "note": "same step in a fresh process under torch.set_num_threads(os.cpu_count()), BASELINE.md section 3: "
+                                          + vals[-1]["sample"].split(" of the fp32")[0]}
             print(json.dumps(first), flush=True)
 
 
@@ -540,7 +554,9 @@ def resolve_world(gpus: int, env: dict, visible_devices: int) -> tuple[str, int]
 def main():
     if "--cpu-baseline-child" in sys.argv:
         i = sys.argv.index("--cpu-baseline-child")
-        _cpu_baseline_child(sys.argv[i + 1] if i + 1 < len(sys.argv) else None)
+        fx = sys.argv[i + 1] if i + 1 < len(sys.argv) else None
+        nt = int(sys.argv[sys.argv.index("--threads") + 1]) if "--threads" in sys.argv else None
+        _cpu_baseline_child(None if fx == "-" else fx, nt)
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node to run on: one rank per GPU.  Started as a single process "
