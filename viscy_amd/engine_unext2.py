@@ -370,6 +370,8 @@ class Engine:
         weight gradient is a plain TN GEMM on y with a rank-1 correction, the data-gradient GEMM's LayerNorm epilogue re-forms
         x^ from y.  Needs that epilogue (C <= 256): the stand-alone LayerNorm backward reads a stored x^."""
         flag = self._mlp_flag()
+        if str(C) in os.environ.get("VSX_DROPXH_SKIP", "").split(","):  # A/B knob: widths that keep x^ stored (MODE 5) under bit 7
+            return False
         return bool(flag & 128) and bool(flag & 32) and self._mlp_recompute_h(C, hw, M, dt, B) and self.ops.mlp_supported(C, hw, M, dt, 7) \
             and hasattr(self.ops, "dgrad_ln_bwd") and bool(L.lib().vsx_gemm_nt_ln_bwd_supported(M, C, 4 * C, L.dtype_code(dt)))
 
