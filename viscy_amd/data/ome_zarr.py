@@ -152,16 +152,18 @@ class ImageArray:
             return _codecs.decode_v3(f.read_bytes(), self.codecs, self.dtype, self.chunks)
         per = tuple(o // c for o, c in zip(self.shard, self.chunks))
         sidx = tuple(i // p for i, p in zip(idx, per))
-        if self._shard_cache is None or self._shard_cache[0] != sidx:  # one shard stays open: neighbouring chunks share it
+        cache = self._shard_cache  # a local snapshot: another thread sharing this array may swap the cache between check and use
+        if cache is None or cache[0] != sidx:  # one shard stays open: neighbouring chunks share it
             f = self._v3_file(sidx)
             if not f.exists():
-                self._shard_cache = (sidx, None, None)
+                cache = (sidx, None, None)
             else:
                 raw = np.memmap(f, dtype=np.uint8, mode="r")
-                self._shard_cache = (sidx, raw, _codecs.read_shard_index(bytes(raw[-(int(np.prod(per)) * 16 + 4):]) if self.index_location == "end"
-                                                                          else bytes(raw[: int(np.prod(per)) * 16 + 4]), per,
-                                                                          self.index_codecs, self.index_location))
-        _, raw, table = self._shard_cache
+                cache = (sidx, raw, _codecs.read_shard_index(bytes(raw[-(int(np.prod(per)) * 16 + 4):]) if self.index_location == "end"
+                                                             else bytes(raw[: int(np.prod(per)) * 16 + 4]), per,
+                                                             self.index_codecs, self.index_location))
+            self._shard_cache = cache
+        _, raw, table = cache
         if raw is None:
             return np.full(self.chunks, self.fill, dtype=self.dtype)
         off, nb = (int(v) for v in table[tuple(i % p for i, p in zip(idx, per))])
