@@ -295,6 +295,15 @@ class Position:
         """iohub ``Position.append_channel`` (prediction_writer.py:205-207)."""
         if name in self.channel_names:
             raise ValueError(f"channel {name!r} already exists")
+        if resize_arrays:  # fail BEFORE the metadata is touched when the arrays' chunks cannot be written here (ADVICE r5)
+            for d in self.zattrs.get("multiscales", [{}])[0].get("datasets", []):
+                img = self[d["path"]]
+                if getattr(img, "v3", False):
+                    raise NotImplementedError("appending channels to a zarr v3 store is not built (read-only support)")
+                try:
+                    _codecs.encode_v2(b"\0" * 16, img.compressor)
+                except NotImplementedError as e:
+                    raise NotImplementedError(f"cannot append channel {name!r}: {e} — write the predictions to a new store") from e
         self.channel_names.append(name)
         self.zattrs["omero"]["channels"].append({"label": name})
         self._save()
