@@ -454,15 +454,16 @@ def test_baseline_size_fp32_and_bf16_engines_vs_reference_golden():
     for gname, (omc, rel) in stages.items():
         assert omc <= 1.25 * ys[gname][0], (gname, omc, ys[gname])
         assert rel <= 1.25 * ys[gname][1], (gname, rel, ys[gname])
-    # the block schedules behind the other values of `mlp_fused` are held to the same yardstick: 111 = the normalised rows x^
-    # are stored (MODE 6 / 5; the default 239 re-forms them from the depthwise output, MODE 7), 47 = the pre-activation h is
-    # stored as well (MODE 2 / 4), 15 = LayerNorm as a pass of its own
+    # the block schedules behind the other values of `mlp_fused` are held to the same yardstick: 239 = the normalised rows x^ are
+    # NOT stored but re-formed from the depthwise output (MODE 7; the default of rounds 4 - 5; round 6 ships 111 = x^ stored,
+    # MODE 6 / 5: 0.6 % faster on the step), 47 = the pre-activation h is stored as well (MODE 2 / 4), 15 = LayerNorm as a pass
+    # of its own
     from viscy_amd import _lib as L
 
     saved = L.lib().vsx_get_flag(b"mlp_fused")
-    assert saved & 128, "the shipped schedule does not store the normalised rows"
+    assert saved == 111, "the shipped schedule stores the normalised rows and recomputes h"
     try:
-        for flag in (111, 47, 15):
+        for flag in (239, 47, 15):
             L.lib().vsx_set_flag(b"mlp_fused", flag)
             fwd, lrel, stages = run_engine(torch.bfloat16)
             print(f"bf16 engine @256, mlp_fused = {flag}: forward {fwd:.2e} loss {lrel:.2e}", {k: f"{v[0]:.1e}" for k, v in stages.items()})

@@ -27,7 +27,7 @@ int g_vsx_tn_want = 768;  // TN split target: workgroups per launch (tiles x spl
 int g_vsx_ln_stream = 3;  // non-temporal loads of operands with no later reader: bit 0 = ln_bwd (dy, x: -2 % on the kernel), bit 1 = ln_fwd (x: -4.5 %)
 int g_vsx_tn_stream = 3;  // lean TN kernel: non-temporal loads of an operand that the launch reads exactly once (its dimension fits one tile): bit 0 = X [M, N], bit 1 = Y [M, K] (round 4)
 int g_vsx_tn_contig = 1;  // lean TN kernel: contiguous step range per split
-int g_vsx_mlp_fused = 239;  // fused GRN-MLP kernels (csrc/mlp.hip): bit 0 = inference forward (statistics + output passes, hidden activation on chip), bit 1 = training fc1 (statistics pass that also stores h and g), bit 3 = block backward without a stored dz (statistics from the per-sample weight-gradient products or MODE 3, then MODE 4 writes dh once) — on the C = 96 / 192 / 224 blocks; bit 2 = the training passes also on the C = 384 blocks (same step time, 7.7 GB less traffic per step); (bit 4 was the inference pair on the C = 384 blocks, slower than the unfused GEMMs there: removed in round 4); bit 5 = the block LayerNorm in the prologue of the fused passes (vsx_mlp_fwd_ln / vsx_mlp_fc1_ln: no separate LayerNorm pass); bit 6 = the pre-activation h is never stored on the C <= 224 blocks: the training fc1 writes g only (MODE 6) and the dh pass recomputes h from the C-wide normalised rows (MODE 5, vsx_mlp_bwd_dh_re); bit 7 (with 5 and 6) = the normalised rows x^ are not stored either: the forward keeps the depthwise output y + the row mean / rstd, the dh pass re-normalises y and writes dh * rstd (MODE 7, vsx_mlp_bwd_dh_ln), the fc1 weight gradient is a plain TN GEMM on y with a rank-1 correction, the LayerNorm backward in the data-gradient GEMM re-forms x^ from y
+int g_vsx_mlp_fused = 111;  // fused GRN-MLP kernels (csrc/mlp.hip): bit 0 = inference forward (statistics + output passes, hidden activation on chip), bit 1 = training fc1 (statistics pass that also stores h and g), bit 3 = block backward without a stored dz (statistics from the per-sample weight-gradient products or MODE 3, then MODE 4 writes dh once) — on the C = 96 / 192 / 224 blocks; bit 2 = the training passes also on the C = 384 blocks (same step time, 7.7 GB less traffic per step); (bit 4 was the inference pair on the C = 384 blocks, slower than the unfused GEMMs there: removed in round 4); bit 5 = the block LayerNorm in the prologue of the fused passes (vsx_mlp_fwd_ln / vsx_mlp_fc1_ln: no separate LayerNorm pass); bit 6 = the pre-activation h is never stored on the C <= 224 blocks: the training fc1 writes g only (MODE 6) and the dh pass recomputes h from the C-wide normalised rows (MODE 5, vsx_mlp_bwd_dh_re); bit 7 (with 5 and 6) = the normalised rows x^ are not stored either: the forward keeps the depthwise output y + the row mean / rstd, the dh pass re-normalises y and writes dh * rstd (MODE 7, vsx_mlp_bwd_dh_ln), the fc1 weight gradient is a plain TN GEMM on y with a rank-1 correction, the LayerNorm backward in the data-gradient GEMM re-forms x^ from y.  Round 6 ships 111 (bit 7 off: x^ stored again, MODE 5): 92.28 -> 91.72 ms on the bench step, 90.42 -> 89.95 ms on the gate shape, four alternating pairs each on one box (and -0.25 / -0.7 ms on two other boxes), for 5.2 GB / step more C-wide writes: at round 6's kernels the re-normalisation in the dh pass and the rank-1 correction cost more than the bytes they save
 int g_vsx_mlp_sf32 = 1 | 4 | 64;  // fused GRN-MLP kernels: bit m = MODE m runs the build without packed-fp32 VALU instructions (csrc/mlp.hip, round 5: a v_pk_*_f32 next to MFMAs costs ~15 cycles; the forward passes gain 6 - 20 %, the dh passes are VALU-bound and keep the packed build)
 int g_vsx_det_reduce = 0;  // 1: the forward's per-sample sums — GRN sum g^2 of the fused GRN-MLP passes and of gemm_nt2's GELU epilogue, InstanceNorm sum / sum^2 of the direct head convolution — are formed in a FIXED order (per-workgroup partials in a caller-owned workspace, vsx_det_workspace, then one ordered pass) instead of by fp32 atomics: the bf16 forward is then bit-identical from run to run (with atomics: 7e-3 of the output maximum at 2048^2).  Cost: one small launch per pass, tools/det_fwd.py
 thread_local float* g_vsx_det_ws = nullptr;
