@@ -1740,6 +1740,8 @@ def test_fused_passes_scalar_and_packed_fp32_builds_agree(C, hw, B):
     M, H4 = B * hw, 4 * C
     lib = L.lib()
     saved = lib.vsx_get_flag(b"mlp_sf32")
+    saved_fused = lib.vsx_get_flag(b"mlp_fused")
+    lib.vsx_set_flag(b"mlp_fused", saved_fused | 128)  # every pass, also the one the shipped schedule no longer takes (MODE 7)
     y = rnd(M, C, dt=dt, seed=1, scale=2.0).cuda()
     W1 = rnd(H4, C, dt=dt, seed=2, scale=C ** -0.5).cuda()
     W2 = rnd(C, H4, dt=dt, seed=3, scale=H4 ** -0.5).cuda()
@@ -1783,6 +1785,7 @@ def test_fused_passes_scalar_and_packed_fp32_builds_agree(C, hw, B):
         scalar = passes()
     finally:
         lib.vsx_set_flag(b"mlp_sf32", saved)
+        lib.vsx_set_flag(b"mlp_fused", saved_fused)
     assert packed.keys() == scalar.keys() and len(packed) >= 6
     for k in packed:
         if packed[k].dtype == torch.float32 and ("sums" in k or "stats" in k or k.startswith("db1")):
