@@ -604,7 +604,10 @@ def test_gemm_tn_eight_wave_tiles(M, N, K):
                                               (3, 32, 32, 32, 96),     # gw = 32: two grid rows per step
                                               (2, 16, 16, 192, 384),   # the 192 -> 384 projection's shape per sample
                                               (6, 4, 4, 64, 128),      # 16-pixel samples
-                                              (2, 12, 24, 32, 96)])    # gw does not divide 32: generic kernel
+                                              (1, 8, 64, 32, 96),      # gw = 64: one grid row per 64-row step
+                                              (2, 4, 128, 64, 128),    # wide grids (the 2048 x 2048 gate shape): a step inside one grid row
+                                              (1, 3, 256, 32, 96),
+                                              (2, 12, 24, 32, 96)])    # gw divides neither: generic kernel
 def test_gemm_tn_patch2_gather_shapes(dt, B, gh, gw, cin, cout):
     """weight gradient of a 2 x 2 stride-2 projection: W[cout, (ky, kx, c)] = sum over output pixels of d^T . patch(src)"""
     H = _hip()

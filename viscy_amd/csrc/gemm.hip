@@ -1252,6 +1252,9 @@ __global__ __launch_bounds__(WG, WG == 512 ? 1 : ((BTK_ != 0 || PRO == 2) ? 2 : 
   // pixel of row m is 4 gw (m / gw) + 2 (m % gw) whatever the sample, so a step advances the operand by 4 BMS input pixels and
   // the lane offsets below never change
   const bool ypatch = p.a_mode == VSX_A_PATCH2;
+  // ... and with BMS | gw (wide grids: the 2048 x 2048 gate shape's 256 / 128 / 64-pixel rows) a step lies inside ONE grid row:
+  // lane offsets 2 * crow, the step's first input pixel from the formula above (a scalar division per step)
+  const bool ywide = ypatch && p.gw > BMS;
   const size_t xstep = (size_t)BMS * p.ldb * ES, ystep = (size_t)(ypatch ? 4 * BMS : BMS) * p.lda * ES;
   uint32_t xoff[NCHX], yoff[NCHY];
   int ldsx[NCHX], ldsy[NCHY], kcol[NCHY];
@@ -1274,7 +1277,7 @@ __global__ __launch_bounds__(WG, WG == 512 ? 1 : ((BTK_ != 0 || PRO == 2) ? 2 : 
     kcol[i] = kk;
     if (ypatch) {
       const int tap = kk / p.cs, c = kk - tap * p.cs;
-      const int pix = (crow / p.gw) * (4 * p.gw) + 2 * (crow % p.gw) + (tap >> 1) * (2 * p.gw) + (tap & 1);
+      const int pix = (ywide ? 2 * crow : (crow / p.gw) * (4 * p.gw) + 2 * (crow % p.gw)) + (tap >> 1) * (2 * p.gw) + (tap & 1);
       yoff[i] = (uint32_t)(pix * p.lda + c) * ES;
     } else
     yoff[i] = (uint32_t)(crow * p.lda + kk) * ES;
@@ -1290,6 +1293,10 @@ __global__ __launch_bounds__(WG, WG == 512 ? 1 : ((BTK_ != 0 || PRO == 2) ? 2 : 
   auto load_tiles = [&](int step, vec* xr, vec* yr) {
     const char* Xs = Xb + (size_t)step * xstep;
     const char* Ys = Yb + (size_t)step * ystep;
+    if (ywide) {
+      const long m = (long)step * BMS;
+      Ys = Yb + (size_t)(4 * p.gw * (m / p.gw) + 2 * (m % p.gw)) * (size_t)p.lda * ES;
+    }
 #pragma unroll
     for (int i = 0; i < NCHX; ++i)
       if (livex[i]) xr[i] = ldvec_stream<T>(reinterpret_cast<const T*>(Xs + xoff[i]), x_once);
@@ -1691,8 +1698,8 @@ static int launch_tn(const VsxGemm* p, hipStream_t s) {
     }
   }
   dim3 grid(tiles, splits, nz);
-  const bool patch_ok = (g_vsx_nt_fast & 2) && p->a_mode == VSX_A_PATCH2 && p->pro == VSX_PRO_NONE && p->gw > 0 && 32 % p->gw == 0 &&
-                        p->cs % VT<T>::N == 0 && (unsigned long long)512 * p->lda * sizeof(T) < (1ull << 31);
+  const bool patch_ok = (g_vsx_nt_fast & 2) && p->a_mode == VSX_A_PATCH2 && p->pro == VSX_PRO_NONE && p->gw > 0 && (32 % p->gw == 0 || p->gw % 64 == 0) &&
+                        p->cs % VT<T>::N == 0 && (unsigned long long)(512 + 4 * p->gw) * p->lda * sizeof(T) < (1ull << 31);
   const bool fast = g_vsx_nt_fast && (p->a_mode == VSX_A_ROWS || patch_ok) && p->M % 32 == 0 && p->N >= VT<T>::N && p->K >= VT<T>::N &&
                     (p->pro == VSX_PRO_NONE || (p->pro == VSX_PRO_GRN && p->hw > 0 && p->hw % 32 == 0)) &&
                     (unsigned long long)32 * (p->lda > p->ldb ? p->lda : p->ldb) * sizeof(T) < (1ull << 31);
