@@ -862,10 +862,14 @@ def test_voxel_shuffle_head(dt, pool):
           dt, "voxel shuffle bwd")
 
 
+@pytest.mark.parametrize("geom", [(2, 6, 10, 5, 32, 2), (2, 3, 128, 5, 32, 2), (1, 4, 64, 3, 64, 4)],
+                         ids=["thread-per-voxel", "row-tiles", "row-tiles-mid64"])
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
-def test_head_tail_fwd_bwd(dt):
+def test_head_tail_fwd_bwd(dt, geom):
+    """`row-tiles*`: W2 is a multiple of 64, so the bf16 forward and backward pass 2 run the row-tiled MFMA kernels
+    (csrc/head.hip, `head_rows` bits 0 / 1); fp32 stays on the thread-per-voxel kernels at every geometry."""
     H = _hip()
-    B, H2, W2, Z, Cmid, Cout = 2, 6, 10, 5, 32, 2
+    B, H2, W2, Z, Cmid, Cout = geom
     Mh = B * H2 * W2
     U = rnd(Mh, Z * Cmid, dt=dt, seed=1, scale=2.0) + 0.3
     w2, b2, alpha = rnd(4 * Cout, Cmid, seed=2, scale=0.2), rnd(4 * Cout, seed=3), torch.tensor([0.25])
@@ -901,8 +905,10 @@ def test_head_tail_fwd_bwd(dt):
         close(g[4], al.grad, dt, "dalpha vs autograd")
 
 
-@pytest.mark.parametrize("cfg", [(2, 6, 10, 5, 32, 2), (3, 9, 7, 3, 32, 2), (1, 40, 52, 5, 64, 4), (2, 64, 80, 5, 32, 2)],
-                         ids=["mid32", "mid32-ragged", "mid64-multi-iter", "mid32-multi-iter"])
+@pytest.mark.parametrize("cfg", [(2, 6, 10, 5, 32, 2), (3, 9, 7, 3, 32, 2), (1, 40, 52, 5, 64, 4), (2, 64, 80, 5, 32, 2),
+                                 (2, 5, 64, 5, 32, 2), (1, 70, 128, 5, 32, 2), (2, 9, 64, 3, 32, 2), (1, 6, 128, 5, 64, 4)],
+                         ids=["mid32", "mid32-ragged", "mid64-multi-iter", "mid32-multi-iter", "rows", "rows-multi-tile", "rows-z3",
+                              "rows-mid64"])
 def test_head_bwd1_with_folded_weight_gradient(cfg):
     """bf16 pass 1 with the 1x1x1 weight gradient folded in (voxel contraction on MFMA inside the kernel) against
     pass 1 + the explicit dv^T . act product; dW2 / db2 are accumulated into (non-zero start)."""

@@ -8,7 +8,13 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from viscy_amd import ops  # noqa: E402
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+from viscy_amd import _lib as L  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 512
+for f in sys.argv[1:]:  # flag=value (e.g. head_rows=0: the thread-per-voxel passes)
+    if "=" in f:
+        k, v = f.split("=")
+        assert L.lib().vsx_set_flag(k.encode(), int(v)) == 0, f
 dt = torch.bfloat16
 h = w = 64
 C3, D, Zo, Cmid, Cout = 8, 7, 5, 32, 2

@@ -33,6 +33,7 @@ int g_vsx_det_reduce = 0;  // 1: the forward's per-sample sums — GRN sum g^2 o
 thread_local float* g_vsx_det_ws = nullptr;
 thread_local long g_vsx_det_ws_floats = 0;
 int g_vsx_nt2 = 17;  // second-generation NT kernel (gemm_nt2.hip: 256 x 128 tiles, LDS-DMA operand path, wave-private epilogue): bit 0 = on for the launches it supports, bit 1 = also below 512 tiles
+int g_vsx_head_rows = 7;  // PixelToVoxelHead tail on row tiles with the 1x1x1 contraction on the matrix cores (head.hip, round 6; bf16, 64 | W2, Z <= 8): bit 0 = forward, bit 1 = backward pass 2, bit 2 = backward pass 1 with the folded weight gradient
 int g_vsx_loss_fused = 1;  // MixedLoss training forward: one pass per scale (SSIM sums + gradient field + next scale's pooling / data range + L1 / L2 sums: vsx_ssim_scale_fwd_fused) instead of a pooling pass and an SSIM pass; read by viscy_amd/losses.py
 
 void vsx_set_error(const char* fmt, ...) {
@@ -78,6 +79,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "loss_fused")) { g_vsx_loss_fused = value; return 0; }
   if (name && !strcmp(name, "mlp_sf32")) { g_vsx_mlp_sf32 = value; return 0; }
   if (name && !strcmp(name, "det_reduce")) { g_vsx_det_reduce = value; return 0; }
+  if (name && !strcmp(name, "head_rows")) { g_vsx_head_rows = value; return 0; }
   vsx_set_error("vsx_set_flag: unknown flag '%s'", name ? name : "(null)");
   return 1;
 }
@@ -107,5 +109,6 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "loss_fused")) return g_vsx_loss_fused;
   if (name && !strcmp(name, "mlp_sf32")) return g_vsx_mlp_sf32;
   if (name && !strcmp(name, "det_reduce")) return g_vsx_det_reduce;
+  if (name && !strcmp(name, "head_rows")) return g_vsx_head_rows;
   return -1;
 }

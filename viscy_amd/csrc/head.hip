@@ -393,6 +393,428 @@ __global__ __launch_bounds__(256) void head_out_bwd2_kernel(const T* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------------ round 6: row-tiled passes
+// The three passes above give one thread one voxel with z fastest: a lane's 16-byte loads of its U row sit 64 bytes apart and
+// a wave's 8-byte stores into the X-contiguous output rows come in 104-byte runs (13 pixels x 5 planes per wave); the 1x1x1
+// contraction is 256 VALU FMAs per voxel against weights broadcast from LDS.  The row-tiled passes (bf16, 64 | W2, Z <= 8):
+//   * a workgroup owns 64 consecutive x of one image row, all Z planes = Z waves, wave z <-> plane z, and 64*Z*Cmid*2 contiguous
+//     bytes of U, which enter LDS with fully coalesced 16-byte loads (row pitch + 16 bytes: the fragment reads below are
+//     conflict-free at Z = 5);
+//   * the 1x1x1 convolution and its transpose run on the matrix cores with the VOXELS as the MFMA's N dimension: lane
+//     (p16, kq) of a 16-voxel fragment holds voxel x = 16 xb + p16 and, in the accumulator, the four values m = 4 kq + r — for
+//     the forward the 2 x 2 sub-pixels of output channel co = kq (two 8-byte stores per lane, 16 lanes = one full 128-byte line
+//     of an output row), for the backward the channels c = 16 cb + 4 kq + r of dA = W2^T dv.  The operands are what autocast
+//     hands the reference's Conv3d: bf16 activations, bf16 weights, fp32 accumulation;
+//   * dv (the gathered output gradient) is laid out by the lanes that loaded it: lane (x, co) reads its 2 x 2 sub-pixels
+//     (128-byte lines again) and they ARE its slice k = 4 co + s of the MFMA's K dimension — no shuffle;
+//   * the voxel contraction of the weight gradient takes both operands with the transposing LDS read (ds_read_b64_tr_b16)
+//     from row-major tiles: the activation is written back over the U tile in place (8 bytes per lane), dv sits in its own
+//     16-byte rows — the 2-byte transposing stores of the first version are gone;
+//   * S1 / S2 / dalpha partial sums live in the lane that owns the channel (8 per lane instead of 2 x Cmid per thread).
+typedef __attribute__((ext_vector_type(4))) short head_s16x4;
+constexpr int HR_TX = 64;
+#ifndef HR_DBG
+#define HR_DBG 0  // timing experiments (results wrong): 1 = no final atomics, 2 = no weight-gradient contraction, 4 = no per-voxel pass
+#endif
+
+template <int CMID>
+struct HeadRows {
+  static constexpr int RP = CMID * 2 + 16;  // LDS bytes per voxel row
+  static constexpr int CPR = CMID / 8;      // 16-byte chunks per row
+};
+
+// 64*Z*CMID contiguous bf16 of U -> LDS rows (row = xl * Z + z): every thread moves exactly CPR 16-byte chunks (nt = 64 Z threads,
+// nt rows).  Issue and commit are separate so that the loads of all chunks (and of the next tile, in the pass that loops over
+// tiles) are in flight together: as ONE loop with a run-time trip count the compiler emitted load / s_waitcnt vmcnt(0) /
+// ds_write per chunk — four exposed round trips per tile.
+template <int CMID>
+__device__ __forceinline__ void hr_issue(const bf16_t* __restrict__ src, int tid, int nt, vsx_u32x4* regs) {
+  const vsx_u32x4* s4 = reinterpret_cast<const vsx_u32x4*>(src);
+#pragma unroll
+  for (int i = 0; i < HeadRows<CMID>::CPR; ++i) regs[i] = __builtin_nontemporal_load(s4 + tid + i * nt);
+}
+template <int CMID>
+__device__ __forceinline__ void hr_commit(const vsx_u32x4* regs, unsigned char* tile, int tid, int nt) {
+  typedef HeadRows<CMID> G;
+#pragma unroll
+  for (int i = 0; i < G::CPR; ++i) {
+    const int j = tid + i * nt;
+    const int r = j / G::CPR, p = j - r * G::CPR;
+    *reinterpret_cast<vsx_u32x4*>(tile + r * G::RP + p * 16) = regs[i];
+  }
+}
+
+__device__ __forceinline__ head_bf16x8 hr_pack8(const float* f) {
+  union { uint4 u; head_bf16x8 v; } t;
+  t.u = make_uint4(f32x2_to_bf16x2_bits(f[0], f[1]), f32x2_to_bf16x2_bits(f[2], f[3]), f32x2_to_bf16x2_bits(f[4], f[5]),
+                   f32x2_to_bf16x2_bits(f[6], f[7]));
+  return t.v;
+}
+
+// 8 voxels (contraction slots of a 32-row step, see gemm.hip lds_frag_mn_bf16) of column col0 + p16 out of a row-major LDS tile
+__device__ __forceinline__ head_bf16x8 hr_tr(const unsigned char* tile, int ldb, int col0, int p16, int kq) {
+  const unsigned char* a0 = tile + (kq * 4 + (p16 >> 2)) * ldb + (col0 + (p16 & 3) * 4) * 2;
+  const unsigned char* a1 = a0 + 16 * ldb;
+  union { struct { head_s16x4 lo, hi; } s; head_bf16x8 v; } u;
+  u.s.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((head_s16x4 __attribute__((address_space(3)))*)(a0));
+  u.s.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((head_s16x4 __attribute__((address_space(3)))*)(a1));
+  return u.v;
+}
+
+template <int CMID, int CO4>
+__global__ __launch_bounds__(512) void head_out_fwd_rows_kernel(const bf16_t* __restrict__ U, const float* __restrict__ ssum,
+                                                                const float* __restrict__ ssq, const float* __restrict__ w2,
+                                                                const float* __restrict__ b2, const float* __restrict__ alpha_p,
+                                                                float* __restrict__ out, HeadDims d, float eps) {
+  typedef HeadRows<CMID> G;
+  constexpr int KB = CMID / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hr_smem[];
+  float* mu = reinterpret_cast<float*>(hr_smem);
+  float* rs = mu + CMID;
+  unsigned char* tile = hr_smem + 2 * CMID * sizeof(float);
+  const int Z = d.Z, nt = 64 * Z;
+  const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * HR_TX;
+  const int tid = threadIdx.x, lane = tid & 63, z = tid >> 6;
+  const int p16 = lane & 15, kq = lane >> 4;
+  vsx_u32x4 ureg[G::CPR];
+  hr_issue<CMID>(U + (((size_t)b * d.H2 + y) * d.W2 + x0) * Z * CMID, tid, nt, ureg);
+  head_load_stats(ssum, ssq, b, CMID, (float)d.Z * d.H2 * d.W2, eps, mu, rs);
+  // A = W2 rows (m = output index) as bf16, rows past CO4 zero
+  head_bf16x8 wf[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = p16 < CO4 ? w2[p16 * CMID + kb * 32 + kq * 8 + j] : 0.f;
+    wf[kb] = hr_pack8(t);
+  }
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = kq * 4 + r < CO4 ? b2[kq * 4 + r] : 0.f;
+  const float alpha = alpha_p[0];
+  hr_commit<CMID>(ureg, tile, tid, nt);
+  __syncthreads();
+  float mc[KB][8], rc[KB][8];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mc[kb][j] = mu[kb * 32 + kq * 8 + j];
+      rc[kb][j] = rs[kb * 32 + kq * 8 + j];
+    }
+  const int H = 2 * d.H2, W = 2 * d.W2;
+#pragma unroll
+  for (int xb = 0; xb < HR_TX / 16; ++xb) {
+    const unsigned char* row = tile + ((xb * 16 + p16) * Z + z) * G::RP;
+    head_f32x4 acc = (head_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      float u[8];
+      unpack<bf16_t>(*reinterpret_cast<const uint4*>(row + (kb * 32 + kq * 8) * 2), u);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float n = (u[j] - mc[kb][j]) * rc[kb][j];
+        u[j] = n > 0.f ? n : alpha * n;
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kb], hr_pack8(u), acc, 0, 0, 0);
+    }
+    if (kq * 4 < CO4) {
+      const int x = x0 + xb * 16 + p16;
+      float* o = out + ((((size_t)b * d.Cout + kq) * d.Z + z) * H + 2 * y) * W + 2 * x;
+      *reinterpret_cast<float2*>(o) = make_float2(acc[0] + bias[0], acc[1] + bias[1]);
+      *reinterpret_cast<float2*>(o + W) = make_float2(acc[2] + bias[2], acc[3] + bias[3]);
+    }
+  }
+}
+
+// backward pass 2 on row tiles: dU = rstd * (dn - S1/cnt - n^ * S2/cnt), dn = prelu'(n^) * (W2^T dv)
+template <int CMID, int CO4>
+__global__ __launch_bounds__(512) void head_out_bwd2_rows_kernel(const bf16_t* __restrict__ U, const float* __restrict__ ssum,
+                                                                 const float* __restrict__ ssq, const float* __restrict__ w2,
+                                                                 const float* __restrict__ alpha_p,
+                                                                 const bf16_t* __restrict__ dvin, const float* __restrict__ S1,
+                                                                 const float* __restrict__ S2, bf16_t* __restrict__ dU,
+                                                                 HeadDims d, float eps) {
+  typedef HeadRows<CMID> G;
+  constexpr int NCB = CMID / 16, DVR = CO4 * 2;  // channel fragments; bytes per dv row
+  extern __shared__ __attribute__((aligned(16))) unsigned char hr_smem[];
+  float* mu = reinterpret_cast<float*>(hr_smem);
+  float* rs = mu + CMID;
+  float* m1 = rs + CMID;
+  float* m2 = m1 + CMID;
+  unsigned char* tile = hr_smem + 4 * CMID * sizeof(float);
+  const int Z = d.Z, nt = 64 * Z;
+  unsigned char* dvs = tile + nt * G::RP;
+  const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * HR_TX;
+  const int tid = threadIdx.x, lane = tid & 63, z = tid >> 6;
+  const int p16 = lane & 15, kq = lane >> 4;
+  const float cnt = (float)d.Z * d.H2 * d.W2;
+  const size_t vox0 = (((size_t)b * d.H2 + y) * d.W2 + x0) * Z;
+  vsx_u32x4 ureg[G::CPR], dreg[CO4 / 8];
+  hr_issue<CMID>(U + vox0 * CMID, tid, nt, ureg);
+#pragma unroll
+  for (int i = 0; i < CO4 / 8; ++i) dreg[i] = __builtin_nontemporal_load(reinterpret_cast<const vsx_u32x4*>(dvin + vox0 * CO4) + tid + i * nt);
+  head_load_stats(ssum, ssq, b, CMID, cnt, eps, mu, rs);
+  for (int i = tid; i < CMID; i += nt) {
+    m1[i] = S1[b * CMID + i] / cnt;
+    m2[i] = S2[b * CMID + i] / cnt;
+  }
+  // A = W2^T: lane (p16 = channel within the fragment, kq) holds W2[k = 8 kq + j][16 cb + p16], k >= CO4 zero
+  head_bf16x8 wf[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = kq * 8 + j < CO4 ? w2[(kq * 8 + j) * CMID + cb * 16 + p16] : 0.f;
+    wf[cb] = hr_pack8(t);
+  }
+  const float alpha = alpha_p[0];
+  hr_commit<CMID>(ureg, tile, tid, nt);
+#pragma unroll
+  for (int i = 0; i < CO4 / 8; ++i) reinterpret_cast<vsx_u32x4*>(dvs)[tid + i * nt] = dreg[i];
+  __syncthreads();
+  float mc[NCB][4], rc[NCB][4], m1c[NCB][4], m2c[NCB][4];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = cb * 16 + kq * 4 + r;
+      mc[cb][r] = mu[c]; rc[cb][r] = rs[c]; m1c[cb][r] = m1[c]; m2c[cb][r] = m2[c];
+    }
+#pragma unroll
+  for (int xb = 0; xb < HR_TX / 16; ++xb) {
+    const int rloc = (xb * 16 + p16) * Z + z;
+    unsigned char* row = tile + rloc * G::RP;
+    union { uint4 u; head_bf16x8 v; } bv;
+    bv.u = kq * 8 < CO4 ? *reinterpret_cast<const uint4*>(dvs + rloc * DVR + kq * 16) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const head_f32x4 dA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb], bv.v, (head_f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      uint2* up = reinterpret_cast<uint2*>(row + (cb * 16 + kq * 4) * 2);
+      const uint2 uu = *up;
+      const float u[4] = {bf16_bits_to_f32(uu.x & 0xFFFFu), bf16_bits_to_f32(uu.x >> 16), bf16_bits_to_f32(uu.y & 0xFFFFu),
+                          bf16_bits_to_f32(uu.y >> 16)};
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float n = (u[r] - mc[cb][r]) * rc[cb][r];
+        const float dn = n > 0.f ? dA[r] : alpha * dA[r];
+        o[r] = rc[cb][r] * (dn - m1c[cb][r] - n * m2c[cb][r]);
+      }
+      *up = make_uint2(f32x2_to_bf16x2_bits(o[0], o[1]), f32x2_to_bf16x2_bits(o[2], o[3]));
+    }
+  }
+  __syncthreads();
+  uint4* d4 = reinterpret_cast<uint4*>(dU + vox0 * CMID);
+#pragma unroll
+  for (int i = 0; i < G::CPR; ++i) {
+    const int j = tid + i * nt;
+    const int r = j / G::CPR, p = j - r * G::CPR;
+    d4[j] = *reinterpret_cast<const uint4*>(tile + r * G::RP + p * 16);
+  }
+}
+
+// backward pass 1 + the 1x1x1 weight / bias gradient on row tiles.  Everything this pass has to deliver is a contraction over
+// the voxels of dv with a function of the normalised activation alone — dz = W2^T dv is linear in dv, so with f = prelu'(n^)
+// in {1, alpha}, m = [n^ <= 0], neg = min(n^, 0), a = prelu(n^) = f n^:
+//     dW2[k][c]  = sum_v dv[v][k] a[v][c]                                         (the weight gradient, as before)
+//     S2[c] = sum_v dn n^ = sum_v f n^ (W2^T dv)[c] = sum_k W2[k][c] dW2[k][c]    (no work of its own)
+//     S1[c] = sum_v dn    = sum_k W2[k][c] (db2[k] + (alpha - 1) M[k][c]),        M = dv^T m
+//     dalpha = sum_{v,c} dA n^ [n^ <= 0] = sum_{k,c} W2[k][c] N[k][c],            N = dv^T neg
+// — three MFMA contractions (a, neg and the 0 / 1 mask as bf16 B operands read straight out of the U tile with the transposing
+// LDS read: lane (c, kq) holds 8 voxels of ONE channel, so mean / rstd are two scalars per lane) and a per-workgroup
+// epilogue on [CO4][CMID] matrices.  The first row-tiled version formed dA per voxel and accumulated S1 / S2 / dalpha on the
+// VALU as the thread-per-voxel pass does: ~100 VALU instructions per 16 voxels and wave = 1.50 ms, the same as the old
+// kernel, 0.89 ms with that loop removed (profiles/r06_head_rows.txt); this form needs ~6 VALU instructions per element.
+// W2 enters S1 / S2 / dalpha rounded to bf16: the operand precision of pass 2's dA = W2^T dv, whose mean S1 / cnt subtracts.
+template <int CMID, int CO4>
+__device__ __forceinline__ void head_out_bwd1_rows_body(const bf16_t* __restrict__ U, const float* __restrict__ ssum,
+                                                        const float* __restrict__ ssq, const float* __restrict__ w2,
+                                                        const float* __restrict__ alpha_p, const float* __restrict__ dout,
+                                                        bf16_t* __restrict__ dvout, float* __restrict__ S1,
+                                                        float* __restrict__ S2, float* __restrict__ dalpha,
+                                                        float* __restrict__ dwp, HeadDims d, float eps, int tiles_per_wg) {
+  typedef HeadRows<CMID> G;
+  constexpr int NF = CMID / 16, DVR = CO4 * 2, COUT = CO4 / 4;
+  constexpr int NW = CO4 * CMID + CO4;
+  constexpr int NACC = 3 * CO4 * CMID + CO4;  // per-wave partials: A | N | M as [CO4][CMID], then db[CO4]
+  extern __shared__ __attribute__((aligned(16))) unsigned char hr_smem[];
+  float* mu = reinterpret_cast<float*>(hr_smem);
+  float* rs = mu + CMID;
+  unsigned char* tile = hr_smem + 2 * CMID * sizeof(float);
+  const int Z = d.Z, nt = 64 * Z;
+  unsigned char* dvs = tile + nt * G::RP;   // two buffers of nt rows
+  float* red = reinterpret_cast<float*>(tile);  // epilogue scratch over the U tile (and the dv rows) once the tile loop is done
+  static_assert(NACC * sizeof(float) <= 64 * (G::RP + 2 * DVR), "the partials of a wave fit in its share of the tiles");
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, z = tid >> 6;
+  const int p16 = lane & 15, kq = lane >> 4;
+  head_load_stats(ssum, ssq, b, CMID, (float)d.Z * d.H2 * d.W2, eps, mu, rs);
+  const float alpha = alpha_p[0];
+  const uint32_t one2 = p16 == 0 ? 0x3F803F80u : 0u;  // ones in column 0: the extra fragment sums dv over the voxels (bias gradient)
+  union { uint4 u; head_bf16x8 v; } ones;
+  ones.u = make_uint4(one2, one2, one2, one2);
+  head_f32x4 accA[NF], accN[NF], accM[NF], accB = (head_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    accA[f] = (head_f32x4){0.f, 0.f, 0.f, 0.f};
+    accN[f] = (head_f32x4){0.f, 0.f, 0.f, 0.f};
+    accM[f] = (head_f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  float mc[NF], rc[NF];  // this lane's channel c = 16 f + p16
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    mc[f] = mu[f * 16 + p16];
+    rc[f] = rs[f * 16 + p16];
+  }
+  const float am1 = alpha - 1.f;
+  const int txn = d.W2 / HR_TX, ntile = d.H2 * txn;
+  const int H = 2 * d.H2, W = 2 * d.W2;
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntile, t_begin + tiles_per_wg);
+  // Software pipeline over the tiles: the U chunks and the dout sub-pixels of tile t + 1 are requested before tile t is
+  // computed and land in registers meanwhile (CPR x 4 + 16 registers).
+  vsx_u32x4 ureg[G::CPR];
+  float dv4[HR_TX / 16][4];
+  auto request = [&](int t) {
+    const int y = t / txn, x0 = (t - y * txn) * HR_TX;
+    hr_issue<CMID>(U + (((size_t)b * d.H2 + y) * d.W2 + x0) * Z * CMID, tid, nt, ureg);
+    // this lane's slice of dv: the 2 x 2 sub-pixels of output channel kq at (x, z)
+#pragma unroll
+    for (int xb = 0; xb < HR_TX / 16; ++xb) {
+      if (kq < COUT) {
+        const float* o = dout + ((((size_t)b * d.Cout + kq) * d.Z + z) * H + 2 * y) * W + 2 * (x0 + xb * 16 + p16);
+        const vsx_v2f t0 = __builtin_nontemporal_load(reinterpret_cast<const vsx_v2f*>(o));
+        const vsx_v2f t1 = __builtin_nontemporal_load(reinterpret_cast<const vsx_v2f*>(o + W));
+        dv4[xb][0] = t0.x; dv4[xb][1] = t0.y; dv4[xb][2] = t1.x; dv4[xb][3] = t1.y;
+      } else {
+        dv4[xb][0] = dv4[xb][1] = dv4[xb][2] = dv4[xb][3] = 0.f;
+      }
+    }
+  };
+  if (t_begin < t_end) request(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int y = t / txn, x0 = (t - y * txn) * HR_TX;
+    const size_t vox0 = (((size_t)b * d.H2 + y) * d.W2 + x0) * Z;
+    // (the previous tile's last readers of the U tile are behind the barrier in front of its dv copy-out)
+    hr_commit<CMID>(ureg, tile, tid, nt);
+    unsigned char* dvt = dvs + (t & 1) * (nt * DVR);  // dv rows are double-buffered: the previous tile's are still being copied out
+    if (kq < COUT) {
+#pragma unroll
+      for (int xb = 0; xb < HR_TX / 16; ++xb)  // rounded as the reference's bf16 gradient
+        *reinterpret_cast<uint2*>(dvt + ((xb * 16 + p16) * Z + z) * DVR + kq * 8) =
+            make_uint2(f32x2_to_bf16x2_bits(dv4[xb][0], dv4[xb][1]), f32x2_to_bf16x2_bits(dv4[xb][2], dv4[xb][3]));
+    }
+    __syncthreads();  // U tile and dv rows complete
+    if (t + 1 < t_end) request(t + 1);
+    // contraction over this wave's 64 voxels (rows xl * Z + z of both tiles), two 32-row steps
+#pragma unroll
+    for (int kb = 0; kb < ((HR_DBG & 2) ? 0 : 2); ++kb) {
+      const unsigned char* t0 = tile + ((kb * 32) * Z + z) * G::RP;
+      const unsigned char* v0 = dvt + ((kb * 32) * Z + z) * DVR;
+      // every lane supplies its own slot address (the transposition takes column p16's values from the reads of the lanes
+      // with (q & 3) == p16 / 4, whatever their own column); lanes past CO4 read into the next row and are zeroed
+      head_bf16x8 af = hr_tr(v0, Z * DVR, 0, p16, kq);
+      if (p16 >= CO4) af = (head_bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        union { head_bf16x8 v; uint32_t w[4]; } raw, fa, fn, fm;
+        raw.v = hr_tr(t0, Z * G::RP, f * 16, p16, kq);
+        if (!(HR_DBG & 4)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float n0 = (bf16_bits_to_f32(raw.w[i] & 0xFFFFu) - mc[f]) * rc[f];
+            const float n1 = (bf16_bits_to_f32(raw.w[i] >> 16) - mc[f]) * rc[f];
+            const float g0 = fminf(n0, 0.f), g1 = fminf(n1, 0.f);
+            fa.w[i] = f32x2_to_bf16x2_bits(fmaf(am1, g0, n0), fmaf(am1, g1, n1));  // prelu(n^) = n^ + (alpha - 1) min(n^, 0)
+            fn.w[i] = f32x2_to_bf16x2_bits(g0, g1);
+            // mask [n^ <= 0] as bf16 1.0 / 0.0 (the derivative at n^ = 0 is alpha, as torch's prelu backward has it)
+            fm.w[i] = (n0 > 0.f ? 0u : 0x3F80u) | (n1 > 0.f ? 0u : 0x3F800000u);
+          }
+        } else {
+          fa = raw; fn = raw; fm = raw;
+        }
+        accA[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, fa.v, accA[f], 0, 0, 0);
+        accN[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, fn.v, accN[f], 0, 0, 0);
+        accM[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, fm.v, accM[f], 0, 0, 0);
+      }
+      accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones.v, accB, 0, 0, 0);
+    }
+    __syncthreads();  // dv rows of every wave are in LDS, every wave is done with the U tile
+    {
+      uint4* o4 = reinterpret_cast<uint4*>(dvout + vox0 * CO4);
+#pragma unroll
+      for (int i = 0; i < CO4 / 8; ++i) o4[tid + i * nt] = reinterpret_cast<const uint4*>(dvt)[tid + i * nt];
+    }
+  }
+  // ---- epilogue: per-wave partials -> LDS, over the tiles
+  __syncthreads();  // every wave has copied its share of the last dv rows out
+  // accumulator lane (p16, kq), register r holds D[m = kq*4 + r][n = p16]
+  float* my = red + z * NACC;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = kq * 4 + r;
+    if (m < CO4) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        my[m * CMID + f * 16 + p16] = accA[f][r];
+        my[CO4 * CMID + m * CMID + f * 16 + p16] = accN[f][r];
+        my[2 * CO4 * CMID + m * CMID + f * 16 + p16] = accM[f][r];
+      }
+      if (p16 == 0) my[3 * CO4 * CMID + m] = accB[r];
+    }
+  }
+  __syncthreads();
+  // sum over the waves, in place into wave 0's slots
+  for (int i = tid; i < NACC; i += nt) {
+    float v = red[i];
+    for (int w = 1; w < Z; ++w) v += red[w * NACC + i];
+    red[i] = v;
+  }
+  __syncthreads();
+  if (HR_DBG & 1) return;
+  const float* RA = red;
+  const float* RN = red + CO4 * CMID;
+  const float* RM = red + 2 * CO4 * CMID;
+  const float* RB = red + 3 * CO4 * CMID;
+  for (int i = tid; i < NW; i += nt) atomicAdd(dwp + (size_t)b * NW + i, i < CO4 * CMID ? RA[i] : RB[i - CO4 * CMID]);
+  if (tid < CMID) {  // wave 0 (CMID <= 64): S1 / S2 of channel c, this channel's share of dalpha
+    const int c = tid;
+    float s1 = 0.f, s2 = 0.f, da = 0.f;
+#pragma unroll
+    for (int k = 0; k < CO4; ++k) {
+      const float wb = round_bf16(w2[k * CMID + c]);
+      s1 = fmaf(wb, fmaf(am1, RM[k * CMID + c], RB[k]), s1);
+      s2 = fmaf(wb, RA[k * CMID + c], s2);
+      da = fmaf(wb, RN[k * CMID + c], da);
+    }
+    atomicAdd(S1 + b * CMID + c, s1);
+    atomicAdd(S2 + b * CMID + c, s2);
+    da = group_sum<CMID < 64 ? CMID : 64>(da);
+    if (tid == 0) atomicAdd(dalpha, da);
+  }
+}
+
+// The Cmid = 32 instantiation is capped at 128 registers (4 waves per SIMD = three 5-wave workgroups per CU instead of two:
+// 1.20 -> 1.00 ms at B = 512; 3 spilled registers); Cmid = 64 needs 190 and keeps them.
+#define HR_BWD1_ARGS                                                                                                         \
+  const bf16_t *__restrict__ U, const float *__restrict__ ssum, const float *__restrict__ ssq, const float *__restrict__ w2, \
+      const float *__restrict__ alpha_p, const float *__restrict__ dout, bf16_t *__restrict__ dvout, float *__restrict__ S1, \
+      float *__restrict__ S2, float *__restrict__ dalpha, float *__restrict__ dwp, HeadDims d, float eps, int tiles_per_wg
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void head_out_bwd1_rows32_kernel(HR_BWD1_ARGS) {
+  head_out_bwd1_rows_body<32, 8>(U, ssum, ssq, w2, alpha_p, dout, dvout, S1, S2, dalpha, dwp, d, eps, tiles_per_wg);
+}
+__global__ __launch_bounds__(512) void head_out_bwd1_rows64_kernel(HR_BWD1_ARGS) {
+  head_out_bwd1_rows_body<64, 16>(U, ssum, ssq, w2, alpha_p, dout, dvout, S1, S2, dalpha, dwp, d, eps, tiles_per_wg);
+}
+#undef HR_BWD1_ARGS
+
+static bool head_rows_ok(const HeadDims& d, int dtype, int bit) {
+  return dtype == VSX_BF16 && (g_vsx_head_rows >> bit & 1) && d.W2 % HR_TX == 0 && d.Z >= 1 && d.Z <= 8 &&
+         ((d.Cmid == 32 && d.Cout == 2) || (d.Cmid == 64 && d.Cout == 4)) && d.H2 <= 65535 && d.B <= 65535 &&
+         4 * d.Cmid * 4 + 64 * d.Z * (d.Cmid * 2 + 16 + 16 * d.Cout) + 16 <= 65536;  // static LDS limit of a plain launch
+}
+
 #define HEAD_DISPATCH(KERNEL, TT, ...)                                                                         \
   do {                                                                                                          \
     if (Cmid == 16 && Cout == 1) hipLaunchKernelGGL((KERNEL<TT, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
@@ -423,6 +845,18 @@ extern "C" int32_t vsx_head_out_fwd(const void* U, const float* ssum, const floa
   HeadDims d{B, H2, W2, Z, Cmid, Cout};
   if (int e = head_check("vsx_head_out_fwd", d, dtype)) return e;
   VSX_CHECK(U && ssum && ssq && w2 && b2 && alpha && out, "vsx_head_out_fwd: null pointer");
+  if (head_rows_ok(d, dtype, 0)) {
+    const size_t lds = 2 * Cmid * sizeof(float) + (size_t)64 * Z * (Cmid * 2 + 16);
+    dim3 g(W2 / HR_TX, H2, B);
+    if (Cmid == 32)
+      hipLaunchKernelGGL((head_out_fwd_rows_kernel<32, 8>), g, dim3(64 * Z), lds, (hipStream_t)stream, (const bf16_t*)U, ssum, ssq,
+                         w2, b2, alpha, out, d, eps);
+    else
+      hipLaunchKernelGGL((head_out_fwd_rows_kernel<64, 16>), g, dim3(64 * Z), lds, (hipStream_t)stream, (const bf16_t*)U, ssum,
+                         ssq, w2, b2, alpha, out, d, eps);
+    VSX_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid(vsx_cdiv((long)H2 * W2 * Z, 256), B);
   if (dtype == VSX_BF16)
     HEAD_DISPATCH(head_out_fwd_kernel, bf16_t, (const bf16_t*)U, ssum, ssq,
@@ -481,7 +915,21 @@ extern "C" int32_t vsx_head_out_bwd1_wgrad(const void* U, const float* ssum, con
 #define HEAD_WG(CM, C4)                                                                                                   \
   hipLaunchKernelGGL((head_out_bwd1_wgrad_kernel<CM, C4>), grid, dim3(256), 0, st, (const bf16_t*)U, ssum, ssq, w2, alpha, \
                      dout, (bf16_t*)dv, S1, S2, dalpha, scratch, d, eps, (int)vpt)
-  if (Cmid == 32 && Cout == 2) HEAD_WG(32, 8);  // bf16 rows of dv are 16-byte vectors: 4*Cout is a multiple of 8 (head_check)
+  if (head_rows_ok(d, dtype, 2)) {
+    // row tiles: the same number of workgroups per sample as above, each a run of consecutive 64-pixel row pieces
+    const long ntile = (long)H2 * (W2 / HR_TX);
+    long tpw = ntile / bps;
+    if (tpw < 1) tpw = 1;
+    const size_t lds = 2 * Cmid * sizeof(float) + (size_t)64 * Z * (Cmid * 2 + 16) + 2 * (size_t)64 * Z * 8 * Cout + 16;
+    dim3 g(vsx_cdiv(ntile, tpw), B);
+    if (Cmid == 32)
+      hipLaunchKernelGGL(head_out_bwd1_rows32_kernel, g, dim3(64 * Z), lds, st, (const bf16_t*)U, ssum, ssq, w2, alpha, dout,
+                         (bf16_t*)dv, S1, S2, dalpha, scratch, d, eps, (int)tpw);
+    else
+      hipLaunchKernelGGL(head_out_bwd1_rows64_kernel, g, dim3(64 * Z), lds, st, (const bf16_t*)U, ssum, ssq, w2, alpha, dout,
+                         (bf16_t*)dv, S1, S2, dalpha, scratch, d, eps, (int)tpw);
+  }
+  else if (Cmid == 32 && Cout == 2) HEAD_WG(32, 8);  // bf16 rows of dv are 16-byte vectors: 4*Cout is a multiple of 8 (head_check)
   else if (Cmid == 64 && Cout == 4) HEAD_WG(64, 16);
   else VSX_CHECK(false, "vsx_head_out_bwd1_wgrad: unsupported (Cmid=%d, out_channels=%d)", Cmid, Cout);
 #undef HEAD_WG
@@ -499,6 +947,18 @@ extern "C" int32_t vsx_head_out_bwd2(const void* U, const float* ssum, const flo
   HeadDims d{B, H2, W2, Z, Cmid, Cout};
   if (int e = head_check("vsx_head_out_bwd2", d, dtype)) return e;
   VSX_CHECK(U && ssum && ssq && w2 && alpha && dv && S1 && S2 && dU, "vsx_head_out_bwd2: null pointer");
+  if (head_rows_ok(d, dtype, 1)) {
+    const size_t lds = 4 * Cmid * sizeof(float) + (size_t)64 * Z * (Cmid * 2 + 16) + (size_t)64 * Z * 8 * Cout;
+    dim3 g(W2 / HR_TX, H2, B);
+    if (Cmid == 32)
+      hipLaunchKernelGGL((head_out_bwd2_rows_kernel<32, 8>), g, dim3(64 * Z), lds, (hipStream_t)stream, (const bf16_t*)U, ssum, ssq,
+                         w2, alpha, (const bf16_t*)dv, S1, S2, (bf16_t*)dU, d, eps);
+    else
+      hipLaunchKernelGGL((head_out_bwd2_rows_kernel<64, 16>), g, dim3(64 * Z), lds, (hipStream_t)stream, (const bf16_t*)U, ssum,
+                         ssq, w2, alpha, (const bf16_t*)dv, S1, S2, (bf16_t*)dU, d, eps);
+    VSX_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid(vsx_cdiv((long)H2 * W2 * Z, 256), B);
   if (dtype == VSX_BF16)
     HEAD_DISPATCH(head_out_bwd2_kernel, bf16_t, (const bf16_t*)U, ssum, ssq,
