@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 
 extern int g_vsx_ln_fblk;
 extern int g_vsx_ln_bblk;
+extern int g_vsx_ln_ablk;
 template <typename T, int G, int CPL>
 static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float* mean, float* rstd,
                      const float* gamma, const float* beta, const void* add, float* dgamma, float* dbeta, int rows,
@@ -246,7 +247,16 @@ static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float*
   } else {
     // with an affine LayerNorm: <= 512 blocks → <= 512 same-address atomics on dgamma / dbeta; the block LayerNorms have no
     // affine here (folded into fc1) and no such limit — their cap is the flag ln_bblk
-    int iters = vsx_cdiv(rows, RPI * (dgamma ? 512 : g_vsx_ln_bblk));
+    // affine: every workgroup ends with one atomic per dgamma / dbeta element, and same-address atomics retire at ~40 ns each
+    // (tools/perf_ln.py: 8 192 workgroups at C = 768 take 339 us for a 33 us stream), so the workgroup count is what the pass
+    // can stream meanwhile: bytes / (4.5 TB/s x 80 ns), 256 .. 4 096 (C = 96 / 192 / 384 at B = 512: 336 -> 262, 171 -> 132,
+    // 91 -> 81 us against the fixed 512 of rounds 1 - 5); ln_ablk != 0 forces a count
+    int acap = g_vsx_ln_ablk;
+    if (dgamma && acap <= 0) {
+      const long cap = 3L * rows * C * (long)sizeof(T) / 360000L;
+      acap = (int)(cap < 256 ? 256 : (cap > 4096 ? 4096 : cap));
+    }
+    int iters = vsx_cdiv(rows, RPI * (dgamma ? acap : g_vsx_ln_bblk));
     if (iters < 1) iters = 1;
     int grid = vsx_cdiv(rows, RPI * iters);
     size_t sh = dgamma ? 2 * (size_t)C * sizeof(float) : 0;
