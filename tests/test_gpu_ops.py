@@ -835,11 +835,14 @@ def test_pixel_shuffle_cat(dt, c, cs):
         assert torch.equal(ds_g.cpu(), ds_r)
 
 
+@pytest.mark.parametrize("geom", [(2, 4, 6), (2, 5, 64), (1, 20, 128)], ids=["tiles", "strip", "strips-3-row-ranges"])
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("pool", [True, False])
-def test_head_shuffle(dt, pool):
+def test_head_shuffle(dt, pool, geom):
+    """`strip*`: 64 | w, so the pooled bf16 permutations run on column strips (csrc/spatial.hip, `head_rows` bits 3 / 4); the
+    20-row case splits every strip over three workgroups (the row above a range only feeds the carried sums)."""
     H = _hip()
-    B, h, w, C3, D = 2, 4, 6, 8, 7
+    (B, h, w), C3, D = geom, 8, 7
     dec = rnd(B * h * w, 4 * C3 * D, dt=dt, seed=1)
     dh = rnd(B * 4 * h * w, C3 * D, dt=dt, seed=2)
     close(H.head_shuffle_fwd(dec.to(DEV), B, h, w, C3, D, pool), R.head_shuffle_fwd(dec, B, h, w, C3, D, pool), dt, "fwd")

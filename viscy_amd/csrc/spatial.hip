@@ -579,6 +579,212 @@ __global__ __launch_bounds__(256) void head_shuffle_bwd_tiled_kernel(const T* __
   }
 }
 
+// ------------------------------------------------------------------ round 6: the two permutations on column strips (bf16, pooled)
+// The tiled kernels above do the in-pixel transpose with 2-byte LDS reads: 4 taps x Cm scalar reads per output pixel (896 per
+// decoder pixel) — the LDS instruction rate, not HBM, sets their 3.0 / 4.0 TB/s.  Here a workgroup walks DOWN a strip of 64
+// decoder columns; thread (xl, q) keeps the 16-byte chunk q (two shuffle groups cp' = 2q, 2q + 1 x the 2 x 2 sub-pixels) of its
+// pixel for the whole walk, so of the four decoder pixels an output pixel's pool window touches
+//     out(2y+1, 2x+1) = s00 + s01 + s10 + s11                 of (y, x)
+//     out(2y,   2x+1) = (s00 + s01)(y, x) + (s10 + s11)(y-1, x)
+//     out(2y+1, 2x  ) = (s00 + s10)(y, x) + (s01 + s11)(y, x-1)
+//     out(2y,   2x  ) = s00(y, x) + s10(y-1, x) + s01(y, x-1) + s11(y-1, x-1)          (all x 0.25)
+// the row above comes out of the thread's own registers (three partial sums per group carried from the previous row), the left
+// neighbour's chunk is one 16-byte LDS read of the row the workgroup just staged, and its row-above part is carried too.  The
+// eight results of a chunk go to four output pixels at channel z C3 + c3 (2-byte LDS scatter, 224 per decoder pixel instead of
+// 896 gathers) and leave as whole 112-byte pixels: two output rows x 128 pixels per walk step, contiguous in HBM.  The next
+// row's chunks are requested a step ahead.
+constexpr int HS_TX = 64;  // decoder columns per strip
+template <int K>           // chunks per thread and row = Cm / 8 (64 pixels x Cm / 2 chunks over 256 threads)
+__global__ __launch_bounds__(256) void head_shuffle_fwd_strip_kernel(const bf16_t* __restrict__ dec, bf16_t* __restrict__ hin, int h,
+                                                                    int w, int C3, int D, int rows_per_wg) {
+  constexpr int NQ = 4 * K;            // chunks per decoder pixel
+  constexpr int Cm = 8 * K, C4 = 32 * K;
+  constexpr int PB = C4 * 2;           // bytes per decoder pixel
+  constexpr int OB = Cm * 2;           // bytes per output pixel
+  __shared__ __attribute__((aligned(16))) unsigned char rowb[(HS_TX + 1) * PB];        // staged decoder row, slot 0 = column x0 - 1
+  __shared__ __attribute__((aligned(16))) unsigned char outb[2 * 2 * HS_TX * OB];      // two output rows of the strip
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, x0 = blockIdx.x * HS_TX;
+  const int y0 = blockIdx.y * rows_per_wg, y1 = min(h, y0 + rows_per_wg);
+  int xl[K], q[K];
+  uint32_t cpo[K];  // byte offsets of the two groups' output channels (z C3 + c3) * 2, packed 16 | 16
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = tid + k * 256;
+    xl[k] = i / NQ;
+    q[k] = i - xl[k] * NQ;
+    const int c0 = 2 * q[k], c1 = c0 + 1;
+    const int o0 = ((c0 % D) * C3 + c0 / D) * 2, o1 = ((c1 % D) * C3 + c1 / D) * 2;
+    cpo[k] = (uint32_t)o0 | ((uint32_t)o1 << 16);
+  }
+  const bool halo_thread = tid < NQ;  // also fetches chunk tid of column x0 - 1
+  const size_t img = (size_t)b * h * w;
+  auto request = [&](int y, vsx_u32x4 (&cur)[K], vsx_u32x4& hl) {
+    const vsx_u32x4* src = reinterpret_cast<const vsx_u32x4*>(dec + (img + (size_t)y * w + x0) * C4);
+#pragma unroll
+    for (int k = 0; k < K; ++k) cur[k] = __builtin_nontemporal_load(src + tid + k * 256);
+    hl = (vsx_u32x4){0u, 0u, 0u, 0u};
+    if (halo_thread && x0 > 0) hl = __builtin_nontemporal_load(src - NQ + tid);
+  };
+  // carried from the row above, per chunk and group c: u1 = s10 + s11, u2 = s10 (own pixel), ul = s11 (left pixel)
+  float u1[K][2], u2[K][2], ul[K][2];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) u1[k][c] = u2[k][c] = ul[k][c] = 0.f;
+  vsx_u32x4 cur[K], hl;
+  const int ys = y0 > 0 ? y0 - 1 : 0;  // the row above the strip only feeds the carries
+  request(ys, cur, hl);
+  for (int y = ys; y < y1; ++y) {
+    // stage this row (every thread its own chunks; the halo column by the first NQ threads)
+#pragma unroll
+    for (int k = 0; k < K; ++k) *reinterpret_cast<vsx_u32x4*>(rowb + PB + (size_t)(tid + k * 256) * 16) = cur[k];
+    if (halo_thread) *reinterpret_cast<vsx_u32x4*>(rowb + tid * 16) = hl;
+    vsx_u32x4 me[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) me[k] = cur[k];
+    __syncthreads();  // row staged; nobody still copies the previous output rows out (they finished before staging)
+    if (y + 1 < y1) request(y + 1, cur, hl);
+    const bool emit = y >= y0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const vsx_u32x4 lf = *reinterpret_cast<const vsx_u32x4*>(rowb + (size_t)xl[k] * PB + q[k] * 16);  // column x - 1, same chunk
+      unsigned char* o11 = outb + ((size_t)(1 * 2 * HS_TX + 2 * xl[k] + 1)) * OB;
+      unsigned char* o10 = o11 - OB;
+      unsigned char* o01 = outb + ((size_t)(2 * xl[k] + 1)) * OB;
+      unsigned char* o00 = o01 - OB;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t w0 = me[k][2 * c], w1 = me[k][2 * c + 1], l0 = lf[2 * c], l1 = lf[2 * c + 1];
+        const float s00 = bf16_bits_to_f32(w0 & 0xFFFFu), s01 = bf16_bits_to_f32(w0 >> 16);
+        const float s10 = bf16_bits_to_f32(w1 & 0xFFFFu), s11 = bf16_bits_to_f32(w1 >> 16);
+        const float l01 = bf16_bits_to_f32(l0 >> 16), l11 = bf16_bits_to_f32(l1 >> 16);
+        const float top = s00 + s01, bot = s10 + s11;
+        if (emit) {
+          const float v11 = 0.25f * (top + bot);
+          const float v01 = 0.25f * (top + u1[k][c]);
+          const float v10 = 0.25f * ((s00 + s10) + (l01 + l11));
+          const float v00 = 0.25f * ((s00 + u2[k][c]) + (l01 + ul[k][c]));
+          const uint32_t off = c ? cpo[k] >> 16 : cpo[k] & 0xFFFFu;
+          *reinterpret_cast<unsigned short*>(o11 + off) = (unsigned short)f32_to_bf16_bits(v11);
+          *reinterpret_cast<unsigned short*>(o10 + off) = (unsigned short)f32_to_bf16_bits(v10);
+          *reinterpret_cast<unsigned short*>(o01 + off) = (unsigned short)f32_to_bf16_bits(v01);
+          *reinterpret_cast<unsigned short*>(o00 + off) = (unsigned short)f32_to_bf16_bits(v00);
+        }
+        u1[k][c] = bot;
+        u2[k][c] = s10;
+        ul[k][c] = l11;
+      }
+    }
+    __syncthreads();  // output rows complete; every thread has read its left neighbours out of the staged row
+    if (emit) {
+      // rows 2y and 2y + 1 of the strip: 2 x 128 pixels x OB bytes, each row contiguous in HBM
+      constexpr int CPO = 2 * HS_TX * OB / 16;  // chunks per output row of the strip
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        vsx_u32x4* dst = reinterpret_cast<vsx_u32x4*>(hin + (((size_t)b * 2 * h + 2 * y + r) * (2 * w) + 2 * x0) * Cm);
+        for (int i = tid; i < CPO; i += 256) dst[i] = *reinterpret_cast<const vsx_u32x4*>(outb + (size_t)r * (2 * HS_TX * OB) + i * 16);
+      }
+    }
+  }
+}
+
+// adjoint on the same strips: ddec[y, x, 4 cp' + 2 i + j] = 0.25 * sum_{a, b in {0, 1}} g[2y + i + a, 2x + j + b, z C3 + c3], g = dhin, zero
+// beyond the image.  With the column-pair sums P_r0 = g[r, 2x] + g[r, 2x+1], P_r1 = g[r, 2x+1] + g[r, 2x+2] of the three output
+// rows r = 2y, 2y+1, 2y+2:  ds00 = P_00 + P_10, ds01 = P_01 + P_11, ds10 = P_10 + P_20, ds11 = P_11 + P_21 (x 0.25) — row 2y + 2
+// is row 2(y + 1) of the next step, so a step stages two output rows (+ the halo column), gathers 12 two-byte values per chunk
+// and carries two sums per group; the chunk leaves straight from the registers (16 bytes per thread, contiguous over the strip).
+template <int K>
+__global__ __launch_bounds__(256) void head_shuffle_bwd_strip_kernel(const bf16_t* __restrict__ dhin, bf16_t* __restrict__ ddec, int h,
+                                                                    int w, int C3, int D, int rows_per_wg) {
+  constexpr int NQ = 4 * K;
+  constexpr int Cm = 8 * K, C4 = 32 * K;
+  constexpr int OB = Cm * 2;                      // bytes per output-resolution pixel
+  constexpr int NPX = 2 * HS_TX + 1;              // staged pixels per output row (last = halo column 2 x0 + 128)
+  constexpr int CPR = 2 * HS_TX * OB / 16;        // 16-byte chunks of an output row inside the strip (896 at Cm = 56)
+  constexpr int KR = CPR / 256;                   // whole rounds of the 256 threads per row
+  __shared__ __attribute__((aligned(16))) unsigned char gb[2 * NPX * OB];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, x0 = blockIdx.x * HS_TX;
+  const int y0 = blockIdx.y * rows_per_wg, y1 = min(h, y0 + rows_per_wg);
+  const int H2 = 2 * h, W2 = 2 * w;
+  int xl[K];
+  uint32_t cpo[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = tid + k * 256;
+    xl[k] = i / NQ;
+    const int qq = i - xl[k] * NQ;
+    const int c0 = 2 * qq, c1 = c0 + 1;
+    const int o0 = ((c0 % D) * C3 + c0 / D) * 2, o1 = ((c1 % D) * C3 + c1 / D) * 2;
+    cpo[k] = (uint32_t)o0 | ((uint32_t)o1 << 16);
+  }
+  constexpr int REM = CPR - KR * 256;             // leftover chunks of a row (threads tid < REM)
+  constexpr int HC = OB / 16;                     // chunks of the halo pixel (threads tid < HC)
+  // registers of one staged row pair: [row][KR + 1 (remainder) + 1 (halo)]
+  auto request = [&](int y, vsx_u32x4 (&rg)[2][KR + 2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int Y = 2 * y + 1 + r;
+      const bool okr = Y >= 0 && Y < H2;
+      const vsx_u32x4* src = reinterpret_cast<const vsx_u32x4*>(dhin + (((size_t)b * H2 + (okr ? Y : 0)) * W2 + 2 * x0) * Cm);
+#pragma unroll
+      for (int k = 0; k < KR; ++k) rg[r][k] = okr ? __builtin_nontemporal_load(src + tid + k * 256) : (vsx_u32x4){0u, 0u, 0u, 0u};
+      rg[r][KR] = (okr && REM > 0 && tid < REM) ? __builtin_nontemporal_load(src + tid + KR * 256) : (vsx_u32x4){0u, 0u, 0u, 0u};
+      rg[r][KR + 1] = (okr && tid < HC && 2 * x0 + 2 * HS_TX < W2) ? __builtin_nontemporal_load(src + CPR + tid) : (vsx_u32x4){0u, 0u, 0u, 0u};
+    }
+  };
+  float p0[K][2], p1[K][2];  // P_20 / P_21 of the previous step = P_00 / P_01 of this one
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) p0[k][c] = p1[k][c] = 0.f;
+  vsx_u32x4 rg[2][KR + 2];
+  request(y0 - 1, rg);
+  const size_t img = (size_t)b * h * w;
+  for (int y = y0 - 1; y < y1; ++y) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned char* dst = gb + (size_t)r * NPX * OB;
+#pragma unroll
+      for (int k = 0; k < KR; ++k) *reinterpret_cast<vsx_u32x4*>(dst + (size_t)(tid + k * 256) * 16) = rg[r][k];
+      if (REM > 0 && tid < REM) *reinterpret_cast<vsx_u32x4*>(dst + (size_t)(tid + KR * 256) * 16) = rg[r][KR];
+      if (tid < HC) *reinterpret_cast<vsx_u32x4*>(dst + (size_t)(CPR + tid) * 16) = rg[r][KR + 1];
+    }
+    __syncthreads();
+    if (y + 1 < y1) request(y + 1, rg);
+    const bool emit = y >= y0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      uint32_t ow[4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t off = c ? cpo[k] >> 16 : cpo[k] & 0xFFFFu;
+        const unsigned char* r1 = gb + (size_t)(2 * xl[k]) * OB + off;   // row 2y + 1
+        const unsigned char* r2 = r1 + (size_t)NPX * OB;                 // row 2y + 2
+        const float a0 = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(r1));
+        const float a1 = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(r1 + OB));
+        const float a2 = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(r1 + 2 * OB));
+        const float b0 = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(r2));
+        const float b1 = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(r2 + OB));
+        const float b2 = bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(r2 + 2 * OB));
+        const float P10 = a0 + a1, P11 = a1 + a2, P20 = b0 + b1, P21 = b1 + b2;
+        const float d00 = 0.25f * (p0[k][c] + P10), d01 = 0.25f * (p1[k][c] + P11);
+        const float d10 = 0.25f * (P10 + P20), d11 = 0.25f * (P11 + P21);
+        ow[2 * c] = f32x2_to_bf16x2_bits(d00, d01);
+        ow[2 * c + 1] = f32x2_to_bf16x2_bits(d10, d11);
+        p0[k][c] = P20;
+        p1[k][c] = P21;
+      }
+      if (emit) {
+        vsx_u32x4* dst = reinterpret_cast<vsx_u32x4*>(ddec + (img + (size_t)y * w + x0) * C4);
+        dst[tid + k * 256] = (vsx_u32x4){ow[0], ow[1], ow[2], ow[3]};
+      }
+    }
+    __syncthreads();  // gathers done before the next pair of rows is staged
+  }
+}
+
 /* K12: PixelToVoxelHead.upsample + reshape (viscy_models/components/heads.py:607-615,632-637).
  * dec: [B, h, w, 4*C3*D] → hin: [B, 2h, 2w, D*C3] with the depth axis outermost inside a pixel
  * (channel = z*C3 + c3), so the 3x3x3 head convolution reads contiguous channel slices per z. */
@@ -589,6 +795,16 @@ extern "C" int32_t vsx_head_shuffle_fwd(const void* dec, void* hin, int32_t B, i
   VSX_CHECK((C3 * D) % vn == 0, "vsx_head_shuffle_fwd: C3*D=%d must be a multiple of %d", C3 * D, vn);
   long total = (long)B * 4 * h * w * (C3 * D / vn);
   dim3 grid(vsx_cdiv(total, 256));
+  if (dtype == VSX_BF16 && pool && (g_vsx_head_rows & 8) && C3 * D == 56 && w % HS_TX == 0 && B <= 65535) {
+    // column strips (round 6); rows per workgroup: two workgroups per CU in one round when the batch allows it
+    const long strips = (long)B * (w / HS_TX);
+    long rpw = (long)h * strips / 512;
+    rpw = rpw < 8 ? 8 : (rpw > h ? h : rpw);
+    hipLaunchKernelGGL((head_shuffle_fwd_strip_kernel<7>), dim3(w / HS_TX, vsx_cdiv(h, rpw), B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dec, (bf16_t*)hin, h, w, C3, D, (int)rpw);
+    VSX_LAUNCH_CHECK();
+    return 0;
+  }
   if (C3 * D <= 64 && B <= 65535) {  // LDS-tiled permutation
     if (dtype == VSX_BF16)
       hipLaunchKernelGGL((head_shuffle_fwd_tiled_kernel<bf16_t, 8>), dim3(vsx_cdiv(w, 8), vsx_cdiv(h, 8), B), dim3(256), 0,
@@ -615,6 +831,15 @@ extern "C" int32_t vsx_head_shuffle_bwd(const void* dhin, void* ddec, int32_t B,
   VSX_CHECK((4 * C3 * D) % vn == 0, "vsx_head_shuffle_bwd: 4*C3*D must be a multiple of %d", vn);
   long total = (long)B * h * w * (4 * C3 * D / vn);
   dim3 grid(vsx_cdiv(total, 256));
+  if (dtype == VSX_BF16 && pool && (g_vsx_head_rows & 16) && C3 * D == 56 && w % HS_TX == 0 && B <= 65535) {
+    const long strips = (long)B * (w / HS_TX);
+    long rpw = (long)h * strips / 512;
+    rpw = rpw < 8 ? 8 : (rpw > h ? h : rpw);
+    hipLaunchKernelGGL((head_shuffle_bwd_strip_kernel<7>), dim3(w / HS_TX, vsx_cdiv(h, rpw), B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dhin, (bf16_t*)ddec, h, w, C3, D, (int)rpw);
+    VSX_LAUNCH_CHECK();
+    return 0;
+  }
   if (C3 * D <= 64 && B <= 65535) {  // LDS-tiled permutation
     if (dtype == VSX_BF16)
       hipLaunchKernelGGL((head_shuffle_bwd_tiled_kernel<bf16_t, 8>), dim3(vsx_cdiv(w, 8), vsx_cdiv(h, 8), B), dim3(256), 0,
