@@ -34,7 +34,7 @@ int g_vsx_det_reduce = 0;  // 1: the forward's per-sample sums — GRN sum g^2 o
 thread_local float* g_vsx_det_ws = nullptr;
 thread_local long g_vsx_det_ws_floats = 0;
 int g_vsx_nt2 = 17;  // second-generation NT kernel (gemm_nt2.hip: 256 x 128 tiles, LDS-DMA operand path, wave-private epilogue): bit 0 = on for the launches it supports, bit 1 = also below 512 tiles
-int g_vsx_head_rows = 31;  // PixelToVoxelHead tail on row tiles with the 1x1x1 contraction on the matrix cores (head.hip, round 6; bf16, 64 | W2, Z <= 8): bit 0 = forward, bit 1 = backward pass 2, bit 2 = backward pass 1 with the folded weight gradient; bits 3 / 4 = the pixel shuffle + pad-pool in front of the head convolution and its adjoint on column strips (spatial.hip head_shuffle_{fwd,bwd}_strip_kernel; bf16, pooled, C3 * D = 56, 64 | w)
+int g_vsx_head_rows = 63;  // PixelToVoxelHead tail on row tiles with the 1x1x1 contraction on the matrix cores (head.hip, round 6; bf16, 64 | W2, Z <= 8): bit 0 = forward, bit 1 = backward pass 2, bit 2 = backward pass 1 with the folded weight gradient; bits 3 / 4 = the pixel shuffle + pad-pool in front of the head convolution and its adjoint on column strips (spatial.hip head_shuffle_{fwd,bwd}_strip_kernel; bf16, pooled, C3 * D = 56, 64 | w); bit 5 = the direct head convolution forward as a persistent kernel that requests the next halo tile ahead (headconv.hip)
 int g_vsx_loss_fused = 1;  // MixedLoss training forward: one pass per scale (SSIM sums + gradient field + next scale's pooling / data range + L1 / L2 sums: vsx_ssim_scale_fwd_fused) instead of a pooling pass and an SSIM pass; read by viscy_amd/losses.py
 
 void vsx_set_error(const char* fmt, ...) {

@@ -181,6 +181,159 @@ __global__ __launch_bounds__(256, 3) void head_conv_fwd_kernel(const bf16_t* __r
   }
 }
 
+// Round 6: the same pass as a persistent kernel.  One tile per workgroup put the tile's phases in a row — 5 halo loads per thread,
+// wait, LDS stores, barrier, 140 MFMAs per wave, stores — with three workgroups per CU to overlap them: 3.5 TB/s of its bytes at
+// 0.27 ms of MFMA and as much LDS time per launch.  Here a workgroup walks a contiguous range of tiles (x fastest, so a tile shares
+// its halo columns with the one before it and its halo rows with the tile 8 x W2 / 16 steps back), keeps the weight fragments in
+// registers for the whole launch and requests the NEXT tile's halo (5 x 16 bytes per thread) before it starts on the current one;
+// the per-tile statistics leave as before (one atomic per (sample, channel) and tile, or the tile's det_reduce row).
+// Two workgroups per CU: the unrolled plane loop with the next tile's five chunks in flight wants 230 registers (at the three
+// workgroups of the one-tile kernel: 70 spilled, 1.67 ms; with the plane loop rolled: 10 spilled, 1.12 ms); measured at B = 512:
+// 1 022 -> 945 us, 1 034 -> 968 us on a second box.
+constexpr int HCF_WPE = 2;
+__global__ __launch_bounds__(256, HCF_WPE) void head_conv_fwd_persist_kernel(const bf16_t* __restrict__ hin, const bf16_t* __restrict__ Wc,
+                                                                    const float* __restrict__ bias, bf16_t* __restrict__ U,
+                                                                    float* __restrict__ ssum, float* __restrict__ ssq, int H2,
+                                                                    int W2, float* __restrict__ det_ws, int ntiles,
+                                                                    int tiles_per_wg) {
+  __shared__ __attribute__((aligned(16))) char tile[(HF_TY + 2) * 18 * HF_PS];
+  __shared__ __attribute__((aligned(16))) char stage[4 * 16 * HF_SR];
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p16 = lane & 15, kq = lane >> 4;
+  const int tiles_x = W2 / 16, tiles_y = H2 / HF_TY, tiles_img = tiles_x * tiles_y;
+  constexpr int NPIX = (HF_TY + 2) * 18;
+  constexpr int NST = (NPIX * HC_D7 + 255) / 256;
+  // this thread's chunks of a halo tile never change: (pixel, plane) slots and their LDS addresses
+  int slot[NST];  // py | px << 8 | (plane + 1) << 16 (0: no chunk)
+#pragma unroll
+  for (int it = 0; it < NST; ++it) {
+    const int c = tid + it * 256;
+    const int pix = c / HC_D7;
+    const int py = pix / 18;
+    slot[it] = c < NPIX * HC_D7 ? (py | (pix - py * 18) << 8 | (c - pix * HC_D7 + 1) << 16) : 0;
+  }
+  auto issue = [&](int t, uint4 (&sv)[NST]) {
+    const int b = t / tiles_img, r = t - b * tiles_img;
+    const int ty0 = (r / tiles_x) * HF_TY, tx0 = (r % tiles_x) * 16;
+    const size_t img = (size_t)b * H2 * W2;
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int y = ty0 + (slot[it] & 0xff) - 1, x = tx0 + ((slot[it] >> 8) & 0xff) - 1, zc = (slot[it] >> 16) - 1;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (zc >= 0 && y >= 0 && y < H2 && x >= 0 && x < W2)
+        v = *reinterpret_cast<const uint4*>(hin + (img + (size_t)y * W2 + x) * (HC_D7 * HC_C3) + zc * HC_C3);
+      sv[it] = v;
+    }
+  };
+  // weights: 2 channel fragments x 7 K-steps (4 taps each; tap 27 does not exist -> zero), resident in registers
+  bf16x8 wf[2][7];
+  int toff[7];
+#pragma unroll
+  for (int kk = 0; kk < 7; ++kk) {
+    const int t = kk * 4 + kq;
+    const int tt = t < 27 ? t : 26;
+    const int dyx = tt / 3, dz = tt - dyx * 3;
+    const int dy = dyx / 3, dx = dyx - dy * 3;
+    toff[kk] = (dy * 18 + dx) * HF_PS + dz * 16;
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+      wf[nf][kk] = t < 27 ? *reinterpret_cast<const bf16x8*>(Wc + (size_t)(nf * 16 + p16) * HC_K + t * 8) : hc_zero8();
+  }
+  float bs[2][4];
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bs[nf][r] = bias ? bias[nf * 16 + kq * 4 + r] : 0.f;
+  const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
+  if (t_begin >= t_end) return;
+  uint4 sv[NST];
+  issue(t_begin, sv);
+  char* st = stage + wave * (16 * HF_SR);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int b = t / tiles_img, rr = t - b * tiles_img;
+    const int tyi = rr / tiles_x, txi = rr - tyi * tiles_x;
+    const int ty0 = tyi * HF_TY, tx0 = txi * 16;
+    const size_t img = (size_t)b * H2 * W2;
+    // (every wave is done with the previous tile: it passed the statistics barrier at the end of the last step)
+#pragma unroll
+    for (int it = 0; it < NST; ++it)
+      if (slot[it]) *reinterpret_cast<uint4*>(tile + ((slot[it] & 0xff) * 18 + ((slot[it] >> 8) & 0xff)) * HF_PS + ((slot[it] >> 16) - 1) * 16) = sv[it];
+    __syncthreads();
+    if (t + 1 < t_end) issue(t + 1, sv);
+    float s1[2][4], s2[2][4];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1[nf][r] = 0.f;
+        s2[nf][r] = 0.f;
+      }
+#pragma unroll 1
+    for (int mf = 0; mf < 2; ++mf) {
+      const int pbase = ((wave * 2 + mf) * 18 + p16) * HF_PS;
+#pragma unroll
+      for (int z = 0; z < HC_ZO; ++z) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < 7; ++kk) {
+          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(tile + pbase + toff[kk] + z * 16);
+#pragma unroll
+          for (int nf = 0; nf < 2; ++nf) acc[nf] = hc_mfma(wf[nf][kk], pf, acc[nf]);
+        }
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          float c[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = acc[nf][r] + bs[nf][r];
+          uint2 o;
+          o.x = f32x2_to_bf16x2_bits(c[0], c[1]);
+          o.y = f32x2_to_bf16x2_bits(c[2], c[3]);
+          *reinterpret_cast<uint2*>(st + p16 * HF_SR + (z * HC_CMID + nf * 16 + kq * 4) * 2) = o;
+          // InstanceNorm statistics of the STORED (rounded) value, like VSX_EPI_BIAS_STATS
+          const float q0 = __uint_as_float(o.x << 16), q1 = __uint_as_float(o.x & 0xffff0000u);
+          const float q2 = __uint_as_float(o.y << 16), q3 = __uint_as_float(o.y & 0xffff0000u);
+          s1[nf][0] += q0; s1[nf][1] += q1; s1[nf][2] += q2; s1[nf][3] += q3;
+          s2[nf][0] += q0 * q0; s2[nf][1] += q1 * q1; s2[nf][2] += q2 * q2; s2[nf][3] += q3 * q3;
+        }
+      }
+      // the row of 16 pixels x 320 bytes is contiguous in U: 320 16-byte chunks, 64 per store instruction
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      char* dst = reinterpret_cast<char*>(U + (img + (size_t)(ty0 + wave * 2 + mf) * W2 + tx0) * (HC_ZO * HC_CMID));
+#pragma unroll
+      for (int it = 0; it < 5; ++it) {
+        const int c = lane + it * 64;
+        const int px = c / 20, ch = c - px * 20;
+        const uint4 v = *reinterpret_cast<const uint4*>(st + px * HF_SR + ch * 16);
+        *reinterpret_cast<uint4*>(dst + c * 16) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // lanes of one kq group (16 pixels) -> one partial per channel; waves -> LDS; one atomic per (sample, channel) per tile
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = group_sum<16>(s1[nf][r]), q = group_sum<16>(s2[nf][r]);
+        if (p16 == 0) {
+          red[wave][nf * 16 + kq * 4 + r] = a;
+          red[wave][32 + nf * 16 + kq * 4 + r] = q;
+        }
+      }
+    __syncthreads();  // (also: every wave is done reading the halo tile)
+    if (tid < 64) {
+      const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+      if (det_ws) {  // det_reduce: one row of 64 partials per tile, added up in tile order by vsx_det_group_sum
+        det_ws[((size_t)b * tiles_img + (size_t)tyi * tiles_x + txi) * 64 + tid] = v;
+      } else {
+        atomicAdd((tid < 32 ? ssum : ssq) + (size_t)b * HC_CMID + (tid & 31), v);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // persistent workgroups walk 8x16-pixel tiles; contraction index of the MFMA = 32 pixels (2 tile rows), both operands
 // come out of row-major LDS tiles through the transposing read.  Output 32 x 217 (216 weight columns + a ones column
@@ -467,6 +620,12 @@ extern "C" int32_t vsx_head_conv_fwd(const void* hin, const void* Wc, const floa
     VSX_CHECK(g_vsx_det_ws != nullptr && g_vsx_det_ws_floats >= need, "vsx_head_conv_fwd: det_reduce needs vsx_det_workspace(>= %ld floats)", need);
     det_ws = g_vsx_det_ws;
   }
+  const long ntiles = (long)B * tiles;
+  if ((g_vsx_head_rows & 32) && ntiles <= 0x7fffffffL) {  // persistent (round 6): three workgroups per CU, a contiguous tile range each
+    const int tpw = vsx_cdiv(ntiles, 256L * HCF_WPE);
+    hipLaunchKernelGGL(head_conv_fwd_persist_kernel, dim3(vsx_cdiv(ntiles, (long)tpw)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)hin, (const bf16_t*)Wc, bias, (bf16_t*)U, ssum, ssq, H2, W2, det_ws, (int)ntiles, tpw);
+  } else
   hipLaunchKernelGGL(head_conv_fwd_kernel, dim3(W2 / 16, H2 / HF_TY, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hin,
                      (const bf16_t*)Wc, bias, (bf16_t*)U, ssum, ssq, H2, W2, det_ws);
   VSX_LAUNCH_CHECK();
