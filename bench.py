@@ -64,7 +64,7 @@ def build_info() -> dict:
 
 
 FLAG_NAMES = ["tn_tr", "nt_wide", "nt_fast", "tn_wide", "nt2", "nt_stream", "grn_stream", "ggb_contig", "tn_want", "tn_contig", "tn_stream",
-              "ln_stream", "ggb_blocks", "tn_rect", "dw_mfma", "ln_fblk", "ln_bblk", "mlp_fused", "loss_fused", "mlp_sf32"]
+              "ln_stream", "ggb_blocks", "tn_rect", "dw_mfma", "ln_fblk", "ln_bblk", "ln_ablk", "mlp_fused", "loss_fused", "mlp_sf32", "head_rows", "det_reduce"]
 
 
 def make_batch(B, H, W, device, seed=42):

@@ -17,6 +17,7 @@ int g_vsx_dw_mfma = 15;  // depthwise conv on the matrix cores (dwconv_mfma.hip)
 int g_vsx_ln_fblk = 32768;  // LayerNorm forward: cap on workgroups per launch (each sweeps rows / cap windows).  Measured at B = 512 (64x64x96 / x224): 2048 -> 209 / 438 us, 8192 -> 172 / 351, 32768 -> 162 / 331 (a grid-stride sweep by few workgroups streams at 5.0 TB/s where one vector per thread reaches 6.8: tools/micro/write_rate.hip)
 int g_vsx_ln_bblk = 8192;   // LayerNorm backward WITHOUT affine gradients (the block LayerNorms): cap on workgroups (with dgamma: 512, same-address atomics).  512 -> 319 / 651 us, 2048 -> 254 / 586, 8192 -> 240 / 541 (16x16x384: 83 -> 61), 32768 -> 225 / 516 but 78 at 16x16x384
 int g_vsx_ln_ablk = 512;  // LayerNorm backward WITH affine gradients: workgroup count = same-address atomics per dgamma / dbeta element; 0 = sized from the bytes of the pass (norm.hip ln_launch: isolated launches 336 -> 262 us at C = 96, 171 -> 132 at C = 192; bench step +-0: 91.47 vs 91.38 ms, profiles/r06_ln_affine_cap.txt), so the fixed 512 of rounds 1 - 5 stays
+int g_vsx_ln_pack = 1;  // LayerNorm backward: rows of 24 / 48 16-byte vectors (C = 192 / 384 in bf16) on 8- / 16-lane groups with three vectors per lane instead of 32 / 64 lanes a quarter idle (norm.hip ln_dispatch, round 6)
 int g_vsx_nt_stream = 3;  // (round 4: a non-temporal LDS-DMA of the A panel in the second-generation NT kernel measured 14.9 -> 17.1 ms for the class: not kept) lean NT kernel: bit 0 = non-temporal stores of the wide outputs (fc1 h / g, fc2 data gradient dz): +0.6..1.9 % on the step; bit 1 = non-temporal load of the stored activation in the dZ epilogue (its last reader): +0.7 % (same-box A/B).  ON since round 3: the streaming stores are compiler builtins now (round 1 used inline asm, see vsx_common.h stvec_stream), soak / determinism / poison tests run with them
 int g_vsx_grn_stream = 2;  // grn_gelu_bwd: bit 0 = non-temporal store of dz (no effect), bit 1 = non-temporal load of h, its last reader (-3 % on the kernel)
 int g_vsx_ggb_contig = 1;  // grn_gelu_bwd: contiguous row range per workgroup instead of grid-strided rows
@@ -77,6 +78,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "ln_fblk") && value > 0) { g_vsx_ln_fblk = value; return 0; }
   if (name && !strcmp(name, "ln_bblk") && value > 0) { g_vsx_ln_bblk = value; return 0; }
   if (name && !strcmp(name, "ln_ablk") && value >= 0) { g_vsx_ln_ablk = value; return 0; }
+  if (name && !strcmp(name, "ln_pack")) { g_vsx_ln_pack = value; return 0; }
   if (name && !strcmp(name, "mlp_fused")) { g_vsx_mlp_fused = value; return 0; }
   if (name && !strcmp(name, "loss_fused")) { g_vsx_loss_fused = value; return 0; }
   if (name && !strcmp(name, "mlp_sf32")) { g_vsx_mlp_sf32 = value; return 0; }
@@ -108,6 +110,7 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "ln_fblk")) return g_vsx_ln_fblk;
   if (name && !strcmp(name, "ln_bblk")) return g_vsx_ln_bblk;
   if (name && !strcmp(name, "ln_ablk")) return g_vsx_ln_ablk;
+  if (name && !strcmp(name, "ln_pack")) return g_vsx_ln_pack;
   if (name && !strcmp(name, "mlp_fused")) return g_vsx_mlp_fused;
   if (name && !strcmp(name, "loss_fused")) return g_vsx_loss_fused;
   if (name && !strcmp(name, "mlp_sf32")) return g_vsx_mlp_sf32;

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 extern int g_vsx_ln_fblk;
 extern int g_vsx_ln_bblk;
 extern int g_vsx_ln_ablk;
+extern int g_vsx_ln_pack;
 template <typename T, int G, int CPL>
 static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float* mean, float* rstd,
                      const float* gamma, const float* beta, const void* add, float* dgamma, float* dbeta, int rows,
@@ -240,7 +241,11 @@ static int ln_launch(bool fwd, const void* a0, const void* a1, void* out, float*
   constexpr int RPI = 256 / G;
   if (fwd) {
     constexpr int R = CPL == 1 ? 4 : (CPL == 2 ? 2 : 1);  // rows per lane group (see the kernel)
-    int iters = vsx_cdiv(rows, RPI * R * g_vsx_ln_fblk);  // <= ln_fblk workgroups, each sweeping `iters` windows
+    // <= ln_fblk workgroups, each sweeping `iters` windows.  With an affine every workgroup first fetches its gamma / beta
+    // vectors — a memory round trip before its first row — so short-lived workgroups pay it once per 64 rows: an eighth of the
+    // plain cap (C = 96 / 192 / 384 at B = 512: 258 -> 183, 115 -> 89, 65 -> 55 us; the plain pass is best at 8 192 .. 32 768)
+    const int fcap = gamma ? (g_vsx_ln_fblk >= 8 ? g_vsx_ln_fblk / 8 : 1) : g_vsx_ln_fblk;
+    int iters = vsx_cdiv(rows, RPI * R * fcap);
     if (iters < 1) iters = 1;
     hipLaunchKernelGGL((ln_fwd_kernel<T, G, CPL>), dim3(vsx_cdiv(rows, RPI * R * iters)), dim3(256), 0, s, (const T*)a0,
                        (T*)out, mean, rstd, gamma, beta, rows, C, eps, iters, g_vsx_ln_stream & 2);
@@ -279,6 +284,14 @@ static int ln_dispatch(bool fwd, const void* a0, const void* a1, void* out, floa
                        int C, float eps, hipStream_t s) {
   const int nch = C / VT<T>::N;
 #define LN_CASE(G, CPL) return ln_launch<T, G, CPL>(fwd, a0, a1, out, mean, rstd, gamma, beta, add, dgamma, dbeta, rows, C, eps, s)
+  // ln_pack: rows of 3 x 2^k vectors on groups of 2^k lanes with three vectors each — every lane loads, where the next power of
+  // two leaves a quarter of the lanes idle
+  // (backward only, 24 and 48 vectors = C = 192 / 384 in bf16: 113 -> 94, 58 -> 48 us, with affine gradients 186 -> 129, 91 -> 85;
+  // the forward and the 12- / 96-vector rows are slower packed: tools/perf_ln.py pack)
+  if (g_vsx_ln_pack && !fwd) {
+    if (nch == 24) LN_CASE(8, 3);
+    if (nch == 48) LN_CASE(16, 3);
+  }
   if (nch <= 4) LN_CASE(4, 1);
   if (nch <= 8) LN_CASE(8, 1);
   if (nch <= 16) LN_CASE(16, 1);
