@@ -403,13 +403,13 @@ __global__ __launch_bounds__(256) void head_out_bwd2_kernel(const T* __restrict_
 //   * the 1x1x1 convolution and its transpose run on the matrix cores with the VOXELS as the MFMA's N dimension: lane
 //     (p16, kq) of a 16-voxel fragment holds voxel x = 16 xb + p16 and, in the accumulator, the four values m = 4 kq + r — for
 //     the forward the 2 x 2 sub-pixels of output channel co = kq (two 8-byte stores per lane, 16 lanes = one full 128-byte line
-//     of an output row), for the backward the channels c = 16 cb + 4 kq + r of dA = W2^T dv.  The operands are what autocast
-//     hands the reference's Conv3d: bf16 activations, bf16 weights, fp32 accumulation;
+//     of an output row), for the backward the channels c = 16 cb + 4 kq + r of dA = W2^T dv.  The activation enters as bf16 (what
+//     autocast hands the reference's Conv3d), the weights as two bf16 fragments hi + lo (16 mantissa bits), fp32 accumulation;
 //   * dv (the gathered output gradient) is laid out by the lanes that loaded it: lane (x, co) reads its 2 x 2 sub-pixels
 //     (128-byte lines again) and they ARE its slice k = 4 co + s of the MFMA's K dimension — no shuffle;
 //   * the voxel contraction of the weight gradient takes both operands with the transposing LDS read (ds_read_b64_tr_b16)
-//     from row-major tiles: the activation is written back over the U tile in place (8 bytes per lane), dv sits in its own
-//     16-byte rows — the 2-byte transposing stores of the first version are gone;
+//     from row-major tiles (the U tile itself and the 16-byte dv rows) — the 2-byte transposing stores of the thread-per-voxel
+//     pass are gone;
 //   * S1 / S2 / dalpha partial sums live in the lane that owns the channel (8 per lane instead of 2 x Cmid per thread).
 typedef __attribute__((ext_vector_type(4))) short head_s16x4;
 constexpr int HR_TX = 64;
@@ -479,14 +479,20 @@ __global__ __launch_bounds__(512) void head_out_fwd_rows_kernel(const bf16_t* __
   vsx_u32x4 ureg[G::CPR];
   hr_issue<CMID>(U + (((size_t)b * d.H2 + y) * d.W2 + x0) * Z * CMID, tid, nt, ureg);
   head_load_stats(ssum, ssq, b, CMID, (float)d.Z * d.H2 * d.W2, eps, mu, rs);
-  // A = W2 rows (m = output index) as bf16, rows past CO4 zero
-  head_bf16x8 wf[KB];
+  // A = W2 rows (m = output index), rows past CO4 zero, as TWO bf16 fragments hi + lo (lo = bf16(W2 - hi)): the weights enter with
+  // 16 mantissa bits for one more MFMA per fragment on an idle pipe (bf16 weights alone moved the per-stage gradient error of the
+  // bf16 engine from 0.6 - 0.9 x to 1.0 - 1.2 x the autocast yardstick of tests/test_gpu_model.py: every gradient passes here)
+  head_bf16x8 wf[KB], wl[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
-    float t[8];
+    float t[8], tl[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = p16 < CO4 ? w2[p16 * CMID + kb * 32 + kq * 8 + j] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      t[j] = p16 < CO4 ? w2[p16 * CMID + kb * 32 + kq * 8 + j] : 0.f;
+      tl[j] = t[j] - round_bf16(t[j]);
+    }
     wf[kb] = hr_pack8(t);
+    wl[kb] = hr_pack8(tl);
   }
   float bias[4];
 #pragma unroll
@@ -516,7 +522,9 @@ __global__ __launch_bounds__(512) void head_out_fwd_rows_kernel(const bf16_t* __
         const float n = (u[j] - mc[kb][j]) * rc[kb][j];
         u[j] = n > 0.f ? n : alpha * n;
       }
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kb], hr_pack8(u), acc, 0, 0, 0);
+      const head_bf16x8 af = hr_pack8(u);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[kb], af, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kb], af, acc, 0, 0, 0);
     }
     if (kq * 4 < CO4) {
       const int x = x0 + xb * 16 + p16;
@@ -560,13 +568,18 @@ __global__ __launch_bounds__(512) void head_out_bwd2_rows_kernel(const bf16_t* _
     m2[i] = S2[b * CMID + i] / cnt;
   }
   // A = W2^T: lane (p16 = channel within the fragment, kq) holds W2[k = 8 kq + j][16 cb + p16], k >= CO4 zero
-  head_bf16x8 wf[NCB];
+  // (hi + lo bf16 fragments: dv IS bf16, so dA = W2^T dv comes out as with fp32 weights — see the forward)
+  head_bf16x8 wf[NCB], wl[NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
-    float t[8];
+    float t[8], tl[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = kq * 8 + j < CO4 ? w2[(kq * 8 + j) * CMID + cb * 16 + p16] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      t[j] = kq * 8 + j < CO4 ? w2[(kq * 8 + j) * CMID + cb * 16 + p16] : 0.f;
+      tl[j] = t[j] - round_bf16(t[j]);
+    }
     wf[cb] = hr_pack8(t);
+    wl[cb] = hr_pack8(tl);
   }
   const float alpha = alpha_p[0];
   hr_commit<CMID>(ureg, tile, tid, nt);
@@ -589,7 +602,8 @@ __global__ __launch_bounds__(512) void head_out_bwd2_rows_kernel(const bf16_t* _
     bv.u = kq * 8 < CO4 ? *reinterpret_cast<const uint4*>(dvs + rloc * DVR + kq * 16) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-      const head_f32x4 dA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb], bv.v, (head_f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      head_f32x4 dA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[cb], bv.v, (head_f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      dA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cb], bv.v, dA, 0, 0, 0);
       uint2* up = reinterpret_cast<uint2*>(row + (cb * 16 + kq * 4) * 2);
       const uint2 uu = *up;
       const float u[4] = {bf16_bits_to_f32(uu.x & 0xFFFFu), bf16_bits_to_f32(uu.x >> 16), bf16_bits_to_f32(uu.y & 0xFFFFu),
@@ -626,7 +640,7 @@ __global__ __launch_bounds__(512) void head_out_bwd2_rows_kernel(const bf16_t* _
 // epilogue on [CO4][CMID] matrices.  The first row-tiled version formed dA per voxel and accumulated S1 / S2 / dalpha on the
 // VALU as the thread-per-voxel pass does: ~100 VALU instructions per 16 voxels and wave = 1.50 ms, the same as the old
 // kernel, 0.89 ms with that loop removed (profiles/r06_head_rows.txt); this form needs ~6 VALU instructions per element.
-// W2 enters S1 / S2 / dalpha rounded to bf16: the operand precision of pass 2's dA = W2^T dv, whose mean S1 / cnt subtracts.
+// W2 enters S1 / S2 / dalpha in fp32, as it enters pass 2's dA = W2^T dv (hi + lo bf16 fragments), whose mean S1 / cnt subtracts.
 template <int CMID, int CO4>
 __device__ __forceinline__ void head_out_bwd1_rows_body(const bf16_t* __restrict__ U, const float* __restrict__ ssum,
                                                         const float* __restrict__ ssq, const float* __restrict__ w2,
@@ -783,7 +797,7 @@ __device__ __forceinline__ void head_out_bwd1_rows_body(const bf16_t* __restrict
     float s1 = 0.f, s2 = 0.f, da = 0.f;
 #pragma unroll
     for (int k = 0; k < CO4; ++k) {
-      const float wb = round_bf16(w2[k * CMID + c]);
+      const float wb = w2[k * CMID + c];
       s1 = fmaf(wb, fmaf(am1, RM[k * CMID + c], RB[k]), s1);
       s2 = fmaf(wb, RA[k * CMID + c], s2);
       da = fmaf(wb, RN[k * CMID + c], da);
