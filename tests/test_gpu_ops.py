@@ -936,6 +936,17 @@ def test_head_bwd1_with_folded_weight_gradient(cfg):
         return dv, S, dal, dW - mv(w0), db - mv(b0)
 
     g, r = run(H, DEV), run(R, "cpu")
+    if W2 % 64 == 0:  # the row-tiled pass again with two workgroups per sample: each walks a run of tiles (the software pipeline)
+        from viscy_amd import _lib as L
+
+        assert L.lib().vsx_set_flag(b"head_bps", 2) == 0
+        try:
+            g2 = run(H, DEV)
+        finally:
+            L.lib().vsx_set_flag(b"head_bps", 0)
+        assert torch.equal(g2[0], g[0]), "dv, several tiles per workgroup"
+        for name, a, b in zip(("S", "dalpha", "dW2", "db2"), g2[1:], g[1:]):
+            close(a, b, dt, name + ", several tiles per workgroup")
     assert torch.equal(g[0].cpu(), r[0]), "dv"
     close(g[1], r[1], dt, "S")
     close(g[2], r[2], dt, "dalpha")

@@ -36,6 +36,7 @@ thread_local float* g_vsx_det_ws = nullptr;
 thread_local long g_vsx_det_ws_floats = 0;
 int g_vsx_nt2 = 17;  // second-generation NT kernel (gemm_nt2.hip: 256 x 128 tiles, LDS-DMA operand path, wave-private epilogue): bit 0 = on for the launches it supports, bit 1 = also below 512 tiles
 int g_vsx_head_rows = 63;  // PixelToVoxelHead tail on row tiles with the 1x1x1 contraction on the matrix cores (head.hip, round 6; bf16, 64 | W2, Z <= 8): bit 0 = forward, bit 1 = backward pass 2, bit 2 = backward pass 1 with the folded weight gradient; bits 3 / 4 = the pixel shuffle + pad-pool in front of the head convolution and its adjoint on column strips (spatial.hip head_shuffle_{fwd,bwd}_strip_kernel; bf16, pooled, C3 * D = 56, 64 | w); bit 5 = the direct head convolution forward as a persistent kernel that requests the next halo tile ahead (headconv.hip)
+int g_vsx_head_bps = 0;  // head backward pass 1: workgroups per sample (0 = max(32, 8192 / B)); a small value makes every workgroup walk several tiles (tests)
 int g_vsx_loss_fused = 1;  // MixedLoss training forward: one pass per scale (SSIM sums + gradient field + next scale's pooling / data range + L1 / L2 sums: vsx_ssim_scale_fwd_fused) instead of a pooling pass and an SSIM pass; read by viscy_amd/losses.py
 
 void vsx_set_error(const char* fmt, ...) {
@@ -84,6 +85,7 @@ extern "C" int32_t vsx_set_flag(const char* name, int32_t value) {
   if (name && !strcmp(name, "mlp_sf32")) { g_vsx_mlp_sf32 = value; return 0; }
   if (name && !strcmp(name, "det_reduce")) { g_vsx_det_reduce = value; return 0; }
   if (name && !strcmp(name, "head_rows")) { g_vsx_head_rows = value; return 0; }
+  if (name && !strcmp(name, "head_bps") && value >= 0) { g_vsx_head_bps = value; return 0; }
   vsx_set_error("vsx_set_flag: unknown flag '%s'", name ? name : "(null)");
   return 1;
 }
@@ -116,5 +118,6 @@ extern "C" int32_t vsx_get_flag(const char* name) {
   if (name && !strcmp(name, "mlp_sf32")) return g_vsx_mlp_sf32;
   if (name && !strcmp(name, "det_reduce")) return g_vsx_det_reduce;
   if (name && !strcmp(name, "head_rows")) return g_vsx_head_rows;
+  if (name && !strcmp(name, "head_bps")) return g_vsx_head_bps;
   return -1;
 }

@@ -918,6 +918,7 @@ extern "C" int32_t vsx_head_out_bwd1_wgrad(const void* U, const float* ssum, con
   // enough workgroups to fill the chip, few enough per sample that the per-sample partial sums see a handful of atomics
   long bps = vsx_cdiv(8192L, (long)B);
   if (bps < 32) bps = 32;
+  if (g_vsx_head_bps > 0) bps = g_vsx_head_bps;  // tests: few workgroups per sample = several tiles / voxel windows per workgroup
   long vpt = nvox / (256L * bps);
   if (vpt < 1) vpt = 1;
   dim3 grid(vsx_cdiv(nvox, 256L * vpt), B);

@@ -12,6 +12,7 @@ typedef __bf16 bf16_t;
 
 // ------------------------------------------------------------------ error plumbing (host)
 void vsx_set_error(const char* fmt, ...);
+extern int g_vsx_head_bps;                   // api.hip: workgroups per sample of head backward pass 1 (0 = sized from the batch)
 extern int g_vsx_head_rows;                  // api.hip: row-tiled MFMA passes of the head tail (head.hip)
 extern int g_vsx_det_reduce;                 // api.hip: fixed-order forward sums (vsx_set_flag("det_reduce", 1))
 extern thread_local float* g_vsx_det_ws;     // api.hip: vsx_det_workspace
