@@ -383,6 +383,38 @@ def test_segmented_capture_equals_single_graph_and_leaves_state_untouched():
     assert max(firsts) - min(firsts) < 2e-3 * abs(firsts[0])
 
 
+def test_capture_right_behind_a_collective_survives_the_rccl_watchdog():
+    """Round 6: `bench.py --force-dp` died once in three runs with "operation not permitted when stream is capturing" raised from the
+    ProcessGroupNCCL watchdog thread — it polls the events of collectives it has not retired yet (hipEventQuery), which a capture in
+    the default global error mode forbids to EVERY thread.  The captures of viscy_amd.step run in thread-local mode; here a capture
+    starts right behind asynchronous all-reduces, many times, while the watchdog still holds their work objects."""
+    import torch.distributed as dist
+
+    from viscy_amd.step import InferStep
+
+    assert not dist.is_initialized()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29543")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        m = _bench_model(torch.bfloat16, "convnextv2_atto", seed=0).eval()
+        x = torch.randn(1, 1, 5, 64, 64, device="cuda")
+        buf = torch.ones(1 << 20, device="cuda")
+        ref = None
+        for i in range(12):
+            works = [dist.all_reduce(buf, async_op=True) for _ in range(4)]
+            step = InferStep(m)           # a fresh capture each time, the collectives' work objects still with the watchdog
+            y = step(x).float().clone()
+            for w in works:
+                w.wait()
+            if ref is None:
+                ref = y
+            assert torch.isfinite(y).all() and torch.allclose(y, ref, rtol=0, atol=2e-2 * float(ref.abs().max()))
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_rccl_one_rank_segments_with_interleaved_all_reduce():
     """RCCL at HEAD where the driver can see it: a 1-rank ``nccl`` process group, the step captured as
     three hipGraph segments with each bucket's ``all_reduce(async_op=True)`` issued between two replays (exactly what every

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import contextlib
 import gc
+import os
 
 import torch
 
@@ -36,6 +37,15 @@ def _no_gc():
     finally:
         if was:
             gc.enable()
+
+# Captures run in THREAD-LOCAL error mode.  In the default ("global") mode any thread's call that a capturing stream forbids fails
+# the capture — and a process with an RCCL process group has such a thread: the ProcessGroupNCCL watchdog polls the events of the
+# collectives still on its list (hipEventQuery), so a capture that begins while the work of an earlier all-reduce (the first
+# all-reduce, the parameter checksum of bench.py) has not been retired yet ended the process with "operation not permitted when
+# stream is capturing" raised FROM THE WATCHDOG — one `bench.py --force-dp` run in three at round 6's end.  A DataLoader's
+# pin-memory thread is the same hazard for Trainer.fit.  The capturing thread itself is checked as before.
+_CAPTURE_MODE = os.environ.get("VSX_CAPTURE_MODE", "thread_local")  # ("global" reproduces the failure: tests/test_gpu_soak.py)
+
 
 class TrainStep:
     """``step(x, t) -> loss`` = zero-grad, forward, loss, backward, gradient all-reduce (if data parallel), AdamW.
@@ -173,7 +183,7 @@ class TrainStep:
         def capture(body):
             nonlocal pool
             g = torch.cuda.CUDAGraph()
-            with _no_gc(), torch.cuda.graph(g, pool=pool):
+            with _no_gc(), torch.cuda.graph(g, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 body()
             pool = g.pool()
             graphs.append(g)
@@ -192,7 +202,7 @@ class TrainStep:
 
             capture(body)
         gopt = torch.cuda.CUDAGraph()  # its own graph: with data parallelism it runs after the last bucket's all-reduce
-        with _no_gc(), torch.cuda.graph(gopt, pool=pool):
+        with _no_gc(), torch.cuda.graph(gopt, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.opt.device_step()
         self.gopt = gopt
         # the warm-up steps (and nothing else: a capture records, it does not execute) changed the training state
@@ -258,7 +268,7 @@ class InferStep:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with _no_gc(), torch.cuda.graph(g):
+            with _no_gc(), torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                 self.y = self.model(self.x)
             self.graph = g
         self.x.copy_(x, non_blocking=True)
